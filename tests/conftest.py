@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """the HIP library on a real gfx950; fails (never skips) when -m gpu is requested without one"""
+    import torch
+    from video_similarity_search_amd import _lib
+    lib = _lib.load()
+    assert torch.cuda.is_available(), "gpu-marked test needs a GPU"
+    _lib.check(lib.slic_device_check(), "slic_device_check")
+    return lib

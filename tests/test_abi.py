@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/slic_hip.h declares;
+the ctypes table in _lib.py covers exactly those symbols; no compute entry point runs here."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "slic_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(slic_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_something():
+    syms = _header_symbols()
+    assert "slic_kmeans_assign" in syms and "slic_version" in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from video_similarity_search_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in _header_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_ctypes_table_matches_header():
+    from video_similarity_search_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _header_symbols()
+    lib = _lib.load()
+    assert lib.slic_version() >= 0x000100
+    assert isinstance(lib.slic_last_error(), bytes)
+
+
+def test_no_gpu_fails_loudly():
+    """without a device the product path raises instead of computing on the CPU"""
+    import numpy as np
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd.clustering import fit_cluster
+    with pytest.raises(_lib.SlicError):
+        fit_cluster(torch.randn(64, 8), "kmeans", k=4)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under the package may import or load it"""
+    pkg = os.path.join(ROOT, "video_similarity_search_amd")
+    bad = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                t = open(os.path.join(d, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "libslic_oracle" in t:
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad

@@ -1,0 +1,77 @@
+"""CPU: pins the k-means oracle (oracle/kmeans_oracle.c) against golden vectors produced by sklearn 1.7.2
+(tests/golden/make_goldens_kmeans.py) — the third-party code the reference calls at
+clustering/cluster_masks.py:70-71.  The reference itself has no k-means test."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import kmeans as ok
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, f"kmeans_{name}.npz")))
+
+
+@pytest.mark.parametrize("name", ["unstructured", "clustered_empty", "d128"])
+def test_oracle_matches_sklearn_golden(golden_dir, name):
+    g = _load(golden_dir, name)
+    X, init = g["X"], g["init"]
+    mean = ok.col_mean(X)
+    Xc = X - mean
+    tol_abs = ok.tolerance(Xc, 1e-4)
+    r = ok.lloyd(Xc, init - mean, max_iter=300, tol_abs=tol_abs, trace=True)
+    assert r["n_iter"] == int(g["n_iter"])
+    mism = np.nonzero(r["labels"] != g["labels"])[0]
+    assert mism.size == 0, f"{mism.size} final-label mismatches vs sklearn"
+    # every intermediate E-step: oracle trace[m] == sklearn labels after m centre updates
+    tr = g["trace"]
+    for m in range(1, min(r["n_iter"], tr.shape[0] + 1)):
+        assert np.array_equal(r["trace"][m], tr[m - 1]), f"iteration {m}"
+    assert abs(r["inertia"] - float(g["inertia"])) <= 1e-5 * float(g["inertia"])
+    np.testing.assert_allclose(r["centers"] + mean, g["centers"], atol=2e-6)
+    if name == "clustered_empty":
+        assert r["n_relocations"] >= 1
+
+
+def test_oracle_sharded_sums_equal_sklearn_threads_semantics():
+    """n_shards>1 = per-shard ascending sums added in shard order; labels stay identical on benign data"""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((3000, 16)).astype(np.float32)
+    init = X[:12].copy()
+    a = ok.lloyd(X, init, max_iter=50, tol_abs=0.0, n_shards=1)
+    b = ok.lloyd(X, init, max_iter=50, tol_abs=0.0, n_shards=2)
+    assert a["n_iter"] == b["n_iter"] and np.array_equal(a["labels"], b["labels"])
+    s1, c1 = ok.accumulate(X, a["labels"], 12, 1)
+    s2, c2 = ok.accumulate(X, a["labels"], 12, 2)
+    assert np.array_equal(c1, c2) and np.allclose(s1, s2, rtol=1e-5, atol=1e-5)
+
+
+def test_oracle_assign_is_first_index_on_ties():
+    X = np.zeros((5, 8), np.float32)
+    C = np.zeros((4, 8), np.float32)        # all scores equal -> label 0
+    assert np.array_equal(ok.assign(X, C), np.zeros(5, np.int32))
+    C[2, 0] = 1.0
+    X[:, 0] = 1.0                           # closest is centre 2 only
+    assert np.array_equal(ok.assign(X, C), np.full(5, 2, np.int32))
+
+
+def test_oracle_edge_cases():
+    # K == 1, N < K-ish tiny, duplicated points (max dist == 0 -> no relocation)
+    X = np.ones((6, 8), np.float32)
+    r = ok.lloyd(X, np.ones((3, 8), np.float32) * np.array([[1], [2], [3]], np.float32), max_iter=5)
+    assert r["labels"].min() == 0 and r["labels"].max() == 0
+    assert np.isfinite(r["centers"]).all()
+    r1 = ok.lloyd(X, X[:1].copy(), max_iter=5)
+    # shift == 0 <= tol == 0 stops at the first iteration (tol test, _kmeans.py:725-731), not strict
+    assert (not r1["strict"]) and r1["n_iter"] == 1 and r1["inertia"] == 0.0
+
+
+def test_reference_shaped_call_statistics(golden_dir):
+    """KMeans(n_clusters=k, n_init=10) with explicit restarts: best-of-10 inertia within 2 % of sklearn's"""
+    g = _load(golden_dir, "reference_call")
+    X = g["X"]
+    rng = np.random.default_rng(0)
+    inits = [X[rng.choice(len(X), 8, replace=False)] for _ in range(10)]
+    r = ok.kmeans_fit(X, inits)
+    assert r["inertia"] <= 1.02 * float(g["inertia"])

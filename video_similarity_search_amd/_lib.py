@@ -1,0 +1,112 @@
+"""ctypes binding of libslic_hip.so (C ABI: include/slic_hip.h).  Fails loudly — no fallback."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libslic_hip.so")
+
+c_void_p, c_int, c_int64, c_size_t, c_float, c_double = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_double)
+P, I, L, F, Dbl = c_void_p, c_int, c_int64, c_float, c_double
+
+# name -> (restype, argtypes).  Must list every symbol include/slic_hip.h declares
+# (tests/test_abi.py parses the header and checks).
+SIGNATURES = {
+    "slic_version": (I, []),
+    "slic_last_error": (ctypes.c_char_p, []),
+    "slic_device_check": (I, []),
+    # k-means
+    "slic_kmeans_cnorm": (I, [P, I, I, I, P, P]),
+    "slic_kmeans_assign_workspace_bytes": (c_size_t, [L, I]),
+    "slic_kmeans_assign": (I, [P, L, I, I, P, I, I, P, P, P, P, P, P, P]),
+    "slic_kmeans_accumulate_workspace_bytes": (c_size_t, [L, I]),
+    "slic_kmeans_accumulate": (I, [P, L, I, I, P, I, P, P, P, P]),
+    "slic_kmeans_combine_shards": (I, [P, P, L, I, I, I, P, P, P]),
+    "slic_kmeans_dist_to_assigned": (I, [P, L, I, I, P, I, P, P, P]),
+    "slic_sum_f32_to_f64_workspace_bytes": (c_size_t, [L]),
+    "slic_sum_f32_to_f64": (I, [P, L, P, P, P]),
+    "slic_kmeans_select_far": (I, [P, L, I, P, P, P]),
+    "slic_kmeans_apply_relocation": (I, [P, I, P, P, I, I, P, P, P]),
+    "slic_kmeans_finalize": (I, [P, P, P, I, I, P, P, P, P, P]),
+    "slic_col_stats_workspace_bytes": (c_size_t, [L, I]),
+    "slic_col_stats": (I, [P, L, I, I, P, P, P, P]),
+    "slic_sub_rowvec": (I, [P, L, I, I, P, P, I, P]),
+    "slic_l2norm_rows": (I, [P, L, I, I, P, I, P]),
+    "slic_kmeanspp_step_workspace_bytes": (c_size_t, [L, I]),
+    "slic_kmeanspp_step": (I, [P, L, I, I, P, I, P, P, P, P, P]),
+    "slic_cumsum_search_workspace_bytes": (c_size_t, [L]),
+    "slic_cumsum_search": (I, [P, L, P, I, P, P, P]),
+}
+
+
+class SlicError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libslic_hip.so (built by `make -C video_similarity_search_amd/csrc` or
+    __graft_entry__.build()).  Raises if it is missing: there is no other implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlicError(
+                f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C video_similarity_search_amd/csrc`; this package has no CPU/PyTorch fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().slic_last_error().decode("utf-8", "replace")
+        raise SlicError(f"{what} failed (rc={rc}): {msg}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise SlicError on a non-zero return."""
+    check(getattr(load(), name)(*args), name)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    """torch's current HIP stream as the void* the C ABI takes"""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    """every tensor must live on a HIP device, be fp32/int32/float64 as the ABI expects and contiguous
+    in its last dimension; the current device must be gfx950"""
+    if not torch.cuda.is_available():
+        raise SlicError("no HIP device: video_similarity_search_amd needs an MI355X (gfx950); no CPU fallback")
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SlicError("expected a device tensor, got a CPU tensor (no CPU fallback)")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """grow-only per-(device, tag) scratch buffer (the C ABI never allocates)"""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf

@@ -1,0 +1,59 @@
+"""
+Drop-in for the reference's clustering/cluster_masks.py on the k-means path:
+    preprocess_features_kmeans(data)                                   <- cluster_masks.py:30-34
+    fit_cluster(embeddings, method, k, l2normalize, finch_partition)   <- cluster_masks.py:38-98
+Same names, argument meaning, prints and return type (np.ndarray[N] int32 labels).  Only
+method='kmeans' is on the accelerated path; the other methods the reference
+dispatches to sklearn/FINCH on the host are outside this package and raise.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import call, ptr, stream
+from .kmeans_hip import KMeans
+
+_METHODS = ['DBSCAN', 'Agglomerative', 'OPTICS', 'kmeans', 'spherical_kmeans', 'finch']
+
+
+def _to_device(embeddings):
+    if not torch.cuda.is_available():
+        raise _lib.SlicError("fit_cluster needs a gfx950 device (no CPU fallback)")
+    if not torch.is_tensor(embeddings):
+        embeddings = torch.as_tensor(np.ascontiguousarray(embeddings, dtype=np.float32))
+    return embeddings.detach().to(device="cuda", dtype=torch.float32).contiguous()
+
+
+def preprocess_features_kmeans(data):
+    """row L2-normalise: data / torch.norm(data, dim=1, keepdim=True) (no epsilon), on the device.
+    Returns a tensor on the device the data ended up on (CPU input is moved to the current GPU)."""
+    x = _to_device(data)
+    out = torch.empty_like(x)
+    N, D = x.shape
+    call("slic_l2norm_rows", ptr(x), N, D, x.stride(0), ptr(out), out.stride(0), stream())
+    print('l2-normalized data')
+    return out
+
+
+def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, finch_partition=0,
+                n_init=10, init='k-means++', process_group=None, random_state=None):
+    """Reference signature + keyword-only extras (n_init / init / process_group / random_state) that default
+    to the reference's behaviour: KMeans(n_clusters=k, n_init=10).fit(embeddings).labels_."""
+    assert (method in _METHODS)
+    print("Clustering with {}...".format(method))
+    if method != 'kmeans':
+        raise NotImplementedError(
+            f"method={method!r}: only 'kmeans' is on the MI355X hot path (SURVEY.md §8); the reference runs the "
+            "others on the host through sklearn / FINCH")
+    print("k:", k)
+    x = _to_device(embeddings)
+    if l2normalize:
+        x = preprocess_features_kmeans(x)
+    km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group,
+                random_state=random_state).fit(x)
+    labels = km.labels_
+    print(labels.shape)
+    n_clusters = len(set(labels.tolist())) - (1 if -1 in labels else 0)
+    print("Fitted " + str(n_clusters) + " clusters with " + str(method))
+    fit_cluster.last_model = km
+    return labels

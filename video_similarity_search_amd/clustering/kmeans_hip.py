@@ -1,0 +1,401 @@
+"""
+Host driver of the gfx950 k-means (C ABI: include/slic_hip.h, kernels: csrc/kmeans.hip).
+
+Mirrors the object the reference builds at clustering/cluster_masks.py:70-71,
+    KMeans(n_clusters=k, n_init=10).fit(embeddings).labels_
+i.e. sklearn.cluster.KMeans (algorithm='lloyd'):
+    KMeans.fit             sklearn/cluster/_kmeans.py:1427-1540  (centre X, tol, n_init loop, best inertia)
+    _kmeans_single_lloyd   sklearn/cluster/_kmeans.py:624-752    (loop, strict / tol convergence, final E-step)
+    _kmeans_plusplus       sklearn/cluster/_kmeans.py:174-277    (seeding; host RNG, device distances)
+Only control flow lives here; every reduction/contraction is a HIP kernel reached through
+`HipKernels` (one method per C-ABI entry point).  One host sync per Lloyd iteration (a 4-double
+status word).
+
+Multi-GPU: pass `process_group`; X is then this rank's contiguous row shard
+(rank order == row order).  Per iteration the per-rank partial sums/counts are all-gathered
+(RCCL over xGMI) and added in rank order on every GPU, so all ranks hold bit-identical centres
+and the result equals the oracle run with n_shards = world size.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import call, ptr, stream
+
+
+class HipKernels:
+    """Thin argument marshalling for the k-means entry points of libslic_hip.so.  The only kernel
+    provider the package ships; `KMeans(kernels=...)` exists so the multi-process control flow can be
+    exercised under gloo on a GPU-less host by the tests (tests/kmeans_cpu_kernels.py)."""
+
+    device_type = "cuda"
+
+    def check(self):
+        if not torch.cuda.is_available():
+            raise _lib.SlicError("k-means needs a gfx950 device: libslic_hip.so has no CPU path")
+        _lib.check(_lib.load().slic_device_check(), "slic_device_check")
+
+    def to_device(self, X):
+        if not torch.is_tensor(X):
+            X = torch.as_tensor(np.ascontiguousarray(X, dtype=np.float32))
+        return X.detach().to(device="cuda", dtype=torch.float32).contiguous()
+
+    def col_stats(self, X):
+        N, Dp = X.shape
+        cs = torch.empty(2, Dp, dtype=torch.float64, device=X.device)
+        ws = _lib.workspace(_lib.load().slic_col_stats_workspace_bytes(N, Dp), X.device, "km_cs")
+        call("slic_col_stats", ptr(X), N, Dp, X.stride(0), ptr(cs[0]), ptr(cs[1]), ptr(ws), stream())
+        return cs
+
+    def sub_rowvec(self, X, v, out):
+        call("slic_sub_rowvec", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(v), ptr(out), out.stride(0), stream())
+
+    def cnorm(self, C, cnorm):
+        call("slic_kmeans_cnorm", ptr(C), C.shape[0], C.shape[1], C.stride(0), ptr(cnorm), stream())
+
+    def assign(self, X, C, cnorm, labels, labels_old, n_changed):
+        N, Dp = X.shape
+        K = C.shape[0]
+        ws = _lib.workspace(_lib.load().slic_kmeans_assign_workspace_bytes(N, K), X.device, "km_assign")
+        call("slic_kmeans_assign", ptr(X), N, Dp, X.stride(0), ptr(C), K, C.stride(0), ptr(cnorm), ptr(labels),
+             ptr(labels_old), ptr(n_changed), None, ptr(ws), stream())
+
+    def accumulate(self, X, labels, K, sums, counts):
+        N, Dp = X.shape
+        ws = _lib.workspace(_lib.load().slic_kmeans_accumulate_workspace_bytes(N, K), X.device, "km_accum")
+        call("slic_kmeans_accumulate", ptr(X), N, Dp, X.stride(0), ptr(labels), K, ptr(sums), ptr(counts),
+             ptr(ws), stream())
+
+    def combine_shards(self, allpart, K, Dp, sums, counts):
+        W, stride = allpart.shape
+        call("slic_kmeans_combine_shards", ptr(allpart), ptr(allpart[0, K * Dp:]), stride, W, K, Dp,
+             ptr(sums), ptr(counts), stream())
+
+    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status):
+        K, Dp = C_old.shape
+        call("slic_kmeans_finalize", ptr(C_old), ptr(sums), ptr(counts), K, Dp, ptr(C_new), ptr(shift),
+             ptr(n_changed), ptr(status), stream())
+
+    def dist_to_assigned(self, X, C, labels, dist):
+        call("slic_kmeans_dist_to_assigned", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(C), C.stride(0),
+             ptr(labels), ptr(dist), stream())
+
+    def sum_f64(self, v, out):
+        ws = _lib.workspace(_lib.load().slic_sum_f32_to_f64_workspace_bytes(v.numel()), v.device, "km_sum")
+        call("slic_sum_f32_to_f64", ptr(v), v.numel(), ptr(out), ptr(ws), stream())
+
+    def select_far(self, dist, n_sel, far_idx, far_dist):
+        call("slic_kmeans_select_far", ptr(dist), dist.numel(), n_sel, ptr(far_idx), ptr(far_dist), stream())
+
+    def apply_relocation(self, xfar, old_ids, new_ids, sums, counts):
+        n, Dp = xfar.shape
+        call("slic_kmeans_apply_relocation", ptr(xfar), xfar.stride(0), ptr(old_ids), ptr(new_ids), n, Dp,
+             ptr(sums), ptr(counts), stream())
+
+    def kpp_step(self, X, cand, T, closest, newdist, pot):
+        N, Dp = X.shape
+        ws = _lib.workspace(_lib.load().slic_kmeanspp_step_workspace_bytes(N, T), X.device, "kpp_p")
+        call("slic_kmeanspp_step", ptr(X), N, Dp, X.stride(0), ptr(cand), T, ptr(closest), ptr(newdist), ptr(pot),
+             ptr(ws), stream())
+
+    def cumsum_search(self, v, vals, T, idx_out):
+        ws = _lib.workspace(_lib.load().slic_cumsum_search_workspace_bytes(v.numel()), v.device, "kpp_c")
+        call("slic_cumsum_search", ptr(v), v.numel(), ptr(vals), T, ptr(idx_out), ptr(ws), stream())
+
+
+def _dist_on(pg):
+    return pg is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(pg) > 1
+
+
+class KMeans:
+    """sklearn-shaped: KMeans(n_clusters, n_init=10, max_iter=300, tol=1e-4).fit(X) -> labels_, cluster_centers_,
+    inertia_, n_iter_.  `init` may be 'k-means++' (default, as the reference uses), an [K, D] array, or a list of
+    such arrays (one per run).  X: torch tensor [N, D] fp32 on a gfx950 device (a CPU tensor / ndarray is
+    copied to the current device)."""
+
+    def __init__(self, n_clusters, n_init=10, max_iter=300, tol=1e-4, init="k-means++", random_state=None,
+                 process_group=None, fixed_iters=False, trace=False, kernels=None):
+        self.n_clusters = int(n_clusters)
+        self.n_init = int(n_init)
+        self.max_iter = int(max_iter)
+        self.tol = float(tol)
+        self.init = init
+        self.random_state = random_state
+        self.process_group = process_group
+        self.fixed_iters = bool(fixed_iters)   # throughput runs: skip the stopping tests
+        self.trace = bool(trace)               # keep every iteration's labels (tests)
+        self.k = kernels if kernels is not None else HipKernels()
+
+    # ------------------------------------------------------------------ helpers
+    def _rng(self):
+        rs = self.random_state
+        if rs is None:
+            return np.random.mtrand._rand     # sklearn check_random_state(None): numpy's global RandomState
+        if isinstance(rs, (int, np.integer)):
+            return np.random.RandomState(rs)
+        return rs
+
+    def _gather(self, t):
+        """all-gather a per-rank tensor [*] -> [W, *] (same shape on every rank)"""
+        W = torch.distributed.get_world_size(self.process_group)
+        out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        torch.distributed.all_gather_into_tensor(out, t.contiguous(), group=self.process_group)
+        return out
+
+    def _col_stats(self, X):
+        """global column sum / sum of squares as float64 numpy (rank partials added in rank order)"""
+        cs = self.k.col_stats(X)
+        if self._sharded:
+            allcs = self._gather(cs).cpu().numpy()      # [W, 2, Dp]
+            tot = np.zeros_like(allcs[0])
+            for r in range(allcs.shape[0]):
+                tot += allcs[r]
+            return tot
+        return cs.cpu().numpy()
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, X):
+        self.k.check()
+        X = self.k.to_device(X)
+        N, D = X.shape
+        K = self.n_clusters
+        self._sharded = _dist_on(self.process_group)
+        dev = X.device
+        # pad the feature dim to a multiple of 8 with zero columns (they add exact zeros to every chain)
+        Dp = (D + 7) // 8 * 8
+        if Dp != D:
+            Xp = torch.zeros(N, Dp, dtype=torch.float32, device=dev)
+            Xp[:, :D] = X
+            X = Xp
+        if self._sharded:
+            sizes = self._gather(torch.tensor([N], dtype=torch.int64, device=dev)).cpu().numpy().reshape(-1)
+            rank = torch.distributed.get_rank(self.process_group)
+            self._row0 = int(sizes[:rank].sum())
+            self._sizes = sizes
+            Ng = int(sizes.sum())
+        else:
+            self._row0, self._sizes, Ng = 0, np.array([N]), N
+
+        # X -= X.mean(axis=0)   (_kmeans.py:1479-1481)
+        cs = self._col_stats(X)
+        mean = (cs[0] / float(Ng)).astype(np.float32)
+        mean_d = torch.from_numpy(mean).to(dev)
+        Xc = torch.empty_like(X)
+        self.k.sub_rowvec(X, mean_d, Xc)
+        # tol = mean(var(Xc, axis=0)) * tol   (_tolerance, _kmeans.py:279-288)
+        if self.tol == 0:
+            tol_abs = 0.0
+        else:
+            cs2 = self._col_stats(Xc)
+            m = cs2[0] / float(Ng)
+            var = cs2[1] / float(Ng) - m * m
+            tol_abs = float(var[:D].sum() / D) * self.tol
+        self.tol_abs_ = tol_abs
+
+        inits = self.init
+        if isinstance(inits, str):
+            assert inits == "k-means++", inits
+            inits = None
+        elif isinstance(inits, (list, tuple)):
+            inits = [np.asarray(a, np.float32) for a in inits]
+        else:
+            a = inits.detach().cpu().numpy() if torch.is_tensor(inits) else np.asarray(inits)
+            inits = [np.asarray(a, np.float32)]
+        n_runs = self.n_init if inits is None else len(inits)
+
+        best = None
+        for run in range(n_runs):
+            if inits is None:
+                C0 = self._kmeans_plusplus(Xc, K)          # rows of the centred matrix
+            else:
+                c = np.zeros((K, Dp), np.float32)
+                c[:, :D] = inits[run] - mean[None, :D]
+                C0 = torch.from_numpy(c).to(dev)
+            res = self._lloyd_single(Xc, C0, tol_abs)
+            if best is None or res["inertia"] < best["inertia"]:
+                best = res
+        self.labels_ = best["labels"].cpu().numpy()                 # np.int32, like sklearn's labels_
+        self.labels_device_ = best["labels"]
+        self.cluster_centers_ = best["centers"].cpu().numpy()[:, :D] + mean[None, :D]
+        self.inertia_ = best["inertia"]
+        self.n_iter_ = best["n_iter"]
+        self.strict_ = best["strict"]
+        self.n_relocations_ = best["n_relocations"]
+        self.trace_ = best.get("trace")
+        return self
+
+    # ------------------------------------------------------------------ one Lloyd run
+    def _lloyd_single(self, Xc, C, tol_abs):
+        k = self.k
+        N, Dp = Xc.shape
+        K = C.shape[0]
+        dev = Xc.device
+        C = C.contiguous().clone()
+        Cn = torch.empty_like(C)
+        cnorm = torch.empty(K, dtype=torch.float32, device=dev)
+        labels = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        labels_old = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        n_changed = torch.zeros(1, dtype=torch.int32, device=dev)
+        part = torch.empty(K * Dp + K, dtype=torch.float32, device=dev)   # [sums | counts]: the all-gather unit
+        sums, counts = part[: K * Dp], part[K * Dp:]
+        shift = torch.empty(K, dtype=torch.float32, device=dev)
+        status = torch.empty(4, dtype=torch.float64, device=dev)
+        if self._sharded:
+            W = torch.distributed.get_world_size(self.process_group)
+            allpart = torch.empty(W, K * Dp + K, dtype=torch.float32, device=dev)
+            gsums = torch.empty(K * Dp, dtype=torch.float32, device=dev)
+            gcounts = torch.empty(K, dtype=torch.float32, device=dev)
+        else:
+            gsums, gcounts = sums, counts
+        trace = [] if self.trace else None
+        strict = False
+        n_reloc = 0
+        it, cur = 0, labels
+        for it in range(self.max_iter):
+            k.cnorm(C, cnorm)
+            n_changed.zero_()
+            k.assign(Xc, C, cnorm, labels, labels_old, n_changed)
+            cur = labels
+            k.accumulate(Xc, labels, K, sums, counts)
+            if self._sharded:
+                torch.distributed.all_gather_into_tensor(allpart, part, group=self.process_group)
+                k.combine_shards(allpart, K, Dp, gsums, gcounts)
+                torch.distributed.all_reduce(n_changed, group=self.process_group)
+            k.finalize(C, gsums, gcounts, Cn, shift, n_changed, status)
+            shift_tot, n_empty, n_chg, _ = status.cpu().tolist()      # the one sync of the iteration
+            if n_empty > 0:
+                # rare: _relocate_empty_clusters_dense, then redo the averaging
+                if self._relocate(Xc, C, labels, gsums, gcounts, int(n_empty)):
+                    n_reloc += 1
+                    k.finalize(C, gsums, gcounts, Cn, shift, n_changed, status)
+                    shift_tot = status.cpu().tolist()[0]
+            C, Cn = Cn, C                                              # centers, centers_new = centers_new, centers
+            if trace is not None:
+                trace.append(labels.cpu().numpy().copy())
+            if not self.fixed_iters:
+                if n_chg == 0:                                         # np.array_equal(labels, labels_old)
+                    strict = True
+                    break
+                if shift_tot <= tol_abs:
+                    break
+            labels, labels_old = labels_old, labels                    # labels_old[:] = labels
+        n_iter = it + 1
+        if not strict:
+            # rerun the E-step so labels match the final centres (_kmeans.py:736-748)
+            other = labels_old if cur is labels else labels
+            k.cnorm(C, cnorm)
+            k.assign(Xc, C, cnorm, other, None, None)
+            cur = other
+        labels = cur
+        inertia = self._inertia(Xc, C, labels)
+        res = dict(labels=labels, centers=C, inertia=inertia, n_iter=n_iter, strict=strict, n_relocations=n_reloc)
+        if trace is not None:
+            res["trace"] = np.stack(trace) if trace else np.zeros((0, N), np.int32)
+        return res
+
+    def _inertia(self, Xc, C, labels):
+        N = Xc.shape[0]
+        dist = torch.empty(N, dtype=torch.float32, device=Xc.device)
+        out = torch.empty(1, dtype=torch.float64, device=Xc.device)
+        self.k.dist_to_assigned(Xc, C, labels, dist)
+        self.k.sum_f64(dist, out)
+        if self._sharded:
+            tot = 0.0
+            for v in self._gather(out).cpu().numpy().reshape(-1):
+                tot += float(v)
+            return tot
+        return float(out.item())
+
+    def _relocate(self, Xc, C_old, labels, gsums, gcounts, n_empty):
+        """_relocate_empty_clusters_dense (_k_means_common.pyx:167-211).  Returns False when max(dist) == 0."""
+        k = self.k
+        N, Dp = Xc.shape
+        dev = Xc.device
+        n_sel = n_empty
+        dist = torch.empty(N, dtype=torch.float32, device=dev)
+        k.dist_to_assigned(Xc, C_old, labels, dist)
+        far_idx = torch.empty(n_sel, dtype=torch.int32, device=dev)
+        far_dist = torch.empty(n_sel, dtype=torch.float32, device=dev)
+        k.select_far(dist, n_sel, far_idx, far_dist)
+        fi = far_idx.long()
+        valid = fi < N                                   # a shard smaller than n_empty runs out of rows
+        fi = fi.clamp(max=N - 1)
+        xfar = Xc.index_select(0, fi)
+        old_ids = labels.index_select(0, fi)
+        fd = torch.where(valid, far_dist, torch.full_like(far_dist, -1.0))
+        if self._sharded:
+            # merge the per-rank candidates by (dist desc, global row asc), keep n_empty
+            gidx = fi + self._row0
+            fdh = self._gather(fd).reshape(-1).cpu().numpy()
+            gih = self._gather(gidx).reshape(-1).cpu().numpy()
+            allx = self._gather(xfar).reshape(-1, Dp)
+            allold = self._gather(old_ids).reshape(-1)
+            order = np.lexsort((gih, -fdh))[:n_empty]
+            order = order[fdh[order] >= 0]
+            sel = torch.from_numpy(order).to(dev)
+            xfar = allx.index_select(0, sel).contiguous()
+            old_ids = allold.index_select(0, sel).contiguous()
+            fdh = fdh[order]
+        else:
+            fdh = fd.cpu().numpy()
+        if len(fdh) == 0 or fdh[0] == 0.0:
+            return False
+        empty = np.nonzero(gcounts.cpu().numpy() == 0)[0].astype(np.int32)[: len(fdh)]
+        new_ids = torch.from_numpy(empty).to(dev)
+        k.apply_relocation(xfar[: len(empty)].contiguous(), old_ids[: len(empty)].contiguous(), new_ids, gsums, gcounts)
+        return True
+
+    # ------------------------------------------------------------------ k-means++
+    def _kmeans_plusplus(self, Xc, K):
+        """_kmeans_plusplus (_kmeans.py:174-277): RNG draws on the host from numpy's legacy RandomState (as
+        sklearn), distances / potentials / cumsum-search on the device.  In sharded runs every rank seeds on the
+        all-gathered matrix and follows rank 0's draws (identical centres everywhere)."""
+        k = self.k
+        if self._sharded:
+            W = len(self._sizes)
+            mx = int(self._sizes.max())
+            if int(self._sizes.min()) == mx:
+                Xs = self._gather(Xc).reshape(-1, Xc.shape[1]).contiguous()
+            else:
+                pad = torch.zeros(mx, Xc.shape[1], dtype=Xc.dtype, device=Xc.device)
+                pad[: Xc.shape[0]] = Xc
+                allp = self._gather(pad)
+                Xs = torch.cat([allp[r, : int(self._sizes[r])] for r in range(W)], 0).contiguous()
+        else:
+            Xs = Xc
+        N, Dp = Xs.shape
+        dev = Xs.device
+        rs = self._rng()
+        T = 2 + int(np.log(K))
+        newdist = torch.empty(T, N, dtype=torch.float32, device=dev)
+        closest = torch.empty(N, dtype=torch.float32, device=dev)
+        pot = torch.empty(T, dtype=torch.float64, device=dev)
+        cand = torch.zeros(T, dtype=torch.int32, device=dev)
+        vals = torch.empty(T, dtype=torch.float64, device=dev)
+        idx = np.full(K, -1, np.int64)
+
+        def bcast(a):
+            if not self._sharded:
+                return a
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            src = torch.distributed.get_global_rank(self.process_group, 0)
+            torch.distributed.broadcast(t, src, group=self.process_group)
+            return t.cpu().numpy()
+
+        first = int(bcast(np.array([rs.choice(N, p=np.full(N, 1.0 / N))], np.int64))[0])
+        idx[0] = first
+        cand[0] = first
+        k.kpp_step(Xs, cand, 1, None, closest, pot)
+        cur_pot = float(pot[0].item())
+        for c in range(1, K):
+            rv = bcast(rs.uniform(size=T)) * cur_pot
+            vals.copy_(torch.from_numpy(rv))
+            k.cumsum_search(closest, vals, T, cand)
+            k.kpp_step(Xs, cand, T, closest, newdist, pot)
+            ph = pot.cpu().numpy()
+            b = int(np.argmin(ph))
+            cur_pot = float(ph[b])
+            closest.copy_(newdist[b])
+            idx[c] = int(cand[b].item())
+        self.init_indices_ = idx
+        return Xs.index_select(0, torch.from_numpy(idx).to(dev)).contiguous()

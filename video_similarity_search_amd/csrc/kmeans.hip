@@ -1,0 +1,803 @@
+// k-means on gfx950: E-step on fp32 MFMA, deterministic M-step, sklearn's bookkeeping.
+//
+// Replaces sklearn.cluster.KMeans as called from /root/reference/clustering/cluster_masks.py:64-71
+// (arithmetic: sklearn/cluster/_k_means_lloyd.pyx:168-218, _k_means_common.pyx:167-311,
+//  _kmeans.py:174-277).  Floating-point contract shared with oracle/kmeans_oracle.c:
+//   score = cnorm[j] - 2 * dot(x_i, c_j),  dot = k-ascending chain of fmaf from +0.
+// v_mfma_f32_32x32x2_f32 computes exactly that chain along K (one rounding per product, k = 0
+// then k = 1 inside one instruction), so labels are bit-identical to the oracle as long as
+// (a) every (point, centroid) pair accumulates in ONE accumulator over the whole D and
+// (b) the LDS image hands the MFMA its k's in ascending order.  Both hold below.
+//
+// Build: -ffp-contract=off (nothing fuses except explicit fmaf/MFMA).
+#include "common.h"
+#include <math.h>
+
+#define KM_BP 128  // points per workgroup (4 waves x 32)
+#define KM_BC 128  // centroids per workgroup (4 MFMA row tiles per wave)
+#define KM_BK 32   // k per LDS tile
+
+// LDS tile = [128 rows][32 floats]; 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7):
+// the 16 lanes of a ds_read_b128 group (rows distinct mod 16, same chunk) hit 16 different
+// 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int km_off(int row, int chunk) {
+  return row * KM_BK + ((chunk ^ ((row >> 1) & 7)) << 2);
+}
+
+// One workgroup: 128 points x 128 centroids, full D.  Wave w owns points [32w, 32w+32).
+// MFMA roles: A = centroid tile (rows i), B = point tile (cols j)  =>  each lane holds ONE point
+// (col = lane&31) and 16 centroid rows per accumulator, so the running argmin is in-register.
+__global__ __launch_bounds__(256, 2) void km_assign_partial(
+    const float* __restrict__ X, int64_t N, int D, int ldx, const float* __restrict__ C, int K,
+    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore,
+    int32_t* __restrict__ pidx) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][KM_BP * KM_BK];  // [buf][0 = C, 1 = X]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t pblock = (int64_t)blockIdx.x * KM_BP;
+  const int cblock = blockIdx.y * KM_BC;
+
+  // staging: thread t loads 8 consecutive floats (k0 + 8*(t&3)) of rows (t>>2) and (t>>2)+64
+  const int srow = tid >> 2, scp = tid & 3;
+  const float* xr[2];
+  const float* cr[2];
+  bool cvalid[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int64_t pr = pblock + srow + 64 * p;
+    if (pr > N - 1) pr = N - 1;
+    xr[p] = X + pr * (int64_t)ldx + scp * 8;
+    int c = cblock + srow + 64 * p;
+    cvalid[p] = c < K;
+    if (c > K - 1) c = K - 1;
+    cr[p] = C + (int64_t)c * ldc + scp * 8;
+  }
+  f32x4 gx[2][2], gc[2][2];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](int kt) {
+    const int k0 = kt * KM_BK;
+    const bool kin = (k0 + scp * 8) < D;  // D % 8 == 0: a pair of chunks is all in or all out
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      if (kin) {
+        gx[p][0] = *(const f32x4*)(xr[p] + k0);
+        gx[p][1] = *(const f32x4*)(xr[p] + k0 + 4);
+      } else {
+        gx[p][0] = z4; gx[p][1] = z4;
+      }
+      if (kin && cvalid[p]) {
+        gc[p][0] = *(const f32x4*)(cr[p] + k0);
+        gc[p][1] = *(const f32x4*)(cr[p] + k0 + 4);
+      } else {
+        gc[p][0] = z4; gc[p][1] = z4;
+      }
+    }
+  };
+  // de-interleave: chunk 2*scp gets k = 0,2,4,6 of the 8-group, chunk 2*scp+1 gets k = 1,3,5,7,
+  // so lane half h reads its four k's (2t+h, t = 0..3) with one ds_read_b128.
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = srow + 64 * p;
+      f32x4 e = {gx[p][0].x, gx[p][0].z, gx[p][1].x, gx[p][1].z};
+      f32x4 o = {gx[p][0].y, gx[p][0].w, gx[p][1].y, gx[p][1].w};
+      *(f32x4*)&lds[buf][1][km_off(row, 2 * scp)] = e;
+      *(f32x4*)&lds[buf][1][km_off(row, 2 * scp + 1)] = o;
+      f32x4 ce = {gc[p][0].x, gc[p][0].z, gc[p][1].x, gc[p][1].z};
+      f32x4 co = {gc[p][0].y, gc[p][0].w, gc[p][1].y, gc[p][1].w};
+      *(f32x4*)&lds[buf][0][km_off(row, 2 * scp)] = ce;
+      *(f32x4*)&lds[buf][0][km_off(row, 2 * scp + 1)] = co;
+    }
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  const int r = lane & 31, h = lane >> 5;
+  const int nk = (D + KM_BK - 1) / KM_BK;
+  gload(0);
+  lwrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const float* Cs = lds[buf][0];
+    const float* Xs = lds[buf][1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * q + h)];
+      f32x4 a[4];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) a[ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, 2 * q + h)];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][t], b[t], acc[ct], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lwrite(buf ^ 1);
+    __syncthreads();
+  }
+
+  // running argmin over this workgroup's 128 centroids for the lane's point
+  float best = INFINITY;
+  int bidx = 0x7fffffff;
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int c = cblock + ct * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (c < K) {
+        const float s = cnorm[c] - 2.0f * acc[ct][g];
+        if (s < best || (s == best && c < bidx)) { best = s; bidx = c; }
+      }
+    }
+  const float ob = __shfl_xor(best, 32);
+  const int oi = __shfl_xor(bidx, 32);
+  if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  const int64_t p = pblock + 32 * wave + r;
+  if (h == 0 && p < N) {
+    pscore[(int64_t)blockIdx.y * N + p] = best;
+    pidx[(int64_t)blockIdx.y * N + p] = bidx;
+  }
+}
+
+// labels = argmin over the G centroid groups (groups ascending, strict '<' => first index wins)
+__global__ void km_combine(const float* __restrict__ pscore, const int32_t* __restrict__ pidx,
+                           int G, int64_t N, int K, int32_t* __restrict__ labels,
+                           const int32_t* __restrict__ labels_old, int32_t* n_changed,
+                           float* __restrict__ best_score) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int changed = 0;
+  if (i < N) {
+    float best = pscore[i];
+    int idx = pidx[i];
+    for (int g = 1; g < G; ++g) {
+      const float s = pscore[(int64_t)g * N + i];
+      if (s < best) { best = s; idx = pidx[(int64_t)g * N + i]; }
+    }
+    if (idx < 0 || idx >= K) idx = 0;  // all-NaN row: sklearn's argmin also yields 0
+    labels[i] = idx;
+    if (best_score) best_score[i] = best;
+    if (labels_old) changed = labels_old[i] != idx;
+  }
+  if (labels_old) {
+    const unsigned long long m = __ballot(changed);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_changed, (int)__popcll(m));
+  }
+}
+
+__global__ void km_cnorm(const float* __restrict__ C, int K, int D, int ldc,
+                         float* __restrict__ cnorm) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  const float* c = C + (int64_t)j * ldc;
+  float acc = 0.f;
+  for (int k = 0; k < D; ++k) acc = fmaf(c[k], c[k], acc);
+  cnorm[j] = acc;
+}
+
+// ---------------- M-step: stable counting sort by label, then per-cluster ordered sums --------
+#define KM_SB 256  // rows per sort block
+
+__global__ void km_block_hist(const int32_t* __restrict__ labels, int64_t N, int K,
+                              int32_t* __restrict__ bc /* [nblk][K], zeroed */) {
+  const int64_t i = (int64_t)blockIdx.x * KM_SB + threadIdx.x;
+  if (i < N) atomicAdd(&bc[(int64_t)blockIdx.x * K + labels[i]], 1);
+}
+
+// per cluster: exclusive scan over blocks (in place) and total count
+__global__ void km_scan_blocks(int32_t* __restrict__ bc, int nblk, int K,
+                               int32_t* __restrict__ cnt) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  int run = 0;
+  for (int b = 0; b < nblk; ++b) {
+    const int t = bc[(int64_t)b * K + j];
+    bc[(int64_t)b * K + j] = run;
+    run += t;
+  }
+  cnt[j] = run;
+}
+
+// exclusive scan of cnt over clusters (K is small: one workgroup, serial per 1024-chunk)
+__global__ void km_scan_clusters(const int32_t* __restrict__ cnt, int K,
+                                 int32_t* __restrict__ off, float* __restrict__ counts_f) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (K + 1023) / 1024;
+  int s = 0;
+  for (int u = 0; u < per; ++u) {
+    const int j = t * per + u;
+    if (j < K) s += cnt[j];
+  }
+  part[t] = s;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int u = 0; u < 1024; ++u) { const int v = part[u]; part[u] = run; run += v; }
+  }
+  __syncthreads();
+  int run = part[t];
+  for (int u = 0; u < per; ++u) {
+    const int j = t * per + u;
+    if (j < K) {
+      off[j] = run;
+      run += cnt[j];
+      if (counts_f) counts_f[j] = (float)cnt[j];
+    }
+  }
+}
+
+__global__ void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
+                         const int32_t* __restrict__ bc, const int32_t* __restrict__ off,
+                         int32_t* __restrict__ order) {
+  __shared__ int lab[KM_SB];
+  const int t = threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.x * KM_SB + t;
+  const int l = i < N ? labels[i] : -1;
+  lab[t] = l;
+  __syncthreads();
+  if (i >= N) return;
+  int rank = 0;
+  for (int u = 0; u < t; ++u) rank += (lab[u] == l);
+  order[off[l] + bc[(int64_t)blockIdx.x * K + l] + rank] = (int32_t)i;
+}
+
+// sums[j, 4*c4 .. 4*c4+3] = sequential fp32 sum over the cluster's rows in ascending order
+__global__ __launch_bounds__(128) void km_accumulate(
+    const float* __restrict__ X, int D, int ldx, const int32_t* __restrict__ order,
+    const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
+    float* __restrict__ sums) {
+  const int j = blockIdx.x;
+  const int c4 = blockIdx.y * 128 + threadIdx.x;
+  if (c4 * 4 >= D) return;
+  const int n = cnt[j];
+  const int32_t* ord = order + off[j];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int m = 0;
+  for (; m + 8 <= n; m += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(X + (int64_t)ord[m + u] * ldx + c4 * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; m < n; ++m) acc += *(const f32x4*)(X + (int64_t)ord[m] * ldx + c4 * 4);
+  *(f32x4*)(sums + (int64_t)j * D + c4 * 4) = acc;
+}
+
+__global__ void km_combine_shards(const float* __restrict__ ps, const float* __restrict__ pc,
+                                  int64_t stride, int S, int K, int D, float* __restrict__ sums,
+                                  float* __restrict__ counts) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t KD = (int64_t)K * D;
+  if (e < KD) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += ps[(int64_t)s * stride + e];
+    sums[e] = a;
+  }
+  if (e < K) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += pc[(int64_t)s * stride + e];
+    counts[e] = a;
+  }
+}
+
+__global__ void km_dist_to_assigned(const float* __restrict__ X, int64_t N, int D, int ldx,
+                                    const float* __restrict__ C, int ldc,
+                                    const int32_t* __restrict__ labels, float* __restrict__ dist) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float* x = X + i * (int64_t)ldx;
+  const float* c = C + (int64_t)labels[i] * ldc;
+  float acc = 0.f;
+  for (int k = 0; k < D; k += 4) {
+    const f32x4 xv = *(const f32x4*)(x + k);
+    const f32x4 cv = *(const f32x4*)(c + k);
+    float d;
+    d = xv.x - cv.x; acc = fmaf(d, d, acc);
+    d = xv.y - cv.y; acc = fmaf(d, d, acc);
+    d = xv.z - cv.z; acc = fmaf(d, d, acc);
+    d = xv.w - cv.w; acc = fmaf(d, d, acc);
+  }
+  dist[i] = acc;
+}
+
+// partial[b] = sum of v[256 b .. 256 b + 255] in double, ascending
+__global__ void sum_blocks_f64(const float* __restrict__ v, int64_t N, double* __restrict__ partial) {
+  __shared__ float s[256];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  s[threadIdx.x] = i < N ? v[i] : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    for (int u = 0; u < 256; ++u) a += (double)s[u];
+    partial[blockIdx.x] = a;
+  }
+}
+__global__ void sum_serial_f64(const double* __restrict__ partial, int64_t n, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0;
+    for (int64_t u = 0; u < n; ++u) a += partial[u];
+    *out = a;
+  }
+}
+
+// One workgroup: the n_sel farthest rows by (dist desc, row asc); dist is clobbered (-2 marks taken)
+__global__ __launch_bounds__(1024) void km_select_far(float* __restrict__ dist, int64_t N, int n_sel,
+                                                      int32_t* __restrict__ far_idx,
+                                                      float* __restrict__ far_dist) {
+  __shared__ float rv[1024];
+  __shared__ int64_t ri[1024];
+  const int t = threadIdx.x;
+  for (int e = 0; e < n_sel; ++e) {
+    float bv = -1.0f;
+    int64_t bi = N;
+    for (int64_t i = t; i < N; i += 1024) {
+      const float d = dist[i];
+      if (d > bv) { bv = d; bi = i; }  // ascending i per thread: first max kept
+    }
+    rv[t] = bv; ri[t] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+      if (t < s) {
+        const float ov = rv[t + s];
+        const int64_t oi = ri[t + s];
+        if (ov > rv[t] || (ov == rv[t] && oi < ri[t])) { rv[t] = ov; ri[t] = oi; }
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      far_idx[e] = (int32_t)ri[0];
+      far_dist[e] = rv[0];
+      if (ri[0] < N) dist[ri[0]] = -2.0f;
+    }
+    __syncthreads();
+  }
+}
+
+// One workgroup, e ascending: sums[old] -= x; sums[new] = x; counts[new] = 1; counts[old] -= 1
+__global__ void km_apply_relocation(const float* __restrict__ xfar, int ldf,
+                                    const int32_t* __restrict__ old_ids,
+                                    const int32_t* __restrict__ new_ids, int n, int D,
+                                    float* __restrict__ sums, float* __restrict__ counts) {
+  for (int e = 0; e < n; ++e) {
+    const int o = old_ids[e], w = new_ids[e];
+    const float* x = xfar + (int64_t)e * ldf;
+    for (int k = threadIdx.x; k < D; k += blockDim.x) {
+      sums[(int64_t)o * D + k] -= x[k];
+      sums[(int64_t)w * D + k] = x[k];
+    }
+    if (threadIdx.x == 0) { counts[w] = 1.0f; counts[o] -= 1.0f; }
+    __syncthreads();
+  }
+}
+
+// _average_centers in sklearn's in-place j-ascending order + _center_shift
+__global__ void km_average(const float* __restrict__ sums, const float* __restrict__ counts, int K,
+                           int D, float* __restrict__ Cn) {
+  __shared__ int amax_s;
+  const int j = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int u = 1; u < K; ++u) if (counts[u] > counts[a]) a = u;
+    amax_s = a;
+  }
+  __syncthreads();
+  const float w = counts[j];
+  int src = j;
+  float alpha;
+  if (w > 0.0f) {
+    alpha = (float)(1.0 / (double)w);
+  } else {
+    src = amax_s;  // copy of the biggest cluster: averaged already iff it precedes j
+    alpha = (src < j && counts[src] > 0.0f) ? (float)(1.0 / (double)counts[src]) : 1.0f;
+  }
+  for (int k = threadIdx.x; k < D; k += blockDim.x)
+    Cn[(int64_t)j * D + k] = sums[(int64_t)src * D + k] * alpha;
+}
+
+__global__ void km_shift(const float* __restrict__ Co, const float* __restrict__ Cn, int K, int D,
+                         float* __restrict__ shift) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= K) return;
+  const float* a = Cn + (int64_t)j * D;
+  const float* b = Co + (int64_t)j * D;
+  float r = 0.f;
+  int k = 0;
+  for (; k + 4 <= D; k += 4) {
+    const float d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2],
+                d3 = a[k + 3] - b[k + 3];
+    const float t = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    r += t;
+  }
+  for (; k < D; ++k) { const float d = a[k] - b[k]; r += d * d; }
+  shift[j] = sqrtf(r);
+}
+__global__ void km_status(const float* __restrict__ shift, const float* __restrict__ counts, int K,
+                          const int32_t* n_changed, double* status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double t = 0.0;
+    int ne = 0;
+    for (int j = 0; j < K; ++j) {
+      t += (double)shift[j] * (double)shift[j];
+      ne += counts[j] == 0.0f;
+    }
+    status[0] = t;
+    status[1] = (double)ne;
+    status[2] = n_changed ? (double)*n_changed : -1.0;
+    status[3] = 0.0;
+  }
+}
+
+// column sums in double: thread = column, blockIdx.y = 1024-row segment
+__global__ void col_stats_seg(const float* __restrict__ X, int64_t N, int D, int ldx,
+                              double* __restrict__ part /* [nseg][2][D] */) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= D) return;
+  const int64_t s = (int64_t)blockIdx.y * 1024;
+  const int64_t e = s + 1024 < N ? s + 1024 : N;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t i = s; i < e; ++i) {
+    const double v = (double)X[i * (int64_t)ldx + k];
+    s1 += v;
+    s2 += v * v;
+  }
+  part[((int64_t)blockIdx.y * 2 + 0) * D + k] = s1;
+  part[((int64_t)blockIdx.y * 2 + 1) * D + k] = s2;
+}
+__global__ void col_stats_fin(const double* __restrict__ part, int nseg, int D,
+                              double* __restrict__ cs, double* __restrict__ cq) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= D) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int s = 0; s < nseg; ++s) {
+    t1 += part[((int64_t)s * 2 + 0) * D + k];
+    t2 += part[((int64_t)s * 2 + 1) * D + k];
+  }
+  cs[k] = t1;
+  cq[k] = t2;
+}
+
+__global__ void sub_rowvec(const float* __restrict__ X, int64_t N, int D4, int ldx,
+                           const float* __restrict__ v, float* __restrict__ out, int ldo) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * D4) return;
+  const int64_t i = e / D4;
+  const int c = (int)(e - i * D4);
+  const f32x4 x = *(const f32x4*)(X + i * ldx + c * 4);
+  const f32x4 m = *(const f32x4*)(v + c * 4);
+  *(f32x4*)(out + i * ldo + c * 4) = x - m;
+}
+
+// one wave per row: ||x|| via double partials (torch.norm accumulates pairwise in fp32; the
+// result agrees to <= 1 ulp), then a true division like `data / l2norms`
+__global__ void l2norm_rows(const float* __restrict__ X, int64_t N, int D, int ldx,
+                            float* __restrict__ out, int ldo) {
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = X + row * ldx;
+  double s = 0.0;
+  for (int k = lane; k < D; k += 64) { const double v = (double)x[k]; s += v * v; }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float nrm = (float)sqrt(s);
+  for (int k = lane; k < D; k += 64) out[row * ldo + k] = x[k] / nrm;
+}
+
+// k-means++ : squared distances of every row to T candidate rows, min with closest, potentials
+// thread = row (x kept in registers is impossible for D=512; stream x once per candidate pair)
+#define PP_TMAX 16
+__global__ __launch_bounds__(256) void kpp_dist(const float* __restrict__ X, int64_t N, int D,
+                                                int ldx, const int32_t* __restrict__ cand, int T,
+                                                const float* __restrict__ closest,
+                                                float* __restrict__ newdist,
+                                                double* __restrict__ bpart /* [nblk][T] */) {
+  extern __shared__ float cs[];  // [T][D] candidate rows
+  for (int e = threadIdx.x; e < T * D; e += blockDim.x) {
+    const int t = e / D, k = e - t * D;
+    cs[e] = X[(int64_t)cand[t] * ldx + k];
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float acc[PP_TMAX];
+#pragma unroll
+  for (int t = 0; t < PP_TMAX; ++t) acc[t] = 0.f;
+  if (i < N) {
+    const float* x = X + i * (int64_t)ldx;
+    for (int k = 0; k < D; k += 4) {
+      const f32x4 xv = *(const f32x4*)(x + k);
+#pragma unroll
+      for (int t = 0; t < PP_TMAX; ++t) {
+        if (t < T) {
+          const float* c = cs + t * D + k;
+          float d;
+          d = xv.x - c[0]; acc[t] = fmaf(d, d, acc[t]);
+          d = xv.y - c[1]; acc[t] = fmaf(d, d, acc[t]);
+          d = xv.z - c[2]; acc[t] = fmaf(d, d, acc[t]);
+          d = xv.w - c[3]; acc[t] = fmaf(d, d, acc[t]);
+        }
+      }
+    }
+    const float cl = closest ? closest[i] : INFINITY;
+#pragma unroll
+    for (int t = 0; t < PP_TMAX; ++t)
+      if (t < T) {
+        acc[t] = fminf(acc[t], cl);
+        newdist[(int64_t)t * N + i] = acc[t];
+      }
+  }
+  // block potentials (double, wave shuffle then LDS)
+  __shared__ double wp[4][PP_TMAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < PP_TMAX; ++t) {
+    if (t < T) {
+      double v = i < N ? (double)acc[t] : 0.0;
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) wp[wave][t] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < T)
+    bpart[(int64_t)blockIdx.x * T + threadIdx.x] =
+        wp[0][threadIdx.x] + wp[1][threadIdx.x] + wp[2][threadIdx.x] + wp[3][threadIdx.x];
+}
+__global__ void kpp_pot(const double* __restrict__ bpart, int64_t nblk, int T, double* pot) {
+  const int t = threadIdx.x;
+  if (t >= T) return;
+  double a = 0.0;
+  for (int64_t b = 0; b < nblk; ++b) a += bpart[b * T + t];
+  pot[t] = a;
+}
+
+// cumsum (double) of v in 1024-element chunks + searchsorted('left')
+__global__ void cs_chunk_sums(const float* __restrict__ v, int64_t N, double* __restrict__ csum) {
+  __shared__ double w[4];
+  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  double s = 0.0;
+  for (int u = 0; u < 4; ++u) if (i + u < N) s += (double)v[i + u];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) csum[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+__global__ void cs_scan_chunks(double* csum, int64_t n) {  // inclusive, serial (n ~ N/1024)
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0;
+    for (int64_t u = 0; u < n; ++u) { a += csum[u]; csum[u] = a; }
+  }
+}
+// one thread per query value: binary search the chunk, then walk the chunk serially
+__global__ void cs_search(const float* __restrict__ v, int64_t N, const double* __restrict__ csum,
+                          int64_t nchunk, const double* __restrict__ vals, int T,
+                          int32_t* __restrict__ idx) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const double x = vals[t];
+  int64_t lo = 0, hi = nchunk;  // first chunk whose inclusive sum >= x
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (csum[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  int64_t res = N;
+  if (lo < nchunk) {
+    double a = lo ? csum[lo - 1] : 0.0;
+    const int64_t s = lo * 1024, e = s + 1024 < N ? s + 1024 : N;
+    res = e;
+    for (int64_t i = s; i < e; ++i) {
+      a += (double)v[i];
+      if (a >= x) { res = i; break; }
+    }
+  }
+  if (res > N - 1) res = N - 1;
+  idx[t] = (int32_t)res;
+}
+
+// ------------------------------------ C ABI ------------------------------------------------
+static inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+extern "C" int slic_kmeans_cnorm(const float* C, int K, int D, int ldc, float* cnorm, void* stream) {
+  SLIC_REQUIRE(C && cnorm && K > 0 && D > 0 && ldc >= D, "slic_kmeans_cnorm: bad args");
+  km_cnorm<<<dim3((unsigned)slic_cdiv(K, 64)), dim3(64), 0, S(stream)>>>(C, K, D, ldc, cnorm);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_kmeans_assign_workspace_bytes(int64_t N, int K) {
+  const int64_t G = slic_cdiv(K, KM_BC);
+  return 2 * slic_align_up((size_t)(G * N) * 4, 256);
+}
+
+extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, const float* C, int K,
+                                  int ldc, const float* cnorm, int32_t* labels,
+                                  const int32_t* labels_old, int32_t* n_changed, float* best_score,
+                                  void* workspace, void* stream) {
+  SLIC_REQUIRE(X && C && cnorm && labels && workspace, "slic_kmeans_assign: null pointer");
+  SLIC_REQUIRE(N > 0 && K > 0 && D > 0, "slic_kmeans_assign: N=%lld K=%d D=%d", (long long)N, K, D);
+  SLIC_REQUIRE(D % 8 == 0 && ldx % 4 == 0 && ldc % 4 == 0 && ldx >= D && ldc >= D,
+               "slic_kmeans_assign: need D %% 8 == 0 and 16-byte aligned rows (D=%d ldx=%d ldc=%d)",
+               D, ldx, ldc);
+  SLIC_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)C % 16) == 0, "slic_kmeans_assign: unaligned");
+  SLIC_REQUIRE(!labels_old || n_changed, "slic_kmeans_assign: labels_old needs n_changed");
+  const int G = (int)slic_cdiv(K, KM_BC);
+  SlicCarver w(workspace);
+  float* pscore = w.take<float>((size_t)G * N);
+  int32_t* pidx = w.take<int32_t>((size_t)G * N);
+  dim3 grid((unsigned)slic_cdiv(N, KM_BP), (unsigned)G);
+  km_assign_partial<<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
+  SLIC_LAUNCH_CHECK();
+  km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, S(stream)>>>(
+      pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
+  const int64_t nblk = slic_cdiv(N, KM_SB);
+  return slic_align_up((size_t)nblk * K * 4, 256) + 2 * slic_align_up((size_t)K * 4, 256) +
+         slic_align_up((size_t)N * 4, 256);
+}
+
+extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
+                                      const int32_t* labels, int K, float* sums, float* counts,
+                                      void* workspace, void* stream) {
+  SLIC_REQUIRE(X && labels && sums && counts && workspace, "slic_kmeans_accumulate: null pointer");
+  SLIC_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldx >= D,
+               "slic_kmeans_accumulate: need D %% 4 == 0 (N=%lld K=%d D=%d ldx=%d)", (long long)N, K, D, ldx);
+  SLIC_REQUIRE(N < (1ll << 31), "slic_kmeans_accumulate: N too large for int32 row ids");
+  const int nblk = (int)slic_cdiv(N, KM_SB);
+  SlicCarver w(workspace);
+  int32_t* bc = w.take<int32_t>((size_t)nblk * K);
+  int32_t* cnt = w.take<int32_t>(K);
+  int32_t* off = w.take<int32_t>(K);
+  int32_t* order = w.take<int32_t>((size_t)N);
+  hipStream_t st = S(stream);
+  SLIC_HIP_CHECK(hipMemsetAsync(bc, 0, (size_t)nblk * K * 4, st));
+  km_block_hist<<<dim3(nblk), dim3(KM_SB), 0, st>>>(labels, N, K, bc);
+  SLIC_LAUNCH_CHECK();
+  km_scan_blocks<<<dim3((unsigned)slic_cdiv(K, 64)), dim3(64), 0, st>>>(bc, nblk, K, cnt);
+  SLIC_LAUNCH_CHECK();
+  km_scan_clusters<<<dim3(1), dim3(1024), 0, st>>>(cnt, K, off, counts);
+  SLIC_LAUNCH_CHECK();
+  km_place<<<dim3(nblk), dim3(KM_SB), 0, st>>>(labels, N, K, bc, off, order);
+  SLIC_LAUNCH_CHECK();
+  km_accumulate<<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, off, cnt, sums);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_combine_shards(const float* ps, const float* pc, int64_t shard_stride,
+                                          int n_shards, int K, int D, float* sums, float* counts,
+                                          void* stream) {
+  SLIC_REQUIRE(ps && pc && sums && counts && n_shards > 0 && K > 0 && D > 0 && shard_stride > 0,
+               "slic_kmeans_combine_shards: bad args");
+  const int64_t KD = (int64_t)K * D;
+  km_combine_shards<<<dim3((unsigned)slic_cdiv(KD, 256)), dim3(256), 0, S(stream)>>>(ps, pc, shard_stride, n_shards, K, D, sums, counts);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_dist_to_assigned(const float* X, int64_t N, int D, int ldx,
+                                            const float* C, int ldc, const int32_t* labels,
+                                            float* dist, void* stream) {
+  SLIC_REQUIRE(X && C && labels && dist && N > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldc % 4 == 0,
+               "slic_kmeans_dist_to_assigned: bad args (D %% 4 == 0 required)");
+  km_dist_to_assigned<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, ldc, labels, dist);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_sum_f32_to_f64_workspace_bytes(int64_t N) {
+  return slic_align_up((size_t)slic_cdiv(N, 256) * 8, 256);
+}
+extern "C" int slic_sum_f32_to_f64(const float* v, int64_t N, double* out, void* workspace, void* stream) {
+  SLIC_REQUIRE(v && out && workspace && N > 0, "slic_sum_f32_to_f64: bad args");
+  const int64_t nb = slic_cdiv(N, 256);
+  sum_blocks_f64<<<dim3((unsigned)nb), dim3(256), 0, S(stream)>>>(v, N, (double*)workspace);
+  SLIC_LAUNCH_CHECK();
+  sum_serial_f64<<<dim3(1), dim3(64), 0, S(stream)>>>((const double*)workspace, nb, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_select_far(float* dist, int64_t N, int n_sel, int32_t* far_idx,
+                                      float* far_dist, void* stream) {
+  SLIC_REQUIRE(dist && far_idx && far_dist && N > 0 && n_sel > 0, "slic_kmeans_select_far: bad args");
+  km_select_far<<<dim3(1), dim3(1024), 0, S(stream)>>>(dist, N, n_sel, far_idx, far_dist);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_apply_relocation(const float* xfar, int ldf, const int32_t* old_ids,
+                                            const int32_t* new_ids, int n, int D, float* sums,
+                                            float* counts, void* stream) {
+  SLIC_REQUIRE(xfar && old_ids && new_ids && sums && counts && n > 0 && D > 0 && ldf >= D,
+               "slic_kmeans_apply_relocation: bad args");
+  km_apply_relocation<<<dim3(1), dim3(256), 0, S(stream)>>>(xfar, ldf, old_ids, new_ids, n, D, sums, counts);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts,
+                                    int K, int D, float* C_new, float* shift,
+                                    const int32_t* n_changed, double* status, void* stream) {
+  SLIC_REQUIRE(C_old && sums && counts && C_new && shift && status && K > 0 && D > 0,
+               "slic_kmeans_finalize: bad args");
+  SLIC_REQUIRE(C_new != sums && C_new != C_old, "slic_kmeans_finalize: C_new must not alias");
+  hipStream_t st = S(stream);
+  km_average<<<dim3(K), dim3(128), 0, st>>>(sums, counts, K, D, C_new);
+  SLIC_LAUNCH_CHECK();
+  km_shift<<<dim3((unsigned)slic_cdiv(K, 64)), dim3(64), 0, st>>>(C_old, C_new, K, D, shift);
+  SLIC_LAUNCH_CHECK();
+  km_status<<<dim3(1), dim3(64), 0, st>>>(shift, counts, K, n_changed, status);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_col_stats_workspace_bytes(int64_t N, int D) {
+  return slic_align_up((size_t)slic_cdiv(N, 1024) * 2 * D * 8, 256);
+}
+extern "C" int slic_col_stats(const float* X, int64_t N, int D, int ldx, double* col_sum,
+                              double* col_sumsq, void* workspace, void* stream) {
+  SLIC_REQUIRE(X && col_sum && col_sumsq && workspace && N > 0 && D > 0 && ldx >= D, "slic_col_stats: bad args");
+  const int nseg = (int)slic_cdiv(N, 1024);
+  col_stats_seg<<<dim3((unsigned)slic_cdiv(D, 64), nseg), dim3(64), 0, S(stream)>>>(X, N, D, ldx, (double*)workspace);
+  SLIC_LAUNCH_CHECK();
+  col_stats_fin<<<dim3((unsigned)slic_cdiv(D, 64)), dim3(64), 0, S(stream)>>>((const double*)workspace, nseg, D, col_sum, col_sumsq);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_sub_rowvec(const float* X, int64_t N, int D, int ldx, const float* v, float* out,
+                               int ldo, void* stream) {
+  SLIC_REQUIRE(X && v && out && N > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0,
+               "slic_sub_rowvec: bad args (D %% 4 == 0 required)");
+  const int64_t tot = N * (D / 4);
+  sub_rowvec<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S(stream)>>>(X, N, D / 4, ldx, v, out, ldo);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_l2norm_rows(const float* X, int64_t N, int D, int ldx, float* out, int ldo, void* stream) {
+  SLIC_REQUIRE(X && out && N > 0 && D > 0 && ldx >= D && ldo >= D, "slic_l2norm_rows: bad args");
+  l2norm_rows<<<dim3((unsigned)slic_cdiv(N, 4)), dim3(256), 0, S(stream)>>>(X, N, D, ldx, out, ldo);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_kmeanspp_step_workspace_bytes(int64_t N, int T) {
+  return slic_align_up((size_t)slic_cdiv(N, 256) * T * 8, 256);
+}
+extern "C" int slic_kmeanspp_step(const float* X, int64_t N, int D, int ldx, const int32_t* cand,
+                                  int T, const float* closest, float* newdist, double* pot,
+                                  void* workspace, void* stream) {
+  SLIC_REQUIRE(X && cand && newdist && pot && workspace, "slic_kmeanspp_step: null pointer");
+  SLIC_REQUIRE(T >= 1 && T <= PP_TMAX && D % 4 == 0 && ldx % 4 == 0 && (size_t)T * D * 4 <= 64 * 1024,
+               "slic_kmeanspp_step: need 1 <= T <= %d, D %% 4 == 0, T*D*4 <= 64 KiB", PP_TMAX);
+  const int64_t nblk = slic_cdiv(N, 256);
+  kpp_dist<<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, S(stream)>>>(X, N, D, ldx, cand, T, closest, newdist, (double*)workspace);
+  SLIC_LAUNCH_CHECK();
+  kpp_pot<<<dim3(1), dim3(64), 0, S(stream)>>>((const double*)workspace, nblk, T, pot);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_cumsum_search_workspace_bytes(int64_t N) {
+  return slic_align_up((size_t)slic_cdiv(N, 1024) * 8, 256);
+}
+extern "C" int slic_cumsum_search(const float* v, int64_t N, const double* vals, int T,
+                                  int32_t* idx_out, void* workspace, void* stream) {
+  SLIC_REQUIRE(v && vals && idx_out && workspace && N > 0 && T > 0, "slic_cumsum_search: bad args");
+  const int64_t nc = slic_cdiv(N, 1024);
+  cs_chunk_sums<<<dim3((unsigned)nc), dim3(256), 0, S(stream)>>>(v, N, (double*)workspace);
+  SLIC_LAUNCH_CHECK();
+  cs_scan_chunks<<<dim3(1), dim3(64), 0, S(stream)>>>((double*)workspace, nc);
+  SLIC_LAUNCH_CHECK();
+  cs_search<<<dim3((unsigned)slic_cdiv(T, 64)), dim3(64), 0, S(stream)>>>(v, N, (const double*)workspace, nc, vals, T, idx_out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
