@@ -135,6 +135,100 @@ size_t slic_cumsum_search_workspace_bytes(int64_t N);
 int slic_cumsum_search(const float* v, int64_t N, const double* vals, int T, int32_t* idx_out,
                        void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3-D convolution / linear layers as a table-driven gather-GEMM on fp32 MFMA
+ * (models/resnet.py:11-25,126-131 nn.Conv3d forward + autograd dgrad/wgrad -> cuDNN in the
+ * reference; models/resnet.py:182-184 nn.Linear).  Activations are NDHWC fp32
+ * ([B, T, H, W, C], C % 4 == 0), weights packed K-contiguous.  See csrc/conv.hip.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct SlicConvArgs {
+  const float* src;        /* gathered operand: [B, Ts, Hs, Ws, Cs] */
+  const float* wgt;        /* packed weights [N][ldw], k = table column (conv_gemm only) */
+  float* dst;              /* output (conv_gemm only) */
+  const int32_t* tab;      /* [nchunks][4] per 16-byte K-chunk: {src element delta, packed tap offsets
+                              ((oa+128) | (ob+128)<<8 | (oc+128)<<16, or -1 = all-zero chunk),
+                              weight column of the chunk, 0} */
+  const float* bias;       /* [N] or NULL */
+  const float* scale;      /* [N] or NULL: v = v*scale + shift (eval-mode BatchNorm) */
+  const float* shift;      /* [N] or NULL */
+  const float* addend;     /* same addressing as dst, or NULL: v += addend (residual / grad accumulate) */
+  float* stat_partial;     /* [ceil(M/tile_m)][2][N] per-workgroup sum / sum-of-squares of (acc+bias), or NULL */
+  int64_t M;               /* rows = B * Ga * Gb * Gc */
+  int N;                   /* output channels */
+  int nchunks;             /* K / 4, multiple of 8 */
+  int Cs, Ts, Hs, Ws;      /* source dims */
+  int Ga, Gb, Gc;          /* output grid per batch item */
+  int sa, sb, sc;          /* source coordinate of grid point g = g*s (+ tap offset) */
+  int ldw, ldo;            /* weight row stride, dst row stride (elements) */
+  int dst_strided;         /* 0: dst row = m; 1: dst row = ((b*Da + ga*da+ea)*Db + gb*db+eb)*Dc + gc*dc+ec */
+  int Da, Db, Dc, da, db, dc, ea, eb, ec;
+  int relu;                /* clamp at 0 last */
+} SlicConvArgs;
+
+/* rows per workgroup of the tile slic_conv_gemm picks for (args, variant); variant 0 = auto,
+ * 1 = 128-row, 2 = 64-row, 3 = 256x64 tiles.  Sizes stat_partial. */
+int slic_conv_tile_m(const SlicConvArgs* args, int variant);
+/* dst = epilogue(gather(src) x wgt^T): forward conv, data gradient, linear. */
+int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);
+/* dW[N][C][ntaps] (reference layout) = sum_m gather(src)[m, tap*Cs + c] * dy[m, n]; `splits` slices of
+ * m reduced in fixed order.  args->wgt/dst unused. */
+size_t slic_conv_wgrad_workspace_bytes(const SlicConvArgs* args, int splits);
+int slic_conv_wgrad(const SlicConvArgs* args, const float* dy, int ldy, int splits, int C, int ntaps,
+                    float* dW, void* workspace, void* stream);
+/* Wp[n][tap*Cs + c] = W[n][c][tap] (zero padded to Cs channels / Kp columns) — forward operand */
+int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp, float* Wp, void* stream);
+/* Wd[c][tap*N + n] = W[n][c][tap] (Cs rows, Kd columns) — data-gradient operand */
+int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int Kd, float* Wd, void* stream);
+/* [B, C, S] -> [B, S, Cp] with channels zero-padded to Cp (clip NCDHW -> NDHWC4, datasets/dataset_utils.py:104) */
+int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm3d/1d + ReLU + residual + global average pool (models/resnet.py:34-57,132-133,173,183,
+ * 294-299; torch defaults eps = 1e-5, momentum = 0.1).  Activations [M, C] row-major, C % 4 == 0.
+ * ---------------------------------------------------------------------------------------- */
+/* batch statistics from the conv epilogue's per-workgroup slab partial[R][2][C] (added in row order, double):
+ * mean, invstd = 1/sqrt(biased var + eps), scale = gamma*invstd, shift = beta - mean*scale; running stats
+ * (optional pair) get the momentum update with the unbiased variance. */
+int slic_bn_finalize(const float* partial, int R, int C, int64_t M, float eps, float momentum,
+                     const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                     float* shift, float* running_mean, float* running_var, void* stream);
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
+int slic_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* y = relu?(z*scale + shift (+ res)) */
+int slic_bn_apply(const float* z, const float* scale, const float* shift, const float* res, int relu,
+                  int64_t M, int C, float* y, void* stream);
+/* backward of y = relu?(BN(z) (+res)) in train mode: g = dy * (out > 0) when `out` (the saved post-ReLU
+ * output) is given, else g = dy; g_out (optional) receives g (it is also the gradient of `res`);
+ * dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); dgamma = sum g*xhat; dbeta = sum g. */
+size_t slic_bn_bwd_workspace_bytes(int64_t M, int C, int need_g_buffer);
+int slic_bn_bwd_rows_per_partial(void);
+int slic_bn_bwd(const float* dy, const float* out, const float* z, const float* mean, const float* invstd,
+                const float* gamma, int64_t M, int C, float* g_out, float* dz, float* dgamma, float* dbeta,
+                void* workspace, void* stream);
+/* AdaptiveAvgPool3d(1): y[b,c] = mean_s x[b,s,c]; backward dx = dy / S */
+int slic_avgpool_fwd(const float* x, int B, int S, int C, float* y, void* stream);
+int slic_avgpool_bwd(const float* dy, int B, int S, int C, float* dx, void* stream);
+/* out[c] = sum_m x[m,c] (rows ascending, double accumulator): nn.Linear bias gradient */
+int slic_colsum(const float* x, int64_t M, int C, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * InfoNCE / NT-Xent (loss/triplet_loss.py:95-116 'noise_contrastive' + pdist :429-437):
+ * loss = CE( (1 - (1 - cos(e_i, e_j))) with diag := 0, / T ;  target (n/2 + i) mod n ), mean over n rows.
+ * fwd keeps (e_hat, 1/norm, row log-sum-exp) in `workspace` for bwd.  gscale: device scalar upstream
+ * gradient (NULL = 1).  D even.
+ * ---------------------------------------------------------------------------------------- */
+size_t slic_ntxent_workspace_bytes(int n, int D);
+int slic_ntxent_fwd(const float* E, int n, int D, int lde, float temperature, float* loss, void* workspace,
+                    void* stream);
+int slic_ntxent_bwd(const void* workspace, int n, int D, float temperature, const float* gscale, float* dE,
+                    int ldd, void* stream);
+/* rowwise distance of two [n, D] matrices: 1 - cos (per-norm clamp 1e-8) or ||x - y + 1e-6||_2
+ * (models/triplet_net.py:29-33: F.cosine_similarity / F.pairwise_distance) */
+int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclidean, float* out, void* stream);
+/* [n, n] distance matrix of the rows of V (loss/triplet_loss.py:429-437 pdist) */
+int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

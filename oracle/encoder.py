@@ -1,0 +1,178 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY (not the product path; only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this).
+
+CPU restatement (PyTorch CPU ops, fp32 or fp64) of the reference's encoder and InfoNCE loss, written
+functionally over a plain state_dict so that it needs nothing from /root/reference at run time:
+
+  encoder_forward      <- models/resnet.py:255-312 (ResNet.forward), :41-57 (BasicBlock.forward),
+                          :223-233 (shortcut 'B' = conv1x1x1 + BN), :294-299 (projection head)
+  ntxent_loss          <- loss/triplet_loss.py:95-116 ('noise_contrastive') + pdist :429-437
+  nce_average / nce_softmax_loss <- loss/NCE_loss.py:26-88, 341-352
+  sgd_step             <- online_train.py:543 (SGD lr .1, momentum .5, no weight decay)
+
+Pinned against the imported reference modules by tests/golden/make_goldens_encoder.py (goldens in
+tests/golden/encoder_tiny.npz, loss_ntxent.npz), checked by tests/test_oracle_encoder.py.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def make_state_dict(rng, layers=(2, 2, 2, 2), widen=1.0, n_in=3, conv1_t=7, hidden=2048, out_dim=128,
+                    projection_head=True, dtype=np.float32):
+    """weights by the reference's init RULES (models/resnet.py:203-210: Conv3d kaiming_normal_(fan_out, relu),
+    BN3d gamma=1 beta=0; Linear / BN1d PyTorch defaults) drawn from a numpy Generator so the GPU box
+    regenerates them without torch's RNG.  Keys/shapes = the reference's state_dict."""
+    planes = [int(c * widen) for c in (64, 128, 256, 512)]
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        fan_out = cout * k[0] * k[1] * k[2]
+        sd[name] = (rng.standard_normal((cout, cin) + tuple(k)) * math.sqrt(2.0 / fan_out)).astype(dtype)
+
+    def bn(name, c):
+        sd[name + ".weight"] = np.ones(c, dtype)
+        sd[name + ".bias"] = np.zeros(c, dtype)
+        sd[name + ".running_mean"] = np.zeros(c, dtype)
+        sd[name + ".running_var"] = np.ones(c, dtype)
+        sd[name + ".num_batches_tracked"] = np.zeros((), np.int64)
+
+    def linear(name, cout, cin):
+        b = 1.0 / math.sqrt(cin)
+        sd[name + ".weight"] = rng.uniform(-b, b, (cout, cin)).astype(dtype)    # kaiming_uniform(a=sqrt(5))
+        sd[name + ".bias"] = rng.uniform(-b, b, cout).astype(dtype)
+
+    conv("conv1.weight", planes[0], n_in, (conv1_t, 7, 7))
+    bn("bn1", planes[0])
+    inp = planes[0]
+    for li, (p, nb) in enumerate(zip(planes, layers), start=1):
+        for b in range(nb):
+            stride = 2 if (li > 1 and b == 0) else 1
+            pre = f"layer{li}.{b}"
+            conv(pre + ".conv1.weight", p, inp, (3, 3, 3))
+            bn(pre + ".bn1", p)
+            conv(pre + ".conv2.weight", p, p, (3, 3, 3))
+            bn(pre + ".bn2", p)
+            if stride != 1 or inp != p:
+                conv(pre + ".downsample.0.weight", p, inp, (1, 1, 1))
+                bn(pre + ".downsample.1", p)
+            inp = p
+    if projection_head:
+        linear("fc1", hidden, planes[3])
+        bn("bn_proj", hidden)
+        linear("fc2", out_dim, hidden)
+    return sd
+
+
+def to_torch(sd, dtype=torch.float32, requires_grad=False):
+    out = {}
+    for k, v in sd.items():
+        t = torch.as_tensor(np.asarray(v))
+        if t.dtype.is_floating_point:
+            t = t.to(dtype).clone()
+            if requires_grad and "running" not in k:
+                t.requires_grad_(True)
+        else:
+            t = t.clone()
+        out[k] = t
+    return out
+
+
+def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
+    y = F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
+                     sd[name + ".bias"], training, momentum, eps)
+    if training:
+        sd[name + ".num_batches_tracked"] += 1
+    return y
+
+
+def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None):
+    """x: [B, C, T, H, W].  sd: dict of torch tensors (running stats are updated in place when training).
+    taps (optional dict) receives intermediate activations by name."""
+    kt = sd["conv1.weight"].shape[2]
+    x = F.conv3d(x, sd["conv1.weight"], None, conv1_stride, (kt // 2, 3, 3))
+    x = F.relu(_bn(x, sd, "bn1", training))
+    if taps is not None:
+        taps["stem"] = x
+    li = 1
+    while f"layer{li}.0.conv1.weight" in sd:
+        b = 0
+        while f"layer{li}.{b}.conv1.weight" in sd:
+            pre = f"layer{li}.{b}"
+            stride = 2 if (li > 1 and b == 0) else 1
+            res = x
+            out = F.conv3d(x, sd[pre + ".conv1.weight"], None, stride, 1)
+            out = F.relu(_bn(out, sd, pre + ".bn1", training))
+            out = F.conv3d(out, sd[pre + ".conv2.weight"], None, 1, 1)
+            out = _bn(out, sd, pre + ".bn2", training)
+            if pre + ".downsample.0.weight" in sd:
+                res = F.conv3d(x, sd[pre + ".downsample.0.weight"], None, stride, 0)
+                res = _bn(res, sd, pre + ".downsample.1", training)
+            x = F.relu(out + res)
+            if taps is not None:
+                taps[pre] = x
+            b += 1
+        li += 1
+    x = F.adaptive_avg_pool3d(x, 1).flatten(1)
+    if taps is not None:
+        taps["pooled"] = x
+    if not projection_head or "fc1.weight" not in sd:
+        return x
+    h = F.linear(x, sd["fc1.weight"], sd["fc1.bias"])
+    h = F.relu(_bn(h, sd, "bn_proj", training))
+    return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def cosine_similarity_rows(x, Y, eps=1e-8):
+    """F.cosine_similarity(x[None], Y, dim=1): x.y / (max(|x|, eps) * max(|y|, eps))"""
+    xn = x.norm().clamp_min(eps)
+    yn = Y.norm(dim=1).clamp_min(eps)
+    return (Y @ x) / (xn * yn)
+
+
+def ntxent_loss(emb, temperature=0.5):
+    """loss/triplet_loss.py:97-116"""
+    n = emb.shape[0]
+    rows = [1 - cosine_similarity_rows(emb[i], emb) for i in range(n)]          # pdist (:429-437)
+    sim = 1 - torch.stack(rows, 0)
+    sim = sim.masked_fill(torch.eye(n, dtype=torch.bool), 0)                       # diagonal -> 0, not -inf
+    sim = sim / temperature
+    tgt = (torch.arange(n) + n // 2) % n
+    return F.cross_entropy(sim, tgt)
+
+
+def nce_average(l, ab, y, idx, memory_l, memory_ab, T=0.07, momentum=0.5):
+    """NCEAverage.forward with use_softmax=True (loss/NCE_loss.py:26-88).  Banks are updated in place.
+    Note the cross-wiring: out_ab uses memory_l, out_l uses memory_ab."""
+    B, D = l.shape
+    K1 = idx.shape[1]
+    w_l = memory_l.index_select(0, idx.reshape(-1)).detach().view(B, K1, D)
+    out_ab = torch.bmm(w_l, ab.view(B, D, 1)) / T
+    w_ab = memory_ab.index_select(0, idx.reshape(-1)).detach().view(B, K1, D)
+    out_l = torch.bmm(w_ab, l.view(B, D, 1)) / T
+    with torch.no_grad():
+        for mem, f in ((memory_l, l), (memory_ab, ab)):
+            pos = mem.index_select(0, y) * momentum + f * (1 - momentum)
+            pos = pos / pos.pow(2).sum(1, keepdim=True).pow(0.5)
+            mem.index_copy_(0, y, pos)
+    return out_l, out_ab
+
+
+def nce_softmax_loss(x):
+    """NCESoftmaxLoss (loss/NCE_loss.py:347-352): CE of [B, K+1] logits against class 0"""
+    x = x.squeeze(-1)
+    return F.cross_entropy(x, torch.zeros(x.shape[0], dtype=torch.long))
+
+
+def sgd_step(params, grads, bufs, lr=0.1, momentum=0.5):
+    """torch.optim.SGD(lr, momentum) (online_train.py:543): buf = m*buf + g (first step buf = g); p -= lr*buf"""
+    for k in params:
+        g = grads[k]
+        if k not in bufs:
+            bufs[k] = g.clone()
+        else:
+            bufs[k].mul_(momentum).add_(g)
+        params[k].data.add_(bufs[k], alpha=-lr)

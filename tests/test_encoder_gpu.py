@@ -1,0 +1,243 @@
+"""GPU parity of the encoder path (conv gather-GEMM, BN, pool, heads, NT-Xent) vs the CPU oracle and the
+goldens generated from the reference.  Tolerance: 1e-4 fp32 (BASELINE.json north_star) on embeddings / loss."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+R3D18_KW = dict(hidden_layer=2048, out_dim=128, num_classes=101, n_input_channels=3, shortcut_type='B',
+                conv1_t_size=7, conv1_t_stride=1, no_max_pool=True, widen_factor=1.0, projection_head=True,
+                predict_temporal_ds=False, spatio_temporal_attention=False, classifier=False, dropout=None)
+
+
+def _ndhwc(x, Cs):
+    B, C, T, H, W = x.shape
+    y = torch.zeros(B, T, H, W, Cs)
+    y[..., :C] = x.permute(0, 2, 3, 4, 1)
+    return y.contiguous()
+
+
+CONV_CASES = [
+    # C, N, kernel, stride, pad, B, (T, H, W)
+    (3, 8, (7, 7, 7), (1, 2, 2), (3, 3, 3), 2, (8, 20, 20)),
+    (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, (4, 10, 10)),
+    (8, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), 2, (8, 10, 10)),
+    (8, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0), 2, (8, 10, 10)),
+    (64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), 1, (4, 14, 14)),
+    (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, (4, 14, 14)),
+    (128, 256, (3, 3, 3), (2, 2, 2), (1, 1, 1), 3, (3, 7, 7)),     # odd sizes
+    (256, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), 5, (1, 1, 1)),     # linear
+]
+
+
+@pytest.mark.parametrize("C,N,k,s,p,B,dims", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(C * 7 + N)
+    x = torch.from_numpy(rng.standard_normal((B, C) + dims).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((N, C) + k) / np.sqrt(C * np.prod(k))).astype(np.float32))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, None, s, p)
+    dy = torch.from_numpy(rng.standard_normal(tuple(y64.shape)).astype(np.float32))
+    gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy.double())
+    plan = ConvPlan(C, N, k, s, p, dims, "cuda")
+    xd, wd_ = _ndhwc(x, plan.Cs).cuda(), w.cuda().contiguous()
+    for variant in (0, 1, 2, 3):
+        z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
+        got = z.cpu().permute(0, 4, 1, 2, 3)
+        tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6
+        assert (got - y64.float()).abs().max() <= tol * max(1.0, y64.abs().max().item()), f"fwd variant {variant}"
+        # fused BN partial sums
+        s1 = part[:, 0].double().sum(0).cpu()
+        s2 = part[:, 1].double().sum(0).cpu()
+        ref1 = y64.detach().sum((0, 2, 3, 4))
+        ref2 = (y64.detach() ** 2).sum((0, 2, 3, 4))
+        assert torch.allclose(s1, ref1, atol=1e-3, rtol=1e-4) and torch.allclose(s2, ref2, atol=1e-3, rtol=1e-4)
+    dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B).cpu()[..., :C].permute(0, 4, 1, 2, 3)
+    assert (dx - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item())
+    dW = plan.wgrad(xd, dyd, B, torch.empty_like(wd_)).cpu()
+    assert (dW - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
+    dW3 = plan.wgrad(xd, dyd, B, torch.empty_like(wd_), splits=3).cpu()
+    assert (dW3 - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
+
+
+def test_conv_epilogue_affine_relu_addend(gpu):
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(3)
+    B, C, N, dims = 2, 16, 32, (3, 6, 6)
+    x = torch.from_numpy(rng.standard_normal((B, C) + dims).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((N, C, 3, 3, 3)) * 0.05).astype(np.float32))
+    sc, sh, bias = [torch.from_numpy(rng.standard_normal(N).astype(np.float32)) for _ in range(3)]
+    res = torch.from_numpy(rng.standard_normal((B, N) + dims).astype(np.float32))
+    ref = F.relu((F.conv3d(x, w, bias, 1, 1)) * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) + res)
+    plan = ConvPlan(C, N, (3, 3, 3), (1, 1, 1), (1, 1, 1), dims, "cuda")
+    y, _ = plan.forward(_ndhwc(x, C).cuda(), plan.pack_fwd(w.cuda()), B, bias=bias.cuda(), scale=sc.cuda(), shift=sh.cuda(),
+                        addend=_ndhwc(res, N).cuda(), relu=True)
+    assert (y.cpu().permute(0, 4, 1, 2, 3) - ref).abs().max() < 2e-5
+
+
+def test_bn_train_fwd_bwd(gpu):
+    from video_similarity_search_amd._lib import call, ptr, stream
+    from video_similarity_search_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    for M, C in [(5000, 64), (300, 2048), (77, 8), (1031, 48)]:
+        z = torch.from_numpy((rng.standard_normal((M, C)) * 2 + 0.5).astype(np.float32))
+        gam = torch.from_numpy((1 + 0.1 * rng.standard_normal(C)).astype(np.float32))
+        bet = torch.from_numpy((0.1 * rng.standard_normal(C)).astype(np.float32))
+        res = torch.from_numpy(rng.standard_normal((M, C)).astype(np.float32))
+        dy = torch.from_numpy(rng.standard_normal((M, C)).astype(np.float32))
+        z64 = z.double().requires_grad_(True)
+        g64, b64, r64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True), res.double().requires_grad_(True)
+        rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+        y64 = F.relu(F.batch_norm(z64, rm, rv, g64, b64, True, 0.1, 1e-5) + r64)
+        gz, gg, gb, gr = torch.autograd.grad(y64, [z64, g64, b64, r64], dy.double())
+        # device: partial slab of 128-row groups (what the conv epilogue would emit)
+        R = (M + 127) // 128
+        part = torch.zeros(R, 2, C)
+        for r in range(R):
+            blk = z[r * 128:(r + 1) * 128]
+            part[r, 0], part[r, 1] = blk.sum(0), (blk * blk).sum(0)
+        zd, gd, bd, resd, dyd, partd = [t.cuda() for t in (z, gam, bet, res, dy, part)]
+        mean, invstd, scale, shift = [torch.empty(C, device="cuda") for _ in range(4)]
+        rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        call("slic_bn_finalize", ptr(partd), R, C, M, 1e-5, 0.1, ptr(gd), ptr(bd), ptr(mean), ptr(invstd), ptr(scale),
+             ptr(shift), ptr(rmd), ptr(rvd), stream())
+        y = torch.empty_like(zd)
+        call("slic_bn_apply", ptr(zd), ptr(scale), ptr(shift), ptr(resd), 1, M, C, ptr(y), stream())
+        assert (y.cpu() - y64.float()).abs().max() < 2e-5
+        assert torch.allclose(rmd.cpu().double(), rm, atol=1e-6) and torch.allclose(rvd.cpu().double(), rv, atol=1e-5, rtol=1e-5)
+        dz, g = torch.empty_like(zd), torch.empty_like(zd)
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        ws = torch.empty(lib.slic_bn_bwd_workspace_bytes(M, C, 0), dtype=torch.uint8, device="cuda")
+        call("slic_bn_bwd", ptr(dyd), ptr(y), ptr(zd), ptr(mean), ptr(invstd), ptr(gd), M, C, ptr(g), ptr(dz), ptr(dg),
+             ptr(db), ptr(ws), stream())
+        assert (g.cpu() - gr.float()).abs().max() < 1e-6
+        assert (dz.cpu() - gz.float()).abs().max() < 2e-5 * max(1.0, gz.abs().max().item())
+        assert (dg.cpu() - gg.float()).abs().max() < 1e-4 * max(1.0, gg.abs().max().item())
+        assert (db.cpu() - gb.float()).abs().max() < 1e-4 * max(1.0, gb.abs().max().item())
+
+
+@pytest.mark.parametrize("n,D", [(64, 128), (26, 128), (8, 32), (208, 128)])
+def test_ntxent_matches_reference_golden(gpu, golden_dir, n, D):
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
+    e = torch.from_numpy(g[f"E_{n}_{D}"]).cuda().requires_grad_(True)
+    crit = OnlineTripletLoss(0.2, 'cosine')
+    loss, ntrip = crit(e, torch.arange(n // 2).repeat(2).cuda(), sampling_strategy='noise_contrastive')
+    assert ntrip == 0
+    (loss * 1.0).backward()
+    assert abs(loss.item() - float(g[f"loss_{n}_{D}"])) < 1e-5
+    np.testing.assert_allclose(e.grad.cpu().numpy(), g[f"grad_{n}_{D}"], atol=2e-7, rtol=1e-4)
+
+
+def test_ntxent_tiny_norm_and_scaled_grad(gpu, golden_dir):
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    from oracle import encoder as oe
+    g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
+    l = ntxent_loss(torch.from_numpy(g["E_tiny"]).cuda())
+    assert abs(l.item() - float(g["loss_tiny"])) < 1e-5
+    e = torch.from_numpy(g["E_8_32"])
+    ec = e.clone().requires_grad_(True)
+    (oe.ntxent_loss(ec) * 3.5).backward()
+    ed = e.cuda().requires_grad_(True)
+    (ntxent_loss(ed) * 3.5).backward()
+    np.testing.assert_allclose(ed.grad.cpu().numpy(), ec.grad.numpy(), atol=1e-6, rtol=1e-4)
+
+
+def _load_into(model, sd):
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+
+
+def test_tiny_encoder_train_step_vs_reference_golden(gpu, golden_dir):
+    """(inputs, initial weights) -> (embeddings, loss, every gradient, weights after one SGD step, eval forward):
+    the triplet_train_epoch step structure (online_train.py:307-380) on the tiny R3D-18"""
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    enc = dict(np.load(os.path.join(golden_dir, "encoder_tiny.npz")))
+    sd = {k[3:]: v for k, v in enc.items() if k.startswith("sd/")}
+    kw = dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32)
+    m = generate_model(18, **kw)
+    assert sorted(m.state_dict()) == sorted(sd)
+    _load_into(m, sd)
+    m = m.cuda().train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.5)
+    x = torch.from_numpy(enc["x"]).cuda()
+    emb = m(x)
+    loss, _ = OnlineTripletLoss(0.2, 'cosine')(emb, torch.arange(2).repeat(2).cuda(), sampling_strategy='noise_contrastive')
+    opt.zero_grad()
+    loss.backward()
+    np.testing.assert_allclose(emb.detach().cpu().numpy(), enc["train/emb"], atol=1e-4, rtol=0)
+    assert abs(loss.item() - float(enc["train/loss"])) < 1e-4
+    for k, p in m.named_parameters():
+        ref = enc["grad/" + k]
+        assert p.grad is not None, k
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-5 + 2e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+    opt.step()
+    after = m.state_dict()
+    for k in after:
+        ref = enc["after/" + k]
+        np.testing.assert_allclose(after[k].cpu().numpy(), ref, atol=1e-5 + 1e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    np.testing.assert_allclose(ev.cpu().numpy(), enc["eval/emb"], atol=5e-4, rtol=1e-3)
+
+
+def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
+    """BASELINE config 1 shape (2 x 3 x 16 x 112 x 112) on the real R3D-18: eval and train-mode embeddings within
+    1e-4 of the CPU oracle; one train step's loss and a few gradients"""
+    from oracle import encoder as oe
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    rng = np.random.default_rng(7)
+    sd = oe.make_state_dict(rng)
+    x = rng.standard_normal((2, 3, 16, 112, 112)).astype(np.float32)
+    m = generate_model(18, **R3D18_KW)
+    _load_into(m, sd)
+    m = m.cuda()
+    xt = torch.from_numpy(x)
+    tsd = oe.to_torch(sd, requires_grad=True)
+    emb_ref = oe.encoder_forward(tsd, xt, training=True)
+    loss_ref = oe.ntxent_loss(emb_ref)
+    names = ["conv1.weight", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.bn2.weight",
+             "layer4.1.conv2.weight", "fc1.weight", "fc2.bias", "bn_proj.bias"]
+    gref = dict(zip(names, torch.autograd.grad(loss_ref, [tsd[k] for k in names])))
+    m.train()
+    emb = m(xt.cuda())
+    loss = ntxent_loss(emb)
+    loss.backward()
+    scale = emb_ref.abs().max().item()
+    assert (emb.detach().cpu() - emb_ref.detach()).abs().max().item() <= 1e-4 * max(1.0, scale)
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4
+    pd = dict(m.named_parameters())
+    for k in names:
+        ref = gref[k]
+        err = (pd[k].grad.cpu() - ref).abs().max().item()
+        assert err <= 1e-5 + 5e-3 * ref.abs().max().item(), (k, err, ref.abs().max().item())
+    # eval mode (running stats after the one update on both sides)
+    m.eval()
+    with torch.no_grad():
+        ev = m(xt.cuda()).cpu()
+        ev_ref = oe.encoder_forward({k: v.detach() for k, v in tsd.items()}, xt, training=False)
+    assert (ev - ev_ref).abs().max().item() <= 1e-4 * max(1.0, ev_ref.abs().max().item())
+
+
+def test_tripletnet_surface(gpu):
+    from video_similarity_search_amd.models import generate_model, Tripletnet
+    m = generate_model(18, **dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32)).cuda().eval()
+    net = Tripletnet(m, 'cosine')
+    xs = [torch.randn(2, 3, 8, 32, 32, device="cuda") for _ in range(3)]
+    with torch.no_grad():
+        da, db, ex, ey, ez = net(*xs)
+    ref_a = 1 - F.cosine_similarity(ex.cpu(), ey.cpu(), dim=1)
+    assert da.shape == (2,) and torch.allclose(da.cpu(), ref_a, atol=1e-6)
+    net2 = Tripletnet(m, 'euclidean')
+    with torch.no_grad():
+        da2 = net2(*xs)[0]
+    assert torch.allclose(da2.cpu(), F.pairwise_distance(ex.cpu(), ey.cpu(), 2), atol=1e-5)

@@ -38,7 +38,46 @@ SIGNATURES = {
     "slic_kmeanspp_step": (I, [P, L, I, I, P, I, P, P, P, P, P]),
     "slic_cumsum_search_workspace_bytes": (c_size_t, [L]),
     "slic_cumsum_search": (I, [P, L, P, I, P, P, P]),
+    # conv / linear
+    "slic_conv_tile_m": (I, [P, I]),
+    "slic_conv_gemm": (I, [P, I, P]),
+    "slic_conv_wgrad_workspace_bytes": (c_size_t, [P, I]),
+    "slic_conv_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
+    "slic_pack_weight_fwd": (I, [P, I, I, I, I, I, P, P]),
+    "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
+    "slic_ncdhw_to_ndhwc": (I, [P, I, I, L, I, P, P]),
+    # batch norm / pool
+    "slic_bn_finalize": (I, [P, I, I, L, F, F, P, P, P, P, P, P, P, P, P]),
+    "slic_bn_eval_affine": (I, [P, P, P, P, F, I, P, P, P]),
+    "slic_bn_apply": (I, [P, P, P, P, I, L, I, P, P]),
+    "slic_bn_bwd_workspace_bytes": (c_size_t, [L, I, I]),
+    "slic_bn_bwd_rows_per_partial": (I, []),
+    "slic_bn_bwd": (I, [P, P, P, P, P, P, L, I, P, P, P, P, P, P]),
+    "slic_avgpool_fwd": (I, [P, I, I, I, P, P]),
+    "slic_avgpool_bwd": (I, [P, I, I, I, P, P]),
+    "slic_colsum": (I, [P, L, I, P, P]),
+    # losses
+    "slic_ntxent_workspace_bytes": (c_size_t, [I, I]),
+    "slic_ntxent_fwd": (I, [P, I, I, I, F, P, P, P]),
+    "slic_ntxent_bwd": (I, [P, I, I, F, P, P, I, P]),
+    "slic_pair_distance": (I, [P, P, I, I, I, P, P]),
+    "slic_pdist": (I, [P, I, I, F, I, P, P]),
 }
+
+
+class SlicConvArgs(ctypes.Structure):
+    """mirror of `struct SlicConvArgs` in include/slic_hip.h"""
+    _fields_ = [
+        ("src", P), ("wgt", P), ("dst", P), ("tab", P), ("bias", P), ("scale", P), ("shift", P),
+        ("addend", P), ("stat_partial", P),
+        ("M", L),
+        ("N", I), ("nchunks", I), ("Cs", I), ("Ts", I), ("Hs", I), ("Ws", I),
+        ("Ga", I), ("Gb", I), ("Gc", I), ("sa", I), ("sb", I), ("sc", I),
+        ("ldw", I), ("ldo", I),
+        ("dst_strided", I), ("Da", I), ("Db", I), ("Dc", I), ("da", I), ("db", I), ("dc", I),
+        ("ea", I), ("eb", I), ("ec", I),
+        ("relu", I),
+    ]
 
 
 class SlicError(RuntimeError):

@@ -1,0 +1,221 @@
+// InfoNCE / NT-Xent pairwise-similarity loss, fused.
+//
+// Replaces OnlineTripletLoss.forward(..., sampling_strategy='noise_contrastive') of
+// /root/reference/loss/triplet_loss.py:95-116 with pdist (:429-437): a Python loop of 2B
+// F.cosine_similarity launches + masked_fill + F.cross_entropy becomes
+//   ntxent_normalize  : e_hat = e / max(||e||, 1e-8)            (F.cosine_similarity's per-norm clamp)
+//   ntxent_fwd        : S = e_hat e_hat^T on fp32 MFMA, sim = 1 - (1 - S), diag := 0 (NOT -inf: exp(0)
+//                       stays in the denominator, :101), / T, row log-sum-exp, target (n/2 + i) mod n (:106-109)
+//   ntxent_bwd        : gradient to all n embeddings, through the normalisation.
+// MFMA roles are swapped (A = column block j, B = row block i) so a lane owns ONE row i and sees 16 j's
+// per accumulator: the softmax reduction stays in registers, then one shuffle + one LDS step.
+#include "common.h"
+#include <math.h>
+
+__global__ void ntxent_normalize(const float* __restrict__ E, int n, int D, int lde,
+                                 float* __restrict__ Eh, float* __restrict__ rnorm) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* e = E + (int64_t)row * lde;
+  float s = 0.f;
+  for (int k = lane; k < D; k += 64) s = fmaf(e[k], e[k], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float nrm = fmaxf(sqrtf(s), 1e-8f);
+  const float rn = 1.0f / nrm;
+  if (lane == 0) rnorm[row] = rn;
+  for (int k = lane; k < D; k += 64) Eh[(int64_t)row * D + k] = e[k] / nrm;
+}
+
+// workgroup = 32 rows i; wave w walks column tiles w, w+4, ...
+__global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict__ Eh, int n, int D, float invT,
+                                                         float* __restrict__ lse,
+                                                         float* __restrict__ rowloss) {
+  __shared__ float wsum[4][32], wtgt[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.x * 32;
+  const int i = i0 + r;
+  const int ic = i < n ? i : n - 1;
+  const int tgt = (n / 2 + i) % n;
+  const float m = invT;  // sim/T <= 1/T: fixed shift for the log-sum-exp
+  float sum = 0.f, st = 0.f;
+  const int ntile = (n + 31) / 32;
+  for (int jt = wave; jt < ntile; jt += 4) {
+    const int j0 = jt * 32;
+    const int jr = (j0 + r) < n ? (j0 + r) : n - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+    const float* pa = Eh + (int64_t)jr * D + h;   // A: rows = j
+    const float* pb = Eh + (int64_t)ic * D + h;   // B: cols = i
+    for (int k = 0; k < D; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[k], pb[k], acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int j = j0 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (j < n) {
+        float s = 1.0f - (1.0f - acc[g]);   // sim_matrix = 1 - pdist (:100)
+        if (j == i) s = 0.f;                // masked_fill_(eye, 0) (:101)
+        s *= invT;
+        sum += expf(s - m);
+        if (j == tgt) st = s;
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32);
+  st += __shfl_xor(st, 32);
+  if (h == 0) { wsum[wave][r] = sum; wtgt[wave][r] = st; }
+  __syncthreads();
+  if (threadIdx.x < 32 && i0 + threadIdx.x < n) {
+    const int t = threadIdx.x;
+    const float s = wsum[0][t] + wsum[1][t] + wsum[2][t] + wsum[3][t];
+    const float tg = wtgt[0][t] + wtgt[1][t] + wtgt[2][t] + wtgt[3][t];
+    const float l = m + logf(s);
+    lse[i0 + t] = l;
+    rowloss[i0 + t] = l - tg;
+  }
+}
+
+__global__ void mean_serial(const float* __restrict__ v, int n, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) a += (double)v[i];
+    *out = (float)(a / (double)n);
+  }
+}
+
+// workgroup = row i.  H_ij = (p_ij - [j == t(i)]) + (p_ji - [i == t(j)]), zero on the diagonal;
+// d e_hat_i = (gscale / (n T)) * sum_j H_ij e_hat_j ;  d e_i = (d e_hat_i - e_hat_i <e_hat_i, d e_hat_i>) * rnorm_i
+__global__ __launch_bounds__(256) void ntxent_bwd_kernel(const float* __restrict__ Eh,
+                                                         const float* __restrict__ rnorm,
+                                                         const float* __restrict__ lse, int n, int D,
+                                                         float invT, const float* __restrict__ gscale,
+                                                         float* __restrict__ dE, int ldd) {
+  extern __shared__ float sm[];  // [n] H row, [D] d e_hat, [4] reduce
+  float* Hrow = sm;
+  float* dh = sm + n;
+  float* red = sm + n + D;
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float* ei = Eh + (int64_t)i * D;
+  const int ti = (n / 2 + i) % n;
+  const float li = lse[i];
+  for (int j = t; j < n; j += 256) {
+    float hv = 0.f;
+    if (j != i) {
+      const float* ej = Eh + (int64_t)j * D;
+      float c = 0.f;
+      for (int k = 0; k < D; ++k) c = fmaf(ei[k], ej[k], c);
+      const float s = (1.0f - (1.0f - c)) * invT;
+      const int tj = (n / 2 + j) % n;
+      hv = (expf(s - li) - (j == ti ? 1.f : 0.f)) + (expf(s - lse[j]) - (i == tj ? 1.f : 0.f));
+    }
+    Hrow[j] = hv;
+  }
+  __syncthreads();
+  const float gs = (gscale ? *gscale : 1.0f) * invT / (float)n;
+  float part = 0.f;
+  for (int k = t; k < D; k += 256) {
+    float a = 0.f;
+    for (int j = 0; j < n; ++j) a = fmaf(Hrow[j], Eh[(int64_t)j * D + k], a);
+    a *= gs;
+    dh[k] = a;
+    part = fmaf(a, ei[k], part);
+  }
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  if ((t & 63) == 0) red[t >> 6] = part;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3];
+  const float rn = rnorm[i];
+  for (int k = t; k < D; k += 256) dE[(int64_t)i * ldd + k] = (dh[k] - ei[k] * dot) * rn;
+}
+
+// one wave per row: 1 - cos(x, y) with F.cosine_similarity's per-norm clamp, or ||x - y + 1e-6||_2
+// (F.pairwise_distance default eps) — models/triplet_net.py:29-33
+__global__ void pair_distance_kernel(const float* __restrict__ X, const float* __restrict__ Y, int n, int D,
+                                     int euclid, float* __restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = X + (int64_t)row * D;
+  const float* y = Y + (int64_t)row * D;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    if (euclid) { const float d = x[k] - y[k] + 1e-6f; a = fmaf(d, d, a); }
+    else { a = fmaf(x[k], y[k], a); b = fmaf(x[k], x[k], b); c = fmaf(y[k], y[k], c); }
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  if (lane == 0) out[row] = euclid ? sqrtf(a) : 1.0f - a / (fmaxf(sqrtf(b), 1e-8f) * fmaxf(sqrtf(c), 1e-8f));
+}
+
+// full distance matrix (loss/triplet_loss.py:429-437): one wave per (i, j)
+__global__ void pdist_kernel(const float* __restrict__ V, int n, int D, float eps, int euclid,
+                             float* __restrict__ out) {
+  const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (int64_t)n * n) return;
+  const int i = (int)(pair / n), j = (int)(pair % n);
+  const int lane = threadIdx.x & 63;
+  const float* x = V + (int64_t)i * D;
+  const float* y = V + (int64_t)j * D;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    if (euclid) { const float d = x[k] - y[k] + eps; a = fmaf(d, d, a); }
+    else { a = fmaf(x[k], y[k], a); b = fmaf(x[k], x[k], b); c = fmaf(y[k], y[k], c); }
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  if (lane == 0) out[pair] = euclid ? sqrtf(a) : 1.0f - a / (fmaxf(sqrtf(b), 1e-8f) * fmaxf(sqrtf(c), 1e-8f));
+}
+
+static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+
+extern "C" int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclidean, float* out,
+                                  void* stream) {
+  SLIC_REQUIRE(X && Y && out && n > 0 && D > 0, "slic_pair_distance: bad args");
+  pair_distance_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, n, D, euclidean, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* out, void* stream) {
+  SLIC_REQUIRE(V && out && n > 0 && D > 0, "slic_pdist: bad args");
+  pdist_kernel<<<dim3((unsigned)slic_cdiv((int64_t)n * n, 4)), dim3(256), 0, S_(stream)>>>(V, n, D, eps, euclidean, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+
+extern "C" size_t slic_ntxent_workspace_bytes(int n, int D) {
+  return slic_align_up((size_t)n * D * 4, 256) + 3 * slic_align_up((size_t)n * 4, 256);
+}
+
+// workspace keeps (e_hat, rnorm, lse, rowloss) for the backward call
+extern "C" int slic_ntxent_fwd(const float* E, int n, int D, int lde, float temperature, float* loss,
+                               void* workspace, void* stream) {
+  SLIC_REQUIRE(E && loss && workspace && n >= 2 && D >= 2 && D % 2 == 0 && lde >= D && temperature > 0.f,
+               "slic_ntxent_fwd: bad args (n >= 2, D even)");
+  hipStream_t st = S_(stream);
+  SlicCarver w(workspace);
+  float* Eh = w.take<float>((size_t)n * D);
+  float* rnorm = w.take<float>(n);
+  float* lse = w.take<float>(n);
+  float* rowloss = w.take<float>(n);
+  ntxent_normalize<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, st>>>(E, n, D, lde, Eh, rnorm);
+  SLIC_LAUNCH_CHECK();
+  ntxent_fwd_kernel<<<dim3((unsigned)slic_cdiv(n, 32)), dim3(256), 0, st>>>(Eh, n, D, 1.0f / temperature, lse, rowloss);
+  SLIC_LAUNCH_CHECK();
+  mean_serial<<<dim3(1), dim3(64), 0, st>>>(rowloss, n, loss);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_ntxent_bwd(const void* workspace, int n, int D, float temperature, const float* gscale,
+                               float* dE, int ldd, void* stream) {
+  SLIC_REQUIRE(workspace && dE && n >= 2 && D >= 2 && ldd >= D, "slic_ntxent_bwd: bad args");
+  SLIC_REQUIRE((size_t)(n + D + 4) * 4 <= 64 * 1024, "slic_ntxent_bwd: n + D too large for one workgroup's LDS");
+  SlicCarver w((void*)workspace);
+  float* Eh = w.take<float>((size_t)n * D);
+  float* rnorm = w.take<float>(n);
+  float* lse = w.take<float>(n);
+  ntxent_bwd_kernel<<<dim3(n), dim3(256), (size_t)(n + D + 4) * 4, S_(stream)>>>(Eh, rnorm, lse, n, D, 1.0f / temperature, gscale, dE, ldd);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}

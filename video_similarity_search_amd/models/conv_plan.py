@@ -1,0 +1,180 @@
+"""
+Host-side plans for the table-driven gather-GEMM (csrc/conv.hip): builds the K-chunk tables for
+forward / data-gradient launches of one 3-D convolution (or linear layer) and marshals
+`SlicConvArgs`.  Stands in for what cuDNN's descriptors/algorithm search do behind nn.Conv3d in the
+reference (models/resnet.py:11-25,126-131; cudnn.benchmark, online_train.py:444).
+
+Layout contract: activations NDHWC fp32 contiguous [B, T, H, W, C] with C % 4 == 0; weights stay in
+the reference layout [N, C, kt, kh, kw] (state_dict-compatible) and are re-packed on the device.
+"""
+import ctypes
+import itertools
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import SlicConvArgs, call, ptr, stream
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _pack_off(oa, ob, oc):
+    assert -128 <= oa < 128 and -128 <= ob < 128 and -128 <= oc < 128
+    return (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
+
+
+class ConvPlan:
+    """One conv layer at one input size.  kernel/stride/pad are (t, h, w) triples."""
+
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device):
+        self.C, self.N = int(C), int(N)
+        self.Cs = (self.C + 3) // 4 * 4
+        self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
+        self.in_dims = tuple(int(v) for v in in_dims)
+        self.out_dims = tuple((i + 2 * p - k) // s + 1 for i, p, k, s in zip(self.in_dims, self.pad, self.kernel, self.stride))
+        self.ntaps = int(np.prod(self.kernel))
+        self.device = device
+        assert self.N % 4 == 0, "output channels must be a multiple of 4"
+        # ---- forward table: k = tap*Cs + c
+        T, H, W = self.in_dims
+        kt, kh, kw = self.kernel
+        nch = self.ntaps * self.Cs // 4
+        self.nchunks_fwd = _pad8(nch)
+        tab = np.zeros((self.nchunks_fwd, 4), np.int32)
+        tab[:, 1] = -1
+        q = np.arange(nch)
+        tap, c = (q * 4) // self.Cs, (q * 4) % self.Cs
+        dt, dh, dw = tap // (kh * kw), (tap // kw) % kh, tap % kw
+        oa, ob, oc = dt - self.pad[0], dh - self.pad[1], dw - self.pad[2]
+        tab[:nch, 0] = ((oa * H + ob) * W + oc) * self.Cs + c
+        tab[:nch, 1] = (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
+        tab[:nch, 2] = q * 4
+        self.tab_fwd = torch.from_numpy(tab).to(device)
+        self.Kp = self.nchunks_fwd * 4                      # packed forward weight row length
+        # ---- data-gradient tables: src = dY [B, To, Ho, Wo, N], k = tap*N + n, one per parity class
+        self.Kd = _pad8(self.ntaps * self.N // 4) * 4
+        To, Ho, Wo = self.out_dims
+        self.dgrad_classes = []
+        nq = self.N // 4
+        for cls in itertools.product(*[range(s) for s in self.stride]):
+            grid = tuple((d - p + s - 1) // s for d, p, s in zip(self.in_dims, cls, self.stride))
+            if min(grid) <= 0:
+                continue
+            valid = []
+            for dim in range(3):
+                v = []
+                for d in range(self.kernel[dim]):
+                    num = cls[dim] + self.pad[dim] - d
+                    if num % self.stride[dim] == 0:
+                        v.append((d, num // self.stride[dim]))
+                valid.append(v)
+            rows = []
+            for (dt_, oa_), (dh_, ob_), (dw_, oc_) in itertools.product(*valid):
+                tap_ = (dt_ * kh + dh_) * kw + dw_
+                base = ((oa_ * Ho + ob_) * Wo + oc_) * self.N
+                po = _pack_off(oa_, ob_, oc_)
+                for n4 in range(nq):
+                    rows.append((base + n4 * 4, po, tap_ * self.N + n4 * 4, 0))
+            nchd = _pad8(len(rows))
+            t = np.zeros((max(nchd, 8), 4), np.int32)
+            t[:, 1] = -1
+            if rows:
+                t[: len(rows)] = np.asarray(rows, np.int32)
+            self.dgrad_classes.append(dict(cls=cls, grid=grid, nchunks=nchd if rows else 0,
+                                           tab=torch.from_numpy(t).to(device)))
+        self._wp = None
+        self._wd = None
+
+    # ------------------------------------------------------------------ weights
+    def pack_fwd(self, weight):
+        if self._wp is None:
+            self._wp = torch.empty(self.N, self.Kp, dtype=torch.float32, device=self.device)
+        call("slic_pack_weight_fwd", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kp, ptr(self._wp), stream())
+        return self._wp
+
+    def pack_dgrad(self, weight):
+        if self._wd is None:
+            self._wd = torch.empty(self.Cs, self.Kd, dtype=torch.float32, device=self.device)
+        call("slic_pack_weight_dgrad", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kd, ptr(self._wd), stream())
+        return self._wd
+
+    # ------------------------------------------------------------------ launches
+    def _fwd_args(self, x, B):
+        a = SlicConvArgs()
+        T, H, W = self.in_dims
+        To, Ho, Wo = self.out_dims
+        a.src = x.data_ptr()
+        a.tab = self.tab_fwd.data_ptr()
+        a.M = B * To * Ho * Wo
+        a.N = self.N
+        a.nchunks = self.nchunks_fwd
+        a.Cs, a.Ts, a.Hs, a.Ws = self.Cs, T, H, W
+        a.Ga, a.Gb, a.Gc = To, Ho, Wo
+        a.sa, a.sb, a.sc = self.stride
+        a.ldw, a.ldo = self.Kp, self.N
+        return a
+
+    def forward(self, x, wp, B, bias=None, scale=None, shift=None, addend=None, relu=False, want_stats=False,
+                variant=0):
+        """x: [B, T, H, W, Cs] -> z: [B, To, Ho, Wo, N]; returns (z, stat_partial or None, rows_per_partial)"""
+        lib = _lib.load()
+        a = self._fwd_args(x, B)
+        z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
+        a.wgt = wp.data_ptr()
+        a.dst = z.data_ptr()
+        a.bias = bias.data_ptr() if bias is not None else None
+        a.scale = scale.data_ptr() if scale is not None else None
+        a.shift = shift.data_ptr() if shift is not None else None
+        a.addend = addend.data_ptr() if addend is not None else None
+        a.relu = int(relu)
+        part = None
+        tm = lib.slic_conv_tile_m(ctypes.byref(a), variant)
+        if want_stats:
+            R = (a.M + tm - 1) // tm
+            part = torch.empty(R, 2, self.N, dtype=torch.float32, device=x.device)
+            a.stat_partial = part.data_ptr()
+        call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+        return z, part
+
+    def dgrad(self, dz, wd, B, addend=None, out=None, variant=0):
+        """dz: [B, To, Ho, Wo, N] -> dx: [B, T, H, W, Cs] = conv_transpose(dz) (+ addend; addend may be `out`
+        itself: every element is read and written by the same lane)"""
+        T, H, W = self.in_dims
+        To, Ho, Wo = self.out_dims
+        dx = out if out is not None else torch.empty((B, T, H, W, self.Cs), dtype=torch.float32, device=dz.device)
+        for dc in self.dgrad_classes:
+            a = SlicConvArgs()
+            a.src = dz.data_ptr()
+            a.wgt = wd.data_ptr()
+            a.dst = dx.data_ptr()
+            a.tab = dc["tab"].data_ptr()
+            a.addend = addend.data_ptr() if addend is not None else None
+            ga, gb, gc = dc["grid"]
+            a.M = B * ga * gb * gc
+            a.N = self.Cs
+            a.nchunks = dc["nchunks"]
+            a.Cs, a.Ts, a.Hs, a.Ws = self.N, To, Ho, Wo
+            a.Ga, a.Gb, a.Gc = ga, gb, gc
+            a.sa = a.sb = a.sc = 1
+            a.ldw, a.ldo = self.Kd, self.Cs
+            strided = self.stride != (1, 1, 1)
+            a.dst_strided = int(strided)
+            a.Da, a.Db, a.Dc = T, H, W
+            a.da, a.db, a.dc = self.stride
+            a.ea, a.eb, a.ec = dc["cls"]
+            call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+        return dx
+
+    def wgrad(self, x, dz, B, dW, splits=None):
+        """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
+        lib = _lib.load()
+        a = self._fwd_args(x, B)
+        if splits is None:
+            blocks = ((self.nchunks_fwd + 31) // 32) * ((self.N + 63) // 64)
+            splits = max(1, min((1024 + blocks - 1) // blocks, (a.M + 255) // 256))
+        ws = _lib.workspace(lib.slic_conv_wgrad_workspace_bytes(ctypes.byref(a), splits), x.device, "wgrad")
+        call("slic_conv_wgrad", ctypes.byref(a), ptr(dz), self.N, splits, self.C, self.ntaps, ptr(dW), ptr(ws), stream())
+        return dW

@@ -1,0 +1,381 @@
+"""
+MI355X drop-in for the reference's models/resnet.py (Hara 3D-ResNet, the "R3D-18" of SLIC):
+
+    generate_model(model_depth, **kwargs) -> nn.Module      <- models/resnet.py:436-456
+    ResNet / BasicBlock                                      <- models/resnet.py:100-312, 27-57
+    ctor kwargs exactly as model_selector passes them        <- models/model_utils.py:37-51
+
+The module tree only HOLDS parameters (torch's own Conv3d / BatchNorm / Linear objects, so the
+reference's init rules (:203-210) and its 129 state_dict keys hold by construction, and
+checkpoints written by models/model_utils.py:161-176 load unchanged).  forward() never calls those
+modules: the whole encoder runs as one hand-written execution plan over the HIP kernels of
+libslic_hip.so (csrc/conv.hip, bn.hip), forward AND backward, exposed to autograd as a single
+Function — NDHWC activations, fp32 MFMA gather-GEMM convs with fused BatchNorm statistics,
+deterministic reductions.  There is no PyTorch/CPU fallback path.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import call, ptr, stream
+from .conv_plan import ConvPlan
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def conv3x3x3(in_planes, out_planes, stride=1):
+    return nn.Conv3d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1x1(in_planes, out_planes, stride=1):
+    return nn.Conv3d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    """parameter holder with the reference's attribute names (models/resnet.py:27-57)"""
+    expansion = 1
+
+    def __init__(self, in_planes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3x3(in_planes, planes, stride)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3x3(planes, planes)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("BasicBlock is a parameter holder; the encoder runs through ResNet.forward (HIP plan)")
+
+
+# ------------------------------------------------------------------------------------------------
+class _Bn:
+    """per-call view of one BatchNorm layer: parameters + the statistics this pass produced"""
+
+    def __init__(self, mod):
+        self.mod = mod
+        self.C = mod.num_features
+        self.mean = self.invstd = self.scale = self.shift = None
+
+
+class _Engine:
+    """Execution plan of one ResNet at one input shape: conv plans (tables on the device), forward and backward
+    passes written out layer by layer.  Mirrors ResNet.forward / BasicBlock.forward of the reference
+    (models/resnet.py:255-312, 41-57) and what autograd derives from them."""
+
+    def __init__(self, net, in_shape, device):
+        B, C, T, H, W = in_shape
+        self.net = net
+        self.device = device
+        self.in_shape = tuple(in_shape)
+        c1 = net.conv1
+        self.stem = ConvPlan(C, c1.out_channels, c1.kernel_size, c1.stride, c1.padding, (T, H, W), device)
+        dims = self.stem.out_dims
+        if not net.no_max_pool:
+            raise NotImplementedError("no_max_pool=False: every shipped SLIC config sets RESNET.NO_MAX_POOl true "
+                                      "(config/custom_configs/resnet_ucf_itercluster_flow.yaml:29-37)")
+        self.blocks = []
+        for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            for blk in layer:
+                if not isinstance(blk, BasicBlock):
+                    raise NotImplementedError("Bottleneck depths (50+) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
+                p1 = ConvPlan(blk.conv1.in_channels, blk.conv1.out_channels, blk.conv1.kernel_size, blk.conv1.stride,
+                              blk.conv1.padding, dims, device)
+                p2 = ConvPlan(blk.conv2.in_channels, blk.conv2.out_channels, blk.conv2.kernel_size, blk.conv2.stride,
+                              blk.conv2.padding, p1.out_dims, device)
+                pd = None
+                if blk.downsample is not None:
+                    if not isinstance(blk.downsample, nn.Sequential):
+                        raise NotImplementedError("shortcut_type 'A' is never selected by the shipped configs")
+                    dc = blk.downsample[0]
+                    pd = ConvPlan(dc.in_channels, dc.out_channels, dc.kernel_size, dc.stride, dc.padding, dims, device)
+                    assert pd.out_dims == p2.out_dims
+                self.blocks.append((blk, p1, p2, pd))
+                dims = p2.out_dims
+        self.final_dims = dims
+        self.feat = self.blocks[-1][2].N
+        if net.projection_head:
+            self.fc1 = ConvPlan(net.fc1.in_features, net.fc1.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
+            self.fc2 = ConvPlan(net.fc2.in_features, net.fc2.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
+
+    # ------------------------------------------------------------------ small helpers
+    def _vec(self, C):
+        return torch.empty(C, dtype=torch.float32, device=self.device)
+
+    def _bn_train(self, bn, part, M):
+        """finalize batch statistics (+ running stats, num_batches_tracked) from the conv epilogue's slab"""
+        m = bn.mod
+        bn.mean, bn.invstd, bn.scale, bn.shift = self._vec(bn.C), self._vec(bn.C), self._vec(bn.C), self._vec(bn.C)
+        call("slic_bn_finalize", ptr(part), part.shape[0], bn.C, M, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias),
+             ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var), stream())
+        m.num_batches_tracked += 1
+
+    def _bn_eval(self, bn):
+        m = bn.mod
+        bn.scale, bn.shift = self._vec(bn.C), self._vec(bn.C)
+        call("slic_bn_eval_affine", ptr(m.weight), ptr(m.bias), ptr(m.running_mean), ptr(m.running_var), BN_EPS, bn.C,
+             ptr(bn.scale), ptr(bn.shift), stream())
+
+    @staticmethod
+    def _apply(z, bn, res, relu):
+        y = torch.empty_like(z)
+        M = z.numel() // bn.C
+        call("slic_bn_apply", ptr(z), ptr(bn.scale), ptr(bn.shift), ptr(res), int(relu), M, bn.C, ptr(y), stream())
+        return y
+
+    @staticmethod
+    def _bn_bwd(dy, out, z, bn, want_g):
+        """returns (dz, g or None, dgamma, dbeta)"""
+        lib = _lib.load()
+        M = z.numel() // bn.C
+        dz = torch.empty_like(z)
+        g = torch.empty_like(z) if want_g else None
+        dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        need_buf = int(out is not None and not want_g)
+        ws = _lib.workspace(lib.slic_bn_bwd_workspace_bytes(M, bn.C, need_buf), z.device, "bn_bwd")
+        call("slic_bn_bwd", ptr(dy), ptr(out), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), M, bn.C,
+             ptr(g), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+        return dz, g, dgamma, dbeta
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, training, save):
+        """x: [B, C, T, H, W] fp32 device tensor.  Returns (output [B, out_dim], ctx or None)."""
+        net = self.net
+        B, C, T, H, W = x.shape
+        dev = x.device
+        x = x.contiguous()
+        x4 = torch.empty(B, T, H, W, self.stem.Cs, dtype=torch.float32, device=dev)
+        call("slic_ncdhw_to_ndhwc", ptr(x), B, C, T * H * W, self.stem.Cs, ptr(x4), stream())
+        ctx = dict(x4=x4, blocks=[]) if save else None
+
+        def conv_bn_act(plan, inp, weight, bnmod, res, relu):
+            """conv -> BN -> (+res) -> relu; returns (z or None, y, bn)"""
+            bn = _Bn(bnmod)
+            wp = plan.pack_fwd(weight)
+            if training:
+                z, part = plan.forward(inp, wp, B, want_stats=True)
+                self._bn_train(bn, part, z.numel() // bn.C)
+                y = self._apply(z, bn, res, relu)
+                return z, y, bn
+            self._bn_eval(bn)                     # eval: BN folded into the conv epilogue
+            y, _ = plan.forward(inp, wp, B, scale=bn.scale, shift=bn.shift, addend=res, relu=relu)
+            return None, y, bn
+
+        z0, a, bn0 = conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True)
+        if save:
+            ctx.update(z0=z0, a0=a, bn0=bn0)
+        for blk, p1, p2, pd in self.blocks:
+            xin = a
+            z1, a1, b1 = conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True)
+            if pd is not None:
+                zd, r, bd = conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False)
+            else:
+                zd, r, bd = None, xin, None
+            z2, out, b2 = conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True)
+            if save:
+                ctx["blocks"].append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, out=out, b2=b2, zd=zd, bd=bd))
+            a = out
+        To, Ho, Wo = self.final_dims
+        S = To * Ho * Wo
+        pooled = torch.empty(B, self.feat, dtype=torch.float32, device=dev)
+        call("slic_avgpool_fwd", ptr(a), B, S, self.feat, ptr(pooled), stream())
+        if save:
+            ctx.update(last=a, pooled=pooled)
+        if not net.projection_head:
+            return pooled, ctx
+        # h = fc2(relu(bn_proj(fc1(x))))   (models/resnet.py:294-299)
+        bnp = _Bn(net.bn_proj)
+        w1 = self.fc1.pack_fwd(net.fc1.weight)
+        p5 = pooled.view(B, 1, 1, 1, self.feat)
+        if training:
+            h1, part = self.fc1.forward(p5, w1, B, bias=net.fc1.bias, want_stats=True)
+            self._bn_train(bnp, part, B)
+            ah = self._apply(h1, bnp, None, True)
+        else:
+            self._bn_eval(bnp)
+            # bias first, then the BN affine, then ReLU — all in the epilogue
+            h1 = None
+            ah, _ = self.fc1.forward(p5, w1, B, bias=net.fc1.bias, scale=bnp.scale, shift=bnp.shift, relu=True)
+        w2 = self.fc2.pack_fwd(net.fc2.weight)
+        y, _ = self.fc2.forward(ah.view(B, 1, 1, 1, -1), w2, B, bias=net.fc2.bias)
+        if save:
+            ctx.update(h1=h1, ah=ah, bnp=bnp)
+        return y.view(B, -1), ctx
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx, dy):
+        """dy: [B, out_dim].  Returns {parameter: gradient} (reference layouts)."""
+        net = self.net
+        grads = {}
+        B = dy.shape[0]
+        dev = dy.device
+        dy = dy.contiguous()
+
+        def new_like(p):
+            return torch.empty_like(p, memory_format=torch.contiguous_format)
+
+        def bias_grad(d2, p):
+            g = new_like(p)
+            call("slic_colsum", ptr(d2), d2.shape[0], d2.shape[1], ptr(g), stream())
+            return g
+
+        if net.projection_head:
+            ah, h1, bnp, pooled = ctx["ah"], ctx["h1"], ctx["bnp"], ctx["pooled"]
+            d5 = dy.view(B, 1, 1, 1, -1)
+            grads[net.fc2.weight] = self.fc2.wgrad(ah.view(B, 1, 1, 1, -1), d5, B, new_like(net.fc2.weight))
+            grads[net.fc2.bias] = bias_grad(dy, net.fc2.bias)
+            dah = self.fc2.dgrad(d5, self.fc2.pack_dgrad(net.fc2.weight), B)
+            dh1, _, dg, db = self._bn_bwd(dah.view(B, -1), ah.view(B, -1), h1.view(B, -1), bnp, False)
+            grads[net.bn_proj.weight], grads[net.bn_proj.bias] = dg, db
+            grads[net.fc1.weight] = self.fc1.wgrad(pooled.view(B, 1, 1, 1, -1), dh1.view(B, 1, 1, 1, -1), B, new_like(net.fc1.weight))
+            grads[net.fc1.bias] = bias_grad(dh1.view(B, -1), net.fc1.bias)
+            dpool = self.fc1.dgrad(dh1.view(B, 1, 1, 1, -1), self.fc1.pack_dgrad(net.fc1.weight), B).view(B, -1)
+        else:
+            dpool = dy
+        To, Ho, Wo = self.final_dims
+        S = To * Ho * Wo
+        dout = torch.empty_like(ctx["last"])
+        call("slic_avgpool_bwd", ptr(dpool), B, S, self.feat, ptr(dout), stream())
+
+        for (blk, p1, p2, pd), s in zip(reversed(self.blocks), reversed(ctx["blocks"])):
+            # out = relu(bn2(conv2(a1)) + r)
+            dz2, g, dg2, db2 = self._bn_bwd(dout, s["out"], s["z2"], s["b2"], True)
+            grads[blk.bn2.weight], grads[blk.bn2.bias] = dg2, db2
+            grads[blk.conv2.weight] = p2.wgrad(s["a1"], dz2, B, new_like(blk.conv2.weight))
+            da1 = p2.dgrad(dz2, p2.pack_dgrad(blk.conv2.weight), B)
+            del dz2
+            # a1 = relu(bn1(conv1(x)))
+            dz1, _, dg1, db1 = self._bn_bwd(da1, s["a1"], s["z1"], s["b1"], False)
+            del da1
+            grads[blk.bn1.weight], grads[blk.bn1.bias] = dg1, db1
+            grads[blk.conv1.weight] = p1.wgrad(s["x"], dz1, B, new_like(blk.conv1.weight))
+            if pd is not None:
+                # r = bn_d(conv_d(x)): g is its upstream gradient
+                dzd, _, dgd, dbd = self._bn_bwd(g, None, s["zd"], s["bd"], False)
+                grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dgd, dbd
+                grads[blk.downsample[0].weight] = pd.wgrad(s["x"], dzd, B, new_like(blk.downsample[0].weight))
+                dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B)
+                dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx)
+            else:
+                dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=g)
+            dout = dx
+        # stem: a0 = relu(bn1(conv1(x4))); the input needs no gradient
+        dz0, _, dg0, db0 = self._bn_bwd(dout, ctx["a0"], ctx["z0"], ctx["bn0"], False)
+        grads[net.bn1.weight], grads[net.bn1.bias] = dg0, db0
+        grads[net.conv1.weight] = self.stem.wgrad(ctx["x4"], dz0, B, new_like(net.conv1.weight))
+        return grads
+
+
+class _EncoderFn(torch.autograd.Function):
+    """the whole encoder as one autograd node: forward/backward are the engine's hand-written passes"""
+
+    @staticmethod
+    def forward(ctx, x, net, engine, *params):
+        out, saved = engine.forward(x, training=net.training, save=True)
+        ctx.engine, ctx.saved, ctx.params = engine, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads = ctx.engine.backward(ctx.saved, dy)
+        ctx.saved = None
+        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+class ResNet(nn.Module):
+    """Same constructor, attributes and state_dict as the reference's ResNet (models/resnet.py:100-312)."""
+
+    def __init__(self, block, layers, block_inplanes, n_input_channels=3, conv1_t_size=7, conv1_t_stride=1,
+                 no_max_pool=False, shortcut_type='B', widen_factor=1.0, hidden_layer=2048, out_dim=128,
+                 predict_temporal_ds=False, spatio_temporal_attention=False, projection_head=True,
+                 num_classes=101, classifier=False, dropout=None):
+        super().__init__()
+        if spatio_temporal_attention or predict_temporal_ds or classifier:
+            raise NotImplementedError("attention / temporal-ds / classifier heads are off in every SLIC config "
+                                      "(config/default_params.py:97) and outside the hot path")
+        block_inplanes = [int(x * widen_factor) for x in block_inplanes]
+        self.in_planes = block_inplanes[0]
+        self.no_max_pool = no_max_pool
+        self.conv1 = nn.Conv3d(n_input_channels, self.in_planes, kernel_size=(conv1_t_size, 7, 7),
+                               stride=(conv1_t_stride, 2, 2), padding=(conv1_t_size // 2, 3, 3), bias=False)
+        self.bn1 = nn.BatchNorm3d(self.in_planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool3d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, block_inplanes[0], layers[0], shortcut_type)
+        self.layer2 = self._make_layer(block, block_inplanes[1], layers[1], shortcut_type, stride=2)
+        self.layer3 = self._make_layer(block, block_inplanes[2], layers[2], shortcut_type, stride=2)
+        self.layer4 = self._make_layer(block, block_inplanes[3], layers[3], shortcut_type, stride=2)
+        self.spatio_temporal_attention = spatio_temporal_attention
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.predict_temporal_ds = predict_temporal_ds
+        self.projection_head = projection_head
+        self.classifier = classifier
+        self.num_classes = num_classes
+        self.dropout = dropout
+        if projection_head:
+            print('==> setting up non-linear project heads')
+            self.fc1 = nn.Linear(block_inplanes[3] * block.expansion, hidden_layer)
+            self.bn_proj = nn.BatchNorm1d(hidden_layer)
+            self.fc2 = nn.Linear(hidden_layer, out_dim)
+        for m in self.modules():
+            if isinstance(m, nn.Conv3d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm3d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self._engines = {}
+
+    def _make_layer(self, block, planes, blocks, shortcut_type, stride=1):
+        downsample = None
+        if stride != 1 or self.in_planes != planes * block.expansion:
+            if shortcut_type == 'A':
+                raise NotImplementedError("shortcut_type 'A' is never selected by the shipped configs")
+            downsample = nn.Sequential(conv1x1x1(self.in_planes, planes * block.expansion, stride),
+                                       nn.BatchNorm3d(planes * block.expansion))
+        layers = [block(in_planes=self.in_planes, planes=planes, stride=stride, downsample=downsample)]
+        self.in_planes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.in_planes, planes))
+        return nn.Sequential(*layers)
+
+    def _engine(self, x):
+        key = (tuple(x.shape), str(x.device))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = _Engine(self, x.shape, x.device)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.SlicError("ResNet.forward needs a gfx950 device tensor: the encoder has no CPU/PyTorch fallback")
+        _lib.load()
+        x = x.to(torch.float32)
+        eng = self._engine(x)
+        params = [p for p in self.parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and self.training and params:
+            return _EncoderFn.apply(x, self, eng, *params)
+        if torch.is_grad_enabled() and params and not self.training:
+            # eval-mode graph (BN frozen) is not needed by the SLIC loop (validation runs under no_grad)
+            with torch.no_grad():
+                return eng.forward(x, training=False, save=False)[0]
+        with torch.no_grad():
+            return eng.forward(x, training=self.training, save=False)[0]
+
+
+def generate_model(model_depth, **kwargs):
+    """models/resnet.py:436-456"""
+    def get_inplanes():
+        return [64, 128, 256, 512]
+
+    assert model_depth in [10, 18, 34, 50, 101, 152, 200]
+    if model_depth == 10:
+        return ResNet(BasicBlock, [1, 1, 1, 1], get_inplanes(), **kwargs)
+    if model_depth == 18:
+        return ResNet(BasicBlock, [2, 2, 2, 2], get_inplanes(), **kwargs)
+    if model_depth == 34:
+        return ResNet(BasicBlock, [3, 4, 6, 3], get_inplanes(), **kwargs)
+    raise NotImplementedError("Bottleneck depths (50/101/152/200) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
