@@ -152,7 +152,7 @@ typedef struct SlicConvArgs {
   const float* scale;      /* [N] or NULL: v = v*scale + shift (eval-mode BatchNorm) */
   const float* shift;      /* [N] or NULL */
   const float* addend;     /* same addressing as dst, or NULL: v += addend (residual / grad accumulate) */
-  float* stat_partial;     /* [ceil(M/tile_m)][2][N] per-workgroup sum / sum-of-squares of (acc+bias), or NULL */
+  float* stat_partial;     /* [ceil(M/tile_m)][2][N] per-workgroup (sum, sum (v - mean_wg)^2) of v = acc+bias, or NULL */
   int64_t M;               /* rows = B * Ga * Gb * Gc */
   int N;                   /* output channels */
   int nchunks;             /* K / 4, multiple of 8 */
@@ -186,10 +186,11 @@ int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* 
  * BatchNorm3d/1d + ReLU + residual + global average pool (models/resnet.py:34-57,132-133,173,183,
  * 294-299; torch defaults eps = 1e-5, momentum = 0.1).  Activations [M, C] row-major, C % 4 == 0.
  * ---------------------------------------------------------------------------------------- */
-/* batch statistics from the conv epilogue's per-workgroup slab partial[R][2][C] (added in row order, double):
+/* batch statistics from the conv epilogue's per-workgroup slab partial[R][2][C] = (sum, sum (x - mean_blk)^2)
+ * over `rows` rows per workgroup (the last one ragged), merged in workgroup order in double (Chan's formula):
  * mean, invstd = 1/sqrt(biased var + eps), scale = gamma*invstd, shift = beta - mean*scale; running stats
  * (optional pair) get the momentum update with the unbiased variance. */
-int slic_bn_finalize(const float* partial, int R, int C, int64_t M, float eps, float momentum,
+int slic_bn_finalize(const float* partial, int R, int rows, int C, int64_t M, float eps, float momentum,
                      const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
                      float* shift, float* running_mean, float* running_var, void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */

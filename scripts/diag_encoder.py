@@ -1,0 +1,57 @@
+"""diagnostic (GPU box): accuracy of the HIP encoder vs fp32/fp64 CPU oracle, and first timings"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import encoder as oe
+from video_similarity_search_amd.models import generate_model
+from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+KW = dict(hidden_layer=2048, out_dim=128, num_classes=101, n_input_channels=3, shortcut_type='B', conv1_t_size=7,
+          conv1_t_stride=1, no_max_pool=True, widen_factor=1.0, projection_head=True, predict_temporal_ds=False,
+          spatio_temporal_attention=False, classifier=False, dropout=None)
+rng = np.random.default_rng(7)
+sd = oe.make_state_dict(rng)
+m = generate_model(18, **KW)
+m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+m = m.cuda()
+if "acc" in sys.argv:
+    x = rng.standard_normal((2, 3, 16, 112, 112)).astype(np.float32)
+    xt = torch.from_numpy(x)
+    for mode in ("train", "eval"):
+        t32 = oe.to_torch(sd); t64 = oe.to_torch(sd, dtype=torch.float64)
+        taps32, taps64 = {}, {}
+        with torch.no_grad():
+            r32 = oe.encoder_forward(t32, xt, training=(mode == "train"), taps=taps32)
+            r64 = oe.encoder_forward(t64, xt.double(), training=(mode == "train"), taps=taps64)
+            m.train(mode == "train")
+            m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+            eng = m._engine(xt.cuda())
+            g, ctx = eng.forward(xt.cuda(), training=(mode == "train"), save=True)
+            g = g.cpu()
+            names = ["layer%d.%d" % (l, b) for l in (1, 2, 3, 4) for b in (0, 1)]
+            def cmp(name, t):
+                ref = taps64[name]
+                got = t.cpu().permute(0, 4, 1, 2, 3).double() if t.dim() == 5 else t.cpu().double()
+                print("   gpu-vs-64", name, (got - ref).abs().max().item(), "cpu32-vs-64", (taps32[name].double() - ref).abs().max().item(), "scale", ref.abs().max().item())
+            cmp("stem", ctx["a0"])
+            for nme, blk in zip(names, ctx["blocks"]): cmp(nme, blk["out"])
+            cmp("pooled", ctx["pooled"])
+        print(mode, "gpu-vs-64", (g.double() - r64).abs().max().item(), "cpu32-vs-64", (r32.double() - r64).abs().max().item(),
+              "gpu-vs-cpu32", (g - r32).abs().max().item(), "scale", r64.abs().max().item())
+for B in [int(a) for a in sys.argv[1:] if a.isdigit()]:
+    x = torch.randn(B, 3, 16, 112, 112, device="cuda")
+    m.eval()
+    with torch.no_grad():
+        for _ in range(2): m(x)
+        torch.cuda.synchronize(); t = time.time()
+        for _ in range(3): m(x)
+        torch.cuda.synchronize(); dt = (time.time() - t) / 3
+    print(f"B={B} eval fwd {dt*1e3:.1f} ms  {B/dt:.1f} clips/s  {B*85.17/dt/1e3:.1f} TF")
+    m.train()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.5)
+    def step():
+        emb = m(x); loss = ntxent_loss(emb); opt.zero_grad(); loss.backward(); opt.step()
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t = time.time()
+    for _ in range(3): step()
+    torch.cuda.synchronize(); dt = (time.time() - t) / 3
+    print(f"B={B} train step {dt*1e3:.1f} ms  {B/dt:.1f} clips/s  {B*248.9/dt/1e3:.1f} TF  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")

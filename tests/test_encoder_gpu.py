@@ -51,12 +51,13 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
         got = z.cpu().permute(0, 4, 1, 2, 3)
         tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6
         assert (got - y64.float()).abs().max() <= tol * max(1.0, y64.abs().max().item()), f"fwd variant {variant}"
-        # fused BN partial sums
-        s1 = part[:, 0].double().sum(0).cpu()
-        s2 = part[:, 1].double().sum(0).cpu()
-        ref1 = y64.detach().sum((0, 2, 3, 4))
-        ref2 = (y64.detach() ** 2).sum((0, 2, 3, 4))
-        assert torch.allclose(s1, ref1, atol=1e-3, rtol=1e-4) and torch.allclose(s2, ref2, atol=1e-3, rtol=1e-4)
+        # fused BN partials: (sum, sum (v - mean_wg)^2) per workgroup of `rows` rows
+        part, rows = part
+        flat = y64.detach().permute(0, 2, 3, 4, 1).reshape(-1, N)
+        for rr in range(part.shape[0]):
+            blk = flat[rr * rows:(rr + 1) * rows]
+            assert torch.allclose(part[rr, 0].double().cpu(), blk.sum(0), atol=1e-4, rtol=1e-4)
+            assert torch.allclose(part[rr, 1].double().cpu(), ((blk - blk.mean(0)) ** 2).sum(0), atol=1e-4, rtol=1e-4)
     dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
     dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B).cpu()[..., :C].permute(0, 4, 1, 2, 3)
     assert (dx - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item())
@@ -97,16 +98,16 @@ def test_bn_train_fwd_bwd(gpu):
         rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
         y64 = F.relu(F.batch_norm(z64, rm, rv, g64, b64, True, 0.1, 1e-5) + r64)
         gz, gg, gb, gr = torch.autograd.grad(y64, [z64, g64, b64, r64], dy.double())
-        # device: partial slab of 128-row groups (what the conv epilogue would emit)
+        # device: partial slab of 128-row groups (what the conv epilogue emits)
         R = (M + 127) // 128
         part = torch.zeros(R, 2, C)
         for r in range(R):
             blk = z[r * 128:(r + 1) * 128]
-            part[r, 0], part[r, 1] = blk.sum(0), (blk * blk).sum(0)
+            part[r, 0], part[r, 1] = blk.sum(0), ((blk - blk.mean(0)) ** 2).sum(0)
         zd, gd, bd, resd, dyd, partd = [t.cuda() for t in (z, gam, bet, res, dy, part)]
         mean, invstd, scale, shift = [torch.empty(C, device="cuda") for _ in range(4)]
         rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
-        call("slic_bn_finalize", ptr(partd), R, C, M, 1e-5, 0.1, ptr(gd), ptr(bd), ptr(mean), ptr(invstd), ptr(scale),
+        call("slic_bn_finalize", ptr(partd), R, 128, C, M, 1e-5, 0.1, ptr(gd), ptr(bd), ptr(mean), ptr(invstd), ptr(scale),
              ptr(shift), ptr(rmd), ptr(rvd), stream())
         y = torch.empty_like(zd)
         call("slic_bn_apply", ptr(zd), ptr(scale), ptr(shift), ptr(resd), 1, M, C, ptr(y), stream())
@@ -212,8 +213,15 @@ def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
     emb = m(xt.cuda())
     loss = ntxent_loss(emb)
     loss.backward()
-    scale = emb_ref.abs().max().item()
-    assert (emb.detach().cpu() - emb_ref.detach()).abs().max().item() <= 1e-4 * max(1.0, scale)
+    # train mode at B = 2 puts BatchNorm1d over TWO samples in the head: outputs are +-gamma/sqrt(1 + 4 eps/d^2),
+    # ill-conditioned in d = h[0] - h[1].  Judge both fp32 implementations against an fp64 run of the oracle:
+    # the HIP path must be within 1e-4, or as close to fp64 as the fp32 CPU oracle is (x3).
+    t64 = oe.to_torch(sd, dtype=torch.float64)
+    with torch.no_grad():
+        emb64 = oe.encoder_forward(t64, xt.double(), training=True)
+    err_gpu = (emb.detach().cpu().double() - emb64).abs().max().item()
+    err_cpu = (emb_ref.detach().double() - emb64).abs().max().item()
+    assert err_gpu <= max(1e-4, 3 * err_cpu), (err_gpu, err_cpu)
     assert abs(loss.item() - loss_ref.item()) <= 1e-4
     pd = dict(m.named_parameters())
     for k in names:

@@ -7,10 +7,11 @@
 // bn_bwd_reduce) are added in workgroup order in double.
 #include "common.h"
 
-// mean / biased var from the per-workgroup (sum, sumsq) slab; scale = gamma*invstd, shift = beta - mean*scale;
-// running stats: momentum update with the UNBIASED variance (torch semantics: models/resnet.py uses defaults
-// eps = 1e-5, momentum = 0.1).
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int R, int C, int64_t M, float eps,
+// mean / biased var from the per-workgroup slab of (sum, M2 = sum (x - mean_blk)^2) over `rows` rows each,
+// merged in workgroup order in double (Chan et al. pairwise update);
+// scale = gamma*invstd, shift = beta - mean*scale; running stats: momentum update with the UNBIASED variance
+// (torch semantics; models/resnet.py uses the defaults eps = 1e-5, momentum = 0.1).
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int R, int rows, int C, int64_t M, float eps,
                                    float momentum, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale,
@@ -18,13 +19,17 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int R, int
                                    float* __restrict__ running_var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s += (double)partial[((int64_t)r * 2 + 0) * C + c];
-    q += (double)partial[((int64_t)r * 2 + 1) * C + c];
-  }
+  double s = 0.0;
+  for (int r = 0; r < R; ++r) s += (double)partial[((int64_t)r * 2 + 0) * C + c];
   const double mu = s / (double)M;
-  double var = q / (double)M - mu * mu;
+  double m2 = 0.0;
+  for (int r = 0; r < R; ++r) {
+    const int64_t left = M - (int64_t)r * rows;
+    const double nb = (double)(left < rows ? left : rows);
+    const double d = (double)partial[((int64_t)r * 2 + 0) * C + c] / nb - mu;
+    m2 += (double)partial[((int64_t)r * 2 + 1) * C + c] + nb * d * d;
+  }
+  double var = m2 / (double)M;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -189,14 +194,15 @@ static inline unsigned ew_grid(int64_t tot) {
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
-extern "C" int slic_bn_finalize(const float* partial, int R, int C, int64_t M, float eps, float momentum,
+extern "C" int slic_bn_finalize(const float* partial, int R, int rows, int C, int64_t M, float eps, float momentum,
                                 const float* gamma, const float* beta, float* mean, float* invstd,
                                 float* scale, float* shift, float* running_mean, float* running_var,
                                 void* stream) {
-  SLIC_REQUIRE(partial && mean && invstd && scale && shift && R > 0 && C > 0 && M > 0, "slic_bn_finalize: bad args");
+  SLIC_REQUIRE(partial && mean && invstd && scale && shift && R > 0 && C > 0 && M > 0 && rows > 0 &&
+               (int64_t)R * rows >= M && (int64_t)(R - 1) * rows < M, "slic_bn_finalize: bad args (R*rows must cover M)");
   SLIC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "slic_bn_finalize: running stats come in pairs");
   bn_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, S_(stream)>>>(
-      partial, R, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+      partial, R, rows, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

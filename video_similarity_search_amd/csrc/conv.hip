@@ -125,9 +125,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 
   // ---- epilogue
   const bool want_stats = p.stat_partial != nullptr;
-  float csum[TN], csq[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + r;
@@ -152,9 +149,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
           } else {
             off = m * (int64_t)p.ldo + n;
           }
-          float v = acc[i][j][g] + bias;
-          if (want_stats) { csum[j] += v; csq[j] += v * v; }
-          v = v * sc + sh;
+          float v = (acc[i][j][g] + bias) * sc + sh;
           if (p.addend) v += p.addend[off];
           if (p.relu) v = fmaxf(v, 0.f);
           p.dst[off] = v;
@@ -163,26 +158,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
     }
   }
   if (want_stats) {
-    // column sums: lane halves -> waves along M (fixed order) -> one slab row per workgroup
+    // BatchNorm partials of v = acc + bias over this workgroup's valid rows, per channel:
+    //   slab[blk][0][n] = sum v          slab[blk][1][n] = sum (v - mean_blk)^2   (two passes over registers,
+    // so the variance never comes from E[x^2] - mean^2); bn_finalize merges workgroups with Chan's formula in double.
+    // Reduction order is fixed: lane halves -> waves along M -> one slab row per workgroup.
     __syncthreads();
-    float* red = lds;  // [WM][2][BN]
+    float* red = lds;             // [WM][BN]
+    float* bmean = lds + WM * BN; // [BN]
+    const int64_t left = p.M - m0;
+    const float inv_rows = 1.0f / (float)(left < BM ? left : BM);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float s = csum[j] + __shfl_xor(csum[j], 32);
-      const float q = csq[j] + __shfl_xor(csq[j], 32);
-      if (h == 0) {
-        red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + r] = s;
-        red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + r] = q;
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = wn * WTN + j * 32 + r;
+        const int n = n0 + col;
+        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+        const float mu = pass ? bmean[col] : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+            if (m < p.M) {
+              const float v = acc[i][j][g] + bias;
+              a += pass ? (v - mu) * (v - mu) : v;
+            }
+          }
+        a += __shfl_xor(a, 32);
+        if (h == 0) red[wm * BN + col] = a;
       }
-    }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid % BN;
-      float t = 0.f;
+      __syncthreads();
+      if (tid < BN) {
+        float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + col];
-      const int n = n0 + col;
-      if (n < p.N) p.stat_partial[((int64_t)blockIdx.x * 2 + which) * p.N + n] = t;
+        for (int w = 0; w < WM; ++w) t += red[w * BN + tid];
+        if (!pass) bmean[tid] = t * inv_rows;
+        const int n = n0 + tid;
+        if (n < p.N) p.stat_partial[((int64_t)blockIdx.x * 2 + pass) * p.N + n] = t;
+      }
+      __syncthreads();
     }
   }
 }

@@ -119,7 +119,7 @@ class ConvPlan:
 
     def forward(self, x, wp, B, bias=None, scale=None, shift=None, addend=None, relu=False, want_stats=False,
                 variant=0):
-        """x: [B, T, H, W, Cs] -> z: [B, To, Ho, Wo, N]; returns (z, stat_partial or None, rows_per_partial)"""
+        """x: [B, T, H, W, Cs] -> z: [B, To, Ho, Wo, N]; returns (z, (stat_partial, rows_per_partial) or None)"""
         lib = _lib.load()
         a = self._fwd_args(x, B)
         z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
@@ -137,7 +137,7 @@ class ConvPlan:
             part = torch.empty(R, 2, self.N, dtype=torch.float32, device=x.device)
             a.stat_partial = part.data_ptr()
         call("slic_conv_gemm", ctypes.byref(a), variant, stream())
-        return z, part
+        return z, ((part, tm) if want_stats else None)
 
     def dgrad(self, dz, wd, B, addend=None, out=None, variant=0):
         """dz: [B, To, Ho, Wo, N] -> dx: [B, T, H, W, Cs] = conv_transpose(dz) (+ addend; addend may be `out`

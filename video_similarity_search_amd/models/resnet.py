@@ -108,7 +108,8 @@ class _Engine:
         """finalize batch statistics (+ running stats, num_batches_tracked) from the conv epilogue's slab"""
         m = bn.mod
         bn.mean, bn.invstd, bn.scale, bn.shift = self._vec(bn.C), self._vec(bn.C), self._vec(bn.C), self._vec(bn.C)
-        call("slic_bn_finalize", ptr(part), part.shape[0], bn.C, M, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias),
+        part, rows = part
+        call("slic_bn_finalize", ptr(part), part.shape[0], rows, bn.C, M, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias),
              ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var), stream())
         m.num_batches_tracked += 1
 
