@@ -106,7 +106,11 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
             res = x
             out = F.conv3d(x, sd[pre + ".conv1.weight"], None, stride, 1)
             out = F.relu(_bn(out, sd, pre + ".bn1", training))
+            if taps is not None:
+                taps[pre + ".a1"] = out
             out = F.conv3d(out, sd[pre + ".conv2.weight"], None, 1, 1)
+            if taps is not None:
+                taps[pre + ".z2"] = out
             out = _bn(out, sd, pre + ".bn2", training)
             if pre + ".downsample.0.weight" in sd:
                 res = F.conv3d(x, sd[pre + ".downsample.0.weight"], None, stride, 0)

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 // ka = s1/M, kb = s2/M for pass 2
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int R, int C, int64_t M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ ka, float* __restrict__ kb) {
+                                       double* __restrict__ ka, double* __restrict__ kb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
@@ -137,23 +137,31 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int R,
   }
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
-  ka[c] = (float)(s1 / (double)M);
-  kb[c] = (float)(s2 / (double)M);
+  ka[c] = s1 / (double)M;
+  kb[c] = s2 / (double)M;
 }
 
-// Backward pass 2: dz = gamma*invstd * (g - ka - xhat*kb)
+// Backward pass 2: dz = gamma*invstd * (g - ka - xhat*kb).  The bracket cancels to ~(1 - xhat^2) of its terms
+// when a channel has few samples (BatchNorm1d over a small batch), so it is evaluated in double, like
+// torch's CPU kernel (accscalar = double), with the same fp32 xhat that pass 1 summed.
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ z,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ ka,
-                                    const float* __restrict__ kb, int64_t M, int C4, float* __restrict__ dz) {
+                                    const float* __restrict__ gamma, const double* __restrict__ ka,
+                                    const double* __restrict__ kb, int64_t M, int C4, float* __restrict__ dz) {
   const int64_t tot = M * C4;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e % C4);
     const f32x4 mu = ((const f32x4*)mean)[c], is = ((const f32x4*)invstd)[c];
     const f32x4 gm = ((const f32x4*)gamma)[c];
-    const f32x4 a = ((const f32x4*)ka)[c], b = ((const f32x4*)kb)[c];
     const f32x4 xh = (((const f32x4*)z)[e] - mu) * is;
-    ((f32x4*)dz)[e] = gm * is * (((const f32x4*)g)[e] - a - xh * b);
+    const f32x4 gv = ((const f32x4*)g)[e];
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double br = (double)gv[u] - ka[c * 4 + u] - (double)xh[u] * kb[c * 4 + u];
+      o[u] = (float)((double)gm[u] * (double)is[u] * br);
+    }
+    ((f32x4*)dz)[e] = o;
   }
 }
 
@@ -235,8 +243,8 @@ extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, co
   const int R = (int)slic_cdiv(M, BNB_RB);
   SlicCarver w(workspace);
   float* partial = w.take<float>((size_t)R * 2 * C);
-  float* ka = w.take<float>(C);
-  float* kb = w.take<float>(C);
+  double* ka = w.take<double>(C);
+  double* kb = w.take<double>(C);
   float* gbuf = g_out;
   if (!gbuf && out) gbuf = w.take<float>((size_t)M * C);   // masked gradient must be materialised for pass 2
   bn_bwd_reduce_kernel<<<dim3(R), dim3(256), 0, st>>>(dy, out, z, mean, invstd, M, C / 4, gbuf, partial);
@@ -249,7 +257,7 @@ extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, co
 }
 
 extern "C" size_t slic_bn_bwd_workspace_bytes(int64_t M, int C, int need_g_buffer) {
-  size_t b = slic_align_up((size_t)slic_cdiv(M, BNB_RB) * 2 * C * 4, 256) + 2 * slic_align_up((size_t)C * 4, 256);
+  size_t b = slic_align_up((size_t)slic_cdiv(M, BNB_RB) * 2 * C * 4, 256) + 2 * slic_align_up((size_t)C * 8, 256);
   if (need_g_buffer) b += slic_align_up((size_t)M * C * 4, 256);
   return b;
 }
