@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark of the MI355X hot path (contract: the round driver).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Step = one pass of the training hot path over one synthetic batch: R3D-18 (models/resnet.py depth 18, the SLIC
+encoder) forward + backward + NT-Xent ('noise_contrastive') + SGD(lr .1, momentum .5) on a
+32 x 3 x 16 x 112 x 112 fp32 batch (16 anchors || 16 positives) per GPU — BASELINE.json configs[1].
+Inputs are resident in HBM before the timed region.  N > 1: DistributedDataParallel over RCCL (gradient
+all-reduce inside the step), weak scaling (per-GPU batch fixed), value = clips of all ranks / max-over-ranks time.
+
+One JSON line on rank 0 with: the contract keys, `roofline` for the dominant kernel (the 64->64 3x3x3
+gather-GEMM, HIP events around its launches inside the timed steps), `cpu_baseline` (the CPU oracle timed on
+this host, bounded sample), and `secondary` (k-means embeddings/s at 100k x 512, K = 500 — the second half of
+BASELINE.json's metric — with its own roofline and CPU baseline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak
+GFLOP_PER_CLIP_TRAIN = 248.9         # fwd 85.17 + bwd 163.7 (2*MAC, conv + linear)
+R3D18_KW = dict(hidden_layer=2048, out_dim=128, num_classes=101, n_input_channels=3, shortcut_type='B',
+                conv1_t_size=7, conv1_t_stride=1, no_max_pool=True, widen_factor=1.0, projection_head=True,
+                predict_temporal_ds=False, spatio_temporal_attention=False, classifier=False, dropout=None)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_model(seed=7):
+    """R3D-18 with the reference's init rules (models/resnet.py:203-210), random-init (no checkpoints offline)"""
+    import contextlib
+    import io
+    from video_similarity_search_amd.models import generate_model
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = generate_model(18, **R3D18_KW)
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    return m, sd
+
+
+def cpu_baseline_encoder(sd, seconds_budget=25.0):
+    """the CPU oracle (oracle/encoder.py: the reference's math in PyTorch-CPU ops) on this host's cores:
+    fwd + bwd + NT-Xent + SGD at B = 4 (bounded sample of the same workload)"""
+    from oracle import encoder as oe
+    B = 4
+    rng = np.random.default_rng(7)
+    x = torch.from_numpy(rng.standard_normal((B, 3, 16, 112, 112)).astype(np.float32))
+    t = oe.to_torch(sd, requires_grad=True)
+    params = {k: v for k, v in t.items() if v.requires_grad}
+    bufs = {}
+
+    def step():
+        emb = oe.encoder_forward(t, x, training=True)
+        loss = oe.ntxent_loss(emb)
+        grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+        oe.sgd_step(params, grads, bufs)
+    step()                                   # warm-up
+    n, t0 = 0, time.time()
+    while n < 2 or (time.time() - t0 < seconds_budget * 0.5 and n < 6):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=B / dt, unit="clips/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/encoder.py R3D-18 fwd+bwd+NT-Xent+SGD, B={B} x 3x16x112x112 fp32, {n} steps after 1 warm-up, "
+                       f"{dt:.2f} s/step, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}")
+
+
+def kmeans_secondary(rank, world, pg, run_cpu):
+    """k-means Lloyd throughput at BASELINE configs[2]: 100k x 512, K = 500, rows sharded over the ranks, explicit init,
+    tol = 0, fixed 20 iterations: embeddings/s = N * iters / wall (assign + update + status sync + collective)"""
+    from video_similarity_search_amd.clustering import KMeans
+    N, D, K, iters = 100000, 512, 500, 20
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    init = X[rng.choice(N, K, replace=False)].copy()
+    per = (N + world - 1) // world
+    Xd = torch.from_numpy(X[rank * per:(rank + 1) * per]).cuda()
+    km = KMeans(n_clusters=K, init=init, n_init=1, max_iter=iters, tol=0.0, fixed_iters=True, process_group=pg)
+    km.fit(Xd)                                # warm-up (also allocates workspaces)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    # Lloyd phase only: time _lloyd_single through fit's pieces by re-running fit and subtracting nothing —
+    # fit = centre + tol + Lloyd + inertia; the extra passes are < 2 % of 20 iterations
+    t0 = time.time()
+    km.fit(Xd)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    out = dict(metric="k-means embeddings/sec 100kx512 K=500", value=N * iters / dt, unit="embeddings/s",
+               ms_per_iter=dt / iters * 1e3, iters=iters, n_gpus=world,
+               config=dict(workload="Lloyd, N=100000 D=512 K=500 fp32, explicit init, tol=0, 20 fixed iterations, "
+                                    "rows sharded over ranks, centroid partials all-gathered + ordered add"))
+    # E-step kernel alone (dominant kernel of this path): HIP events on the launch stream
+    from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
+    k = HipKernels()
+    n_loc = Xd.shape[0]
+    C = torch.from_numpy(init).cuda()
+    cn = torch.empty(K, device="cuda")
+    lab = torch.empty(n_loc, dtype=torch.int32, device="cuda")
+    k.cnorm(C, cn)
+    k.assign(Xd, C, cn, lab, None, None)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    e0.record()
+    for _ in range(reps):
+        k.assign(Xd, C, cn, lab, None, None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * n_loc * K * D
+    out["roofline"] = dict(bound="mfma", achieved=flops / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
+                           unit="TFLOP/s", frac=flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, traffic=None,
+                           kernel="km_assign_partial (+ km_combine)", ms_per_launch=ms,
+                           algorithmic_flops_per_launch=flops)
+    if run_cpu:
+        from oracle import kmeans as ok
+        mean = ok.col_mean(X)
+        t0 = time.time()
+        r = ok.lloyd(X - mean, init - mean, max_iter=3, tol_abs=0.0, fixed_iters=True)
+        dtc = time.time() - t0
+        out["cpu_baseline"] = dict(value=N * 4 / dtc, unit="embeddings/s", cores=ok.num_threads(), kind="port",
+                                   sample="oracle/kmeans_oracle.c (OpenMP) 3 Lloyd iterations + final E-step on the same "
+                                          f"100k x 512, K=500 data: {dtc:.2f} s")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (16 anchors || 16 positives)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        log("bench.py: --gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl")      # RCCL on ROCm
+        pg = torch.distributed.group.WORLD
+
+    from video_similarity_search_amd import _lib
+    _lib.check(_lib.load().slic_device_check(), "slic_device_check")
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+
+    model, sd = build_model()
+    model = model.cuda().train()
+    net = model
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    crit = OnlineTripletLoss(0.2, 'cosine')
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.5)
+    B = args.batch
+    rng = np.random.default_rng(7 + rank)
+    x = torch.from_numpy(rng.standard_normal((B, 3, 16, 112, 112)).astype(np.float32)).cuda()   # resident in HBM
+    labels = torch.arange(B // 2).repeat(2).cuda()
+
+    def step():
+        emb = model(x)
+        loss, _ = crit(emb, labels, sampling_strategy='noise_contrastive')
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    # dominant kernel: conv_gemm_kernel<128,64,2,2> on the 64->64 3x3x3 layers (layer1: 4 forward + 4 data-gradient
+    # launches per step, identical M x N x K) — bracket every such launch of the timed steps with HIP events
+    eng = net._engine(x)
+    l1 = [p for (_, p1, p2, _) in eng.blocks[:2] for p in (p1, p2)]
+    for p in l1:
+        p.prof = []
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    lossv = float(loss.item())
+    ev = [a.elapsed_time(b) for p in l1 for (a, b) in p.prof]
+    for p in l1:
+        p.prof = None
+    ms_k = float(np.mean(ev))
+    M = B * 16 * 56 * 56
+    flops_launch = 2.0 * M * 64 * 1728
+    ach = flops_launch / (ms_k * 1e-3) / 1e12
+
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_gemm.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    res = dict(metric="clips/sec R3D-18+NCE (1/2/4/8 GPU); k-means embeddings/sec 100kx512",
+               value=world * B * args.steps / dt, unit="clips/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
+               config=dict(workload="R3D-18 (3D-ResNet-18, 34.52 M params, no maxpool, 7^3 stem) fwd+bwd + NT-Xent "
+                                    "(noise_contrastive, T=0.5) + SGD(lr .1, mom .5); per-GPU batch "
+                                    f"{B} x 3x16x112x112 fp32 = {B//2} anchors || {B//2} positives; BASELINE configs[1]",
+                           global_batch=world * B, parallelism=f"dp{world}", final_loss=lossv),
+               roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                             frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
+                             kernel="conv_gemm_kernel<128,64,2,2> (64->64 3x3x3 gather-GEMM, fwd + dgrad of layer1)",
+                             ms_per_launch=ms_k, launches_timed=len(ev), algorithmic_flops_per_launch=flops_launch,
+                             whole_step_frac=(world * B * args.steps / dt) * GFLOP_PER_CLIP_TRAIN / 1e3 /
+                                             (FP32_MFMA_PEAK_TFLOPS * world)))
+    if not args.no_secondary:
+        try:
+            res["secondary"] = kmeans_secondary(rank, world, pg, run_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        except Exception as e:                                    # never lose the headline line
+            res["secondary"] = dict(error=repr(e))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_encoder(sd)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,7 @@ class ConvPlan:
                                            tab=torch.from_numpy(t).to(device)))
         self._wp = None
         self._wd = None
+        self.prof = None      # bench.py: list collecting (start, end) HIP event pairs around conv_gemm launches
 
     # ------------------------------------------------------------------ weights
     def pack_fwd(self, weight):
@@ -136,8 +137,18 @@ class ConvPlan:
             R = (a.M + tm - 1) // tm
             part = torch.empty(R, 2, self.N, dtype=torch.float32, device=x.device)
             a.stat_partial = part.data_ptr()
-        call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+        self._launch(a, variant)
         return z, ((part, tm) if want_stats else None)
+
+    def _launch(self, a, variant):
+        if self.prof is None:
+            call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                      # torch's current stream == the stream the kernel is launched on
+        call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+        e1.record()
+        self.prof.append((e0, e1))
 
     def dgrad(self, dz, wd, B, addend=None, out=None, variant=0):
         """dz: [B, To, Ho, Wo, N] -> dx: [B, T, H, W, Cs] = conv_transpose(dz) (+ addend; addend may be `out`
@@ -165,7 +176,7 @@ class ConvPlan:
             a.Da, a.Db, a.Dc = T, H, W
             a.da, a.db, a.dc = self.stride
             a.ea, a.eb, a.ec = dc["cls"]
-            call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+            self._launch(a, variant)
         return dx
 
     def wgrad(self, x, dz, B, dW, splits=None):
