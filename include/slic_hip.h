@@ -190,9 +190,10 @@ int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* 
  * over `rows` rows per workgroup (the last one ragged), merged in workgroup order in double (Chan's formula):
  * mean, invstd = 1/sqrt(biased var + eps), scale = gamma*invstd, shift = beta - mean*scale; running stats
  * (optional pair) get the momentum update with the unbiased variance. */
+size_t slic_bn_finalize_workspace_bytes(int R, int C);
 int slic_bn_finalize(const float* partial, int R, int rows, int C, int64_t M, float eps, float momentum,
                      const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
-                     float* shift, float* running_mean, float* running_var, void* stream);
+                     float* shift, float* running_mean, float* running_var, void* workspace, void* stream);
 /* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta - running_mean*scale */
 int slic_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, int C, float* scale, float* shift, void* stream);

@@ -87,7 +87,7 @@ def test_bn_train_fwd_bwd(gpu):
     from video_similarity_search_amd import _lib
     lib = _lib.load()
     rng = np.random.default_rng(4)
-    for M, C in [(5000, 64), (300, 2048), (77, 8), (1031, 48)]:
+    for M, C in [(5000, 64), (300, 2048), (77, 8), (1031, 48), (700000, 64)]:
         z = torch.from_numpy((rng.standard_normal((M, C)) * 2 + 0.5).astype(np.float32))
         gam = torch.from_numpy((1 + 0.1 * rng.standard_normal(C)).astype(np.float32))
         bet = torch.from_numpy((0.1 * rng.standard_normal(C)).astype(np.float32))
@@ -107,8 +107,9 @@ def test_bn_train_fwd_bwd(gpu):
         zd, gd, bd, resd, dyd, partd = [t.cuda() for t in (z, gam, bet, res, dy, part)]
         mean, invstd, scale, shift = [torch.empty(C, device="cuda") for _ in range(4)]
         rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        wsf = torch.empty(lib.slic_bn_finalize_workspace_bytes(R, C), dtype=torch.uint8, device="cuda")
         call("slic_bn_finalize", ptr(partd), R, 128, C, M, 1e-5, 0.1, ptr(gd), ptr(bd), ptr(mean), ptr(invstd), ptr(scale),
-             ptr(shift), ptr(rmd), ptr(rvd), stream())
+             ptr(shift), ptr(rmd), ptr(rvd), ptr(wsf), stream())
         y = torch.empty_like(zd)
         call("slic_bn_apply", ptr(zd), ptr(scale), ptr(shift), ptr(resd), 1, M, C, ptr(y), stream())
         assert (y.cpu() - y64.float()).abs().max() < 2e-5

@@ -47,7 +47,8 @@ SIGNATURES = {
     "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
     "slic_ncdhw_to_ndhwc": (I, [P, I, I, L, I, P, P]),
     # batch norm / pool
-    "slic_bn_finalize": (I, [P, I, I, I, L, F, F, P, P, P, P, P, P, P, P, P]),
+    "slic_bn_finalize_workspace_bytes": (c_size_t, [I, I]),
+    "slic_bn_finalize": (I, [P, I, I, I, L, F, F, P, P, P, P, P, P, P, P, P, P]),
     "slic_bn_eval_affine": (I, [P, P, P, P, F, I, P, P, P]),
     "slic_bn_apply": (I, [P, P, P, P, I, L, I, P, P]),
     "slic_bn_bwd_workspace_bytes": (c_size_t, [L, I, I]),

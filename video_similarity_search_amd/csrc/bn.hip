@@ -7,29 +7,49 @@
 // bn_bwd_reduce) are added in workgroup order in double.
 #include "common.h"
 
-// mean / biased var from the per-workgroup slab of (sum, M2 = sum (x - mean_blk)^2) over `rows` rows each,
-// merged in workgroup order in double (Chan et al. pairwise update);
+// Merging the per-workgroup BatchNorm partials.  A slab row r covers rows_in rows (the last one ragged) and holds
+// (sum, M2 = sum (x - mean_row)^2) per channel.  One level merges groups of MG consecutive slab rows with Chan's
+// pairwise update in double, in row order (deterministic); levels repeat until one row is left, then
+// bn_finalize_last turns it into mean / invstd / scale / shift (+ running stats).  Thread = (group, channel):
+// coalesced across channels, MG serial steps — a 12544-row slab (layer1 at B = 32) takes 3 short launches
+// instead of one 12544-step serial loop.
+#define BN_MG 64
+template <typename Tin>
+__global__ void bn_merge_level(const Tin* __restrict__ in, int R, int64_t rows_in, int C, int64_t M,
+                               double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (c >= C) return;
+  const int r0 = grp * BN_MG;
+  const int r1 = r0 + BN_MG < R ? r0 + BN_MG : R;
+  double n = 0.0, mean = 0.0, m2 = 0.0, sum = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    const int64_t left = M - (int64_t)r * rows_in;
+    const double nb = (double)(left < rows_in ? left : rows_in);
+    const double sb = (double)in[((int64_t)r * 2 + 0) * C + c];
+    const double mb = sb / nb;
+    const double d = mb - mean;
+    const double nn = n + nb;
+    m2 += (double)in[((int64_t)r * 2 + 1) * C + c] + d * d * n * nb / nn;
+    mean += d * nb / nn;
+    sum += sb;
+    n = nn;
+  }
+  out[((int64_t)grp * 2 + 0) * C + c] = sum;
+  out[((int64_t)grp * 2 + 1) * C + c] = m2;
+}
+
 // scale = gamma*invstd, shift = beta - mean*scale; running stats: momentum update with the UNBIASED variance
 // (torch semantics; models/resnet.py uses the defaults eps = 1e-5, momentum = 0.1).
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int R, int rows, int C, int64_t M, float eps,
-                                   float momentum, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
+__global__ void bn_finalize_last(const double* __restrict__ tot, int C, int64_t M, float eps, float momentum,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                 float* __restrict__ shift, float* __restrict__ running_mean,
+                                 float* __restrict__ running_var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s = 0.0;
-  for (int r = 0; r < R; ++r) s += (double)partial[((int64_t)r * 2 + 0) * C + c];
-  const double mu = s / (double)M;
-  double m2 = 0.0;
-  for (int r = 0; r < R; ++r) {
-    const int64_t left = M - (int64_t)r * rows;
-    const double nb = (double)(left < rows ? left : rows);
-    const double d = (double)partial[((int64_t)r * 2 + 0) * C + c] / nb - mu;
-    m2 += (double)partial[((int64_t)r * 2 + 1) * C + c] + nb * d * d;
-  }
-  double var = m2 / (double)M;
+  const double mu = tot[c] / (double)M;
+  double var = tot[C + c] / (double)M;
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -43,6 +63,23 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int R, int
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
   }
+}
+
+// plain two-plane sums in double, groups of BN_MG slab rows in row order (BatchNorm backward partials)
+template <typename Tin>
+__global__ void sum_merge_level(const Tin* __restrict__ in, int R, int C, double* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (c >= C) return;
+  const int r0 = grp * BN_MG;
+  const int r1 = r0 + BN_MG < R ? r0 + BN_MG : R;
+  double a = 0.0, b = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    a += (double)in[((int64_t)r * 2 + 0) * C + c];
+    b += (double)in[((int64_t)r * 2 + 1) * C + c];
+  }
+  out[((int64_t)grp * 2 + 0) * C + c] = a;
+  out[((int64_t)grp * 2 + 1) * C + c] = b;
 }
 
 // eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
@@ -123,18 +160,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   }
 }
 
-// dgamma = s2, dbeta = s1 (sums of the partial slab, workgroup order, double);
-// ka = s1/M, kb = s2/M for pass 2
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int R, int C, int64_t M,
+// dgamma = s2, dbeta = s1 from the merged partials; ka = s1/M, kb = s2/M for pass 2
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ tot, int C, int64_t M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        double* __restrict__ ka, double* __restrict__ kb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < R; ++r) {
-    s1 += (double)partial[((int64_t)r * 2 + 0) * C + c];
-    s2 += (double)partial[((int64_t)r * 2 + 1) * C + c];
-  }
+  const double s1 = tot[c], s2 = tot[C + c];
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
   ka[c] = s1 / (double)M;
@@ -202,15 +234,59 @@ static inline unsigned ew_grid(int64_t tot) {
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
+// scratch for the merge levels: level l holds ceil(R / MG^l) rows of 2*C doubles (two ping-pong buffers)
+static size_t merge_ws_bytes(int R, int C) {
+  const size_t rows1 = (size_t)slic_cdiv(R, BN_MG);
+  return 2 * slic_align_up(rows1 * 2 * C * sizeof(double), 256);
+}
+// runs the levels; returns the pointer to the final [2][C] double row (inside ws)
+template <bool CHAN>
+static int run_merge(const float* partial, int R, int64_t rows, int C, int64_t M, void* ws, hipStream_t st,
+                     const double** final_row) {
+  const size_t half = merge_ws_bytes(R, C) / 2;
+  double* buf[2] = {(double*)ws, (double*)((char*)ws + half)};
+  int cur = 0;
+  int Rl = R;
+  int64_t rows_l = rows;
+  dim3 blk(64);
+  {
+    const int Ro = (int)slic_cdiv(Rl, BN_MG);
+    dim3 grid((unsigned)slic_cdiv(C, 64), (unsigned)Ro);
+    if (CHAN) bn_merge_level<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, buf[cur]);
+    else sum_merge_level<float><<<grid, blk, 0, st>>>(partial, Rl, C, buf[cur]);
+    SLIC_LAUNCH_CHECK();
+    Rl = Ro;
+    rows_l *= BN_MG;
+  }
+  while (Rl > 1) {
+    const int Ro = (int)slic_cdiv(Rl, BN_MG);
+    dim3 grid((unsigned)slic_cdiv(C, 64), (unsigned)Ro);
+    if (CHAN) bn_merge_level<double><<<grid, blk, 0, st>>>(buf[cur], Rl, rows_l, C, M, buf[cur ^ 1]);
+    else sum_merge_level<double><<<grid, blk, 0, st>>>(buf[cur], Rl, C, buf[cur ^ 1]);
+    SLIC_LAUNCH_CHECK();
+    cur ^= 1;
+    Rl = Ro;
+    rows_l *= BN_MG;
+  }
+  *final_row = buf[cur];
+  return SLIC_OK;
+}
+
+extern "C" size_t slic_bn_finalize_workspace_bytes(int R, int C) { return merge_ws_bytes(R, C); }
+
 extern "C" int slic_bn_finalize(const float* partial, int R, int rows, int C, int64_t M, float eps, float momentum,
                                 const float* gamma, const float* beta, float* mean, float* invstd,
                                 float* scale, float* shift, float* running_mean, float* running_var,
-                                void* stream) {
-  SLIC_REQUIRE(partial && mean && invstd && scale && shift && R > 0 && C > 0 && M > 0 && rows > 0 &&
+                                void* workspace, void* stream) {
+  SLIC_REQUIRE(partial && mean && invstd && scale && shift && workspace && R > 0 && C > 0 && M > 0 && rows > 0 &&
                (int64_t)R * rows >= M && (int64_t)(R - 1) * rows < M, "slic_bn_finalize: bad args (R*rows must cover M)");
   SLIC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "slic_bn_finalize: running stats come in pairs");
-  bn_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, S_(stream)>>>(
-      partial, R, rows, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  hipStream_t st = S_(stream);
+  const double* tot = nullptr;
+  int rc = run_merge<true>(partial, R, rows, C, M, workspace, st, &tot);
+  if (rc) return rc;
+  bn_finalize_last<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(
+      tot, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -241,15 +317,19 @@ extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, co
                "slic_bn_bwd: bad args (C %% 4 == 0)");
   hipStream_t st = S_(stream);
   const int R = (int)slic_cdiv(M, BNB_RB);
-  SlicCarver w(workspace);
+  SlicCarver w(workspace);                                   // same order as slic_bn_bwd_workspace_bytes
   float* partial = w.take<float>((size_t)R * 2 * C);
   double* ka = w.take<double>(C);
   double* kb = w.take<double>(C);
+  void* mws = w.take<char>(merge_ws_bytes(R, C));
   float* gbuf = g_out;
-  if (!gbuf && out) gbuf = w.take<float>((size_t)M * C);   // masked gradient must be materialised for pass 2
+  if (!gbuf && out) gbuf = w.take<float>((size_t)M * C);     // masked gradient must be materialised for pass 2
   bn_bwd_reduce_kernel<<<dim3(R), dim3(256), 0, st>>>(dy, out, z, mean, invstd, M, C / 4, gbuf, partial);
   SLIC_LAUNCH_CHECK();
-  bn_bwd_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(partial, R, C, M, dgamma, dbeta, ka, kb);
+  const double* tot = nullptr;
+  int rc = run_merge<false>(partial, R, BNB_RB, C, M, mws, st, &tot);
+  if (rc) return rc;
+  bn_bwd_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(tot, C, M, dgamma, dbeta, ka, kb);
   SLIC_LAUNCH_CHECK();
   bn_bwd_apply_kernel<<<dim3(ew_grid(M * (C / 4))), dim3(256), 0, st>>>(gbuf ? gbuf : dy, z, mean, invstd, gamma, ka, kb, M, C / 4, dz);
   SLIC_LAUNCH_CHECK();
@@ -257,7 +337,9 @@ extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, co
 }
 
 extern "C" size_t slic_bn_bwd_workspace_bytes(int64_t M, int C, int need_g_buffer) {
-  size_t b = slic_align_up((size_t)slic_cdiv(M, BNB_RB) * 2 * C * 4, 256) + 2 * slic_align_up((size_t)C * 8, 256);
+  const int R = (int)slic_cdiv(M, BNB_RB);
+  size_t b = slic_align_up((size_t)R * 2 * C * 4, 256) + 2 * slic_align_up((size_t)C * 8, 256) +
+             slic_align_up(merge_ws_bytes(R, C), 256);
   if (need_g_buffer) b += slic_align_up((size_t)M * C * 4, 256);
   return b;
 }

@@ -109,8 +109,10 @@ class _Engine:
         m = bn.mod
         bn.mean, bn.invstd, bn.scale, bn.shift = self._vec(bn.C), self._vec(bn.C), self._vec(bn.C), self._vec(bn.C)
         part, rows = part
+        ws = _lib.workspace(_lib.load().slic_bn_finalize_workspace_bytes(part.shape[0], bn.C), part.device, "bn_fin")
         call("slic_bn_finalize", ptr(part), part.shape[0], rows, bn.C, M, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias),
-             ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var), stream())
+             ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var),
+             ptr(ws), stream())
         m.num_batches_tracked += 1
 
     def _bn_eval(self, bn):
