@@ -231,6 +231,41 @@ int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclide
 /* [n, n] distance matrix of the rows of V (loss/triplet_loss.py:429-437 pdist) */
 int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Cosine top-k retrieval (iic_retrieve_clips.py:275-314 topk_retrieval; evaluate.py:208-231,287-307):
+ * sklearn cosine_distances + argsort/argpartition on the host become a fused similarity GEMM +
+ * streaming top-k; the Nq x Ng matrix is never written.
+ * ---------------------------------------------------------------------------------------- */
+/* sklearn.preprocessing.normalize(X, 'l2'): out[i,:] = X[i,:] / ||X[i,:]|| (zero rows unchanged); out is dense [N, D] */
+int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, float* out, void* stream);
+/* for every row of Qn the k nearest rows of Gn by cosine distance clip(1 - q.g, 0, 2), ascending (ties -> lower
+ * gallery index).  Qn/Gn: normalised, dense [N, D], D % 8 == 0.  self_mask != 0 skips j == i
+ * (np.fill_diagonal(distance_matrix, inf), evaluate.py:221-222).  k <= 128. */
+size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k);
+int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
+                     int32_t* out_idx, float* out_dist, void* workspace, void* stream);
+/* euclidean_distances(X, Y) as a dense [Nx, Ny] matrix (evaluate.py:216; validation-size inputs) */
+int slic_pairwise_euclidean(const float* X, int Nx, const float* Y, int Ny, int D, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Memory-bank NCE (loss/NCE_loss.py:26-88 NCEAverage, :341-352 NCESoftmaxLoss): gather + dot + /T without
+ * materialising the gathered rows, its backward wrt the features, the momentum bank update, and the
+ * class-0 softmax cross-entropy.  idx / y are int64 (torch.long) as in the reference.
+ * ---------------------------------------------------------------------------------------- */
+/* out[b, j] = <bank[idx[b, j], :], f[b, :]> / T      idx: [B, K1], bank: [n_data, D], D % 4 == 0.
+ * gathered (optional, [B*K1, D]): the rows as scored, written in the same pass — the training path needs them
+ * for the backward because the bank is updated in place right after scoring (NCE_loss.py:73-86). */
+int slic_nce_scores_fwd(const float* bank, const int64_t* idx, const float* f, int B, int K1, int D, float T,
+                        float* out, float* gathered, void* stream);
+/* df[b, :] = (1/T) sum_j dout[b, j] * bank[idx[b, j], :] */
+int slic_nce_scores_bwd(const float* bank, const int64_t* idx, const float* dout, int B, int K1, int D, float T,
+                        float* df, void* stream);
+/* bank[y[b]] = normalise(momentum * bank[y[b]] + (1 - momentum) * f[b])  (NCE_loss.py:73-86) */
+int slic_nce_bank_update(float* bank, const int64_t* y, const float* f, int B, int D, float momentum, void* stream);
+/* loss = mean_b (logsumexp(x[b, :]) - x[b, 0]); lse/rowloss: [B] scratch kept for the backward */
+int slic_softmax_ce0_fwd(const float* x, int B, int K1, float* lse, float* rowloss, float* loss, void* stream);
+int slic_softmax_ce0_bwd(const float* x, const float* lse, int B, int K1, const float* gscale, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

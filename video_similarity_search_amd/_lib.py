@@ -63,6 +63,17 @@ SIGNATURES = {
     "slic_ntxent_bwd": (I, [P, I, I, F, P, P, I, P]),
     "slic_pair_distance": (I, [P, P, I, I, I, P, P]),
     "slic_pdist": (I, [P, I, I, F, I, P, P]),
+    # retrieval
+    "slic_normalize_rows": (I, [P, L, I, I, P, P]),
+    "slic_cosine_topk_workspace_bytes": (c_size_t, [I, I, I]),
+    "slic_cosine_topk": (I, [P, I, P, I, I, I, I, P, P, P, P]),
+    "slic_pairwise_euclidean": (I, [P, I, P, I, I, P, P]),
+    # memory-bank NCE
+    "slic_nce_scores_fwd": (I, [P, P, P, I, I, I, F, P, P, P]),
+    "slic_nce_scores_bwd": (I, [P, P, P, I, I, I, F, P, P]),
+    "slic_nce_bank_update": (I, [P, P, P, I, I, F, P]),
+    "slic_softmax_ce0_fwd": (I, [P, I, I, P, P, P, P]),
+    "slic_softmax_ce0_bwd": (I, [P, P, I, I, P, P, P]),
 }
 
 

@@ -1,0 +1,272 @@
+// Cosine top-k retrieval: fused fp32-MFMA similarity GEMM + per-query streaming top-k.
+//
+// Replaces the host path of /root/reference/iic_retrieve_clips.py:295-296 (sklearn cosine_distances over
+// 10k x 100k, then a full np.argsort per row) and evaluate.py:208-231 (cosine_distances + argpartition):
+// the 4 GB distance matrix is never written.  Rows are L2-normalised first (sklearn normalize: zero rows
+// stay zero), similarity s = q_hat . g_hat on v_mfma_f32_32x32x2_f32, distance = clip(1 - s, 0, 2).
+//
+// Workgroup = 128 queries x one slice of the gallery, walked in 128-row tiles (same LDS staging as
+// kmeans.hip).  MFMA roles: A = gallery tile (rows), B = query tile (cols)  =>  lane (r, h) holds query r and
+// 16 gallery rows per accumulator; the h = 0 lane of each pair owns the query's running top-k (an unsorted
+// k-slot list in LDS + its current worst entry in registers) and also consumes its partner's 16 values.
+// A candidate replaces the worst slot and triggers a k-step rescan — O(k log(Ng/k)) times per query in
+// expectation, negligible next to the 64-cycle MFMAs.  Order: larger s first, ties -> lower gallery index.
+// slic_topk_merge folds the per-slice lists into the final sorted [Nq, k].
+#include "common.h"
+#include <math.h>
+#include <limits.h>
+
+#define TK_BQ 128
+#define TK_BG 128
+#define TK_BK 32
+
+__device__ __forceinline__ int tk_off(int row, int chunk) {
+  return row * TK_BK + ((chunk ^ ((row >> 1) & 7)) << 2);
+}
+
+__device__ __forceinline__ bool tk_better(float s, int i, float t, int ti) {
+  return s > t || (s == t && i < ti);
+}
+
+__global__ __launch_bounds__(256) void topk_partial_kernel(
+    const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
+    int g_per_slice, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* stage = lds;                                   // [2][2][128*32]
+  float* lval = lds + 2 * 2 * TK_BQ * TK_BK;             // [4 waves][k][32]
+  int* lidx = (int*)(lval + 4 * k * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * TK_BQ;
+  const int gbeg = blockIdx.y * g_per_slice;
+  const int gend = min(gbeg + g_per_slice, Ng);
+  float* myv = lval + wave * k * 32;
+  int* myi = lidx + wave * k * 32;
+  if (h == 0)
+    for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
+  float thr = -INFINITY;     // worst kept entry
+  int thr_i = INT_MAX, thr_slot = 0;
+  const int q = q0 + 32 * wave + r;
+
+  const int srow = tid >> 2, scp = tid & 3;
+  const float* qr[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    int qq = q0 + srow + 64 * p;
+    if (qq > Nq - 1) qq = Nq - 1;
+    qr[p] = Q + (int64_t)qq * D + scp * 8;
+  }
+  const int nk = (D + TK_BK - 1) / TK_BK;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int g0 = gbeg; g0 < gend; g0 += TK_BG) {
+    const float* gr[2];
+    bool gv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int gg = g0 + srow + 64 * p;
+      gv[p] = gg < gend;
+      if (gg > Ng - 1) gg = Ng - 1;
+      gr[p] = G + (int64_t)gg * D + scp * 8;
+    }
+    f32x4 xq[2][2], xg[2][2];
+    auto gload = [&](int kt) {
+      const int k0 = kt * TK_BK;
+      const bool kin = (k0 + scp * 8) < D;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        if (kin) { xq[p][0] = *(const f32x4*)(qr[p] + k0); xq[p][1] = *(const f32x4*)(qr[p] + k0 + 4); }
+        else { xq[p][0] = z4; xq[p][1] = z4; }
+        if (kin && gv[p]) { xg[p][0] = *(const f32x4*)(gr[p] + k0); xg[p][1] = *(const f32x4*)(gr[p] + k0 + 4); }
+        else { xg[p][0] = z4; xg[p][1] = z4; }
+      }
+    };
+    auto lwrite = [&](int buf) {
+      float* Gs = stage + (buf * 2 + 0) * TK_BQ * TK_BK;
+      float* Qs = stage + (buf * 2 + 1) * TK_BQ * TK_BK;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = srow + 64 * p;
+        *(f32x4*)&Qs[tk_off(row, 2 * scp)] = xq[p][0];
+        *(f32x4*)&Qs[tk_off(row, 2 * scp + 1)] = xq[p][1];
+        *(f32x4*)&Gs[tk_off(row, 2 * scp)] = xg[p][0];
+        *(f32x4*)&Gs[tk_off(row, 2 * scp + 1)] = xg[p][1];
+      }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ct][v] = 0.f;
+    __syncthreads();           // previous tile's readers are done with the staging buffers
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      const float* Gs = stage + (buf * 2 + 0) * TK_BQ * TK_BK;
+      const float* Qs = stage + (buf * 2 + 1) * TK_BQ * TK_BK;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 b = *(const f32x4*)&Qs[tk_off(32 * wave + r, 2 * qd + h)];
+        f32x4 a[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) a[ct] = *(const f32x4*)&Gs[tk_off(32 * ct + r, 2 * qd + h)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][t], b[t], acc[ct], 0, 0, 0);
+      }
+      if (kt + 1 < nk) lwrite(buf ^ 1);
+      __syncthreads();
+    }
+    // ---- top-k update: the h == 0 lane of a pair consumes both halves' values
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float own = acc[ct][v];
+        const float oth = __shfl_xor(own, 32);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float s = half ? oth : own;
+          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+          const bool cand = (h == 0) && (q < Nq) && (gi < gend) && !(self_mask && gi == q) &&
+                            tk_better(s, gi, thr, thr_i);
+          if (cand) {
+            myv[thr_slot * 32 + r] = s;
+            myi[thr_slot * 32 + r] = gi;
+            float w = INFINITY; int wi = -1, ws = 0;       // rescan for the new worst entry
+            for (int t = 0; t < k; ++t) {
+              const float tv = myv[t * 32 + r];
+              const int ti = myi[t * 32 + r];
+              if (tk_better(w, wi, tv, ti)) { w = tv; wi = ti; ws = t; }
+            }
+            thr = w; thr_i = wi; thr_slot = ws;
+          }
+        }
+      }
+  }
+  if (h == 0 && q < Nq) {
+    float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
+    int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq + q) * k;
+    for (int s = 0; s < k; ++s) { ov[s] = myv[s * 32 + r]; oi[s] = myi[s * 32 + r]; }
+  }
+}
+
+// one thread per query: k rounds of selection over the slices' lists (best = larger s, ties -> lower index)
+__global__ void topk_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx, int slices,
+                                  int Nq, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Nq) return;
+  float last = INFINITY;
+  int last_i = -1;
+  for (int o = 0; o < k; ++o) {
+    float bs = -INFINITY;
+    int bi = INT_MAX;
+    for (int sl = 0; sl < slices; ++sl) {
+      const float* v = pval + ((int64_t)sl * Nq + q) * k;
+      const int32_t* ix = pidx + ((int64_t)sl * Nq + q) * k;
+      for (int t = 0; t < k; ++t) {
+        const float s = v[t];
+        const int i = ix[t];
+        // strictly after (last, last_i) in the order, and better than the current best
+        if (tk_better(last, last_i, s, i) && tk_better(s, i, bs, bi)) { bs = s; bi = i; }
+      }
+    }
+    out_idx[(int64_t)q * k + o] = bi == INT_MAX ? -1 : bi;
+    float d = 1.0f - bs;
+    d = fminf(fmaxf(d, 0.f), 2.f);
+    out_dist[(int64_t)q * k + o] = bi == INT_MAX ? INFINITY : d;
+    last = bs; last_i = bi;
+  }
+}
+
+// sklearn.preprocessing.normalize(X) (l2): rows with zero norm are left as they are
+__global__ void normalize_rows_sklearn(const float* __restrict__ X, int64_t N, int D, int ldx,
+                                       float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = X + row * ldx;
+  double s = 0.0;
+  for (int k = lane; k < D; k += 64) { const double v = (double)x[k]; s += v * v; }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  float nrm = (float)sqrt(s);
+  if (nrm == 0.f) nrm = 1.f;
+  for (int k = lane; k < D; k += 64) out[row * D + k] = x[k] / nrm;
+}
+
+// euclidean_distances(X, Y) (evaluate.py:216): one thread per (i, j), direct (x - y)^2 sum
+__global__ void pairwise_euclid_kernel(const float* __restrict__ X, int Nx, const float* __restrict__ Y, int Ny,
+                                       int D, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)Nx * Ny) return;
+  const int i = (int)(e / Ny), j = (int)(e % Ny);
+  const float* x = X + (int64_t)i * D;
+  const float* y = Y + (int64_t)j * D;
+  float a = 0.f;
+  for (int k = 0; k < D; ++k) { const float d = x[k] - y[k]; a = fmaf(d, d, a); }
+  out[e] = sqrtf(a);
+}
+
+static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+
+extern "C" int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, float* out, void* stream) {
+  SLIC_REQUIRE(X && out && N > 0 && D > 0 && ldx >= D, "slic_normalize_rows: bad args");
+  normalize_rows_sklearn<<<dim3((unsigned)slic_cdiv(N, 4)), dim3(256), 0, S_(stream)>>>(X, N, D, ldx, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+static int topk_slices(int Nq, int Ng) {
+  const int qb = (int)slic_cdiv(Nq, TK_BQ);
+  int s = (int)slic_cdiv(1024, qb);                 // aim at ~4 workgroups per CU
+  const int maxs = (int)slic_cdiv(Ng, 4 * TK_BG);   // at least 4 gallery tiles per slice
+  if (s > maxs) s = maxs;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
+  return 2 * slic_align_up((size_t)topk_slices(Nq, Ng) * Nq * k * 4, 256);
+}
+
+// Qn, Gn: L2-normalised rows (slic_normalize_rows).  out_idx / out_dist: [Nq, k], ascending distance.
+extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
+                                int32_t* out_idx, float* out_dist, void* workspace, void* stream) {
+  SLIC_REQUIRE(Qn && Gn && out_idx && out_dist && workspace, "slic_cosine_topk: null pointer");
+  SLIC_REQUIRE(Nq > 0 && Ng > 0 && D > 0 && D % 8 == 0 && k >= 1 && k <= 128 && k <= Ng,
+               "slic_cosine_topk: need D %% 8 == 0, 1 <= k <= min(128, Ng) (Nq=%d Ng=%d D=%d k=%d)", Nq, Ng, D, k);
+  SLIC_REQUIRE(((uintptr_t)Qn % 16) == 0 && ((uintptr_t)Gn % 16) == 0, "slic_cosine_topk: unaligned");
+  hipStream_t st = S_(stream);
+  const int slices = topk_slices(Nq, Ng);
+  int per = (int)slic_cdiv(Ng, slices);
+  per = (int)slic_cdiv(per, TK_BG) * TK_BG;
+  const int S = (int)slic_cdiv(Ng, per);
+  SlicCarver w(workspace);
+  float* pval = w.take<float>((size_t)slices * Nq * k);
+  int32_t* pidx = w.take<int32_t>((size_t)slices * Nq * k);
+  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2) * sizeof(float);
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
+  topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pval, pidx);
+  SLIC_LAUNCH_CHECK();
+  topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 64)), dim3(64), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_pairwise_euclidean(const float* X, int Nx, const float* Y, int Ny, int D, float* out,
+                                       void* stream) {
+  SLIC_REQUIRE(X && Y && out && Nx > 0 && Ny > 0 && D > 0, "slic_pairwise_euclidean: bad args");
+  const int64_t tot = (int64_t)Nx * Ny;
+  pairwise_euclid_kernel<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(X, Nx, Y, Ny, D, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}

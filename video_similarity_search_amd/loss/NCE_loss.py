@@ -1,0 +1,160 @@
+"""
+Drop-in for the memory-bank NCE of the reference's loss/NCE_loss.py:
+    NCEAverage(inputSize, outputSize, K, T, momentum)(l, ab, y, idx=None) -> (out_l, out_ab)   <- :10-88
+    NCESoftmaxLoss()(x) -> scalar                                                               <- :341-352
+    AliasMethod(probs).draw(N)                                                                  <- :246-307
+Same buffers (`params`, `memory_l`, `memory_ab`), same cross-wiring (out_ab is scored against memory_l, out_l
+against memory_ab), bank rows detached, momentum update + renormalise under no_grad.  The gather+bmm, its
+backward, the bank update and the class-0 cross-entropy are HIP kernels (csrc/nce.hip); the
+use_softmax=False branch (Z normalisation constants) is not used by SLIC and raises.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .._lib import call, ptr, stream
+
+
+class AliasMethod(object):
+    """Sampler over `probs`.  The reference builds alias tables on the host and draws with
+    index_select + bernoulli (loss/NCE_loss.py:246-307); NCEAverage always passes uniform weights
+    (`torch.ones(nLem)`, :14-15), for which every alias-table entry has prob 1 and the draw reduces to
+    uniform integers — that is what this class does on the device.  Non-uniform tables are built the
+    reference's way and sampled with torch ops (cold path)."""
+
+    def __init__(self, probs):
+        probs = probs.clone().float()
+        if probs.sum() > 1:
+            probs.div_(probs.sum())
+        K = len(probs)
+        self.n = K
+        self.uniform = bool(torch.allclose(probs, torch.full_like(probs, 1.0 / K)))
+        self.prob = torch.ones(K)
+        self.alias = torch.zeros(K, dtype=torch.long)
+        if not self.uniform:
+            smaller, larger = [], []
+            for kk, p in enumerate(probs):
+                self.prob[kk] = K * p
+                (smaller if self.prob[kk] < 1.0 else larger).append(kk)
+            while len(smaller) > 0 and len(larger) > 0:
+                small, large = smaller.pop(), larger.pop()
+                self.alias[small] = large
+                self.prob[large] = (self.prob[large] - 1.0) + self.prob[small]
+                (smaller if self.prob[large] < 1.0 else larger).append(large)
+            for last_one in smaller + larger:
+                self.prob[last_one] = 1
+        self.device = torch.device("cpu")
+
+    def cuda(self):
+        self.device = torch.device("cuda")
+        self.prob = self.prob.cuda()
+        self.alias = self.alias.cuda()
+
+    def draw(self, N):
+        kk = torch.randint(0, self.n, (N,), dtype=torch.long, device=self.prob.device)
+        if self.uniform:
+            return kk
+        b = torch.bernoulli(self.prob.index_select(0, kk))
+        return kk.mul(b.long()) + self.alias.index_select(0, kk).mul((1 - b).long())
+
+
+class _BankScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, bank, idx, T):
+        f = feat.contiguous().float()
+        B, D = f.shape
+        K1 = idx.shape[1]
+        out = torch.empty(B, K1, 1, dtype=torch.float32, device=f.device)
+        # NCEAverage updates the bank in place right after scoring, so a training pass keeps the rows as scored
+        # (written by the same kernel pass that reads them); under no_grad nothing is kept.
+        rows = torch.empty(B * K1, D, dtype=torch.float32, device=f.device) if ctx.needs_input_grad[0] else None
+        call("slic_nce_scores_fwd", ptr(bank), ptr(idx), ptr(f), B, K1, D, float(T), ptr(out), ptr(rows), stream())
+        ctx.T, ctx.shape, ctx.rows = float(T), (B, K1, D), rows
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, K1, D = ctx.shape
+        g = g.contiguous().float()
+        df = torch.empty(B, D, dtype=torch.float32, device=g.device)
+        ident = torch.arange(B * K1, dtype=torch.long, device=g.device).view(B, K1)
+        call("slic_nce_scores_bwd", ptr(ctx.rows), ptr(ident), ptr(g), B, K1, D, ctx.T, ptr(df), stream())
+        ctx.rows = None
+        return df, None, None, None
+
+
+class NCEAverage(nn.Module):
+    # outputSize = ndata, inputSize = num of features
+    def __init__(self, inputSize, outputSize, K, T=0.07, momentum=0.5, use_softmax=True):
+        super(NCEAverage, self).__init__()
+        _lib.load()
+        self.nLem = outputSize
+        self.unigrams = torch.ones(self.nLem)
+        self.multinomial = AliasMethod(self.unigrams)
+        self.multinomial.cuda()
+        self.K = K
+        self.use_softmax = use_softmax
+        if not use_softmax:
+            raise NotImplementedError("use_softmax=False (Z_l / Z_ab constants) is never selected by SLIC "
+                                      "(online_train.py:701-702 builds NCEAverage with the default)")
+        self.register_buffer('params', torch.tensor([K, T, -1, -1, momentum]))
+        stdv = 1. / math.sqrt(inputSize / 3)
+        self.register_buffer('memory_l', torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
+        self.register_buffer('memory_ab', torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
+
+    def forward(self, l, ab, y, idx=None):  # index = y = label
+        K = int(self.params[0].item())
+        T = self.params[1].item()
+        momentum = self.params[4].item()
+        batchSize = l.size(0)
+        if not l.is_cuda:
+            raise _lib.SlicError("NCEAverage needs device tensors (no CPU fallback)")
+        if idx is None:
+            idx = self.multinomial.draw(batchSize * (self.K + 1)).view(batchSize, -1)
+            idx.select(1, 0).copy_(y.data)
+        idx = idx.contiguous()
+        y = y.contiguous()
+        # out_ab scores ab against memory_l, out_l scores l against memory_ab (NCE_loss.py:41-48)
+        out_ab = _BankScores.apply(ab, self.memory_l, idx, T)
+        out_l = _BankScores.apply(l, self.memory_ab, idx, T)
+        with torch.no_grad():   # update memory (NCE_loss.py:73-86)
+            B, D = l.shape
+            call("slic_nce_bank_update", ptr(self.memory_l), ptr(y), ptr(l.detach().contiguous().float()), B, D,
+                 float(momentum), stream())
+            call("slic_nce_bank_update", ptr(self.memory_ab), ptr(y), ptr(ab.detach().contiguous().float()), B, D,
+                 float(momentum), stream())
+        return out_l, out_ab
+
+
+class _SoftmaxCE0(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, K1 = x.shape
+        lse = torch.empty(B, dtype=torch.float32, device=x.device)
+        rowloss = torch.empty(B, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        call("slic_softmax_ce0_fwd", ptr(x), B, K1, ptr(lse), ptr(rowloss), ptr(loss), stream())
+        ctx.save_for_backward(x, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lse = ctx.saved_tensors
+        B, K1 = x.shape
+        dx = torch.empty_like(x)
+        call("slic_softmax_ce0_bwd", ptr(x), ptr(lse), B, K1, ptr(g.contiguous().float()), ptr(dx), stream())
+        return dx
+
+
+class NCESoftmaxLoss(nn.Module):
+    """Softmax cross-entropy loss (a.k.a., info-NCE loss in CPC paper) against class 0"""
+
+    def __init__(self):
+        super(NCESoftmaxLoss, self).__init__()
+
+    def forward(self, x):
+        bsz = x.shape[0]
+        x = x.reshape(bsz, -1).contiguous().float()      # x.squeeze() of [B, K+1, 1]
+        return _SoftmaxCE0.apply(x)
