@@ -145,15 +145,18 @@ typedef struct SlicConvArgs {
   const float* src;        /* gathered operand: [B, Ts, Hs, Ws, Cs] */
   const float* wgt;        /* packed weights [N][ldw], k = table column (conv_gemm only) */
   float* dst;              /* output (conv_gemm only) */
-  const int32_t* tab;      /* [nchunks][4] per 16-byte K-chunk: {src element delta, packed tap offsets
-                              ((oa+128) | (ob+128)<<8 | (oc+128)<<16, or -1 = all-zero chunk),
-                              weight column of the chunk, 0} */
+  const int32_t* tab;      /* [nchunks][4] per 16-byte K-chunk: {src element delta,
+                              tap mask (1<<(oa+3)) | (1<<(7+ob+3)) | (1<<(14+oc+3)) for tap offsets |o| <= 3, or -1 = all-zero chunk,
+                              weight column of the chunk,
+                              packed tap offsets (oa+128) | (ob+128)<<8 | (oc+128)<<16} */
   const float* bias;       /* [N] or NULL */
   const float* scale;      /* [N] or NULL: v = v*scale + shift (eval-mode BatchNorm) */
   const float* shift;      /* [N] or NULL */
   const float* addend;     /* same addressing as dst, or NULL: v += addend (residual / grad accumulate) */
   float* stat_partial;     /* [ceil(M/tile_m)][2][N] per-workgroup (sum, sum (v - mean_wg)^2) of v = acc+bias, or NULL */
   int64_t M;               /* rows = B * Ga * Gb * Gc */
+  uint32_t src_bytes;      /* size of the src tensor in bytes (< 4 GiB: loads are range-checked buffer loads) */
+  uint32_t wgt_bytes;      /* size of the packed weight matrix in bytes */
   int N;                   /* output channels */
   int nchunks;             /* K / 4, multiple of 8 */
   int Cs, Ts, Hs, Ws;      /* source dims */

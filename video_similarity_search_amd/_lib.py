@@ -83,6 +83,7 @@ class SlicConvArgs(ctypes.Structure):
         ("src", P), ("wgt", P), ("dst", P), ("tab", P), ("bias", P), ("scale", P), ("shift", P),
         ("addend", P), ("stat_partial", P),
         ("M", L),
+        ("src_bytes", ctypes.c_uint32), ("wgt_bytes", ctypes.c_uint32),
         ("N", I), ("nchunks", I), ("Cs", I), ("Ts", I), ("Hs", I), ("Ws", I),
         ("Ga", I), ("Gb", I), ("Gc", I), ("sa", I), ("sb", I), ("sc", I),
         ("ldw", I), ("ldo", I),

@@ -36,52 +36,67 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
-  // ---- staging setup: thread owns chunk column cq of rows srow + 32 i
+  // ---- staging setup: thread owns chunk column cq of rows srow + 32 i.
+  // Loads are buffer loads (raw, stride 0): an out-of-range offset returns zeros, so padding taps, ragged rows
+  // and ragged channels need no branch and no select — the bounds test just picks the offset.
   const int cq = tid & 7, srow = tid >> 3;
-  int64_t abase[AL];
-  int a0[AL], b0[AL], c0[AL];
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned aoff[AL];    // byte offset of the row's base pixel
+  unsigned rmask[AL];   // bit (7*dim + o + 3) set iff base coordinate + o is inside the source along dim
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int64_t m = m0 + srow + 32 * i;
+    aoff[i] = 0; rmask[i] = 0;
     if (m < p.M) {
-      int64_t r = m;
-      const int gc = (int)(r % p.Gc); r /= p.Gc;
-      const int gb = (int)(r % p.Gb); r /= p.Gb;
-      const int ga = (int)(r % p.Ga); r /= p.Ga;   // r = batch
-      a0[i] = ga * p.sa; b0[i] = gb * p.sb; c0[i] = gc * p.sc;
-      abase[i] = ((((int64_t)r * p.Ts + a0[i]) * p.Hs + b0[i]) * p.Ws + c0[i]) * p.Cs;
-    } else {
-      a0[i] = -(1 << 20); b0[i] = 0; c0[i] = 0; abase[i] = 0;
+      unsigned rr = (unsigned)m;                     // M < 2^31 (checked on the host)
+      const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+      const int gb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+      const int ga = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;   // rr = batch
+      const int a0 = ga * p.sa, b0 = gb * p.sb, c0 = gc * p.sc;
+      aoff[i] = (((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
+      unsigned mk = 0;
+#pragma unroll
+      for (int o = -3; o <= 3; ++o) {
+        mk |= ((unsigned)(a0 + o) < (unsigned)p.Ts ? 1u : 0u) << (o + 3);
+        mk |= ((unsigned)(b0 + o) < (unsigned)p.Hs ? 1u : 0u) << (7 + o + 3);
+        mk |= ((unsigned)(c0 + o) < (unsigned)p.Ws ? 1u : 0u) << (14 + o + 3);
+      }
+      rmask[i] = mk;
     }
   }
-  const float* wrow[BL];
-  bool wvalid[BL];
+  unsigned woff[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
     const int n = n0 + srow + 32 * i;
-    wvalid[i] = n < p.N;
-    wrow[i] = p.wgt + (int64_t)(wvalid[i] ? n : 0) * p.ldw;
+    woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 4u : OOB;
   }
-  f32x4 ga[AL], gb[BL];
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  i32x4 ga[AL], gb[BL];
+  const int nk = p.nchunks >> 3;
+  int4 e_next = nk > 0 ? ((const int4*)p.tab)[cq] : make_int4(0, -1, 0, 0);   // table entry one tile ahead
   auto gload = [&](int kt) {
-    const int4 e = ((const int4*)p.tab)[kt * 8 + cq];
-    const bool cv = e.y >= 0;
-    const int oa = (e.y & 255) - 128, ob = ((e.y >> 8) & 255) - 128, oc = ((e.y >> 16) & 255) - 128;
+    const int4 e = e_next;
+    const unsigned tm = (unsigned)e.y;             // 0xFFFFFFFF for an all-zero chunk: never a subset of rmask
+    const unsigned dlt = (unsigned)e.x * 4u;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      const bool ok = cv && (unsigned)(a0[i] + oa) < (unsigned)p.Ts &&
-                      (unsigned)(b0[i] + ob) < (unsigned)p.Hs && (unsigned)(c0[i] + oc) < (unsigned)p.Ws;
-      ga[i] = ok ? *(const f32x4*)(p.src + abase[i] + e.x) : z4;
+      const unsigned off = ((rmask[i] & tm) == tm) ? aoff[i] + dlt : OOB;
+      ga[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)off, 0, 0);
     }
+    const unsigned wc = e.y == -1 ? OOB : (unsigned)e.z * 4u;
 #pragma unroll
-    for (int i = 0; i < BL; ++i) gb[i] = (cv && wvalid[i]) ? *(const f32x4*)(wrow[i] + e.z) : z4;
+    for (int i = 0; i < BL; ++i) {
+      const unsigned off = (woff[i] == OOB || wc == OOB) ? OOB : woff[i] + wc;
+      gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, (int)off, 0, 0);
+    }
+    if (kt + 1 < nk) e_next = ((const int4*)p.tab)[(kt + 1) * 8 + cq];
   };
   auto lwrite = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AL; ++i) *(f32x4*)&As[buf * BM * 32 + cv_off(srow + 32 * i, cq)] = ga[i];
+    for (int i = 0; i < AL; ++i) *(i32x4*)&As[buf * BM * 32 + cv_off(srow + 32 * i, cq)] = ga[i];
 #pragma unroll
-    for (int i = 0; i < BL; ++i) *(f32x4*)&Bs[buf * BN * 32 + cv_off(srow + 32 * i, cq)] = gb[i];
+    for (int i = 0; i < BL; ++i) *(i32x4*)&Bs[buf * BN * 32 + cv_off(srow + 32 * i, cq)] = gb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -93,7 +108,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
   const int r = lane & 31, h = lane >> 5;
-  const int nk = p.nchunks >> 3;
   if (nk > 0) {
     gload(0);
     lwrite(0);
@@ -104,20 +118,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
     if (kt + 1 < nk) gload(kt + 1);
     const float* Ab = As + buf * BM * 32;
     const float* Bb = Bs + buf * BN * 32;
+    f32x4 a[2][TM], b[2][TN];     // LDS operands double-buffered in registers: group q+1 is in flight under q's MFMAs
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      f32x4 a[TM], b[TN];
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * q + h)];
+        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * q + h)];
+        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) lwrite(buf ^ 1);
     __syncthreads();
@@ -125,6 +146,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 
   // ---- epilogue
   const bool want_stats = p.stat_partial != nullptr;
+  int64_t roff[TM][16];           // dst row offsets (elements), one decode per accumulator row
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (p.dst_strided && m < p.M) {
+        unsigned q = (unsigned)m;
+        const unsigned gc = q % (unsigned)p.Gc; q /= (unsigned)p.Gc;
+        const unsigned gbb = q % (unsigned)p.Gb; q /= (unsigned)p.Gb;
+        const unsigned gaa = q % (unsigned)p.Ga; q /= (unsigned)p.Ga;
+        roff[i][g] = ((((int64_t)q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc +
+                      gc * p.dc + p.ec) * (int64_t)p.ldo;
+      } else {
+        roff[i][g] = m * (int64_t)p.ldo;
+      }
+    }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + r;
@@ -138,17 +176,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
       for (int g = 0; g < 16; ++g) {
         const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         if (m < p.M && nv) {
-          int64_t off;
-          if (p.dst_strided) {
-            int64_t q = m;
-            const int gc = (int)(q % p.Gc); q /= p.Gc;
-            const int gbb = (int)(q % p.Gb); q /= p.Gb;
-            const int gaa = (int)(q % p.Ga); q /= p.Ga;
-            off = ((((int64_t)q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc +
-                   gc * p.dc + p.ec) * (int64_t)p.ldo + n;
-          } else {
-            off = m * (int64_t)p.ldo + n;
-          }
+          const int64_t off = roff[i][g] + n;
           float v = (acc[i][j][g] + bias) * sc + sh;
           if (p.addend) v += p.addend[off];
           if (p.relu) v = fmaxf(v, 0.f);
@@ -213,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // ------------------------------------------------------------------------------------------
 template <int G>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, const float* __restrict__ dy,
-                                                         int ldy, float* __restrict__ slab,
+                                                         int ldy, unsigned dy_bytes, float* __restrict__ slab,
                                                          int m_per_split) {
   __shared__ __attribute__((aligned(16))) float Xs[2][G][32 * 64];
   __shared__ __attribute__((aligned(16))) float Ys[2][32 * 64];
@@ -235,34 +263,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
     const int q = kc0 + g * 16 + cq;
     e[g] = q < p.nchunks ? ((const int4*)p.tab)[q] : make_int4(0, -1, 0, 0);
     cv[g] = e[g].y >= 0;
-    oa[g] = (e[g].y & 255) - 128; ob[g] = ((e[g].y >> 8) & 255) - 128; oc[g] = ((e[g].y >> 16) & 255) - 128;
+    oa[g] = (e[g].w & 255) - 128; ob[g] = ((e[g].w >> 8) & 255) - 128; oc[g] = ((e[g].w >> 16) & 255) - 128;
   }
   const bool nvalid = (n0 + cq * 4) < p.N;
-  f32x4 gx[G][2], gy[2];
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  i32x4 gx[G][2], gy[2];
   auto gload = [&](int64_t mt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = mt + srow + 16 * i;
-      if (m < mend) {
-        int64_t rr = m;
-        const int gc = (int)(rr % p.Gc); rr /= p.Gc;
-        const int gbb = (int)(rr % p.Gb); rr /= p.Gb;
-        const int gaa = (int)(rr % p.Ga); rr /= p.Ga;
-        const int a0 = gaa * p.sa, b0 = gbb * p.sb, c0 = gc * p.sc;
-        const int64_t base = ((((int64_t)rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * p.Cs;
+      const bool mv = m < mend;
+      unsigned rr = mv ? (unsigned)m : 0u;
+      const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+      const int gbb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+      const int gaa = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
+      const int a0 = gaa * p.sa, b0 = gbb * p.sb, c0 = gc * p.sc;
+      const unsigned base = (((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const bool ok = cv[g] && (unsigned)(a0 + oa[g]) < (unsigned)p.Ts &&
-                          (unsigned)(b0 + ob[g]) < (unsigned)p.Hs && (unsigned)(c0 + oc[g]) < (unsigned)p.Ws;
-          gx[g][i] = ok ? *(const f32x4*)(p.src + base + e[g].x) : z4;
-        }
-        gy[i] = nvalid ? *(const f32x4*)(dy + m * (int64_t)ldy + n0 + cq * 4) : z4;
-      } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g) gx[g][i] = z4;
-        gy[i] = z4;
+      for (int g = 0; g < G; ++g) {
+        const bool ok = mv && cv[g] && (unsigned)(a0 + oa[g]) < (unsigned)p.Ts &&
+                        (unsigned)(b0 + ob[g]) < (unsigned)p.Hs && (unsigned)(c0 + oc[g]) < (unsigned)p.Ws;
+        gx[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(ok ? base + (unsigned)e[g].x * 4u : OOB), 0, 0);
       }
+      const unsigned yo = (mv && nvalid) ? (unsigned)(m * ldy + n0 + cq * 4) * 4u : OOB;
+      gy[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)yo, 0, 0);
     }
   };
   auto lwrite = [&](int buf) {
@@ -270,8 +296,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
     for (int i = 0; i < 2; ++i) {
       const int row = srow + 16 * i;
 #pragma unroll
-      for (int g = 0; g < G; ++g) *(f32x4*)&Xs[buf][g][row * 64 + cq * 4] = gx[g][i];
-      *(f32x4*)&Ys[buf][row * 64 + cq * 4] = gy[i];
+      for (int g = 0; g < G; ++g) *(i32x4*)&Xs[buf][g][row * 64 + cq * 4] = gx[g][i];
+      *(i32x4*)&Ys[buf][row * 64 + cq * 4] = gy[i];
     }
   };
   f32x16 acc[G];
@@ -372,7 +398,9 @@ static int validate(const SlicConvArgs* a, const char* who) {
   SLIC_REQUIRE(a->M > 0 && a->N > 0 && a->Ga > 0 && a->Gb > 0 && a->Gc > 0 && a->Ts > 0 && a->Hs > 0 && a->Ws > 0,
                "%s: bad shape", who);
   SLIC_REQUIRE(a->M % ((int64_t)a->Ga * a->Gb * a->Gc) == 0, "%s: M is not batch * grid", who);
+  SLIC_REQUIRE(a->M < (1ll << 31), "%s: M >= 2^31 rows (split the batch)", who);
   SLIC_REQUIRE(((uintptr_t)a->src % 16) == 0, "%s: src not 16-byte aligned", who);
+  SLIC_REQUIRE(a->src_bytes > 0 && a->src_bytes < 0xFFFFFF00u, "%s: src_bytes must be set and < 4 GiB (split the batch)", who);
   return SLIC_OK;
 }
 
@@ -397,8 +425,7 @@ extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
   if (variant == 2) return 64;
   if (variant == 3) return 256;
   if (!a) return 128;
-  const int64_t blocks128 = slic_cdiv(a->M, 128) * slic_cdiv(a->N, a->N > 64 ? 128 : 64);
-  return blocks128 >= 512 ? 128 : 64;
+  return 64;   // 64 x 64 tiles (5 workgroups / CU): measured fastest on every R3D-18 shape (scripts/bench_conv.py)
 }
 
 extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) {
@@ -406,6 +433,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   if (rc) return rc;
   SLIC_REQUIRE(a->wgt && a->dst && a->ldw % 4 == 0 && a->ldo >= 1, "slic_conv_gemm: bad weight/dst");
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
+  SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   hipStream_t st = S_(stream);
   const int bm = slic_conv_tile_m(a, variant);
   if (bm == 256) return launch_gemm<256, 64, 4, 1>(*a, st);
@@ -436,7 +464,9 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   const int Kp = a->nchunks * 4;
   constexpr int G = 2;
   dim3 grid((unsigned)slic_cdiv(a->nchunks, 16 * G), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
-  conv_wgrad_kernel<G><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, slab, (int)per);
+  const int64_t dyb = a->M * (int64_t)ldy * 4;
+  SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad: dy larger than 4 GiB (split the batch)");
+  conv_wgrad_kernel<G><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)a->N * C * ntaps;
   conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, dW);

@@ -79,13 +79,15 @@ def get_distance_matrix(x_embeddings, y_embeddings=None, dist_metric='cosine'):
         Np = (Ny + 3) // 4 * 4
         tab = np.zeros((Dp // 4, 4), np.int32)
         tab[:, 0] = np.arange(Dp // 4) * 4
-        tab[:, 1] = 128 | (128 << 8) | (128 << 16)
+        tab[:, 1] = (1 << 3) | (1 << 10) | (1 << 17)          # tap offset (0, 0, 0)
         tab[:, 2] = np.arange(Dp // 4) * 4
+        tab[:, 3] = 128 | (128 << 8) | (128 << 16)
         tabd = torch.from_numpy(tab).to(x.device)
         sc = torch.full((Np,), -1.0, device=x.device)
         sh = torch.full((Np,), 1.0, device=x.device)
         a = SlicConvArgs()
         a.src, a.wgt, a.dst, a.tab = xn.data_ptr(), yn.data_ptr(), out.data_ptr(), tabd.data_ptr()
+        a.src_bytes, a.wgt_bytes = xn.numel() * 4, yn.numel() * 4
         a.scale, a.shift, a.relu = sc.data_ptr(), sh.data_ptr(), 1
         a.M, a.N, a.nchunks = Nx, Ny, Dp // 4
         a.Cs, a.Ts, a.Hs, a.Ws = Dp, 1, 1, 1

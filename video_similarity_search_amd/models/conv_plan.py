@@ -26,6 +26,12 @@ def _pack_off(oa, ob, oc):
     return (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
 
 
+def _tap_mask(oa, ob, oc):
+    """bit (7*dim + o + 3): the row's precomputed in-bounds mask must contain all three"""
+    assert max(abs(oa), abs(ob), abs(oc)) <= 3, "tap offsets beyond +-3 are not supported by the row mask"
+    return (1 << (oa + 3)) | (1 << (7 + ob + 3)) | (1 << (14 + oc + 3))
+
+
 class ConvPlan:
     """One conv layer at one input size.  kernel/stride/pad are (t, h, w) triples."""
 
@@ -50,8 +56,10 @@ class ConvPlan:
         dt, dh, dw = tap // (kh * kw), (tap // kw) % kh, tap % kw
         oa, ob, oc = dt - self.pad[0], dh - self.pad[1], dw - self.pad[2]
         tab[:nch, 0] = ((oa * H + ob) * W + oc) * self.Cs + c
-        tab[:nch, 1] = (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
+        assert max(self.pad) <= 3 and all(k - 1 - p <= 3 for k, p in zip(self.kernel, self.pad))
+        tab[:nch, 1] = (1 << (oa + 3)) | (1 << (7 + ob + 3)) | (1 << (14 + oc + 3))
         tab[:nch, 2] = q * 4
+        tab[:nch, 3] = (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
         self.tab_fwd = torch.from_numpy(tab).to(device)
         self.Kp = self.nchunks_fwd * 4                      # packed forward weight row length
         # ---- data-gradient tables: src = dY [B, To, Ho, Wo, N], k = tap*N + n, one per parity class
@@ -75,9 +83,9 @@ class ConvPlan:
             for (dt_, oa_), (dh_, ob_), (dw_, oc_) in itertools.product(*valid):
                 tap_ = (dt_ * kh + dh_) * kw + dw_
                 base = ((oa_ * Ho + ob_) * Wo + oc_) * self.N
-                po = _pack_off(oa_, ob_, oc_)
+                po, tmk = _pack_off(oa_, ob_, oc_), _tap_mask(oa_, ob_, oc_)
                 for n4 in range(nq):
-                    rows.append((base + n4 * 4, po, tap_ * self.N + n4 * 4, 0))
+                    rows.append((base + n4 * 4, tmk, tap_ * self.N + n4 * 4, po))
             nchd = _pad8(len(rows))
             t = np.zeros((max(nchd, 8), 4), np.int32)
             t[:, 1] = -1
@@ -108,6 +116,7 @@ class ConvPlan:
         T, H, W = self.in_dims
         To, Ho, Wo = self.out_dims
         a.src = x.data_ptr()
+        a.src_bytes = x.numel() * 4
         a.tab = self.tab_fwd.data_ptr()
         a.M = B * To * Ho * Wo
         a.N = self.N
@@ -125,6 +134,7 @@ class ConvPlan:
         a = self._fwd_args(x, B)
         z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
         a.wgt = wp.data_ptr()
+        a.wgt_bytes = wp.numel() * 4
         a.dst = z.data_ptr()
         a.bias = bias.data_ptr() if bias is not None else None
         a.scale = scale.data_ptr() if scale is not None else None
@@ -159,7 +169,9 @@ class ConvPlan:
         for dc in self.dgrad_classes:
             a = SlicConvArgs()
             a.src = dz.data_ptr()
+            a.src_bytes = dz.numel() * 4
             a.wgt = wd.data_ptr()
+            a.wgt_bytes = wd.numel() * 4
             a.dst = dx.data_ptr()
             a.tab = dc["tab"].data_ptr()
             a.addend = addend.data_ptr() if addend is not None else None
