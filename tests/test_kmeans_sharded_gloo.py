@@ -1,0 +1,86 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the sharded k-means (KMeans(process_group=...)) — per-iteration
+all-gather of [sums | counts], rank-ordered combine, n_changed all-reduce, relocation candidate merge — driven with
+the oracle-backed kernel provider, and checked against the single-process oracle run with n_shards = 2.
+Also the reference-shaped collectives of misc/distributed_helper.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.distributed.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    try:
+        from kmeans_cpu_kernels import OracleKernels
+        from video_similarity_search_amd.clustering.kmeans_hip import KMeans
+        import video_similarity_search_amd.misc.distributed_helper as du
+        g = dict(np.load(case))
+        X, init = g["X"], g["init"]
+        N = len(X)
+        per = (N + world - 1) // world
+        shard = torch.from_numpy(X[rank * per:(rank + 1) * per])
+        km = KMeans(n_clusters=init.shape[0], init=init, n_init=1, process_group=torch.distributed.group.WORLD,
+                    kernels=OracleKernels(), trace=True).fit(shard)
+        # reference-shaped helpers (misc/distributed_helper.py:41-64)
+        t = torch.tensor([float(rank + 1)])
+        du.all_reduce([t], avg=True)
+        gl = du.all_gather([torch.from_numpy(km.labels_.astype(np.int64))])[0]
+        assert abs(t.item() - (world + 1) / 2) < 1e-6 and du.get_world_size() == world
+        assert du.is_master_proc() == (rank == 0)
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=km.labels_, centers=km.cluster_centers_, n_iter=km.n_iter_,
+                 strict=km.strict_, inertia=km.inertia_, all_labels=gl.numpy(), nreloc=km.n_relocations_)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["clustered_empty", "d128"])
+def test_sharded_kmeans_two_ranks_gloo(golden_dir, tmp_path, name):
+    from oracle import kmeans as ok
+    case = os.path.join(golden_dir, f"kmeans_{name}.npz")
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    g = dict(np.load(case))
+    X, init = g["X"], g["init"]
+    mean = ok.col_mean(X)
+    Xc = X - mean
+    ref = ok.lloyd(Xc, init - mean, tol_abs=ok.tolerance(Xc, 1e-4), n_shards=world)
+    r0, r1 = (dict(np.load(os.path.join(tmp_path, f"r{r}.npz"))) for r in range(world))
+    labels = np.concatenate([r0["labels"], r1["labels"]])
+    assert np.array_equal(labels, ref["labels"])                      # sharded run == oracle with n_shards = 2
+    assert np.array_equal(labels, g["labels"])                        # and sklearn's golden
+    assert np.array_equal(r0["all_labels"], labels) and np.array_equal(r1["all_labels"], labels)
+    assert int(r0["n_iter"]) == int(r1["n_iter"]) == ref["n_iter"]
+    assert bool(r0["strict"]) == ref["strict"]
+    assert np.array_equal(r0["centers"], r1["centers"])               # every rank holds bit-identical centres
+    np.testing.assert_allclose(r0["centers"], ref["centers"] + mean, rtol=0, atol=1e-6)
+    assert abs(float(r0["inertia"]) - ref["inertia"]) <= 1e-9 * ref["inertia"]
+    if name == "clustered_empty":
+        assert int(r0["nreloc"]) >= 1
+
+
+def test_single_process_driver_matches_oracle_cpu(golden_dir):
+    """the host control flow (no process group) with the oracle-backed kernels reproduces the oracle's Lloyd run"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kmeans_cpu_kernels import OracleKernels
+    from oracle import kmeans as ok
+    from video_similarity_search_amd.clustering.kmeans_hip import KMeans
+    g = dict(np.load(os.path.join(golden_dir, "kmeans_unstructured.npz")))
+    km = KMeans(n_clusters=16, init=g["init"], n_init=1, kernels=OracleKernels(), trace=True).fit(torch.from_numpy(g["X"]))
+    assert km.n_iter_ == int(g["n_iter"]) and np.array_equal(km.labels_, g["labels"])
+    for m in range(1, km.n_iter_):
+        assert np.array_equal(km.trace_[m], g["trace"][m - 1])

@@ -138,9 +138,9 @@ class KMeans:
     def _gather(self, t):
         """all-gather a per-rank tensor [*] -> [W, *] (same shape on every rank)"""
         W = torch.distributed.get_world_size(self.process_group)
-        out = torch.empty((W,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        torch.distributed.all_gather_into_tensor(out, t.contiguous(), group=self.process_group)
-        return out
+        flat = torch.empty(W * t.numel(), dtype=t.dtype, device=t.device)      # concatenated form (gloo and RCCL)
+        torch.distributed.all_gather_into_tensor(flat, t.contiguous().reshape(-1), group=self.process_group)
+        return flat.view((W,) + tuple(t.shape))
 
     def _col_stats(self, X):
         """global column sum / sum of squares as float64 numpy (rank partials added in rank order)"""
@@ -258,7 +258,7 @@ class KMeans:
             cur = labels
             k.accumulate(Xc, labels, K, sums, counts)
             if self._sharded:
-                torch.distributed.all_gather_into_tensor(allpart, part, group=self.process_group)
+                torch.distributed.all_gather_into_tensor(allpart.view(-1), part, group=self.process_group)
                 k.combine_shards(allpart, K, Dp, gsums, gcounts)
                 torch.distributed.all_reduce(n_changed, group=self.process_group)
             k.finalize(C, gsums, gcounts, Cn, shift, n_changed, status)
