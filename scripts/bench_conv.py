@@ -34,6 +34,10 @@ for name, C, N, k, s, p, dims in SHAPES:
     dz = torch.randn((B,) + plan.out_dims + (N,), device="cuda")
     dW = torch.empty_like(w)
     line = f"{name:12s} M={M:8d} N={N:4d} K={C*k[0]*k[1]*k[2]:6d} {fl/1e9:7.1f} GF |"
+    if os.environ.get("WGONLY"):
+        t = timeit(lambda: plan.wgrad(x, dz, B, dW))
+        print(f"{name.split()[0]}:{fl/t/1e9:.0f}", end=" ", flush=True)
+        continue
     for v in (1, 2, 3):
         t = timeit(lambda: plan.forward(x, wp, B, want_stats=True, variant=v))
         line += f" fwd v{v} {fl/t/1e9:6.1f}"

@@ -20,6 +20,7 @@
 // to a slab that bn.hip reduces in fixed order (deterministic train-mode statistics).
 #include "common.h"
 #include "conv_common.h"
+#include <stdlib.h>
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
+      // issue order: next group's LDS reads first, then this group's MFMAs (reads land under 4*TM*TN*64 cycles)
+      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
     if (kt + 1 < nk) lwrite(buf ^ 1);
     __syncthreads();
@@ -462,11 +466,17 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   per = slic_cdiv(per, 32) * 32;
   const int S = (int)slic_cdiv(a->M, per);
   const int Kp = a->nchunks * 4;
-  constexpr int G = 2;
-  dim3 grid((unsigned)slic_cdiv(a->nchunks, 16 * G), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
   const int64_t dyb = a->M * (int64_t)ldy * 4;
   SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad: dy larger than 4 GiB (split the batch)");
-  conv_wgrad_kernel<G><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
+  const char* gv = getenv("SLIC_WGRAD_G");      // tuning knob (scripts/bench_conv.py); default picked below
+  const int G = gv ? atoi(gv) : 2;
+  if (G == 2) {
+    dim3 grid((unsigned)slic_cdiv(a->nchunks, 32), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
+    conv_wgrad_kernel<2><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
+  } else {
+    dim3 grid((unsigned)slic_cdiv(a->nchunks, 16), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
+    conv_wgrad_kernel<1><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
+  }
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)a->N * C * ntaps;
   conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, dW);

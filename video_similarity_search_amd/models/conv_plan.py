@@ -9,6 +9,7 @@ the reference layout [N, C, kt, kh, kw] (state_dict-compatible) and are re-packe
 """
 import ctypes
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -196,8 +197,12 @@ class ConvPlan:
         lib = _lib.load()
         a = self._fwd_args(x, B)
         if splits is None:
-            blocks = ((self.nchunks_fwd + 31) // 32) * ((self.N + 63) // 64)
-            splits = max(1, min((1024 + blocks - 1) // blocks, (a.M + 255) // 256))
+            # measured (scripts/bench_conv.py, WGONLY=1 sweep): 128 x 64 output tiles, ~3000 workgroups, but at
+            # least 1024 positions per slice so the slabs of the small-M layers stay small
+            G = int(os.environ.get("SLIC_WGRAD_G", "2"))
+            target = int(os.environ.get("SLIC_WGRAD_BLOCKS", "3072"))
+            blocks = ((self.nchunks_fwd + 16 * G - 1) // (16 * G)) * ((self.N + 63) // 64)
+            splits = max(1, min((target + blocks - 1) // blocks, (a.M + 1023) // 1024))
         ws = _lib.workspace(lib.slic_conv_wgrad_workspace_bytes(ctypes.byref(a), splits), x.device, "wgrad")
         call("slic_conv_wgrad", ctypes.byref(a), ptr(dz), self.N, splits, self.C, self.ntaps, ptr(dW), ptr(ws), stream())
         return dW
