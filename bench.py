@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (16 anchors || 16 positives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="init the process group / DDP / sharded k-means even at world size 1 (path test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,8 +160,13 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     pg = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.distributed.init_process_group(backend="nccl")      # RCCL on ROCm
         pg = torch.distributed.group.WORLD
 
@@ -171,7 +177,7 @@ def main():
     model, sd = build_model()
     model = model.cuda().train()
     net = model
-    if world > 1:
+    if use_dist:
         model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
     crit = OnlineTripletLoss(0.2, 'cosine')
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.5)
@@ -250,7 +256,7 @@ def main():
         res["cpu_baseline"] = cpu_baseline_encoder(sd)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

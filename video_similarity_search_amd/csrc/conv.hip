@@ -73,10 +73,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
     const int n = n0 + srow + 32 * i;
     woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 4u : OOB;
   }
-  i32x4 ga[AL], gb[BL];
+  // two register staging sets: tile kt+2 is in flight while tile kt is computed and tile kt+1 is written to LDS,
+  // so a load has a whole k-tile (plus the other workgroups' tiles) to come back from L2 / Infinity Cache / HBM
+  i32x4 ga0[AL], gb0[BL], ga1[AL], gb1[BL];
   const int nk = p.nchunks >> 3;
   int4 e_next = nk > 0 ? ((const int4*)p.tab)[cq] : make_int4(0, -1, 0, 0);   // table entry one tile ahead
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, i32x4 (&ga)[AL], i32x4 (&gb)[BL]) {
     const int4 e = e_next;
     const unsigned tm = (unsigned)e.y;             // 0xFFFFFFFF for an all-zero chunk: never a subset of rmask
     const unsigned dlt = (unsigned)e.x * 4u;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
     }
     if (kt + 1 < nk) e_next = ((const int4*)p.tab)[(kt + 1) * 8 + cq];
   };
-  auto lwrite = [&](int buf) {
+  auto lwrite = [&](int buf, i32x4 (&ga)[AL], i32x4 (&gb)[BL]) {
 #pragma unroll
     for (int i = 0; i < AL; ++i) *(i32x4*)&As[buf * BM * 32 + cv_off(srow + 32 * i, cq)] = ga[i];
 #pragma unroll
@@ -109,14 +111,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
   const int r = lane & 31, h = lane >> 5;
-  if (nk > 0) {
-    gload(0);
-    lwrite(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
+  auto compute = [&](int buf) {
     const float* Ab = As + buf * BM * 32;
     const float* Bb = Bs + buf * BN * 32;
     f32x4 a[2][TM], b[2][TN];     // LDS operands double-buffered in registers: group q+1 is in flight under q's MFMAs
@@ -144,7 +139,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
       if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
-    if (kt + 1 < nk) lwrite(buf ^ 1);
+  };
+  if (nk > 0) {
+    gload(0, ga0, gb0);
+    lwrite(0, ga0, gb0);
+    if (nk > 1) gload(1, ga1, gb1);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even tile: set 0 is free (tile kt sits in LDS), set 1 carries tile kt+1
+    if (kt + 2 < nk) gload(kt + 2, ga0, gb0);
+    compute(0);
+    if (kt + 1 < nk) lwrite(1, ga1, gb1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd tile
+    if (kt + 3 < nk) gload(kt + 3, ga1, gb1);
+    compute(1);
+    if (kt + 2 < nk) lwrite(0, ga0, gb0);
     __syncthreads();
   }
 
