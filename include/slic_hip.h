@@ -231,6 +231,13 @@ int slic_ntxent_bwd(const void* workspace, int n, int D, float temperature, cons
 /* rowwise distance of two [n, D] matrices: 1 - cos (per-norm clamp 1e-8) or ||x - y + 1e-6||_2
  * (models/triplet_net.py:29-33: F.cosine_similarity / F.pairwise_distance) */
 int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclidean, float* out, void* stream);
+/* LLC margin term of triplet_train_epoch (online_train.py:317-332): loss = mean_i max(0, (1 - cos(x_i, y_i)) -
+ * (1 - cos(x_i, z_i)) + margin)  (MarginRankingLoss with target -1 on the two cosine distances).
+ * state: [n, 8] floats kept for bwd; rowloss: [n] scratch.  bwd: gradients to all three inputs. */
+int slic_margin_cos_fwd(const float* X, const float* Y, const float* Z, int n, int D, float margin, float* state,
+                        float* rowloss, float* loss, void* stream);
+int slic_margin_cos_bwd(const float* X, const float* Y, const float* Z, const float* state, int n, int D,
+                        const float* gscale, float* dX, float* dY, float* dZ, void* stream);
 /* [n, n] distance matrix of the rows of V (loss/triplet_loss.py:429-437 pdist) */
 int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* out, void* stream);
 

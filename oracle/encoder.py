@@ -148,6 +148,14 @@ def ntxent_loss(emb, temperature=0.5):
     return F.cross_entropy(sim, tgt)
 
 
+def margin_cosine_loss(anchor, near, far, margin):
+    """the LLC term of triplet_train_epoch (online_train.py:317-332): dist_ap = 1 - cos(anc, anc2),
+    dist_an = 1 - cos(anc, pos), MarginRankingLoss(margin)(dist_ap, dist_an, target = -1)"""
+    d_ap = 1 - F.cosine_similarity(anchor, near, dim=1)
+    d_an = 1 - F.cosine_similarity(anchor, far, dim=1)
+    return F.margin_ranking_loss(d_ap, d_an, torch.full_like(d_ap, -1.0), margin=margin)
+
+
 def nce_average(l, ab, y, idx, memory_l, memory_ab, T=0.07, momentum=0.5):
     """NCEAverage.forward with use_softmax=True (loss/NCE_loss.py:26-88).  Banks are updated in place.
     Note the cross-wiring: out_ab uses memory_l, out_l uses memory_ab."""

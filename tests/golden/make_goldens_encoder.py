@@ -95,6 +95,14 @@ def main():
     et = torch.from_numpy(e).requires_grad_(True)
     l, _ = crit(et, torch.arange(4).repeat(2), sampling_strategy='noise_contrastive')
     lo["E_tiny"], lo["loss_tiny"] = e, l.detach().numpy()
+    # LLC margin term exactly as online_train.py:321-332 writes it (torch library calls, cosine metric, margin .04)
+    xa, xn, xf = [torch.from_numpy(rng.standard_normal((13, 128)).astype(np.float32)).requires_grad_(True) for _ in range(3)]
+    dist_ap = 1 - torch.nn.functional.cosine_similarity(xa, xn, dim=1)
+    dist_an = 1 - torch.nn.functional.cosine_similarity(xa, xf, dim=1)
+    llc = torch.nn.MarginRankingLoss(margin=0.04)(dist_ap, dist_an, torch.FloatTensor(dist_ap.size()).fill_(-1))
+    llc.backward()
+    lo.update(llc_a=xa.detach().numpy(), llc_n=xn.detach().numpy(), llc_f=xf.detach().numpy(), llc_loss=llc.detach().numpy(),
+              llc_ga=xa.grad.numpy(), llc_gn=xn.grad.numpy(), llc_gf=xf.grad.numpy())
     # memory-bank NCE (loss/NCE_loss.py): fixed idx
     B, D, K, ndata = 8, 128, 64, 1000
     nce = NCEAverage(D, ndata, K, 0.07, 0.5)

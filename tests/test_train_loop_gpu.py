@@ -1,0 +1,113 @@
+"""GPU: the online_train.py-shaped loops (triplet_train_epoch with the LLC term, contrastive_train_epoch,
+iterative_cluster_step) on a tiny R3D-18 and synthetic loaders, against the CPU oracle's restatement of the same steps."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(hidden_layer=64, out_dim=32, num_classes=101, n_input_channels=3, shortcut_type='B', conv1_t_size=7,
+            conv1_t_stride=1, no_max_pool=True, widen_factor=0.125, projection_head=True, predict_temporal_ds=False,
+            spatio_temporal_attention=False, classifier=False, dropout=None)
+
+
+def _cfg(tmp, **kw):
+    ns = types.SimpleNamespace
+    cfg = ns(LOSS=ns(LOCAL_LOCAL_CONTRAST=True, RELATIVE_SPEED_PERCEPTION=False, INTRA_NEGATIVE=False, DIST_METRIC='cosine',
+                     LOCAL_LOCAL_MARGIN=0.04, LOCAL_LOCAL_WEIGHT=1.0),
+             DATASET=ns(SAMPLING_STRATEGY='noise_contrastive', POSITIVE_SAMPLING_P=0.2), NUM_GPUS=1, TRAIN=ns(LOG_INTERVAL=2),
+             OUTPUT_PATH=str(tmp), ITERCLUSTER=ns(METHOD='kmeans', K=4, L2_NORMALIZE=True, FINCH_PARTITION=0, ADAPTIVEP=True),
+             MODEL=ns(ARCH='3dresnet'))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+class _Loader(list):
+    def __init__(self, batches, n):
+        super().__init__(batches)
+        self.dataset = list(range(n))
+
+
+def test_llc_margin_kernel_vs_reference_golden(gpu, golden_dir):
+    from video_similarity_search_amd.online_train import margin_cosine_loss
+    g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
+    a, n, f = [torch.from_numpy(g[k]).cuda().requires_grad_(True) for k in ("llc_a", "llc_n", "llc_f")]
+    l = margin_cosine_loss(a, n, f, 0.04)
+    (l * 2.0).backward()
+    assert abs(l.item() - float(g["llc_loss"])) < 1e-6
+    for t, k in ((a, "llc_ga"), (n, "llc_gn"), (f, "llc_gf")):
+        np.testing.assert_allclose(t.grad.cpu().numpy(), 2.0 * g[k], atol=1e-7, rtol=1e-4)
+
+
+def test_triplet_train_epoch_llc_vs_oracle(gpu, tmp_path):
+    from oracle import encoder as oe
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    from video_similarity_search_amd.online_train import triplet_train_epoch
+    rng = np.random.default_rng(21)
+    sd = oe.make_state_dict(rng, widen=0.125, hidden=64, out_dim=32)
+    b, steps = 3, 2
+    batches = []
+    for _ in range(steps):
+        views = [torch.from_numpy(rng.standard_normal((b, 3, 8, 32, 32)).astype(np.float32)) for _ in range(3)]
+        tg = (torch.arange(b), torch.arange(b))
+        batches.append((views, tg, torch.arange(b)))
+    m = generate_model(18, **TINY)
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.5)
+    cfg = _cfg(tmp_path)
+    avg = triplet_train_epoch(_Loader(batches, steps * b), m, OnlineTripletLoss(0.2, 'cosine'), opt, 0, cfg, True, "cuda")
+    # oracle: the same two steps (cat 3 views -> one forward -> NT-Xent on the first 2b + LLC margin term -> SGD)
+    t = oe.to_torch(sd, requires_grad=True)
+    params = {k: v for k, v in t.items() if v.requires_grad}
+    bufs, ref_losses = {}, []
+    for views, _, _ in batches:
+        out = oe.encoder_forward(t, torch.cat(views, 0), training=True)
+        loss = oe.ntxent_loss(out[:2 * b]) + oe.margin_cosine_loss(out[:b], out[2 * b:], out[b:2 * b], 0.04) * 1.0
+        grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+        oe.sgd_step(params, grads, bufs)
+        ref_losses.append(loss.item())
+    assert abs(avg - np.mean(ref_losses)) < 2e-4
+    after = m.state_dict()
+    for k in ("conv1.weight", "layer2.0.downsample.0.weight", "fc2.weight", "bn_proj.running_var", "layer4.1.bn2.running_mean"):
+        ref = t[k].detach().numpy()
+        np.testing.assert_allclose(after[k].cpu().numpy(), ref, atol=2e-5 + 2e-3 * np.abs(ref).max(), err_msg=k)
+    assert os.path.exists(os.path.join(tmp_path, "tnet_checkpoints", "train_loss_and_acc.txt"))
+
+
+def test_contrastive_epoch_and_cluster_step(gpu, tmp_path):
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss import NCEAverage, NCESoftmaxLoss
+    from video_similarity_search_amd.online_train import contrastive_train_epoch, iterative_cluster_step, diff
+    torch.manual_seed(0)
+    m = generate_model(18, **TINY).cuda()
+    n_data, b = 24, 4
+    contrast = NCEAverage(32, n_data, 8, 0.07, 0.5).cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.5)
+    data = torch.randn(n_data, 3, 8, 32, 32)
+    batches = [((data[i:i + b],), (torch.zeros(b),), torch.arange(i, i + b)) for i in range(0, n_data, b)]
+    x = data[:2]
+    assert torch.allclose(diff(x), ((x - torch.roll(x, 1, 2)) + 1) / 2)
+    bank0 = contrast.memory_l.clone()
+    avg = contrastive_train_epoch(_Loader(batches, n_data), m, NCESoftmaxLoss(), NCESoftmaxLoss(), contrast, opt, 0,
+                                  _cfg(tmp_path), True, "cuda")
+    assert np.isfinite(avg) and avg > 0
+    assert not torch.equal(bank0, contrast.memory_l)                 # every row was updated once
+    assert torch.allclose(contrast.memory_l.norm(dim=1), torch.ones(n_data, device="cuda"), atol=1e-5)
+    # iterative-cluster block: embeddings -> k-means -> vid_clusters.txt in dataset order
+    labels_true = [int(i % 4) for i in range(n_data)]
+    perm = torch.randperm(n_data)
+    ev = [(data[perm[i:i + b]], torch.tensor([labels_true[j] for j in perm[i:i + b]]), None, perm[i:i + b]) for i in range(0, n_data, b)]
+    np.random.seed(1)
+    cl, nmi = iterative_cluster_step(None, _cfg(tmp_path), m, _Loader(ev, n_data), epoch=5, device="cuda")
+    lines = open(os.path.join(tmp_path, "vid_clusters.txt")).read().split()
+    assert len(lines) == n_data and set(lines) <= {"0", "1", "2", "3"}
+    inv = np.empty(n_data, np.int64)
+    inv[perm.numpy()] = np.arange(n_data)
+    assert [int(v) for v in lines] == [int(cl[inv[i]]) for i in range(n_data)]     # unshuffled order
+    assert nmi is None or 0.0 <= nmi <= 1.0

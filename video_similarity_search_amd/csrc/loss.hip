@@ -165,7 +165,73 @@ __global__ void pdist_kernel(const float* __restrict__ V, int n, int D, float ep
   if (lane == 0) out[pair] = euclid ? sqrtf(a) : 1.0f - a / (fmaxf(sqrtf(b), 1e-8f) * fmaxf(sqrtf(c), 1e-8f));
 }
 
+// LLC / relative-speed margin term of triplet_train_epoch (online_train.py:317-332):
+//   d1 = 1 - cos(x, y), d2 = 1 - cos(x, z), MarginRankingLoss(margin)(d1, d2, target = -1) = mean(max(0, d1 - d2 + margin)).
+// One wave per row; row state (dots and norms) is kept for the backward.
+__global__ void margin_cos_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                      const float* __restrict__ Z, int n, int D, float margin,
+                                      float* __restrict__ st /* [n][8] */, float* __restrict__ rowloss) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float *x = X + (int64_t)row * D, *y = Y + (int64_t)row * D, *z = Z + (int64_t)row * D;
+  float xy = 0.f, xz = 0.f, xx = 0.f, yy = 0.f, zz = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    xy = fmaf(x[k], y[k], xy); xz = fmaf(x[k], z[k], xz);
+    xx = fmaf(x[k], x[k], xx); yy = fmaf(y[k], y[k], yy); zz = fmaf(z[k], z[k], zz);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    xy += __shfl_xor(xy, o); xz += __shfl_xor(xz, o); xx += __shfl_xor(xx, o); yy += __shfl_xor(yy, o); zz += __shfl_xor(zz, o);
+  }
+  if (lane == 0) {
+    const float nx = fmaxf(sqrtf(xx), 1e-8f), ny = fmaxf(sqrtf(yy), 1e-8f), nz = fmaxf(sqrtf(zz), 1e-8f);
+    const float c1 = xy / (nx * ny), c2 = xz / (nx * nz);
+    const float v = (1.f - c1) - (1.f - c2) + margin;
+    float* s = st + (int64_t)row * 8;
+    s[0] = c1; s[1] = c2; s[2] = nx; s[3] = ny; s[4] = nz; s[5] = v > 0.f ? 1.f : 0.f;
+    rowloss[row] = fmaxf(v, 0.f);
+  }
+}
+// d/dx [-(c1) + c2] etc.:  d cos(x,y)/dx = y/(|x||y|) - c x/|x|^2
+__global__ void margin_cos_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                      const float* __restrict__ Z, const float* __restrict__ st, int n, int D,
+                                      const float* __restrict__ gscale, float* __restrict__ dX,
+                                      float* __restrict__ dY, float* __restrict__ dZ) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* s = st + (int64_t)row * 8;
+  const float c1 = s[0], c2 = s[1], nx = s[2], ny = s[3], nz = s[4];
+  const float g = s[5] * (gscale ? *gscale : 1.f) / (float)n;     // d loss / d v
+  const float *x = X + (int64_t)row * D, *y = Y + (int64_t)row * D, *z = Z + (int64_t)row * D;
+  for (int k = lane; k < D; k += 64) {
+    const float dc1_dx = y[k] / (nx * ny) - c1 * x[k] / (nx * nx);
+    const float dc2_dx = z[k] / (nx * nz) - c2 * x[k] / (nx * nx);
+    dX[(int64_t)row * D + k] = g * (-dc1_dx + dc2_dx);
+    dY[(int64_t)row * D + k] = g * -(x[k] / (nx * ny) - c1 * y[k] / (ny * ny));
+    dZ[(int64_t)row * D + k] = g * (x[k] / (nx * nz) - c2 * z[k] / (nz * nz));
+  }
+}
+
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+
+extern "C" int slic_margin_cos_fwd(const float* X, const float* Y, const float* Z, int n, int D, float margin,
+                                   float* state, float* rowloss, float* loss, void* stream) {
+  SLIC_REQUIRE(X && Y && Z && state && rowloss && loss && n > 0 && D > 0, "slic_margin_cos_fwd: bad args");
+  margin_cos_fwd_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, Z, n, D, margin, state, rowloss);
+  SLIC_LAUNCH_CHECK();
+  mean_serial<<<dim3(1), dim3(64), 0, S_(stream)>>>(rowloss, n, loss);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_margin_cos_bwd(const float* X, const float* Y, const float* Z, const float* state, int n, int D,
+                                   const float* gscale, float* dX, float* dY, float* dZ, void* stream) {
+  SLIC_REQUIRE(X && Y && Z && state && dX && dY && dZ && n > 0 && D > 0, "slic_margin_cos_bwd: bad args");
+  margin_cos_bwd_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, Z, state, n, D, gscale, dX, dY, dZ);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 
 extern "C" int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclidean, float* out,
                                   void* stream) {

@@ -1,0 +1,257 @@
+"""
+The hot loops of the reference's online_train.py, with the same function names, argument order and step
+structure, on the HIP path:
+
+    diff(x)                                              <- online_train.py:228-230
+    triplet_train_epoch(train_loader, model, criterion, optimizer, epoch, cfg, cuda, device, is_master_proc)
+                                                         <- online_train.py:245-434  (default and LOCAL_LOCAL_CONTRAST branches)
+    contrastive_train_epoch(train_loader, model, criterion_1, criterion_2, contrast, optimizer, epoch, cfg, cuda,
+                            device, is_master_proc)      <- online_train.py:136-225
+    iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda, device, is_master_proc)
+                                                         <- online_train.py:605-662 (embed -> fit_cluster -> vid_clusters.txt -> barrier)
+
+What stays the reference's: one forward over cat(views), slicing, `loss = criterion + lambda * margin term`,
+zero_grad / backward / step, the two scalar all-reduces, the text logs.  What changes: the encoder, the
+NT-Xent / memory-bank losses, the margin-ranking term on cosine distances, and the clustering run on the GPU;
+the per-step `.item()` host syncs of the reference (`:389,392`) are batched to one per LOG_INTERVAL.
+`cfg` is any object with the reference's key names (cfg.LOSS.LOCAL_LOCAL_CONTRAST, cfg.DATASET.SAMPLING_STRATEGY,
+cfg.NUM_GPUS, cfg.TRAIN.LOG_INTERVAL, cfg.OUTPUT_PATH, cfg.ITERCLUSTER.*): fvcore's CfgNode or a SimpleNamespace tree.
+Branches the shipped SLIC configs never take (RELATIVE_SPEED_PERCEPTION, INTRA_NEGATIVE, slowfast inputs,
+`intra_neg` / `moco`) raise — the reference's own code for them references undefined names.
+"""
+import os
+import time
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+from .misc import distributed_helper as du_helper
+
+modality = 'res'        # module-level switch of the reference (online_train.py:36)
+
+
+class AverageMeter(object):
+    """models/model_utils.py:214-229"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = 0
+        self.avg = 0
+        self.sum = 0
+        self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def diff(x):
+    """residual-frame view (online_train.py:228-230); pure data movement, stays a torch op"""
+    shift_x = torch.roll(x, 1, 2)
+    return ((x - shift_x) + 1) / 2
+
+
+class _MarginCos(torch.autograd.Function):
+    """mean(max(0, (1 - cos(x, y)) - (1 - cos(x, z)) + margin)) — MarginRankingLoss(margin)(d_xy, d_xz, -1)"""
+
+    @staticmethod
+    def forward(ctx, x, y, z, margin):
+        x, y, z = (t.contiguous().float() for t in (x, y, z))
+        n, D = x.shape
+        state = torch.empty(n, 8, dtype=torch.float32, device=x.device)
+        rowloss = torch.empty(n, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        call("slic_margin_cos_fwd", ptr(x), ptr(y), ptr(z), n, D, float(margin), ptr(state), ptr(rowloss), ptr(loss), stream())
+        ctx.save_for_backward(x, y, z, state)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, z, state = ctx.saved_tensors
+        n, D = x.shape
+        dx, dy, dz = torch.empty_like(x), torch.empty_like(y), torch.empty_like(z)
+        call("slic_margin_cos_bwd", ptr(x), ptr(y), ptr(z), ptr(state), n, D, ptr(g.contiguous().float()), ptr(dx), ptr(dy),
+             ptr(dz), stream())
+        return dx, dy, dz, None
+
+
+def margin_cosine_loss(anchor, near, far, margin):
+    """the LLC term: `near` should end up closer to `anchor` than `far` by `margin` in cosine distance"""
+    if not anchor.is_cuda:
+        raise _lib.SlicError("margin_cosine_loss needs device tensors (no CPU fallback)")
+    return _MarginCos.apply(anchor, near, far, margin)
+
+
+def _flag(node, name, default=False):
+    return bool(getattr(node, name, default))
+
+
+def triplet_train_epoch(train_loader, model, criterion, optimizer, epoch, cfg, cuda, device, is_master_proc=True):
+    losses = AverageMeter()
+    running_n_triplets = AverageMeter()
+    world_size = du_helper.get_world_size()
+    model.train()
+    start = time.time()
+    pending = []        # (loss tensor, batch_size_world tensor) kept on the device until the next log line
+    for batch_idx, (inputs, targets, idx) in enumerate(train_loader):
+        if _flag(cfg.LOSS, "RELATIVE_SPEED_PERCEPTION") or _flag(cfg.LOSS, "INTRA_NEGATIVE"):
+            raise NotImplementedError("RELATIVE_SPEED_PERCEPTION / INTRA_NEGATIVE are off in every shipped SLIC config")
+        llc = _flag(cfg.LOSS, "LOCAL_LOCAL_CONTRAST")
+        if llc:
+            anchor, positive, anchor2 = inputs
+            anchor2 = anchor2.to(device)
+        else:
+            anchor, positive = inputs
+        anchor, positive = anchor.to(device), positive.to(device)
+        a_target, p_target = targets
+        batch_size = torch.tensor(anchor.size(0)).to(device)
+        targets = torch.cat((a_target, p_target), 0).to(device)
+        b = anchor.size(0)
+        if llc:
+            outputs = model(torch.cat((anchor, positive, anchor2), 0))      # ONE forward: BN stats over all 3b clips
+            out_anchor_positive = outputs[:b * 2]
+            out_anc, out_pos, out_anc2 = outputs[:b], outputs[b:2 * b], outputs[2 * b:3 * b]
+            triplet_loss, n_triplets = criterion(out_anchor_positive, targets, sampling_strategy=cfg.DATASET.SAMPLING_STRATEGY)
+            if cfg.LOSS.DIST_METRIC != 'cosine':
+                raise NotImplementedError("LLC with euclidean distances is not used by the shipped configs")
+            # dist_ap = 1 - cos(anc, anc2), dist_an = 1 - cos(anc, pos); MarginRankingLoss(margin)(ap, an, -1)
+            llc_loss = margin_cosine_loss(out_anc, out_anc2, out_pos, cfg.LOSS.LOCAL_LOCAL_MARGIN)
+            loss = triplet_loss + llc_loss * cfg.LOSS.LOCAL_LOCAL_WEIGHT
+        else:
+            outputs = model(torch.cat((anchor, positive), 0))
+            loss, n_triplets = criterion(outputs, targets, sampling_strategy=cfg.DATASET.SAMPLING_STRATEGY)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        loss = loss.detach()
+        if cfg.NUM_GPUS > 1:
+            [loss] = du_helper.all_reduce([loss], avg=True)
+            [batch_size_world] = du_helper.all_reduce([batch_size], avg=False)
+        else:
+            batch_size_world = batch_size
+        pending.append((loss, batch_size_world))
+        running_n_triplets.update(n_triplets)
+        log_now = ((batch_idx + 1) * world_size) % cfg.TRAIN.LOG_INTERVAL == 0
+        if log_now or batch_idx + 1 == len(train_loader):
+            for l, bs in pending:                                           # one host sync per log interval
+                losses.update(l.item(), bs.item())
+            pending = []
+            if is_master_proc and log_now:
+                print('Train Epoch: {} [{}/{} | {:.1f}%]\tLoss: {:.4f} ({:.4f}) \tN_Triplets: {:.1f}'.format(
+                    epoch, losses.count, len(train_loader.dataset), 100. * (losses.count / len(train_loader.dataset)),
+                    losses.val, losses.avg, running_n_triplets.avg))
+    for l, bs in pending:
+        losses.update(l.item(), bs.item())
+    if is_master_proc:
+        print('\nTrain set: Average loss: {:.4f}\n'.format(losses.avg))
+        print('epoch:{} runtime:{}'.format(epoch, (time.time() - start) / 3600))
+        _append_log(cfg, 'train_loss_and_acc.txt', 'epoch:{} runtime:{} {:.4f}\n'.format(
+            epoch, round((time.time() - start) / 3600, 2), losses.avg))
+    return losses.avg
+
+
+def contrastive_train_epoch(train_loader, model, criterion_1, criterion_2, contrast, optimizer, epoch, cfg, cuda, device,
+                            is_master_proc=True):
+    losses = AverageMeter()
+    world_size = du_helper.get_world_size()
+    model.train()
+    contrast.train()
+    start = time.time()
+    pending = []
+    for batch_idx, (inputs, labels, index) in enumerate(train_loader):
+        view1 = inputs[0]
+        view2 = inputs[1] if modality == 'rgb' else diff(view1)
+        batch_size = torch.tensor(view1.size(0)).to(device)
+        view1, view2 = view1.to(device), view2.to(device)
+        index = index.to(device)
+        feat_1 = model(view1)                # two separate forwards: BN statistics per view (online_train.py:175-176)
+        feat_2 = model(view2)
+        out_1, out_2 = contrast(feat_1, feat_2, index)
+        view1_loss = criterion_1(out_1)
+        view2_loss = criterion_2(out_2)
+        loss = view1_loss + view2_loss
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        loss = loss.detach()
+        if cfg.NUM_GPUS > 1:
+            [loss] = du_helper.all_reduce([loss], avg=True)
+            [batch_size_world] = du_helper.all_reduce([batch_size], avg=False)
+        else:
+            batch_size_world = batch_size
+        pending.append((loss, batch_size_world))
+        log_now = ((batch_idx + 1) * world_size) % cfg.TRAIN.LOG_INTERVAL == 0
+        if log_now or batch_idx + 1 == len(train_loader):
+            for l, bs in pending:
+                losses.update(l.item(), bs.item())
+            pending = []
+            if is_master_proc and log_now:
+                print('Train Epoch: {} [{}/{} | {:.1f}%]\tLoss: {:.4f} ({:.4f})'.format(
+                    epoch, losses.count, len(train_loader.dataset), 100. * (losses.count / len(train_loader.dataset)),
+                    losses.val, losses.avg))
+    if is_master_proc:
+        print('\nTrain set: Average loss: {:.4f}\n'.format(losses.avg))
+        _append_log(cfg, 'train_loss_and_acc.txt', 'epoch:{} runtime:{} {:.4f}\n'.format(
+            epoch, round((time.time() - start) / 3600, 2), losses.avg))
+    return losses.avg
+
+
+def _append_log(cfg, name, line):
+    out = getattr(cfg, "OUTPUT_PATH", None)
+    if not out:
+        return
+    d = os.path.join(out, 'tnet_checkpoints')
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), "a") as f:
+        f.write(line)
+
+
+def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=True, device=None, is_master_proc=True):
+    """online_train.py:605-662: embeddings of the whole train set -> fit_cluster -> NMI/AMI logs ->
+    vid_clusters.txt in the dataset's unshuffled order -> barrier.  Returns (cluster_labels, NMI or None)."""
+    from .clustering.cluster_masks import fit_cluster
+    from .evaluate import get_embeddings_and_labels
+    if is_master_proc:
+        print('\n=> Computing embeddings')
+    start_time = time.time()
+    embeddings, true_labels, idxs = get_embeddings_and_labels(args, cfg, encoder, cuda, device, eval_train_loader,
+                                                              split='train', is_master_proc=is_master_proc)
+    if is_master_proc:
+        print('Time to get embeddings: {:.2f}s'.format(time.time() - start_time))
+    cluster_labels, NMI = None, None
+    if is_master_proc:
+        print('\n=> Clustering')
+        start_time = time.time()
+        print('embeddings shape', embeddings.size())
+        cluster_labels = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
+                                     getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0))
+        print('Time to cluster: {:.2f}s'.format(time.time() - start_time))
+        try:                                     # O(N) contingency-table metrics stay on the host
+            from sklearn.metrics import adjusted_mutual_info_score, normalized_mutual_info_score
+            NMI = normalized_mutual_info_score(true_labels, cluster_labels)
+            AMI = adjusted_mutual_info_score(true_labels, cluster_labels)
+            print('NMI between true labels and cluster assignments: {:.3f}'.format(NMI))
+            print('AMI between true labels and cluster assignments: {:.3f}\n'.format(AMI))
+            _append_log(cfg, 'NMIs.txt', 'epoch:{} {:.3f}\n'.format(epoch, NMI))
+            _append_log(cfg, 'AMIs.txt', 'epoch:{} {:.3f}\n'.format(epoch, AMI))
+            if getattr(cfg.ITERCLUSTER, "ADAPTIVEP", False):
+                cfg.DATASET.POSITIVE_SAMPLING_P = float(1.0 - NMI)
+        except ImportError:
+            pass
+        # cluster assignments in the unshuffled order of the dataset, one label per line (online_train.py:649-657)
+        order = [None] * len(eval_train_loader.dataset)
+        for i in range(len(cluster_labels)):
+            order[idxs[i]] = cluster_labels[i]
+        cluster_output_path = os.path.join(cfg.OUTPUT_PATH, 'vid_clusters.txt')
+        with open(cluster_output_path, "w") as f:
+            for label in order:
+                f.write('{}\n'.format(label))
+        print('Saved cluster labels to', cluster_output_path)
+    if cfg.NUM_GPUS > 1:
+        torch.distributed.barrier()
+    return cluster_labels, NMI
