@@ -149,6 +149,8 @@ typedef struct SlicConvArgs {
                               tap mask (1<<(oa+3)) | (1<<(7+ob+3)) | (1<<(14+oc+3)) for tap offsets |o| <= 3, or -1 = all-zero chunk,
                               weight column of the chunk,
                               packed tap offsets (oa+128) | (ob+128)<<8 | (oc+128)<<16} */
+  const int32_t* tap_tab;  /* optional [ntaps][4] per-TAP records {src element delta, tap mask, weight column base, 0} for the
+                              LDS-DMA variants (needs Cs % 32 == 0, K = ntaps * Cs exactly); NULL otherwise */
   const float* bias;       /* [N] or NULL */
   const float* scale;      /* [N] or NULL: v = v*scale + shift (eval-mode BatchNorm) */
   const float* shift;      /* [N] or NULL */
@@ -169,7 +171,8 @@ typedef struct SlicConvArgs {
 } SlicConvArgs;
 
 /* rows per workgroup of the tile slic_conv_gemm picks for (args, variant); variant 0 = auto,
- * 1 = 128-row, 2 = 64-row, 3 = 256x64 tiles.  Sizes stat_partial. */
+ * 1 = 128-row, 2 = 64-row, 3 = 256x64 tiles (register-staged kernel); 11..14 = LDS-DMA kernel with
+ * 64x64x3-stage, 64x64x4, 128x64x3, 128x128x3 tiles.  Sizes stat_partial. */
 int slic_conv_tile_m(const SlicConvArgs* args, int variant);
 /* dst = epilogue(gather(src) x wgt^T): forward conv, data gradient, linear. */
 int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);

@@ -46,7 +46,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
     gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy.double())
     plan = ConvPlan(C, N, k, s, p, dims, "cuda")
     xd, wd_ = _ndhwc(x, plan.Cs).cuda(), w.cuda().contiguous()
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 11, 12, 13, 14):
         z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
         got = z.cpu().permute(0, 4, 1, 2, 3)
         tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6
@@ -59,8 +59,9 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
             assert torch.allclose(part[rr, 0].double().cpu(), blk.sum(0), atol=1e-4, rtol=1e-4)
             assert torch.allclose(part[rr, 1].double().cpu(), ((blk - blk.mean(0)) ** 2).sum(0), atol=1e-4, rtol=1e-4)
     dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
-    dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B).cpu()[..., :C].permute(0, 4, 1, 2, 3)
-    assert (dx - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item())
+    for variant in (0, 11, 13):
+        dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B, variant=variant).cpu()[..., :C].permute(0, 4, 1, 2, 3)
+        assert (dx - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item()), f'dgrad variant {variant}'
     dW = plan.wgrad(xd, dyd, B, torch.empty_like(wd_)).cpu()
     assert (dW - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
     dW3 = plan.wgrad(xd, dyd, B, torch.empty_like(wd_), splits=3).cpu()

@@ -82,7 +82,7 @@ SIGNATURES = {
 class SlicConvArgs(ctypes.Structure):
     """mirror of `struct SlicConvArgs` in include/slic_hip.h"""
     _fields_ = [
-        ("src", P), ("wgt", P), ("dst", P), ("tab", P), ("bias", P), ("scale", P), ("shift", P),
+        ("src", P), ("wgt", P), ("dst", P), ("tab", P), ("tap_tab", P), ("bias", P), ("scale", P), ("shift", P),
         ("addend", P), ("stat_partial", P),
         ("M", L),
         ("src_bytes", ctypes.c_uint32), ("wgt_bytes", ctypes.c_uint32),

@@ -22,144 +22,11 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
-  constexpr int TM = WTM / 32, TN = WTN / 32;   // 32x32 MFMA tiles per wave
-  constexpr int AL = BM / 32, BL = BN / 32;     // 16-byte chunks per thread per k-tile
-  static_assert(WM * WN == 4, "4 waves");
-  float* As = lds;                               // [2][BM*32]
-  float* Bs = lds + 2 * BM * 32;                 // [2][BN*32]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
-
-  // ---- staging setup: thread owns chunk column cq of rows srow + 32 i.
-  // Loads are buffer loads (raw, stride 0): an out-of-range offset returns zeros, so padding taps, ragged rows
-  // and ragged channels need no branch and no select — the bounds test just picks the offset.
-  const int cq = tid & 7, srow = tid >> 3;
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFF00u;
-  unsigned aoff[AL];    // byte offset of the row's base pixel
-  unsigned rmask[AL];   // bit (7*dim + o + 3) set iff base coordinate + o is inside the source along dim
-#pragma unroll
-  for (int i = 0; i < AL; ++i) {
-    const int64_t m = m0 + srow + 32 * i;
-    aoff[i] = 0; rmask[i] = 0;
-    if (m < p.M) {
-      unsigned rr = (unsigned)m;                     // M < 2^31 (checked on the host)
-      const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
-      const int gb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
-      const int ga = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;   // rr = batch
-      const int a0 = ga * p.sa, b0 = gb * p.sb, c0 = gc * p.sc;
-      aoff[i] = (((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
-      unsigned mk = 0;
-#pragma unroll
-      for (int o = -3; o <= 3; ++o) {
-        mk |= ((unsigned)(a0 + o) < (unsigned)p.Ts ? 1u : 0u) << (o + 3);
-        mk |= ((unsigned)(b0 + o) < (unsigned)p.Hs ? 1u : 0u) << (7 + o + 3);
-        mk |= ((unsigned)(c0 + o) < (unsigned)p.Ws ? 1u : 0u) << (14 + o + 3);
-      }
-      rmask[i] = mk;
-    }
-  }
-  unsigned woff[BL];
-#pragma unroll
-  for (int i = 0; i < BL; ++i) {
-    const int n = n0 + srow + 32 * i;
-    woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 4u : OOB;
-  }
-  // two register staging sets: tile kt+2 is in flight while tile kt is computed and tile kt+1 is written to LDS,
-  // so a load has a whole k-tile (plus the other workgroups' tiles) to come back from L2 / Infinity Cache / HBM
-  i32x4 ga0[AL], gb0[BL], ga1[AL], gb1[BL];
-  const int nk = p.nchunks >> 3;
-  int4 e_next = nk > 0 ? ((const int4*)p.tab)[cq] : make_int4(0, -1, 0, 0);   // table entry one tile ahead
-  auto gload = [&](int kt, i32x4 (&ga)[AL], i32x4 (&gb)[BL]) {
-    const int4 e = e_next;
-    const unsigned tm = (unsigned)e.y;             // 0xFFFFFFFF for an all-zero chunk: never a subset of rmask
-    const unsigned dlt = (unsigned)e.x * 4u;
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-      const unsigned off = ((rmask[i] & tm) == tm) ? aoff[i] + dlt : OOB;
-      ga[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)off, 0, 0);
-    }
-    const unsigned wc = e.y == -1 ? OOB : (unsigned)e.z * 4u;
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
-      const unsigned off = (woff[i] == OOB || wc == OOB) ? OOB : woff[i] + wc;
-      gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, (int)off, 0, 0);
-    }
-    if (kt + 1 < nk) e_next = ((const int4*)p.tab)[(kt + 1) * 8 + cq];
-  };
-  auto lwrite = [&](int buf, i32x4 (&ga)[AL], i32x4 (&gb)[BL]) {
-#pragma unroll
-    for (int i = 0; i < AL; ++i) *(i32x4*)&As[buf * BM * 32 + cv_off(srow + 32 * i, cq)] = ga[i];
-#pragma unroll
-    for (int i = 0; i < BL; ++i) *(i32x4*)&Bs[buf * BN * 32 + cv_off(srow + 32 * i, cq)] = gb[i];
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
-
-  const int r = lane & 31, h = lane >> 5;
-  auto compute = [&](int buf) {
-    const float* Ab = As + buf * BM * 32;
-    const float* Bb = Bs + buf * BN * 32;
-    f32x4 a[2][TM], b[2][TN];     // LDS operands double-buffered in registers: group q+1 is in flight under q's MFMAs
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int cur = q & 1, nxt = cur ^ 1;
-      if (q < 3) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
-      // issue order: next group's LDS reads first, then this group's MFMAs (reads land under 4*TM*TN*64 cycles)
-      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
-    }
-  };
-  if (nk > 0) {
-    gload(0, ga0, gb0);
-    lwrite(0, ga0, gb0);
-    if (nk > 1) gload(1, ga1, gb1);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    // even tile: set 0 is free (tile kt sits in LDS), set 1 carries tile kt+1
-    if (kt + 2 < nk) gload(kt + 2, ga0, gb0);
-    compute(0);
-    if (kt + 1 < nk) lwrite(1, ga1, gb1);
-    __syncthreads();
-    if (kt + 1 >= nk) break;
-    // odd tile
-    if (kt + 3 < nk) gload(kt + 3, ga1, gb1);
-    compute(1);
-    if (kt + 2 < nk) lwrite(0, ga0, gb0);
-    __syncthreads();
-  }
-
+// Shared epilogue of the gather-GEMM kernels: bias / affine / addend / ReLU store + deterministic BatchNorm partials.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
+                                              int wm, int wn, int r, int h, int tid) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
   // ---- epilogue
   const bool want_stats = p.stat_partial != nullptr;
   int64_t roff[TM][16];           // dst row offsets (elements), one decode per accumulator row
@@ -245,6 +112,290 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
       __syncthreads();
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;   // 32x32 MFMA tiles per wave
+  constexpr int AL = BM / 32, BL = BN / 32;     // 16-byte chunks per thread per k-tile
+  static_assert(WM * WN == 4, "4 waves");
+  float* As = lds;                               // [2][BM*32]
+  float* Bs = lds + 2 * BM * 32;                 // [2][BN*32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // ---- staging setup: thread owns chunk column cq of rows srow + 32 i.
+  // Loads are buffer loads (raw, stride 0): an out-of-range offset returns zeros, so padding taps, ragged rows
+  // and ragged channels need no branch and no select — the bounds test just picks the offset.
+  const int cq = tid & 7, srow = tid >> 3;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned aoff[AL];    // byte offset of the row's base pixel
+  unsigned rmask[AL];   // bit (7*dim + o + 3) set iff base coordinate + o is inside the source along dim
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int64_t m = m0 + srow + 32 * i;
+    aoff[i] = 0; rmask[i] = 0;
+    if (m < p.M) {
+      unsigned rr = (unsigned)m;                     // M < 2^31 (checked on the host)
+      const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+      const int gb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+      const int ga = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;   // rr = batch
+      const int a0 = ga * p.sa, b0 = gb * p.sb, c0 = gc * p.sc;
+      aoff[i] = (((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
+      unsigned mk = 0;
+#pragma unroll
+      for (int o = -3; o <= 3; ++o) {
+        mk |= ((unsigned)(a0 + o) < (unsigned)p.Ts ? 1u : 0u) << (o + 3);
+        mk |= ((unsigned)(b0 + o) < (unsigned)p.Hs ? 1u : 0u) << (7 + o + 3);
+        mk |= ((unsigned)(c0 + o) < (unsigned)p.Ws ? 1u : 0u) << (14 + o + 3);
+      }
+      rmask[i] = mk;
+    }
+  }
+  unsigned woff[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int n = n0 + srow + 32 * i;
+    woff[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 4u : OOB;
+  }
+  // two register staging sets: tile kt+2 is in flight while tile kt is computed and tile kt+1 is written to LDS,
+  // so a load has a whole k-tile (plus the other workgroups' tiles) to come back from L2 / Infinity Cache / HBM
+  i32x4 gA[2][AL], gB[2][BL];
+  const int nk = p.nchunks >> 3;
+  int4 e_next = nk > 0 ? ((const int4*)p.tab)[cq] : make_int4(0, -1, 0, 0);   // table entry one tile ahead
+  auto gload = [&](int kt, i32x4 (&ga)[AL], i32x4 (&gb)[BL]) {
+    const int4 e = e_next;
+    const unsigned tm = (unsigned)e.y;             // 0xFFFFFFFF for an all-zero chunk: never a subset of rmask
+    const unsigned dlt = (unsigned)e.x * 4u;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const unsigned off = ((rmask[i] & tm) == tm) ? aoff[i] + dlt : OOB;
+      ga[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)off, 0, 0);
+    }
+    const unsigned wc = e.y == -1 ? OOB : (unsigned)e.z * 4u;
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const unsigned off = (woff[i] == OOB || wc == OOB) ? OOB : woff[i] + wc;
+      gb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_wgt, (int)off, 0, 0);
+    }
+    if (kt + 1 < nk) e_next = ((const int4*)p.tab)[(kt + 1) * 8 + cq];
+  };
+  auto lwrite = [&](int buf, i32x4 (&ga)[AL], i32x4 (&gb)[BL]) {
+#pragma unroll
+    for (int i = 0; i < AL; ++i) *(i32x4*)&As[buf * BM * 32 + cv_off(srow + 32 * i, cq)] = ga[i];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) *(i32x4*)&Bs[buf * BN * 32 + cv_off(srow + 32 * i, cq)] = gb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+  const int r = lane & 31, h = lane >> 5;
+  auto compute = [&](int buf) {
+    const float* Ab = As + buf * BM * 32;
+    const float* Bb = Bs + buf * BN * 32;
+    f32x4 a[2][TM], b[2][TN];     // LDS operands double-buffered in registers: group q+1 is in flight under q's MFMAs
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
+      // issue order: next group's LDS reads first, then this group's MFMAs (reads land under 4*TM*TN*64 cycles)
+      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+    }
+  };
+  if (nk > 0) {
+    gload(0, gA[0], gB[0]);
+    lwrite(0, gA[0], gB[0]);
+    if (nk > 1) gload(1, gA[1], gB[1]);
+  }
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {       // unrolled: register sets and LDS buffers are compile-time
+      const int kt = kt0 + half;
+      if (kt < nk) {
+        // tile kt sits in LDS buffer `half`; set `half` is free, set `half ^ 1` carries tile kt + 1
+        if (kt + 2 < nk) gload(kt + 2, gA[half], gB[half]);
+        compute(half);
+        if (kt + 1 < nk) lwrite(half ^ 1, gA[half ^ 1], gB[half ^ 1]);
+        __syncthreads();
+      }
+    }
+  }
+
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA variant (source channels % 32 == 0, i.e. every R3D-18 layer but the stem): a 32-wide K tile never
+// straddles a tap, so tap offset / mask / weight base are wave-uniform per k-tile and come from a per-TAP table
+// through scalar loads; operands go global -> LDS directly (buffer_load_dwordx4 ... lds, 1 KB per wave-instruction,
+// out-of-range lanes write zeros), no VGPR staging, no ds_write, and a ring of LDS stages with counted vmcnt keeps
+// two k-tiles in flight across ONE raw barrier per tile.  LDS image = the same [rows][32] swizzled layout: the
+// DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk (p ^ ((row >> 1) & 7)).
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int AL = BM / 32, BL = BN / 32;
+  constexpr int STAGE_FLOATS = (BM + BN) * 32;
+  static_assert(WM * WN == 4, "4 waves");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int srow = tid >> 3;                                  // row inside each 32-row group
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);               // SOURCE chunk column of this lane (LDS slot = tid & 7)
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned aoff[AL], rmask[AL];
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int64_t m = m0 + srow + 32 * i;
+    aoff[i] = 0; rmask[i] = 0;
+    if (m < p.M) {
+      unsigned rr = (unsigned)m;
+      const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+      const int gb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+      const int ga = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
+      const int a0 = ga * p.sa, b0 = gb * p.sb, c0 = gc * p.sc;
+      aoff[i] = ((((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs + cq * 4) * 4u;
+      unsigned mk = 0;
+#pragma unroll
+      for (int o = -3; o <= 3; ++o) {
+        mk |= ((unsigned)(a0 + o) < (unsigned)p.Ts ? 1u : 0u) << (o + 3);
+        mk |= ((unsigned)(b0 + o) < (unsigned)p.Hs ? 1u : 0u) << (7 + o + 3);
+        mk |= ((unsigned)(c0 + o) < (unsigned)p.Ws ? 1u : 0u) << (14 + o + 3);
+      }
+      rmask[i] = mk;
+    }
+  }
+  unsigned woff[BL];
+#pragma unroll
+  for (int i = 0; i < BL; ++i) {
+    const int n = n0 + srow + 32 * i;
+    woff[i] = n < p.N ? ((unsigned)n * (unsigned)p.ldw + cq * 4) * 4u : OOB;
+  }
+  const int nk = p.nchunks >> 3;
+  const int tiles_per_tap = p.Cs >> 5;
+  // per-tap records are read through the constant address space with a wave-uniform index: scalar loads, which
+  // never touch the vmcnt queue the DMAs are counted on
+  const __attribute__((address_space(4))) i32x4* tapc = (const __attribute__((address_space(4))) i32x4*)p.tab;
+  // issue the (AL + BL) DMAs of k-tile kt into ring stage st
+  auto issue = [&](int kt, int st) {
+    const int tap = kt / tiles_per_tap;                      // wave-uniform -> scalar loads of the tap record
+    const int cb = (kt - tap * tiles_per_tap) << 5;          // channel base inside the tap
+    const i32x4 e = tapc[tap];                               // {src delta, tap mask, weight base, -}: s_load (lgkmcnt queue)
+    const unsigned tm = (unsigned)e.y;
+    const unsigned dlt = (unsigned)(e.x + cb) * 4u;
+    const unsigned wc = (unsigned)(e.z + cb) * 4u;
+    float* As = lds + st * STAGE_FLOATS;
+    float* Bs = As + BM * 32;
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      const unsigned off = ((rmask[i] & tm) == tm) ? aoff[i] + dlt : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(As + (8 * wave + 32 * i) * 32),
+                                               16, (int)off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+      const unsigned off = woff[i] == OOB ? OOB : woff[i] + wc;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bs + (8 * wave + 32 * i) * 32),
+                                               16, (int)off, 0, 0, 0);
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  auto compute = [&](int st) {
+    const float* Ab = lds + st * STAGE_FLOATS;
+    const float* Bb = Ab + BM * 32;
+    f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
+      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // prologue: STAGES - 1 tiles in flight
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t)
+    if (t < nk) issue(t, t);
+  for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {          // unrolled: ring stages are compile-time, so the compiler can
+      const int kt = kt0 + sidx;                          // see that the ds_reads and the in-flight DMAs never alias
+      if (kt < nk) {
+        // tile kt has landed once only the DMAs of the younger in-flight tiles are outstanding
+        const int younger = min(STAGES - 2, nk - 1 - kt);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AL + BL)) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL + BL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // every wave's part of tile kt is in LDS; the stage of tile kt-1 is free
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (sidx + STAGES - 1) % STAGES);
+        compute(sidx);
+      }
+    }
+  }
+  __syncthreads();
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -435,7 +586,24 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
   return SLIC_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int STAGES>
+static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)slic_cdiv(a.M, BM), (unsigned)slic_cdiv(a.N, BN));
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES><<<grid, dim3(256), lds, st>>>(a);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
+  if (variant == 11 || variant == 12) return 64;
+  if (variant == 13 || variant == 14) return 128;
   // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
   if (variant == 1) return 128;
   if (variant == 2) return 64;
@@ -451,6 +619,16 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   hipStream_t st = S_(stream);
+  if (variant >= 11 && variant <= 14) {
+    SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
+                 "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
+    SlicConvArgs b = *a;
+    b.tab = a->tap_tab;
+    if (variant == 11) return launch_gemm_dma<64, 64, 2, 2, 3>(b, st);
+    if (variant == 12) return launch_gemm_dma<64, 64, 2, 2, 4>(b, st);
+    if (variant == 13) return launch_gemm_dma<128, 64, 2, 2, 3>(b, st);
+    return launch_gemm_dma<128, 128, 2, 2, 3>(b, st);
+  }
   const int bm = slic_conv_tile_m(a, variant);
   if (bm == 256) return launch_gemm<256, 64, 4, 1>(*a, st);
   if (bm == 128) {

@@ -62,6 +62,17 @@ class ConvPlan:
         tab[:nch, 2] = q * 4
         tab[:nch, 3] = (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
         self.tab_fwd = torch.from_numpy(tab).to(device)
+        # per-TAP records for the LDS-DMA kernel (source channels % 32 == 0: a 32-wide K tile never straddles a tap)
+        self.tap_fwd = None
+        if self.Cs % 32 == 0 and self.ntaps <= 64:
+            tt = np.arange(self.ntaps)
+            tdt, tdh, tdw = tt // (kh * kw), (tt // kw) % kh, tt % kw
+            ta, tb, tc = tdt - self.pad[0], tdh - self.pad[1], tdw - self.pad[2]
+            trec = np.zeros((self.ntaps, 4), np.int32)
+            trec[:, 0] = ((ta * H + tb) * W + tc) * self.Cs
+            trec[:, 1] = (1 << (ta + 3)) | (1 << (7 + tb + 3)) | (1 << (14 + tc + 3))
+            trec[:, 2] = tt * self.Cs
+            self.tap_fwd = torch.from_numpy(trec).to(device)
         self.Kp = self.nchunks_fwd * 4                      # packed forward weight row length
         # ---- data-gradient tables: src = dY [B, To, Ho, Wo, N], k = tap*N + n, one per parity class
         self.Kd = _pad8(self.ntaps * self.N // 4) * 4
@@ -80,11 +91,12 @@ class ConvPlan:
                     if num % self.stride[dim] == 0:
                         v.append((d, num // self.stride[dim]))
                 valid.append(v)
-            rows = []
+            rows, taprec = [], []
             for (dt_, oa_), (dh_, ob_), (dw_, oc_) in itertools.product(*valid):
                 tap_ = (dt_ * kh + dh_) * kw + dw_
                 base = ((oa_ * Ho + ob_) * Wo + oc_) * self.N
                 po, tmk = _pack_off(oa_, ob_, oc_), _tap_mask(oa_, ob_, oc_)
+                taprec.append((base, tmk, tap_ * self.N, 0))
                 for n4 in range(nq):
                     rows.append((base + n4 * 4, tmk, tap_ * self.N + n4 * 4, po))
             nchd = _pad8(len(rows))
@@ -92,8 +104,11 @@ class ConvPlan:
             t[:, 1] = -1
             if rows:
                 t[: len(rows)] = np.asarray(rows, np.int32)
+            tapt = None
+            if self.N % 32 == 0 and 0 < len(taprec) <= 64:
+                tapt = torch.from_numpy(np.asarray(taprec, np.int32)).to(device)
             self.dgrad_classes.append(dict(cls=cls, grid=grid, nchunks=nchd if rows else 0,
-                                           tab=torch.from_numpy(t).to(device)))
+                                           tab=torch.from_numpy(t).to(device), tap=tapt))
         self._wp = None
         self._wd = None
         self.prof = None      # bench.py: list collecting (start, end) HIP event pairs around conv_gemm launches
@@ -119,6 +134,7 @@ class ConvPlan:
         a.src = x.data_ptr()
         a.src_bytes = x.numel() * 4
         a.tab = self.tab_fwd.data_ptr()
+        a.tap_tab = self.tap_fwd.data_ptr() if self.tap_fwd is not None else None
         a.M = B * To * Ho * Wo
         a.N = self.N
         a.nchunks = self.nchunks_fwd
@@ -143,7 +159,7 @@ class ConvPlan:
         a.addend = addend.data_ptr() if addend is not None else None
         a.relu = int(relu)
         part = None
-        tm = lib.slic_conv_tile_m(ctypes.byref(a), variant)
+        tm = lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant))
         if want_stats:
             R = (a.M + tm - 1) // tm
             part = torch.empty(R, 2, self.N, dtype=torch.float32, device=x.device)
@@ -151,7 +167,18 @@ class ConvPlan:
         self._launch(a, variant)
         return z, ((part, tm) if want_stats else None)
 
+    @staticmethod
+    def _pick(a, variant):
+        """variant 0 = auto: the LDS-DMA kernel (64x64 tiles, 3-stage ring) wherever a per-tap table exists
+        (source channels % 32 == 0), else the register-staged kernel (stem, tiny-channel layers)"""
+        if variant == 0:
+            return 11 if a.tap_tab else 0
+        if variant >= 11 and not a.tap_tab:
+            return 0
+        return variant
+
     def _launch(self, a, variant):
+        variant = self._pick(a, variant)
         if self.prof is None:
             call("slic_conv_gemm", ctypes.byref(a), variant, stream())
             return
@@ -175,6 +202,7 @@ class ConvPlan:
             a.wgt_bytes = wd.numel() * 4
             a.dst = dx.data_ptr()
             a.tab = dc["tab"].data_ptr()
+            a.tap_tab = dc["tap"].data_ptr() if dc["tap"] is not None else None
             a.addend = addend.data_ptr() if addend is not None else None
             ga, gb, gc = dc["grid"]
             a.M = B * ga * gb * gc
