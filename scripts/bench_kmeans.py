@@ -1,0 +1,28 @@
+"""micro-benchmark (GPU box): Lloyd iteration time at 100k x 512, K = 500, per-kernel breakdown via events"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from video_similarity_search_amd.clustering import KMeans
+from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
+N, D, K, iters = 100000, 512, 500, 20
+rng = np.random.default_rng(1)
+X = rng.standard_normal((N, D)).astype(np.float32); X /= np.linalg.norm(X, axis=1, keepdims=True)
+init = X[rng.choice(N, K, replace=False)].copy()
+Xd = torch.from_numpy(X).cuda()
+km = KMeans(n_clusters=K, init=init, n_init=1, max_iter=iters, tol=0.0, fixed_iters=True)
+km.fit(Xd); torch.cuda.synchronize()
+t0 = time.time(); km.fit(Xd); torch.cuda.synchronize(); dt = time.time() - t0
+print(f"fit: {dt*1e3:.1f} ms for {iters} iterations -> {dt/iters*1e3:.3f} ms/iter, {N*iters/dt:.3e} emb/s")
+k = HipKernels()
+C = torch.from_numpy(init).cuda(); cn = torch.empty(K, device="cuda"); lab = torch.empty(N, dtype=torch.int32, device="cuda")
+sums = torch.empty(K * D, device="cuda"); counts = torch.empty(K, device="cuda"); Cn = torch.empty_like(C)
+shift = torch.empty(K, device="cuda"); status = torch.empty(4, dtype=torch.float64, device="cuda"); nch = torch.zeros(1, dtype=torch.int32, device="cuda")
+def tm(f, reps=20):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+print(f"cnorm {tm(lambda: k.cnorm(C, cn)):.1f} us | assign {tm(lambda: k.assign(Xd, C, cn, lab, None, None)):.1f} us | "
+      f"accumulate {tm(lambda: k.accumulate(Xd, lab, K, sums, counts)):.1f} us | finalize {tm(lambda: k.finalize(C, sums, counts, Cn, shift, nch, status)):.1f} us")

@@ -12,6 +12,7 @@
 // Build: -ffp-contract=off (nothing fuses except explicit fmaf/MFMA).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define KM_BP 128  // points per workgroup (4 waves x 32)
 #define KM_BC 128  // centroids per workgroup (4 MFMA row tiles per wave)
@@ -27,14 +28,17 @@ __device__ __forceinline__ int km_off(int row, int chunk) {
 // One workgroup: 128 points x 128 centroids, full D.  Wave w owns points [32w, 32w+32).
 // MFMA roles: A = centroid tile (rows i), B = point tile (cols j)  =>  each lane holds ONE point
 // (col = lane&31) and 16 centroid rows per accumulator, so the running argmin is in-register.
-__global__ __launch_bounds__(256, 2) void km_assign_partial(
+template <int NCT>
+__global__ __launch_bounds__(256) void km_assign_partial(
     const float* __restrict__ X, int64_t N, int D, int ldx, const float* __restrict__ C, int K,
     int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore,
     int32_t* __restrict__ pidx) {
-  __shared__ __attribute__((aligned(16))) float lds[2][2][KM_BP * KM_BK];  // [buf][0 = C, 1 = X]
+  constexpr int BC = NCT * 32;
+  __shared__ __attribute__((aligned(16))) float ldsX[2][KM_BP * KM_BK];
+  __shared__ __attribute__((aligned(16))) float ldsC[2][BC * KM_BK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t pblock = (int64_t)blockIdx.x * KM_BP;
-  const int cblock = blockIdx.y * KM_BC;
+  const int cblock = blockIdx.y * BC;
 
   // staging: thread t loads 8 consecutive floats (k0 + 8*(t&3)) of rows (t>>2) and (t>>2)+64
   const int srow = tid >> 2, scp = tid & 3;
@@ -47,13 +51,14 @@ __global__ __launch_bounds__(256, 2) void km_assign_partial(
     if (pr > N - 1) pr = N - 1;
     xr[p] = X + pr * (int64_t)ldx + scp * 8;
     int c = cblock + srow + 64 * p;
-    cvalid[p] = c < K;
+    cvalid[p] = c < K && (srow + 64 * p) < BC;
     if (c > K - 1) c = K - 1;
     cr[p] = C + (int64_t)c * ldc + scp * 8;
   }
-  f32x4 gx[2][2], gc[2][2];
+  // two register staging sets (tile kt+2 in flight while kt is computed and kt+1 goes to LDS)
+  f32x4 gxs[2][2][2], gcs[2][2][2];
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, f32x4 (&gx)[2][2], f32x4 (&gc)[2][2]) {
     const int k0 = kt * KM_BK;
     const bool kin = (k0 + scp * 8) < D;  // D % 8 == 0: a pair of chunks is all in or all out
 #pragma unroll
@@ -74,58 +79,78 @@ __global__ __launch_bounds__(256, 2) void km_assign_partial(
   };
   // de-interleave: chunk 2*scp gets k = 0,2,4,6 of the 8-group, chunk 2*scp+1 gets k = 1,3,5,7,
   // so lane half h reads its four k's (2t+h, t = 0..3) with one ds_read_b128.
-  auto lwrite = [&](int buf) {
+  auto lwrite = [&](int buf, f32x4 (&gx)[2][2], f32x4 (&gc)[2][2]) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int row = srow + 64 * p;
       f32x4 e = {gx[p][0].x, gx[p][0].z, gx[p][1].x, gx[p][1].z};
       f32x4 o = {gx[p][0].y, gx[p][0].w, gx[p][1].y, gx[p][1].w};
-      *(f32x4*)&lds[buf][1][km_off(row, 2 * scp)] = e;
-      *(f32x4*)&lds[buf][1][km_off(row, 2 * scp + 1)] = o;
-      f32x4 ce = {gc[p][0].x, gc[p][0].z, gc[p][1].x, gc[p][1].z};
-      f32x4 co = {gc[p][0].y, gc[p][0].w, gc[p][1].y, gc[p][1].w};
-      *(f32x4*)&lds[buf][0][km_off(row, 2 * scp)] = ce;
-      *(f32x4*)&lds[buf][0][km_off(row, 2 * scp + 1)] = co;
+      *(f32x4*)&ldsX[buf][km_off(row, 2 * scp)] = e;
+      *(f32x4*)&ldsX[buf][km_off(row, 2 * scp + 1)] = o;
+      if (row < BC) {
+        f32x4 ce = {gc[p][0].x, gc[p][0].z, gc[p][1].x, gc[p][1].z};
+        f32x4 co = {gc[p][0].y, gc[p][0].w, gc[p][1].y, gc[p][1].w};
+        *(f32x4*)&ldsC[buf][km_off(row, 2 * scp)] = ce;
+        *(f32x4*)&ldsC[buf][km_off(row, 2 * scp + 1)] = co;
+      }
     }
   };
 
-  f32x16 acc[4];
+  f32x16 acc[NCT];
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
   const int r = lane & 31, h = lane >> 5;
   const int nk = (D + KM_BK - 1) / KM_BK;
-  gload(0);
-  lwrite(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kt + 1);
-    const float* Cs = lds[buf][0];
-    const float* Xs = lds[buf][1];
+  auto compute = [&](int buf) {
+    const float* Cs = ldsC[buf];
+    const float* Xs = ldsX[buf];
+    f32x4 b[2], a[2][NCT];               // LDS operands of group q+1 are read under group q's MFMAs
+    b[0] = *(const f32x4*)&Xs[km_off(32 * wave + r, h)];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) a[0][ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, h)];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * q + h)];
-      f32x4 a[4];
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
+        b[nxt] = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * (q + 1) + h)];
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) a[ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, 2 * q + h)];
+        for (int ct = 0; ct < NCT; ++ct) a[nxt][ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, 2 * (q + 1) + h)];
+      }
+      // k order inside every accumulator: q ascending, t ascending, lane half 0 then 1 => k = 8q + 2t + h ascending
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ct][t], b[t], acc[ct], 0, 0, 0);
+        for (int ct = 0; ct < NCT; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct][t], b[cur][t], acc[ct], 0, 0, 0);
+      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NCT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCT, 0);
     }
-    if (kt + 1 < nk) lwrite(buf ^ 1);
-    __syncthreads();
+  };
+  gload(0, gxs[0], gcs[0]);
+  lwrite(0, gxs[0], gcs[0]);
+  if (nk > 1) gload(1, gxs[1], gcs[1]);
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int kt = kt0 + half;
+      if (kt < nk) {
+        if (kt + 2 < nk) gload(kt + 2, gxs[half], gcs[half]);
+        compute(half);
+        if (kt + 1 < nk) lwrite(half ^ 1, gxs[half ^ 1], gcs[half ^ 1]);
+        __syncthreads();
+      }
+    }
   }
 
   // running argmin over this workgroup's 128 centroids for the lane's point
   float best = INFINITY;
   int bidx = 0x7fffffff;
 #pragma unroll
-  for (int ct = 0; ct < 4; ++ct)
+  for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int c = cblock + ct * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
@@ -175,12 +200,21 @@ __global__ void km_cnorm(const float* __restrict__ C, int K, int D, int ldc,
   if (j >= K) return;
   const float* c = C + (int64_t)j * ldc;
   float acc = 0.f;
-  for (int k = 0; k < D; ++k) acc = fmaf(c[k], c[k], acc);
+  int k = 0;
+  for (; k + 16 <= D; k += 16) {            // four 16-byte loads in flight; the fmaf chain stays k-ascending
+    const f32x4 v0 = *(const f32x4*)(c + k), v1 = *(const f32x4*)(c + k + 4), v2 = *(const f32x4*)(c + k + 8),
+                v3 = *(const f32x4*)(c + k + 12);
+    acc = fmaf(v0.x, v0.x, acc); acc = fmaf(v0.y, v0.y, acc); acc = fmaf(v0.z, v0.z, acc); acc = fmaf(v0.w, v0.w, acc);
+    acc = fmaf(v1.x, v1.x, acc); acc = fmaf(v1.y, v1.y, acc); acc = fmaf(v1.z, v1.z, acc); acc = fmaf(v1.w, v1.w, acc);
+    acc = fmaf(v2.x, v2.x, acc); acc = fmaf(v2.y, v2.y, acc); acc = fmaf(v2.z, v2.z, acc); acc = fmaf(v2.w, v2.w, acc);
+    acc = fmaf(v3.x, v3.x, acc); acc = fmaf(v3.y, v3.y, acc); acc = fmaf(v3.z, v3.z, acc); acc = fmaf(v3.w, v3.w, acc);
+  }
+  for (; k < D; ++k) acc = fmaf(c[k], c[k], acc);
   cnorm[j] = acc;
 }
 
 // ---------------- M-step: stable counting sort by label, then per-cluster ordered sums --------
-#define KM_SB 256  // rows per sort block
+#define KM_SB 1024  // rows per sort block (one workgroup)
 
 __global__ void km_block_hist(const int32_t* __restrict__ labels, int64_t N, int K,
                               int32_t* __restrict__ bc /* [nblk][K], zeroed */) {
@@ -231,7 +265,7 @@ __global__ void km_scan_clusters(const int32_t* __restrict__ cnt, int K,
   }
 }
 
-__global__ void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
+__global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
                          const int32_t* __restrict__ bc, const int32_t* __restrict__ off,
                          int32_t* __restrict__ order) {
   __shared__ int lab[KM_SB];
@@ -377,26 +411,32 @@ __global__ void km_apply_relocation(const float* __restrict__ xfar, int ldf,
 }
 
 // _average_centers in sklearn's in-place j-ascending order + _center_shift
-__global__ void km_average(const float* __restrict__ sums, const float* __restrict__ counts, int K,
-                           int D, float* __restrict__ Cn) {
-  __shared__ int amax_s;
-  const int j = blockIdx.x;
-  if (threadIdx.x == 0) {
-    int a = 0;
-    for (int u = 1; u < K; ++u) if (counts[u] > counts[a]) a = u;
-    amax_s = a;
-  }
-  __syncthreads();
+__global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums, const float* __restrict__ counts, int K,
+                                                  int D, float* __restrict__ Cn) {
+  __shared__ float mv[128];
+  __shared__ int mi[128];
+  const int j = blockIdx.x, t = threadIdx.x;
   const float w = counts[j];
   int src = j;
   float alpha;
-  if (w > 0.0f) {
+  if (w > 0.0f) {                                  // the common case needs no argmax
     alpha = (float)(1.0 / (double)w);
   } else {
-    src = amax_s;  // copy of the biggest cluster: averaged already iff it precedes j
+    // np.argmax(weight_in_clusters): first index of the maximum
+    float bv = -1.f; int bi = 0;
+    for (int u = t; u < K; u += 128) { const float c = counts[u]; if (c > bv) { bv = c; bi = u; } }
+    mv[t] = bv; mi[t] = bi;
+    __syncthreads();
+    for (int s2 = 64; s2 > 0; s2 >>= 1) {
+      if (t < s2) {
+        if (mv[t + s2] > mv[t] || (mv[t + s2] == mv[t] && mi[t + s2] < mi[t])) { mv[t] = mv[t + s2]; mi[t] = mi[t + s2]; }
+      }
+      __syncthreads();
+    }
+    src = mi[0];  // copy of the biggest cluster: averaged already iff it precedes j (sklearn's in-place loop order)
     alpha = (src < j && counts[src] > 0.0f) ? (float)(1.0 / (double)counts[src]) : 1.0f;
   }
-  for (int k = threadIdx.x; k < D; k += blockDim.x)
+  for (int k = t; k < D; k += 128)
     Cn[(int64_t)j * D + k] = sums[(int64_t)src * D + k] * alpha;
 }
 
@@ -417,17 +457,28 @@ __global__ void km_shift(const float* __restrict__ Co, const float* __restrict__
   for (; k < D; ++k) { const float d = a[k] - b[k]; r += d * d; }
   shift[j] = sqrtf(r);
 }
-__global__ void km_status(const float* __restrict__ shift, const float* __restrict__ counts, int K,
-                          const int32_t* n_changed, double* status) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double t = 0.0;
-    int ne = 0;
-    for (int j = 0; j < K; ++j) {
-      t += (double)shift[j] * (double)shift[j];
-      ne += counts[j] == 0.0f;
-    }
-    status[0] = t;
-    status[1] = (double)ne;
+// status word: { sum_j shift_j^2, #empty clusters, n_changed, 0 }.  One workgroup; per-thread partials over a fixed
+// strided partition, then a fixed binary tree in LDS (deterministic).
+__global__ __launch_bounds__(256) void km_status(const float* __restrict__ shift, const float* __restrict__ counts, int K,
+                                                 const int32_t* n_changed, double* status) {
+  __shared__ double st[256];
+  __shared__ int se[256];
+  const int t = threadIdx.x;
+  double a = 0.0;
+  int ne = 0;
+  for (int j = t; j < K; j += 256) {
+    a += (double)shift[j] * (double)shift[j];
+    ne += counts[j] == 0.0f;
+  }
+  st[t] = a; se[t] = ne;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (t < s2) { st[t] += st[t + s2]; se[t] += se[t + s2]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    status[0] = st[0];
+    status[1] = (double)se[0];
     status[2] = n_changed ? (double)*n_changed : -1.0;
     status[3] = 0.0;
   }
@@ -607,8 +658,14 @@ extern "C" int slic_kmeans_cnorm(const float* C, int K, int D, int ldc, float* c
   return SLIC_OK;
 }
 
+static int km_nct() {
+  const char* e = getenv("SLIC_KM_NCT");      // tuning knob: centroid tiles (of 32) per workgroup, 2 or 4
+  const int v = e ? atoi(e) : 4;
+  return v == 2 ? 2 : 4;
+}
+
 extern "C" size_t slic_kmeans_assign_workspace_bytes(int64_t N, int K) {
-  const int64_t G = slic_cdiv(K, KM_BC);
+  const int64_t G = slic_cdiv(K, 64);          // sized for the smaller centroid block
   return 2 * slic_align_up((size_t)(G * N) * 4, 256);
 }
 
@@ -623,12 +680,14 @@ extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, con
                D, ldx, ldc);
   SLIC_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)C % 16) == 0, "slic_kmeans_assign: unaligned");
   SLIC_REQUIRE(!labels_old || n_changed, "slic_kmeans_assign: labels_old needs n_changed");
-  const int G = (int)slic_cdiv(K, KM_BC);
+  const int nct = km_nct();
+  const int G = (int)slic_cdiv(K, nct * 32);
   SlicCarver w(workspace);
-  float* pscore = w.take<float>((size_t)G * N);
-  int32_t* pidx = w.take<int32_t>((size_t)G * N);
+  float* pscore = w.take<float>((size_t)slic_cdiv(K, 64) * N);
+  int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 64) * N);
   dim3 grid((unsigned)slic_cdiv(N, KM_BP), (unsigned)G);
-  km_assign_partial<<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
+  if (nct == 2) km_assign_partial<2><<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
+  else km_assign_partial<4><<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
   SLIC_LAUNCH_CHECK();
   km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, S(stream)>>>(
       pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
@@ -733,7 +792,7 @@ extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const
   SLIC_LAUNCH_CHECK();
   km_shift<<<dim3((unsigned)slic_cdiv(K, 64)), dim3(64), 0, st>>>(C_old, C_new, K, D, shift);
   SLIC_LAUNCH_CHECK();
-  km_status<<<dim3(1), dim3(64), 0, st>>>(shift, counts, K, n_changed, status);
+  km_status<<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, status);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
