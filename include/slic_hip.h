@@ -257,6 +257,11 @@ int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, float* out, v
 size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k);
 int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
                      int32_t* out_idx, float* out_dist, void* workspace, void* stream);
+/* merge W per-GPU result lists ([W, Nq, k] distances ascending + GLOBAL gallery indices, -1 = empty slot) into the
+ * k nearest per query (distance ascending, ties -> lower index): the step after the all-gather when the gallery is
+ * sharded by rows across GPUs */
+int slic_topk_merge_lists(const float* pdist, const int32_t* pidx, int W, int Nq, int k, int32_t* out_idx,
+                          float* out_dist, void* stream);
 /* euclidean_distances(X, Y) as a dense [Nx, Ny] matrix (evaluate.py:216; validation-size inputs) */
 int slic_pairwise_euclidean(const float* X, int Nx, const float* Y, int Ny, int D, float* out, void* stream);
 

@@ -107,3 +107,36 @@ def test_nce_full_size_properties(gpu):
     ref = torch.einsum("bkd,bd->bk", bank[idx], f) / 0.07
     assert torch.allclose(out, ref, atol=1e-3, rtol=1e-5)
     assert torch.equal(rows.view(B, K1, D), bank[idx])
+
+
+def test_sharded_gallery_merge_single_rank_group(gpu):
+    """gallery-sharded retrieval (SURVEY.md §8e): shards searched separately + slic_topk_merge_lists == unsharded search;
+    plus the RCCL path itself on a one-rank group"""
+    import os
+    import torch.distributed as dist
+    from video_similarity_search_amd._lib import call, ptr, stream
+    from video_similarity_search_amd.evaluate import cosine_topk, cosine_topk_sharded
+    rng = np.random.default_rng(8)
+    Q = rng.standard_normal((200, 64)).astype(np.float32)
+    G = rng.standard_normal((3000, 64)).astype(np.float32)
+    k = 10
+    ref_i, ref_d = cosine_topk(Q, G, k=k)
+    parts_i, parts_d, off = [], [], 0
+    for sh in np.array_split(G, 3):
+        i, d = cosine_topk(Q, sh, k=k)
+        parts_i.append(i + off)
+        parts_d.append(d)
+        off += len(sh)
+    pi, pd = torch.stack(parts_i).contiguous(), torch.stack(parts_d).contiguous()
+    oi, od = torch.empty_like(ref_i), torch.empty_like(ref_d)
+    call("slic_topk_merge_lists", ptr(pd), ptr(pi), 3, 200, k, ptr(oi), ptr(od), stream())
+    assert torch.equal(oi, ref_i) and torch.equal(od, ref_d)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        si, sd = cosine_topk_sharded(Q, G, k, dist.group.WORLD)
+        assert torch.equal(si, ref_i) and torch.equal(sd, ref_d)
+    finally:
+        dist.destroy_process_group()

@@ -69,6 +69,7 @@ SIGNATURES = {
     "slic_normalize_rows": (I, [P, L, I, I, P, P]),
     "slic_cosine_topk_workspace_bytes": (c_size_t, [I, I, I]),
     "slic_cosine_topk": (I, [P, I, P, I, I, I, I, P, P, P, P]),
+    "slic_topk_merge_lists": (I, [P, P, I, I, I, P, P, P]),
     "slic_pairwise_euclidean": (I, [P, I, P, I, I, P, P]),
     # memory-bank NCE
     "slic_nce_scores_fwd": (I, [P, P, P, I, I, I, F, P, P, P]),

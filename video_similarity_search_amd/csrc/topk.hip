@@ -184,6 +184,34 @@ __global__ void topk_merge_kernel(const float* __restrict__ pval, const int32_t*
   }
 }
 
+// merge W per-shard result lists [W][Nq][k] (distance ascending within a list, GLOBAL gallery indices) into the
+// k best per query: smaller distance first, ties -> lower index.  One thread per query (lists are tiny).
+__global__ void topk_merge_dist_kernel(const float* __restrict__ pd, const int32_t* __restrict__ pi, int W, int Nq,
+                                       int k, int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Nq) return;
+  float last = -INFINITY;
+  int last_i = -1;
+  for (int o = 0; o < k; ++o) {
+    float bd = INFINITY;
+    int bi = INT_MAX;
+    for (int w = 0; w < W; ++w) {
+      const float* v = pd + ((int64_t)w * Nq + q) * k;
+      const int32_t* ix = pi + ((int64_t)w * Nq + q) * k;
+      for (int t = 0; t < k; ++t) {
+        const float d = v[t];
+        const int i = ix[t];
+        if (i < 0) continue;
+        const bool after_last = d > last || (d == last && i > last_i);
+        if (after_last && (d < bd || (d == bd && i < bi))) { bd = d; bi = i; }
+      }
+    }
+    out_idx[(int64_t)q * k + o] = bi == INT_MAX ? -1 : bi;
+    out_dist[(int64_t)q * k + o] = bd;
+    last = bd; last_i = bi;
+  }
+}
+
 // sklearn.preprocessing.normalize(X) (l2): rows with zero norm are left as they are
 __global__ void normalize_rows_sklearn(const float* __restrict__ X, int64_t N, int D, int ldx,
                                        float* __restrict__ out) {
@@ -258,6 +286,14 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pval, pidx);
   SLIC_LAUNCH_CHECK();
   topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 64)), dim3(64), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_topk_merge_lists(const float* pdist, const int32_t* pidx, int W, int Nq, int k, int32_t* out_idx,
+                                     float* out_dist, void* stream) {
+  SLIC_REQUIRE(pdist && pidx && out_idx && out_dist && W > 0 && Nq > 0 && k > 0, "slic_topk_merge_lists: bad args");
+  topk_merge_dist_kernel<<<dim3((unsigned)slic_cdiv(Nq, 64)), dim3(64), 0, S_(stream)>>>(pdist, pidx, W, Nq, k, out_idx, out_dist);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

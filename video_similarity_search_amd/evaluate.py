@@ -44,6 +44,35 @@ def _normalize(x, Dp):
     return out
 
 
+def cosine_topk_sharded(queries, gallery_shard, k, process_group, row_offset=None):
+    """Gallery sharded by rows across the ranks of `process_group` (queries replicated): every rank searches its
+    shard, the [Nq, k] lists are all-gathered (RCCL) and merged on every GPU.  Returned indices are GLOBAL gallery
+    rows (rank order == row order unless `row_offset` is given)."""
+    import torch.distributed as dist
+    W = dist.get_world_size(process_group)
+    g = _dev(gallery_shard)
+    n_loc = torch.tensor([g.shape[0]], dtype=torch.int64, device=g.device)
+    sizes = torch.empty(W, dtype=torch.int64, device=g.device)
+    dist.all_gather_into_tensor(sizes, n_loc, group=process_group)
+    if row_offset is None:
+        row_offset = int(sizes[: dist.get_rank(process_group)].sum().item())
+    kk = min(k, g.shape[0])
+    idx, dst = cosine_topk(queries, g, k=kk)
+    Nq = idx.shape[0]
+    pi = torch.full((Nq, k), -1, dtype=torch.int32, device=g.device)
+    pd = torch.full((Nq, k), float("inf"), dtype=torch.float32, device=g.device)
+    pi[:, :kk] = idx + row_offset
+    pd[:, :kk] = dst
+    api = torch.empty(W * Nq * k, dtype=torch.int32, device=g.device)
+    apd = torch.empty(W * Nq * k, dtype=torch.float32, device=g.device)
+    dist.all_gather_into_tensor(api, pi.reshape(-1), group=process_group)
+    dist.all_gather_into_tensor(apd, pd.reshape(-1), group=process_group)
+    out_i = torch.empty(Nq, k, dtype=torch.int32, device=g.device)
+    out_d = torch.empty(Nq, k, dtype=torch.float32, device=g.device)
+    call("slic_topk_merge_lists", ptr(apd), ptr(api), W, Nq, k, ptr(out_i), ptr(out_d), stream())
+    return out_i, out_d
+
+
 def cosine_topk(queries, gallery=None, k=20):
     """indices [Nq, k] (int32) and cosine distances [Nq, k] of the k nearest gallery rows, ascending;
     gallery=None searches the queries themselves with the diagonal excluded (evaluate.py:221-222)."""
