@@ -2,9 +2,9 @@
 Drop-in for the reference's clustering/cluster_masks.py on the k-means path:
     preprocess_features_kmeans(data)                                   <- cluster_masks.py:30-34
     fit_cluster(embeddings, method, k, l2normalize, finch_partition)   <- cluster_masks.py:38-98
-Same names, argument meaning, prints and return type (np.ndarray[N] int32 labels).  Only
-method='kmeans' is on the accelerated path; the other methods the reference
-dispatches to sklearn/FINCH on the host are outside this package and raise.
+Same names, argument meaning, prints and return type (np.ndarray[N] labels).  method='kmeans'
+ and method='finch' (§8f row 1: the method the shipped configs select) run on
+the GPU; the other methods the reference dispatches to sklearn on the host raise.
 """
 import numpy as np
 import torch
@@ -41,10 +41,21 @@ def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, fi
     to the reference's behaviour: KMeans(n_clusters=k, n_init=10).fit(embeddings).labels_."""
     assert (method in _METHODS)
     print("Clustering with {}...".format(method))
+    if method == 'finch':
+        # cluster_masks.py:79-86: FINCH(embeddings, distance='cosine'), take partition `finch_partition`
+        from .finch import FINCH
+        emb = embeddings.detach().cpu().numpy() if torch.is_tensor(embeddings) else np.asarray(embeddings)
+        c, num_clust, req_c = FINCH(emb, distance='cosine')
+        PARTITION = finch_partition
+        labels = c[:, PARTITION]
+        n_clusters = num_clust[PARTITION]
+        print('Taking partition {} from finch'.format(PARTITION))
+        print("Fitted " + str(n_clusters) + " clusters with " + str(method))
+        return labels
     if method != 'kmeans':
         raise NotImplementedError(
-            f"method={method!r}: only 'kmeans' is on the MI355X hot path (SURVEY.md §8); the reference runs the "
-            "others on the host through sklearn / FINCH")
+            f"method={method!r}: 'kmeans' and 'finch' are on the MI355X hot path (SURVEY.md §8); the reference runs "
+            "the others on the host through sklearn")
     print("k:", k)
     x = _to_device(embeddings)
     if l2normalize:
