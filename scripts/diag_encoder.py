@@ -32,9 +32,10 @@ if "acc" in sys.argv:
                 ref = taps64[name]
                 got = t.cpu().permute(0, 4, 1, 2, 3).double() if t.dim() == 5 else t.cpu().double()
                 print("   gpu-vs-64", name, (got - ref).abs().max().item(), "cpu32-vs-64", (taps32[name].double() - ref).abs().max().item(), "scale", ref.abs().max().item())
-            cmp("stem", ctx["a0"])
-            for nme, blk in zip(names, ctx["blocks"]): cmp(nme, blk["out"])
-            cmp("pooled", ctx["pooled"])
+            cmp("stem", ctx[0]["a0"])
+            blocks = [b for c in ctx[1:5] for b in c["blocks"]]
+            for nme, blk in zip(names, blocks): cmp(nme, blk["out"])
+            cmp("pooled", ctx[5]["pooled"])
         print(mode, "gpu-vs-64", (g.double() - r64).abs().max().item(), "cpu32-vs-64", (r32.double() - r64).abs().max().item(),
               "gpu-vs-cpu32", (g - r32).abs().max().item(), "scale", r64.abs().max().item())
 for B in [int(a) for a in sys.argv[1:] if a.isdigit()]:

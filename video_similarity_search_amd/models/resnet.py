@@ -77,7 +77,9 @@ class _Engine:
             raise NotImplementedError("no_max_pool=False: every shipped SLIC config sets RESNET.NO_MAX_POOl true "
                                       "(config/custom_configs/resnet_ucf_itercluster_flow.yaml:29-37)")
         self.blocks = []
+        self.layer_blocks = []
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+            self.layer_blocks.append([])
             for blk in layer:
                 if not isinstance(blk, BasicBlock):
                     raise NotImplementedError("Bottleneck depths (50+) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
@@ -93,6 +95,7 @@ class _Engine:
                     pd = ConvPlan(dc.in_channels, dc.out_channels, dc.kernel_size, dc.stride, dc.padding, dims, device)
                     assert pd.out_dims == p2.out_dims
                 self.blocks.append((blk, p1, p2, pd))
+                self.layer_blocks[-1].append((blk, p1, p2, pd))
                 dims = p2.out_dims
         self.final_dims = dims
         self.feat = self.blocks[-1][2].N
@@ -143,53 +146,73 @@ class _Engine:
              ptr(g), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
         return dz, g, dgamma, dbeta
 
-    # ------------------------------------------------------------------ forward
-    def forward(self, x, training, save):
-        """x: [B, C, T, H, W] fp32 device tensor.  Returns (output [B, out_dim], ctx or None)."""
+    # ------------------------------------------------------------------ segments
+    # The plan is cut into segments — stem | layer1 | layer2 | layer3 | layer4 | head — each exposed to autograd as its
+    # own node (_SegmentFn).  Backward then hands the last layers' gradients to autograd first, so under
+    # DistributedDataParallel the bucketed RCCL all-reduce of those gradients overlaps with the backward of the
+    # earlier, heavier layers (the reference gets the same overlap from DDP over per-module autograd nodes).
+    N_SEG = 6
+
+    def seg_params(self, si):
         net = self.net
-        B, C, T, H, W = x.shape
-        dev = x.device
-        x = x.contiguous()
-        x4 = torch.empty(B, T, H, W, self.stem.Cs, dtype=torch.float32, device=dev)
-        call("slic_ncdhw_to_ndhwc", ptr(x), B, C, T * H * W, self.stem.Cs, ptr(x4), stream())
-        ctx = dict(x4=x4, blocks=[]) if save else None
+        if si == 0:
+            mods = [net.conv1, net.bn1]
+        elif si <= 4:
+            mods = [getattr(net, f"layer{si}")]
+        else:
+            mods = [net.fc1, net.bn_proj, net.fc2] if net.projection_head else []
+        return [p for m in mods for p in m.parameters() if p.requires_grad]
 
-        def conv_bn_act(plan, inp, weight, bnmod, res, relu):
-            """conv -> BN -> (+res) -> relu; returns (z or None, y, bn)"""
-            bn = _Bn(bnmod)
-            wp = plan.pack_fwd(weight)
-            if training:
-                z, part = plan.forward(inp, wp, B, want_stats=True)
-                self._bn_train(bn, part, z.numel() // bn.C)
-                y = self._apply(z, bn, res, relu)
-                return z, y, bn
-            self._bn_eval(bn)                     # eval: BN folded into the conv epilogue
-            y, _ = plan.forward(inp, wp, B, scale=bn.scale, shift=bn.shift, addend=res, relu=relu)
-            return None, y, bn
+    def _conv_bn_act(self, plan, inp, weight, bnmod, res, relu, training, B):
+        """conv -> BN -> (+res) -> relu; returns (z or None, y, bn)"""
+        bn = _Bn(bnmod)
+        wp = plan.pack_fwd(weight)
+        if training:
+            z, part = plan.forward(inp, wp, B, want_stats=True)
+            self._bn_train(bn, part, z.numel() // bn.C)
+            y = self._apply(z, bn, res, relu)
+            return z, y, bn
+        self._bn_eval(bn)                     # eval: BN folded into the conv epilogue
+        y, _ = plan.forward(inp, wp, B, scale=bn.scale, shift=bn.shift, addend=res, relu=relu)
+        return None, y, bn
 
-        z0, a, bn0 = conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True)
-        if save:
-            ctx.update(z0=z0, a0=a, bn0=bn0)
-        for blk, p1, p2, pd in self.blocks:
-            xin = a
-            z1, a1, b1 = conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True)
-            if pd is not None:
-                zd, r, bd = conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False)
-            else:
-                zd, r, bd = None, xin, None
-            z2, out, b2 = conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True)
-            if save:
-                ctx["blocks"].append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, out=out, b2=b2, zd=zd, bd=bd))
-            a = out
+    def seg_forward(self, si, inp, training, save):
+        """returns (out, ctx).  Segment 0 takes the NCDHW clip batch; 1..4 take/return NDHWC activations;
+        5 returns the [B, out_dim] (or [B, 512]) embedding."""
+        net = self.net
+        B = inp.shape[0]
+        dev = inp.device
+        if si == 0:
+            _, C, T, H, W = inp.shape
+            x = inp.contiguous()
+            x4 = torch.empty(B, T, H, W, self.stem.Cs, dtype=torch.float32, device=dev)
+            call("slic_ncdhw_to_ndhwc", ptr(x), B, C, T * H * W, self.stem.Cs, ptr(x4), stream())
+            z0, a, bn0 = self._conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True, training, B)
+            return a, (dict(x4=x4, z0=z0, a0=a, bn0=bn0) if save else None)
+        if si <= 4:
+            a = inp
+            saved = []
+            for blk, p1, p2, pd in self.layer_blocks[si - 1]:
+                xin = a
+                z1, a1, b1 = self._conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True, training, B)
+                if pd is not None:
+                    zd, r, bd = self._conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False, training, B)
+                else:
+                    zd, r, bd = None, xin, None
+                z2, out, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True, training, B)
+                if save:
+                    saved.append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, out=out, b2=b2, zd=zd, bd=bd))
+                a = out
+            return a, (dict(blocks=saved) if save else None)
+        # head: pool -> fc2(relu(bn_proj(fc1(x))))   (models/resnet.py:286-299)
+        a = inp
         To, Ho, Wo = self.final_dims
         S = To * Ho * Wo
         pooled = torch.empty(B, self.feat, dtype=torch.float32, device=dev)
         call("slic_avgpool_fwd", ptr(a), B, S, self.feat, ptr(pooled), stream())
-        if save:
-            ctx.update(last=a, pooled=pooled)
+        ctx = dict(last_shape=tuple(a.shape), pooled=pooled) if save else None
         if not net.projection_head:
             return pooled, ctx
-        # h = fc2(relu(bn_proj(fc1(x))))   (models/resnet.py:294-299)
         bnp = _Bn(net.bn_proj)
         w1 = self.fc1.pack_fwd(net.fc1.weight)
         p5 = pooled.view(B, 1, 1, 1, self.feat)
@@ -199,8 +222,7 @@ class _Engine:
             ah = self._apply(h1, bnp, None, True)
         else:
             self._bn_eval(bnp)
-            # bias first, then the BN affine, then ReLU — all in the epilogue
-            h1 = None
+            h1 = None      # bias first, then the BN affine, then ReLU — all in the epilogue
             ah, _ = self.fc1.forward(p5, w1, B, bias=net.fc1.bias, scale=bnp.scale, shift=bnp.shift, relu=True)
         w2 = self.fc2.pack_fwd(net.fc2.weight)
         y, _ = self.fc2.forward(ah.view(B, 1, 1, 1, -1), w2, B, bias=net.fc2.bias)
@@ -208,14 +230,12 @@ class _Engine:
             ctx.update(h1=h1, ah=ah, bnp=bnp)
         return y.view(B, -1), ctx
 
-    # ------------------------------------------------------------------ backward
-    def backward(self, ctx, dy):
-        """dy: [B, out_dim].  Returns {parameter: gradient} (reference layouts)."""
+    def seg_backward(self, si, ctx, dout):
+        """returns (gradient wrt the segment input or None, {parameter: gradient})"""
         net = self.net
         grads = {}
-        B = dy.shape[0]
-        dev = dy.device
-        dy = dy.contiguous()
+        B = dout.shape[0]
+        dout = dout.contiguous()
 
         def new_like(p):
             return torch.empty_like(p, memory_format=torch.contiguous_format)
@@ -225,67 +245,97 @@ class _Engine:
             call("slic_colsum", ptr(d2), d2.shape[0], d2.shape[1], ptr(g), stream())
             return g
 
-        if net.projection_head:
-            ah, h1, bnp, pooled = ctx["ah"], ctx["h1"], ctx["bnp"], ctx["pooled"]
-            d5 = dy.view(B, 1, 1, 1, -1)
-            grads[net.fc2.weight] = self.fc2.wgrad(ah.view(B, 1, 1, 1, -1), d5, B, new_like(net.fc2.weight))
-            grads[net.fc2.bias] = bias_grad(dy, net.fc2.bias)
-            dah = self.fc2.dgrad(d5, self.fc2.pack_dgrad(net.fc2.weight), B)
-            dh1, _, dg, db = self._bn_bwd(dah.view(B, -1), ah.view(B, -1), h1.view(B, -1), bnp, False)
-            grads[net.bn_proj.weight], grads[net.bn_proj.bias] = dg, db
-            grads[net.fc1.weight] = self.fc1.wgrad(pooled.view(B, 1, 1, 1, -1), dh1.view(B, 1, 1, 1, -1), B, new_like(net.fc1.weight))
-            grads[net.fc1.bias] = bias_grad(dh1.view(B, -1), net.fc1.bias)
-            dpool = self.fc1.dgrad(dh1.view(B, 1, 1, 1, -1), self.fc1.pack_dgrad(net.fc1.weight), B).view(B, -1)
-        else:
-            dpool = dy
-        To, Ho, Wo = self.final_dims
-        S = To * Ho * Wo
-        dout = torch.empty_like(ctx["last"])
-        call("slic_avgpool_bwd", ptr(dpool), B, S, self.feat, ptr(dout), stream())
-
-        for (blk, p1, p2, pd), s in zip(reversed(self.blocks), reversed(ctx["blocks"])):
-            # out = relu(bn2(conv2(a1)) + r)
-            dz2, g, dg2, db2 = self._bn_bwd(dout, s["out"], s["z2"], s["b2"], True)
-            grads[blk.bn2.weight], grads[blk.bn2.bias] = dg2, db2
-            grads[blk.conv2.weight] = p2.wgrad(s["a1"], dz2, B, new_like(blk.conv2.weight))
-            da1 = p2.dgrad(dz2, p2.pack_dgrad(blk.conv2.weight), B)
-            del dz2
-            # a1 = relu(bn1(conv1(x)))
-            dz1, _, dg1, db1 = self._bn_bwd(da1, s["a1"], s["z1"], s["b1"], False)
-            del da1
-            grads[blk.bn1.weight], grads[blk.bn1.bias] = dg1, db1
-            grads[blk.conv1.weight] = p1.wgrad(s["x"], dz1, B, new_like(blk.conv1.weight))
-            if pd is not None:
-                # r = bn_d(conv_d(x)): g is its upstream gradient
-                dzd, _, dgd, dbd = self._bn_bwd(g, None, s["zd"], s["bd"], False)
-                grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dgd, dbd
-                grads[blk.downsample[0].weight] = pd.wgrad(s["x"], dzd, B, new_like(blk.downsample[0].weight))
-                dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B)
-                dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx)
+        if si == 5:
+            dy = dout
+            if net.projection_head:
+                ah, h1, bnp, pooled = ctx["ah"], ctx["h1"], ctx["bnp"], ctx["pooled"]
+                d5 = dy.view(B, 1, 1, 1, -1)
+                grads[net.fc2.weight] = self.fc2.wgrad(ah.view(B, 1, 1, 1, -1), d5, B, new_like(net.fc2.weight))
+                grads[net.fc2.bias] = bias_grad(dy, net.fc2.bias)
+                dah = self.fc2.dgrad(d5, self.fc2.pack_dgrad(net.fc2.weight), B)
+                dh1, _, dg, db = self._bn_bwd(dah.view(B, -1), ah.view(B, -1), h1.view(B, -1), bnp, False)
+                grads[net.bn_proj.weight], grads[net.bn_proj.bias] = dg, db
+                grads[net.fc1.weight] = self.fc1.wgrad(pooled.view(B, 1, 1, 1, -1), dh1.view(B, 1, 1, 1, -1), B, new_like(net.fc1.weight))
+                grads[net.fc1.bias] = bias_grad(dh1.view(B, -1), net.fc1.bias)
+                dpool = self.fc1.dgrad(dh1.view(B, 1, 1, 1, -1), self.fc1.pack_dgrad(net.fc1.weight), B).view(B, -1)
             else:
-                dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=g)
-            dout = dx
-        # stem: a0 = relu(bn1(conv1(x4))); the input needs no gradient
+                dpool = dy
+            To, Ho, Wo = self.final_dims
+            S = To * Ho * Wo
+            dx = torch.empty(ctx["last_shape"], dtype=torch.float32, device=dout.device)
+            call("slic_avgpool_bwd", ptr(dpool), B, S, self.feat, ptr(dx), stream())
+            return dx, grads
+        if si >= 1:
+            for (blk, p1, p2, pd), s in zip(reversed(self.layer_blocks[si - 1]), reversed(ctx["blocks"])):
+                # out = relu(bn2(conv2(a1)) + r)
+                dz2, g, dg2, db2 = self._bn_bwd(dout, s["out"], s["z2"], s["b2"], True)
+                grads[blk.bn2.weight], grads[blk.bn2.bias] = dg2, db2
+                grads[blk.conv2.weight] = p2.wgrad(s["a1"], dz2, B, new_like(blk.conv2.weight))
+                da1 = p2.dgrad(dz2, p2.pack_dgrad(blk.conv2.weight), B)
+                del dz2
+                # a1 = relu(bn1(conv1(x)))
+                dz1, _, dg1, db1 = self._bn_bwd(da1, s["a1"], s["z1"], s["b1"], False)
+                del da1
+                grads[blk.bn1.weight], grads[blk.bn1.bias] = dg1, db1
+                grads[blk.conv1.weight] = p1.wgrad(s["x"], dz1, B, new_like(blk.conv1.weight))
+                if pd is not None:
+                    # r = bn_d(conv_d(x)): g is its upstream gradient
+                    dzd, _, dgd, dbd = self._bn_bwd(g, None, s["zd"], s["bd"], False)
+                    grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dgd, dbd
+                    grads[blk.downsample[0].weight] = pd.wgrad(s["x"], dzd, B, new_like(blk.downsample[0].weight))
+                    dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B)
+                    dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx)
+                else:
+                    dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=g)
+                dout = dx
+            return dout, grads
+        # stem: a0 = relu(bn1(conv1(x4))); the clip needs no gradient
         dz0, _, dg0, db0 = self._bn_bwd(dout, ctx["a0"], ctx["z0"], ctx["bn0"], False)
         grads[net.bn1.weight], grads[net.bn1.bias] = dg0, db0
         grads[net.conv1.weight] = self.stem.wgrad(ctx["x4"], dz0, B, new_like(net.conv1.weight))
+        return None, grads
+
+    # ------------------------------------------------------------------ whole passes (inference, tests, diagnostics)
+    def forward(self, x, training, save):
+        """x: [B, C, T, H, W] fp32 device tensor.  Returns (output [B, out_dim], [ctx per segment] or None)."""
+        ctxs = []
+        a = x
+        for si in range(self.N_SEG):
+            a, c = self.seg_forward(si, a, training, save)
+            ctxs.append(c)
+        return a, (ctxs if save else None)
+
+    def backward(self, ctxs, dy):
+        """dy: [B, out_dim].  Returns {parameter: gradient} (reference layouts)."""
+        grads = {}
+        d = dy
+        for si in reversed(range(self.N_SEG)):
+            d, g = self.seg_backward(si, ctxs[si], d)
+            grads.update(g)
         return grads
 
 
-class _EncoderFn(torch.autograd.Function):
-    """the whole encoder as one autograd node: forward/backward are the engine's hand-written passes"""
+class _SegmentFn(torch.autograd.Function):
+    """one segment of the encoder as an autograd node: forward/backward are the engine's hand-written passes"""
 
     @staticmethod
-    def forward(ctx, x, net, engine, *params):
-        out, saved = engine.forward(x, training=net.training, save=True)
-        ctx.engine, ctx.saved, ctx.params = engine, saved, params
+    def forward(ctx, inp, engine, si, training, *params):
+        out, saved = engine.seg_forward(si, inp, training=training, save=True)
+        # the saved context must not hold the output OBJECT (output -> grad_fn -> ctx -> output would be a reference
+        # cycle that pins HBM until Python's cycle collector runs): keep a detached alias of the same storage
+        if si == 0:
+            saved["a0"] = out.detach()
+        elif si <= 4:
+            saved["blocks"][-1]["out"] = out.detach()
+        ctx.engine, ctx.si, ctx.saved, ctx.params = engine, si, saved, params
+        ctx.inp_grad = inp.requires_grad
         return out
 
     @staticmethod
-    def backward(ctx, dy):
-        grads = ctx.engine.backward(ctx.saved, dy)
+    def backward(ctx, dout):
+        dinp, grads = ctx.engine.seg_backward(ctx.si, ctx.saved, dout)
         ctx.saved = None
-        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+        return (dinp if ctx.inp_grad else None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
 class ResNet(nn.Module):
@@ -360,11 +410,11 @@ class ResNet(nn.Module):
         eng = self._engine(x)
         params = [p for p in self.parameters() if p.requires_grad]
         if torch.is_grad_enabled() and self.training and params:
-            return _EncoderFn.apply(x, self, eng, *params)
-        if torch.is_grad_enabled() and params and not self.training:
-            # eval-mode graph (BN frozen) is not needed by the SLIC loop (validation runs under no_grad)
-            with torch.no_grad():
-                return eng.forward(x, training=False, save=False)[0]
+            a = x
+            for si in range(eng.N_SEG):
+                a = _SegmentFn.apply(a, eng, si, True, *eng.seg_params(si))
+            return a
+        # eval-mode graph (BN frozen) is not needed by the SLIC loop (validation runs under no_grad): inference only
         with torch.no_grad():
             return eng.forward(x, training=self.training, save=False)[0]
 
