@@ -263,13 +263,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // two k-tiles in flight across ONE raw barrier per tile.  LDS image = the same [rows][32] swizzled layout: the
 // DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk (p ^ ((row >> 1) & 7)).
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int AL = BM / 32, BL = BN / 32;
-  constexpr int STAGE_FLOATS = (BM + BN) * 32;
+  constexpr int TILE_FLOATS = (BM + BN) * 32;                 // one k-tile (32 deep) of A and B
+  constexpr int STAGE_FLOATS = KT * TILE_FLOATS;              // a ring stage holds KT k-tiles: one barrier per KT tiles
   static_assert(WM * WN == 4, "4 waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -313,15 +314,15 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
   // per-tap records are read through the constant address space with a wave-uniform index: scalar loads, which
   // never touch the vmcnt queue the DMAs are counted on
   const __attribute__((address_space(4))) i32x4* tapc = (const __attribute__((address_space(4))) i32x4*)p.tab;
-  // issue the (AL + BL) DMAs of k-tile kt into ring stage st
-  auto issue = [&](int kt, int st) {
+  // issue the (AL + BL) DMAs of k-tile kt into the LDS tile at float offset `toff`
+  auto issue = [&](int kt, int toff) {
     const int tap = kt / tiles_per_tap;                      // wave-uniform -> scalar loads of the tap record
     const int cb = (kt - tap * tiles_per_tap) << 5;          // channel base inside the tap
     const i32x4 e = tapc[tap];                               // {src delta, tap mask, weight base, -}: s_load (lgkmcnt queue)
     const unsigned tm = (unsigned)e.y;
     const unsigned dlt = (unsigned)(e.x + cb) * 4u;
     const unsigned wc = (unsigned)(e.z + cb) * 4u;
-    float* As = lds + st * STAGE_FLOATS;
+    float* As = lds + toff;
     float* Bs = As + BM * 32;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   const int r = lane & 31, h = lane >> 5;
-  auto compute = [&](int st) {
-    const float* Ab = lds + st * STAGE_FLOATS;
+  auto compute = [&](int toff) {
+    const float* Ab = lds + toff;
     const float* Bb = Ab + BM * 32;
     f32x4 a[2][TM], b[2][TN];
 #pragma unroll
@@ -374,23 +375,36 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  // prologue: STAGES - 1 tiles in flight
+  // prologue: STAGES - 1 stages (of KT k-tiles each) in flight
+  const int ns = (nk + KT - 1) / KT;                         // number of stages' worth of work
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t)
-    if (t < nk) issue(t, t);
-  for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
 #pragma unroll
-    for (int sidx = 0; sidx < STAGES; ++sidx) {          // unrolled: ring stages are compile-time, so the compiler can
-      const int kt = kt0 + sidx;                          // see that the ds_reads and the in-flight DMAs never alias
-      if (kt < nk) {
-        // tile kt has landed once only the DMAs of the younger in-flight tiles are outstanding
-        const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AL + BL)) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AL + BL) : "memory");
+    for (int u = 0; u < KT; ++u)
+      if (t * KT + u < nk) issue(t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
+  constexpr int PER_STAGE = KT * (AL + BL);                  // DMA instructions per stage per wave (a ragged last stage
+                                                             // issues fewer: the counted waits below stay conservative)
+  for (int s0 = 0; s0 < ns; s0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {              // unrolled: ring stages are compile-time, so the compiler can
+      const int sg = s0 + sidx;                               // see that the ds_reads and the in-flight DMAs never alias
+      if (sg < ns) {
+        // stage sg has landed once only the DMAs of the younger in-flight stages are outstanding
+        const int younger = min(STAGES - 2, ns - 1 - sg);
+        const bool ragged = (nk % KT) != 0 && sg + younger == ns - 1;   // the youngest stage is the short one
+        if (younger >= 2 && !ragged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STAGE) : "memory");
+        else if (younger >= 1 && !ragged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // every wave's part of tile kt is in LDS; the stage of tile kt-1 is free
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (sidx + STAGES - 1) % STAGES);
-        compute(sidx);
+        __builtin_amdgcn_s_barrier();      // every wave's part of stage sg is in LDS; the previous stage is free
+        if (sg + STAGES - 1 < ns) {
+#pragma unroll
+          for (int u = 0; u < KT; ++u)
+            if ((sg + STAGES - 1) * KT + u < nk)
+              issue((sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
+        }
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+          if (sg * KT + u < nk) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
       }
     }
   }
@@ -586,23 +600,23 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
   return SLIC_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1>
 static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
-  constexpr size_t lds = (size_t)STAGES * (BM + BN) * 32 * sizeof(float);
+  constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid((unsigned)slic_cdiv(a.M, BM), (unsigned)slic_cdiv(a.N, BN));
-  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES><<<grid, dim3(256), lds, st>>>(a);
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT><<<grid, dim3(256), lds, st>>>(a);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
 
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
-  if (variant == 11 || variant == 12) return 64;
+  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17) return 64;
   if (variant == 13 || variant == 14) return 128;
   // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
   if (variant == 1) return 128;
@@ -619,7 +633,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   hipStream_t st = S_(stream);
-  if (variant >= 11 && variant <= 14) {
+  if (variant >= 11 && variant <= 17) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SlicConvArgs b = *a;
@@ -627,6 +641,9 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     if (variant == 11) return launch_gemm_dma<64, 64, 2, 2, 3>(b, st);
     if (variant == 12) return launch_gemm_dma<64, 64, 2, 2, 4>(b, st);
     if (variant == 13) return launch_gemm_dma<128, 64, 2, 2, 3>(b, st);
+    if (variant == 17) return launch_gemm_dma<64, 64, 2, 2, 2, 1>(b, st);     // 2-stage ring (32 KB: 5 workgroups / CU)
+    if (variant == 15) return launch_gemm_dma<64, 64, 2, 2, 2, 2>(b, st);     // 2 k-tiles per barrier, 2-stage ring (64 KB)
+    if (variant == 16) return launch_gemm_dma<64, 64, 2, 2, 3, 2>(b, st);     // 2 k-tiles per barrier, 3-stage ring (96 KB)
     return launch_gemm_dma<128, 128, 2, 2, 3>(b, st);
   }
   const int bm = slic_conv_tile_m(a, variant);

@@ -169,10 +169,14 @@ class ConvPlan:
 
     @staticmethod
     def _pick(a, variant):
-        """variant 0 = auto: the LDS-DMA kernel (64x64 tiles, 3-stage ring) wherever a per-tap table exists
+        """variant 0 = auto: the LDS-DMA kernel (64x64 tiles, 2- or 3-stage ring) wherever a per-tap table exists
         (source channels % 32 == 0), else the register-staged kernel (stem, tiny-channel layers)"""
         if variant == 0:
-            return 11 if a.tap_tab else 0
+            if not a.tap_tab:
+                return 0
+            # measured (scripts/bench_conv.py): the 2-stage ring (32 KB LDS, 5 workgroups / CU) wins on the large-M
+            # layers, the 3-stage ring on the small-M ones (layer4) where fewer workgroups exist to hide latency
+            return 17 if a.M >= 20000 else 11
         if variant >= 11 and not a.tap_tab:
             return 0
         return variant
