@@ -451,17 +451,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
   i32x4 gx[G][2], gy[2];
+  // row coordinates advance by 32 positions per k'-tile: keep (batch, ga, gb, gc) of the thread's two rows and step
+  // them in mixed radix (a handful of compare/selects) instead of three integer divisions per row per tile
+  int rn[2], ra[2], rb[2], rc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    unsigned rr = (unsigned)(mbeg + srow + 16 * i);
+    rc[i] = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+    rb[i] = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+    ra[i] = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
+    rn[i] = (int)rr;
+  }
+  int st_c, st_b, st_a, st_n;      // 32 = ((st_n * Ga + st_a) * Gb + st_b) * Gc + st_c
+  {
+    unsigned t = 32u;
+    st_c = (int)(t % (unsigned)p.Gc); t /= (unsigned)p.Gc;
+    st_b = (int)(t % (unsigned)p.Gb); t /= (unsigned)p.Gb;
+    st_a = (int)(t % (unsigned)p.Ga); t /= (unsigned)p.Ga;
+    st_n = (int)t;
+  }
+  int64_t mcur = mbeg;             // first row of the tile the coordinates currently describe
   auto gload = [&](int64_t mt) {
+    // gload is called with consecutive tiles (mbeg, mbeg + 32, ...): step the coordinates up to mt
+    while (mcur < mt) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        rc[i] += st_c; const int c1 = rc[i] >= p.Gc; rc[i] -= c1 ? p.Gc : 0;
+        rb[i] += st_b + c1; const int c2 = rb[i] >= p.Gb; rb[i] -= c2 ? p.Gb : 0;
+        ra[i] += st_a + c2; const int c3 = ra[i] >= p.Ga; ra[i] -= c3 ? p.Ga : 0;
+        rn[i] += st_n + c3;
+      }
+      mcur += 32;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int64_t m = mt + srow + 16 * i;
       const bool mv = m < mend;
-      unsigned rr = mv ? (unsigned)m : 0u;
-      const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
-      const int gbb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
-      const int gaa = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
-      const int a0 = gaa * p.sa, b0 = gbb * p.sb, c0 = gc * p.sc;
-      const unsigned base = (((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
+      const int a0 = ra[i] * p.sa, b0 = rb[i] * p.sb, c0 = rc[i] * p.sc;
+      const unsigned base = ((((unsigned)rn[i] * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const bool ok = mv && cv[g] && (unsigned)(a0 + oa[g]) < (unsigned)p.Ts &&
@@ -617,7 +644,7 @@ static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
 
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
   if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17) return 64;
-  if (variant == 13 || variant == 14) return 128;
+  if (variant == 13 || variant == 14 || variant == 18 || variant == 19) return 128;
   // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
   if (variant == 1) return 128;
   if (variant == 2) return 64;
@@ -633,7 +660,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   hipStream_t st = S_(stream);
-  if (variant >= 11 && variant <= 17) {
+  if (variant >= 11 && variant <= 19) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SlicConvArgs b = *a;
@@ -642,6 +669,8 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     if (variant == 12) return launch_gemm_dma<64, 64, 2, 2, 4>(b, st);
     if (variant == 13) return launch_gemm_dma<128, 64, 2, 2, 3>(b, st);
     if (variant == 17) return launch_gemm_dma<64, 64, 2, 2, 2, 1>(b, st);     // 2-stage ring (32 KB: 5 workgroups / CU)
+    if (variant == 18) return launch_gemm_dma<128, 128, 2, 2, 2, 1>(b, st);   // 64 KB: 2 workgroups / CU, 64 acc regs
+    if (variant == 19) return launch_gemm_dma<128, 64, 2, 2, 2, 1>(b, st);    // 48 KB: 3 workgroups / CU
     if (variant == 15) return launch_gemm_dma<64, 64, 2, 2, 2, 2>(b, st);     // 2 k-tiles per barrier, 2-stage ring (64 KB)
     if (variant == 16) return launch_gemm_dma<64, 64, 2, 2, 3, 2>(b, st);     // 2 k-tiles per barrier, 3-stage ring (96 KB)
     return launch_gemm_dma<128, 128, 2, 2, 3>(b, st);
