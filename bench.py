@@ -252,6 +252,37 @@ def main():
             res["secondary"] = kmeans_secondary(rank, world, pg, run_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         except Exception as e:                                    # never lose the headline line
             res["secondary"] = dict(error=repr(e))
+        try:
+            # embedding extraction (evaluate.py:146-205): eval-mode forward only, BN folded into the conv epilogue
+            net.eval()
+            with torch.no_grad():
+                for _ in range(2):
+                    net(x)
+                torch.cuda.synchronize()
+                t1 = time.time()
+                for _ in range(5):
+                    net(x)
+                torch.cuda.synchronize()
+                dte = (time.time() - t1) / 5
+            net.train()
+            res["secondary"]["extract"] = dict(metric="clips/sec R3D-18 eval-mode forward (embedding extraction), per GPU", value=B / dte,
+                                               unit="clips/s", ms_per_batch=dte * 1e3, frac_of_fp32_mfma_roofline=B / dte * 85.17 / 1e3 / FP32_MFMA_PEAK_TFLOPS)
+            if world == 1:
+                # the reference-shaped clustering call end to end: KMeans(n_clusters=500, n_init=10) = 10 x (k-means++ + Lloyd, tol 1e-4)
+                from video_similarity_search_amd.clustering import fit_cluster
+                import contextlib, io
+                rngc = np.random.default_rng(1)
+                cent = rngc.standard_normal((500, 512)); cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+                Xc = torch.from_numpy((cent[rngc.integers(0, 500, 100000)] + 0.35 * rngc.standard_normal((100000, 512)) / np.sqrt(512)).astype(np.float32)).cuda()
+                np.random.seed(1)
+                torch.cuda.synchronize()
+                t1 = time.time()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    fit_cluster(Xc, 'kmeans', k=500, l2normalize=True)
+                torch.cuda.synchronize()
+                res["secondary"]["fit_cluster_reference_call_seconds"] = time.time() - t1
+        except Exception as e:
+            res["secondary"]["extra_error"] = repr(e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_encoder(sd)
     if rank == 0:
