@@ -228,67 +228,96 @@ class KMeans:
 
     # ------------------------------------------------------------------ one Lloyd run
     def _lloyd_single(self, Xc, C, tol_abs):
+        """_kmeans_single_lloyd with the host loop running ONE iteration behind the device: iteration it+1 is enqueued
+        before iteration it's 4-double status word is read, so the read-back (and this Python) hide under the next
+        E-step.  A speculatively launched iteration is simply ignored when the previous one turns out to have converged
+        (it only reads the state it would need to keep: rings of 3 centre / label buffers, 2 partial-sum buffers)."""
         k = self.k
         N, Dp = Xc.shape
         K = C.shape[0]
         dev = Xc.device
-        C = C.contiguous().clone()
-        Cn = torch.empty_like(C)
-        cnorm = torch.empty(K, dtype=torch.float32, device=dev)
-        labels = torch.full((N,), -1, dtype=torch.int32, device=dev)
-        labels_old = torch.full((N,), -1, dtype=torch.int32, device=dev)
-        n_changed = torch.zeros(1, dtype=torch.int32, device=dev)
-        part = torch.empty(K * Dp + K, dtype=torch.float32, device=dev)   # [sums | counts]: the all-gather unit
-        sums, counts = part[: K * Dp], part[K * Dp:]
+        on_gpu = Xc.is_cuda
+        Cb = [C.contiguous().clone(), torch.empty_like(C), torch.empty_like(C)]          # iteration it: Cb[it%3] -> Cb[(it+1)%3]
+        Lb = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in range(3)]      # labels of iteration it: Lb[it%3]
+        cnorm = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(2)]
+        n_changed = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+        part = [torch.empty(K * Dp + K, dtype=torch.float32, device=dev) for _ in range(2)]   # [sums | counts]: the all-gather unit
         shift = torch.empty(K, dtype=torch.float32, device=dev)
-        status = torch.empty(4, dtype=torch.float64, device=dev)
+        status = [torch.empty(4, dtype=torch.float64, device=dev) for _ in range(2)]
+        host = [torch.empty(4, dtype=torch.float64).pin_memory() if on_gpu else torch.empty(4, dtype=torch.float64) for _ in range(2)]
+        ev = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
         if self._sharded:
             W = torch.distributed.get_world_size(self.process_group)
-            allpart = torch.empty(W, K * Dp + K, dtype=torch.float32, device=dev)
-            gsums = torch.empty(K * Dp, dtype=torch.float32, device=dev)
-            gcounts = torch.empty(K, dtype=torch.float32, device=dev)
+            allpart = [torch.empty(W, K * Dp + K, dtype=torch.float32, device=dev) for _ in range(2)]
+            gsums = [torch.empty(K * Dp, dtype=torch.float32, device=dev) for _ in range(2)]
+            gcounts = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(2)]
         else:
-            gsums, gcounts = sums, counts
+            gsums = [p[: K * Dp] for p in part]
+            gcounts = [p[K * Dp:] for p in part]
+
+        def launch(it):
+            """enqueue iteration `it` (E-step, M-step, averaging) and the async read-back of its status word"""
+            sl = it & 1
+            Cin, Cout = Cb[it % 3], Cb[(it + 1) % 3]
+            lab, lab_old = Lb[it % 3], Lb[(it + 2) % 3]            # (it - 1) % 3
+            k.cnorm(Cin, cnorm[sl])
+            n_changed[sl].zero_()
+            k.assign(Xc, Cin, cnorm[sl], lab, lab_old, n_changed[sl])
+            k.accumulate(Xc, lab, K, part[sl][: K * Dp], part[sl][K * Dp:])
+            if self._sharded:
+                torch.distributed.all_gather_into_tensor(allpart[sl].view(-1), part[sl], group=self.process_group)
+                k.combine_shards(allpart[sl], K, Dp, gsums[sl], gcounts[sl])
+                torch.distributed.all_reduce(n_changed[sl], group=self.process_group)
+            k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl])
+            host[sl].copy_(status[sl], non_blocking=True)
+            if on_gpu:
+                ev[sl].record()
+
+        def read(it):
+            if on_gpu:
+                ev[it & 1].synchronize()
+            return host[it & 1].tolist()
+
         trace = [] if self.trace else None
         strict = False
         n_reloc = 0
-        it, cur = 0, labels
-        for it in range(self.max_iter):
-            k.cnorm(C, cnorm)
-            n_changed.zero_()
-            k.assign(Xc, C, cnorm, labels, labels_old, n_changed)
-            cur = labels
-            k.accumulate(Xc, labels, K, sums, counts)
-            if self._sharded:
-                torch.distributed.all_gather_into_tensor(allpart.view(-1), part, group=self.process_group)
-                k.combine_shards(allpart, K, Dp, gsums, gcounts)
-                torch.distributed.all_reduce(n_changed, group=self.process_group)
-            k.finalize(C, gsums, gcounts, Cn, shift, n_changed, status)
-            shift_tot, n_empty, n_chg, _ = status.cpu().tolist()      # the one sync of the iteration
+        it = 0
+        if self.max_iter > 0:
+            launch(0)
+        while it < self.max_iter:
+            speculated = it + 1 < self.max_iter
+            if speculated:
+                launch(it + 1)
+            shift_tot, n_empty, n_chg, _ = read(it)
             if n_empty > 0:
-                # rare: _relocate_empty_clusters_dense, then redo the averaging
-                if self._relocate(Xc, C, labels, gsums, gcounts, int(n_empty)):
+                # rare: _relocate_empty_clusters_dense on iteration it's sums, then redo its averaging — and the
+                # speculative iteration, which ran on the un-relocated centres
+                sl = it & 1
+                if self._relocate(Xc, Cb[it % 3], Lb[it % 3], gsums[sl], gcounts[sl], int(n_empty)):
                     n_reloc += 1
-                    k.finalize(C, gsums, gcounts, Cn, shift, n_changed, status)
-                    shift_tot = status.cpu().tolist()[0]
-            C, Cn = Cn, C                                              # centers, centers_new = centers_new, centers
+                    k.finalize(Cb[it % 3], gsums[sl], gcounts[sl], Cb[(it + 1) % 3], shift, n_changed[sl], status[sl])
+                    shift_tot = status[sl].cpu().tolist()[0]
+                    if speculated:
+                        launch(it + 1)
             if trace is not None:
-                trace.append(labels.cpu().numpy().copy())
+                trace.append(Lb[it % 3].cpu().numpy().copy())
             if not self.fixed_iters:
                 if n_chg == 0:                                         # np.array_equal(labels, labels_old)
                     strict = True
                     break
                 if shift_tot <= tol_abs:
                     break
-            labels, labels_old = labels_old, labels                    # labels_old[:] = labels
-        n_iter = it + 1
+            it += 1
+        n_iter = min(it + 1, self.max_iter)
+        last = n_iter - 1                                              # last executed (and kept) iteration
+        C = Cb[(last + 1) % 3] if self.max_iter > 0 else Cb[0]
+        labels = Lb[last % 3] if self.max_iter > 0 else Lb[0]
         if not strict:
-            # rerun the E-step so labels match the final centres (_kmeans.py:736-748)
-            other = labels_old if cur is labels else labels
-            k.cnorm(C, cnorm)
-            k.assign(Xc, C, cnorm, other, None, None)
-            cur = other
-        labels = cur
+            # rerun the E-step so labels match the final centres (_kmeans.py:736-748); any buffer but `C`'s reader state
+            out = Lb[(last + 1) % 3]
+            k.cnorm(C, cnorm[0])
+            k.assign(Xc, C, cnorm[0], out, None, None)
+            labels = out
         inertia = self._inertia(Xc, C, labels)
         res = dict(labels=labels, centers=C, inertia=inertia, n_iter=n_iter, strict=strict, n_relocations=n_reloc)
         if trace is not None:
