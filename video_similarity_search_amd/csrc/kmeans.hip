@@ -597,12 +597,19 @@ __global__ __launch_bounds__(256) void kpp_dist(const float* __restrict__ X, int
     bpart[(int64_t)blockIdx.x * T + threadIdx.x] =
         wp[0][threadIdx.x] + wp[1][threadIdx.x] + wp[2][threadIdx.x] + wp[3][threadIdx.x];
 }
-__global__ void kpp_pot(const double* __restrict__ bpart, int64_t nblk, int T, double* pot) {
-  const int t = threadIdx.x;
-  if (t >= T) return;
+// pot[t] = sum over workgroups of bpart[b][t]: one workgroup per candidate, fixed strided partition + fixed tree
+__global__ __launch_bounds__(256) void kpp_pot(const double* __restrict__ bpart, int64_t nblk, int T, double* pot) {
+  __shared__ double sm[256];
+  const int t = blockIdx.x, i = threadIdx.x;
   double a = 0.0;
-  for (int64_t b = 0; b < nblk; ++b) a += bpart[b * T + t];
-  pot[t] = a;
+  for (int64_t b = i; b < nblk; b += 256) a += bpart[b * T + t];
+  sm[i] = a;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (i < s2) sm[i] += sm[i + s2];
+    __syncthreads();
+  }
+  if (i == 0) pot[t] = sm[0];
 }
 
 // cumsum (double) of v in 1024-element chunks + searchsorted('left')
@@ -622,12 +629,15 @@ __global__ void cs_scan_chunks(double* csum, int64_t n) {  // inclusive, serial 
     for (int64_t u = 0; u < n; ++u) { a += csum[u]; csum[u] = a; }
   }
 }
-// one thread per query value: binary search the chunk, then walk the chunk serially
+// one WAVE per query value: binary search the chunk (inclusive chunk sums), then inside the 1024-element chunk every
+// lane sums its 16 consecutive elements, lane 0 scans the 64 lane sums in order, and the lane whose range crosses the
+// value walks its 16 elements — searchsorted(cumsum, x, 'left') with the cumsum taken chunk-wise in double
 __global__ void cs_search(const float* __restrict__ v, int64_t N, const double* __restrict__ csum,
                           int64_t nchunk, const double* __restrict__ vals, int T,
                           int32_t* __restrict__ idx) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (t >= T) return;
+  const int lane = threadIdx.x & 63;
   const double x = vals[t];
   int64_t lo = 0, hi = nchunk;  // first chunk whose inclusive sum >= x
   while (lo < hi) {
@@ -636,16 +646,38 @@ __global__ void cs_search(const float* __restrict__ v, int64_t N, const double* 
   }
   int64_t res = N;
   if (lo < nchunk) {
-    double a = lo ? csum[lo - 1] : 0.0;
-    const int64_t s = lo * 1024, e = s + 1024 < N ? s + 1024 : N;
-    res = e;
-    for (int64_t i = s; i < e; ++i) {
-      a += (double)v[i];
-      if (a >= x) { res = i; break; }
+    const double base = lo ? csum[lo - 1] : 0.0;
+    const int64_t s0 = lo * 1024 + (int64_t)lane * 16;
+    double part = 0.0;
+    for (int u = 0; u < 16; ++u) if (s0 + u < N) part += (double)v[s0 + u];
+    // exclusive scan of the lane sums in lane order
+    double run = base;
+    double mine = 0.0;
+    for (int l = 0; l < 64; ++l) {
+      const double pl = __shfl(part, l);
+      if (l == lane) mine = run;
+      run += pl;
     }
+    // the crossing lane: first lane whose inclusive prefix reaches x
+    const bool crosses = (mine + part >= x) && (mine < x || lane == 0);
+    const unsigned long long m = __ballot(mine + part >= x);
+    const int first = m ? __ffsll((long long)m) - 1 : -1;
+    int64_t r = -1;
+    if (lane == first) {
+      double a = mine;
+      const int64_t e = (lo + 1) * 1024 < N ? (lo + 1) * 1024 : N;
+      r = e;
+      for (int u = 0; u < 16 && s0 + u < N; ++u) {
+        a += (double)v[s0 + u];
+        if (a >= x) { r = s0 + u; break; }
+      }
+    }
+    (void)crosses;
+    if (first >= 0) res = __shfl(r, first);
+    else res = (lo + 1) * 1024 < N ? (lo + 1) * 1024 : N;
   }
   if (res > N - 1) res = N - 1;
-  idx[t] = (int32_t)res;
+  if (lane == 0) idx[t] = (int32_t)res;
 }
 
 // ------------------------------------ C ABI ------------------------------------------------
@@ -840,7 +872,7 @@ extern "C" int slic_kmeanspp_step(const float* X, int64_t N, int D, int ldx, con
   const int64_t nblk = slic_cdiv(N, 256);
   kpp_dist<<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, S(stream)>>>(X, N, D, ldx, cand, T, closest, newdist, (double*)workspace);
   SLIC_LAUNCH_CHECK();
-  kpp_pot<<<dim3(1), dim3(64), 0, S(stream)>>>((const double*)workspace, nblk, T, pot);
+  kpp_pot<<<dim3(T), dim3(256), 0, S(stream)>>>((const double*)workspace, nblk, T, pot);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -856,7 +888,7 @@ extern "C" int slic_cumsum_search(const float* v, int64_t N, const double* vals,
   SLIC_LAUNCH_CHECK();
   cs_scan_chunks<<<dim3(1), dim3(64), 0, S(stream)>>>((double*)workspace, nc);
   SLIC_LAUNCH_CHECK();
-  cs_search<<<dim3((unsigned)slic_cdiv(T, 64)), dim3(64), 0, S(stream)>>>(v, N, (const double*)workspace, nc, vals, T, idx_out);
+  cs_search<<<dim3((unsigned)slic_cdiv(T, 4)), dim3(256), 0, S(stream)>>>(v, N, (const double*)workspace, nc, vals, T, idx_out);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
