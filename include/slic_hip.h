@@ -241,6 +241,13 @@ int slic_margin_cos_fwd(const float* X, const float* Y, const float* Z, int n, i
                         float* rowloss, float* loss, void* stream);
 int slic_margin_cos_bwd(const float* X, const float* Y, const float* Z, const float* state, int n, int D,
                         const float* gscale, float* dX, float* dY, float* dZ, void* stream);
+/* negative selection of NegativeTripletSelector.get_one_one_triplets (loss/triplet_loss.py:311-360) for P (anchor,
+ * positive) pairs over the [n, n] distance matrix `dist`: mode 0 random_negative, 1 random_semi_hard, 2 fixed_semi_hard;
+ * u[P] uniform in [0,1) stands in for Python's random.choice (unused for mode 2); fallback = hardest easy negative,
+ * returned as its position in the negatives list exactly like the reference.  labels: int64 [n]. */
+int slic_triplet_select(const float* dist, const int64_t* labels, int n, const int32_t* anchors,
+                        const int32_t* positives, int P, float margin, int mode, const float* u, int32_t* negatives,
+                        void* stream);
 /* [n, n] distance matrix of the rows of V (loss/triplet_loss.py:429-437 pdist) */
 int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* out, void* stream);
 

@@ -103,6 +103,22 @@ def main():
     llc.backward()
     lo.update(llc_a=xa.detach().numpy(), llc_n=xn.detach().numpy(), llc_f=xf.detach().numpy(), llc_loss=llc.detach().numpy(),
               llc_ga=xa.grad.numpy(), llc_gn=xn.grad.numpy(), llc_gf=xf.grad.numpy())
+    # margin-triplet branch with the deterministic 'fixed_semi_hard' selector (loss/triplet_loss.py:205-227, 311-360)
+    for tag, n, labs, margin in [("pairs", 32, np.arange(16).repeat(2).reshape(16, 2).T.reshape(-1), 0.2),
+                                 ("clusters", 30, rng.integers(0, 5, 30), 0.2),
+                                 ("easy", 24, rng.integers(0, 4, 24), 1e-4)]:
+        e = rng.standard_normal((n, 128)).astype(np.float32)
+        if tag == "easy":                      # well-separated classes -> no semi-hard negatives -> hardest-easy fallback
+            cen = rng.standard_normal((4, 128)).astype(np.float32) * 4
+            e = cen[labs] + 0.05 * e
+        et = torch.from_numpy(e).requires_grad_(True)
+        crit_m = OnlineTripletLoss(margin, 'cosine')
+        l, nt = crit_m(et, torch.from_numpy(labs.astype(np.int64)), sampling_strategy='fixed_semi_hard')
+        l.backward()
+        sel = crit_m.triplet_selector.get_triplets(et.detach(), torch.from_numpy(labs.astype(np.int64)))
+        lo[f"trip_{tag}_E"], lo[f"trip_{tag}_labels"], lo[f"trip_{tag}_margin"] = e, labs.astype(np.int64), np.float32(margin)
+        lo[f"trip_{tag}_loss"], lo[f"trip_{tag}_n"], lo[f"trip_{tag}_grad"] = l.detach().numpy(), np.int64(nt), et.grad.numpy().copy()
+        lo[f"trip_{tag}_idx"] = np.array([[int(v) for v in row] for row in sel], np.int64)
     # memory-bank NCE (loss/NCE_loss.py): fixed idx
     B, D, K, ndata = 8, 128, 64, 1000
     nce = NCEAverage(D, ndata, K, 0.07, 0.5)

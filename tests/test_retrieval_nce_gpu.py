@@ -140,3 +140,58 @@ def test_sharded_gallery_merge_single_rank_group(gpu):
         assert torch.equal(si, ref_i) and torch.equal(sd, ref_d)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag", ["pairs", "clusters", "easy"])
+def test_triplet_mining_fixed_semi_hard_matches_reference(gpu, golden_dir, tag):
+    """the deterministic selector: triplet indices, loss, n_triplets and the embedding gradient equal the reference's
+    (incl. the hardest-easy fallback that returns a position in the negatives list)"""
+    from video_similarity_search_amd.loss.triplet_loss import OnlineTripletLoss, get_triplets
+    g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
+    E, labs, margin = g[f"trip_{tag}_E"], g[f"trip_{tag}_labels"], float(g[f"trip_{tag}_margin"])
+    e = torch.from_numpy(E).cuda().requires_grad_(True)
+    l = torch.from_numpy(labs).cuda()
+    a, p, n = get_triplets(e, l, margin, "fixed_semi_hard")
+    ref = g[f"trip_{tag}_idx"]
+    assert np.array_equal(a.cpu().numpy(), ref[0]) and np.array_equal(p.cpu().numpy(), ref[1])
+    assert np.array_equal(n.cpu().numpy(), ref[2])
+    loss, nt = OnlineTripletLoss(margin, 'cosine')(e, l, sampling_strategy='fixed_semi_hard')
+    loss.backward()
+    assert nt == int(g[f"trip_{tag}_n"])
+    assert abs(loss.item() - float(g[f"trip_{tag}_loss"])) < 1e-6
+    np.testing.assert_allclose(e.grad.cpu().numpy(), g[f"trip_{tag}_grad"], atol=2e-7, rtol=1e-4)
+
+
+def test_triplet_mining_random_strategies_properties(gpu, golden_dir):
+    """random_semi_hard (the shipped default) / random_negative: every chosen negative is a member of the reference's
+    candidate set for its pair, choices vary between calls, and the loss equals the oracle's formula on those triplets"""
+    from video_similarity_search_amd.loss.triplet_loss import OnlineTripletLoss, get_triplets, pdist
+    g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
+    E, labs, margin = g["trip_clusters_E"], g["trip_clusters_labels"], 0.2
+    e, l = torch.from_numpy(E).cuda(), torch.from_numpy(labs).cuda()
+    D = pdist(e, 0, 'cosine').cpu().numpy()
+    seen = set()
+    for strat in ("random_semi_hard", "random_negative"):
+        for rep in range(4):
+            a, p, n = [t.cpu().numpy() for t in get_triplets(e, l, margin, strat)]
+            assert len(a) == int(g["trip_clusters_n"])
+            for ai, pi, ni in zip(a, p, n):
+                negs = np.nonzero(labs != labs[ai])[0]
+                if strat == "random_negative":
+                    assert ni in negs
+                else:
+                    cand = negs[(D[ai, pi] + margin - D[ai, negs]) > 0]
+                    if len(cand):
+                        assert ni in cand
+                    else:
+                        assert ni == int(np.argmin(D[ai, negs]))          # reference quirk: list position
+            seen.add(tuple(n.tolist()))
+    assert len(seen) > 2                                                     # the RNG is actually used
+    er = e.clone().requires_grad_(True)
+    torch.manual_seed(3)
+    loss, nt = OnlineTripletLoss(margin, 'cosine')(er, l, sampling_strategy='random_semi_hard')
+    loss.backward()
+    assert nt == int(g["trip_clusters_n"]) and torch.isfinite(er.grad).all() and loss.item() > 0
+    # no label with two members -> no triplets -> zero loss, like the reference
+    z, nz = OnlineTripletLoss(margin, 'cosine')(e[:5], torch.arange(5).cuda(), sampling_strategy='random_semi_hard')
+    assert nz == 0 and float(z) == 0.0

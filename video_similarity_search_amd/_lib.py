@@ -64,6 +64,7 @@ SIGNATURES = {
     "slic_pair_distance": (I, [P, P, I, I, I, P, P]),
     "slic_margin_cos_fwd": (I, [P, P, P, I, I, F, P, P, P, P]),
     "slic_margin_cos_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P]),
+    "slic_triplet_select": (I, [P, P, I, P, P, I, F, I, P, P, P]),
     "slic_pdist": (I, [P, I, I, F, I, P, P]),
     # retrieval
     "slic_normalize_rows": (I, [P, L, I, I, P, P]),

@@ -213,7 +213,93 @@ __global__ void margin_cos_bwd_kernel(const float* __restrict__ X, const float* 
   }
 }
 
+// Negative selection of NegativeTripletSelector.get_one_one_triplets (loss/triplet_loss.py:311-360): one wave per
+// (anchor, positive) pair over the [n, n] distance matrix.
+//   mode 0 'random_negative'  : uniform over the rows with a different label            (:332-333)
+//   mode 1 'random_semi_hard' : uniform over {j : d(a,p) + margin - d(a,j) > 0}         (:334-336, 368-377)
+//   mode 2 'fixed_semi_hard'  : argmax_j d(a,p) + margin - d(a,j) if that set is non-empty (:342-344, 398-406)
+// u[pair] in [0, 1) replaces Python's random.choice (rank floor(u * count) in ascending index order).
+// No semi-hard/hard negative -> hardest_easy_sampling (:350-351, 424-426): argmin of d(a, negatives) — and, exactly
+// like the reference, the POSITION in the negatives list is returned, not the row it stands for.
+__global__ void triplet_select_kernel(const float* __restrict__ Dm, const int64_t* __restrict__ labels, int n,
+                                      const int32_t* __restrict__ anc, const int32_t* __restrict__ pos, int P,
+                                      float margin, int mode, const float* __restrict__ u,
+                                      int32_t* __restrict__ neg) {
+  const int pr = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pr >= P) return;
+  const int lane = threadIdx.x & 63;
+  const int a = anc[pr];
+  const int64_t la = labels[a];
+  const float thr = Dm[(int64_t)a * n + pos[pr]] + margin;
+  const float* row = Dm + (int64_t)a * n;
+  // pass 1: counts, argmax of loss / argmin of distance over the negatives (first index wins)
+  int cnt_neg = 0, cnt_c = 0;
+  float best_loss = -INFINITY, best_d = INFINITY;
+  int best_loss_j = -1, best_d_j = -1;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const bool isneg = j < n && labels[j] != la;
+    const float d = isneg ? row[j] : 0.f;
+    const bool c = isneg && (thr - d > 0.f);
+    cnt_neg += __popcll(__ballot(isneg));
+    cnt_c += __popcll(__ballot(c));
+    if (isneg) {
+      if (thr - d > best_loss) { best_loss = thr - d; best_loss_j = j; }
+      if (d < best_d) { best_d = d; best_d_j = j; }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ol = __shfl_xor(best_loss, o); const int oj = __shfl_xor(best_loss_j, o);
+    if (oj >= 0 && (ol > best_loss || (ol == best_loss && (best_loss_j < 0 || oj < best_loss_j)))) { best_loss = ol; best_loss_j = oj; }
+    const float od = __shfl_xor(best_d, o); const int odj = __shfl_xor(best_d_j, o);
+    if (odj >= 0 && (od < best_d || (od == best_d && (best_d_j < 0 || odj < best_d_j)))) { best_d = od; best_d_j = odj; }
+  }
+  int result = -1;
+  const int want_set = mode == 0 ? cnt_neg : cnt_c;       // size of the set a rank is drawn from
+  if (mode == 2) {
+    if (cnt_c > 0) result = best_loss_j;
+  } else if (want_set > 0) {
+    int rsel = (int)(u[pr] * (float)want_set);
+    if (rsel >= want_set) rsel = want_set - 1;
+    int seen = 0;
+    for (int j0 = 0; j0 < n && result < 0; j0 += 64) {
+      const int j = j0 + lane;
+      const bool isneg = j < n && labels[j] != la;
+      const bool c = mode == 0 ? isneg : (isneg && (thr - row[j] > 0.f));
+      const unsigned long long m = __ballot(c);
+      const int pc = __popcll(m);
+      if (seen + pc > rsel) {
+        unsigned long long mm = m;
+        for (int k = 0; k < rsel - seen; ++k) mm &= mm - 1;      // drop the lowest (rsel - seen) set bits
+        result = j0 + (__ffsll((long long)mm) - 1);
+      }
+      seen += pc;
+    }
+  }
+  if (result < 0) {
+    // hardest_easy_sampling: position of the closest negative inside the negatives list (reference quirk)
+    int rank = 0;
+    for (int j0 = 0; j0 < best_d_j; j0 += 64) {
+      const int j = j0 + lane;
+      rank += __popcll(__ballot(j < best_d_j && labels[j] != la));
+    }
+    result = rank;
+  }
+  if (lane == 0) neg[pr] = result;
+}
+
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+
+extern "C" int slic_triplet_select(const float* dist, const int64_t* labels, int n, const int32_t* anchors,
+                                   const int32_t* positives, int P, float margin, int mode, const float* u,
+                                   int32_t* negatives, void* stream) {
+  SLIC_REQUIRE(dist && labels && anchors && positives && negatives && n > 1 && P > 0 && mode >= 0 && mode <= 2 &&
+               (mode == 2 || u), "slic_triplet_select: bad args");
+  triplet_select_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(dist, labels, n, anchors, positives, P, margin, mode, u, negatives);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 
 extern "C" int slic_margin_cos_fwd(const float* X, const float* Y, const float* Z, int n, int D, float margin,
                                    float* state, float* rowloss, float* loss, void* stream) {

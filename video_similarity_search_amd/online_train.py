@@ -24,8 +24,7 @@ import time
 
 import torch
 
-from . import _lib
-from ._lib import call, ptr, stream
+from .loss.triplet_loss import margin_cosine_loss          # the LLC term shares the margin-triplet kernel
 from .misc import distributed_helper as du_helper
 
 modality = 'res'        # module-level switch of the reference (online_train.py:36)
@@ -54,37 +53,6 @@ def diff(x):
     """residual-frame view (online_train.py:228-230); pure data movement, stays a torch op"""
     shift_x = torch.roll(x, 1, 2)
     return ((x - shift_x) + 1) / 2
-
-
-class _MarginCos(torch.autograd.Function):
-    """mean(max(0, (1 - cos(x, y)) - (1 - cos(x, z)) + margin)) — MarginRankingLoss(margin)(d_xy, d_xz, -1)"""
-
-    @staticmethod
-    def forward(ctx, x, y, z, margin):
-        x, y, z = (t.contiguous().float() for t in (x, y, z))
-        n, D = x.shape
-        state = torch.empty(n, 8, dtype=torch.float32, device=x.device)
-        rowloss = torch.empty(n, dtype=torch.float32, device=x.device)
-        loss = torch.empty((), dtype=torch.float32, device=x.device)
-        call("slic_margin_cos_fwd", ptr(x), ptr(y), ptr(z), n, D, float(margin), ptr(state), ptr(rowloss), ptr(loss), stream())
-        ctx.save_for_backward(x, y, z, state)
-        return loss
-
-    @staticmethod
-    def backward(ctx, g):
-        x, y, z, state = ctx.saved_tensors
-        n, D = x.shape
-        dx, dy, dz = torch.empty_like(x), torch.empty_like(y), torch.empty_like(z)
-        call("slic_margin_cos_bwd", ptr(x), ptr(y), ptr(z), ptr(state), n, D, ptr(g.contiguous().float()), ptr(dx), ptr(dy),
-             ptr(dz), stream())
-        return dx, dy, dz, None
-
-
-def margin_cosine_loss(anchor, near, far, margin):
-    """the LLC term: `near` should end up closer to `anchor` than `far` by `margin` in cosine distance"""
-    if not anchor.is_cuda:
-        raise _lib.SlicError("margin_cosine_loss needs device tensors (no CPU fallback)")
-    return _MarginCos.apply(anchor, near, far, margin)
 
 
 def _flag(node, name, default=False):
