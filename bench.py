@@ -196,7 +196,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # dominant kernel: the gather-GEMM (conv_gemm_dma_kernel<64,64,2,2,2,1>) on the 64->64 3x3x3 layers (layer1: 4 forward +
+    # dominant kernel: the gather-GEMM (conv_gemm_dma_kernel<128,64,2,2,2,1,true>) on the 64->64 3x3x3 layers (layer1: 4 forward +
     # 4 data-gradient launches per step, identical M x N x K) — bracket every such launch of the timed steps with HIP events
     eng = net._engine(x)
     l1 = [p for (_, p1, p2, _) in eng.blocks[:2] for p in (p1, p2)]
@@ -243,7 +243,7 @@ def main():
                            global_batch=world * B, parallelism=f"dp{world}", final_loss=lossv),
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
-                             kernel="conv_gemm_dma_kernel<64,64,2,2,2,1> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring; fwd + dgrad of layer1)",
+                             kernel="conv_gemm_dma_kernel<128,64,2,2,2,1,true> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring, DMA issue interleaved with the MFMAs; fwd + dgrad of layer1)",
                              ms_per_launch=ms_k, launches_timed=len(ev), algorithmic_flops_per_launch=flops_launch,
                              whole_step_frac=(world * B * args.steps / dt) * GFLOP_PER_CLIP_TRAIN / 1e3 /
                                              (FP32_MFMA_PEAK_TFLOPS * world)))

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // two k-tiles in flight across ONE raw barrier per tile.  LDS image = the same [rows][32] swizzled layout: the
 // DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk (p ^ ((row >> 1) & 7)).
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
 __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -375,6 +375,58 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
     }
     __builtin_amdgcn_s_setprio(0);
   };
+  // ILV: the next stage's DMAs (and their address math) are issued BETWEEN the MFMA groups of the current tile instead of
+  // in front of them, so a wave's matrix pipe is not idle while it computes addresses (matters at 1-2 waves / SIMD)
+  auto compute_ilv = [&](int toff, bool do_issue, int ktn, int toffn) {
+    const float* Ab = lds + toff;
+    const float* Bb = Ab + BM * 32;
+    unsigned tm = 0xFFFFFFFFu, dlt = 0, wc = 0;
+    if (do_issue) {
+      const int tap = ktn / tiles_per_tap;
+      const int cb = (ktn - tap * tiles_per_tap) << 5;
+      const i32x4 e = tapc[tap];
+      tm = (unsigned)e.y; dlt = (unsigned)(e.x + cb) * 4u; wc = (unsigned)(e.z + cb) * 4u;
+    }
+    float* Asn = lds + toffn;
+    float* Bsn = Asn + BM * 32;
+    f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
+    constexpr int NPER = (AL + BL + 3) / 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
+      if (do_issue) {
+#pragma unroll
+        for (int d = q * NPER; d < (q + 1) * NPER && d < AL + BL; ++d) {
+          if (d < AL) {
+            const unsigned off = ((rmask[d] & tm) == tm) ? aoff[d] + dlt : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(Asn + (8 * wave + 32 * d) * 32),
+                                                     16, (int)off, 0, 0, 0);
+          } else {
+            const unsigned off = woff[d - AL] == OOB ? OOB : woff[d - AL] + wc;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bsn + (8 * wave + 32 * (d - AL)) * 32),
+                                                     16, (int)off, 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
   // prologue: STAGES - 1 stages (of KT k-tiles each) in flight
   const int ns = (nk + KT - 1) / KT;                         // number of stages' worth of work
 #pragma unroll
@@ -396,15 +448,19 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
         else if (younger >= 1 && !ragged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();      // every wave's part of stage sg is in LDS; the previous stage is free
-        if (sg + STAGES - 1 < ns) {
+        if constexpr (ILV && KT == 1) {
+          compute_ilv(sidx * STAGE_FLOATS, sg + STAGES - 1 < ns, sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
+        } else {
+          if (sg + STAGES - 1 < ns) {
+#pragma unroll
+            for (int u = 0; u < KT; ++u)
+              if ((sg + STAGES - 1) * KT + u < nk)
+                issue((sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
+          }
 #pragma unroll
           for (int u = 0; u < KT; ++u)
-            if ((sg + STAGES - 1) * KT + u < nk)
-              issue((sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
+            if (sg * KT + u < nk) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
         }
-#pragma unroll
-        for (int u = 0; u < KT; ++u)
-          if (sg * KT + u < nk) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
       }
     }
   }
@@ -627,24 +683,24 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
   return SLIC_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
 static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   dim3 grid((unsigned)slic_cdiv(a.M, BM), (unsigned)slic_cdiv(a.N, BN));
-  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT><<<grid, dim3(256), lds, st>>>(a);
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
 
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
-  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17) return 64;
-  if (variant == 13 || variant == 14 || variant == 18 || variant == 19) return 128;
+  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17 || variant == 20) return 64;
+  if (variant == 13 || variant == 14 || variant == 18 || variant == 19 || variant == 21 || variant == 22) return 128;
   // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
   if (variant == 1) return 128;
   if (variant == 2) return 64;
@@ -660,7 +716,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   hipStream_t st = S_(stream);
-  if (variant >= 11 && variant <= 19) {
+  if (variant >= 11 && variant <= 22) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SlicConvArgs b = *a;
@@ -669,6 +725,9 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     if (variant == 12) return launch_gemm_dma<64, 64, 2, 2, 4>(b, st);
     if (variant == 13) return launch_gemm_dma<128, 64, 2, 2, 3>(b, st);
     if (variant == 17) return launch_gemm_dma<64, 64, 2, 2, 2, 1>(b, st);     // 2-stage ring (32 KB: 5 workgroups / CU)
+    if (variant == 20) return launch_gemm_dma<64, 64, 2, 2, 2, 1, true>(b, st);     // v17 + DMA issue interleaved with the MFMAs
+    if (variant == 21) return launch_gemm_dma<128, 128, 2, 2, 2, 1, true>(b, st);   // v18 + interleave
+    if (variant == 22) return launch_gemm_dma<128, 64, 2, 2, 2, 1, true>(b, st);    // v19 + interleave
     if (variant == 18) return launch_gemm_dma<128, 128, 2, 2, 2, 1>(b, st);   // 64 KB: 2 workgroups / CU, 64 acc regs
     if (variant == 19) return launch_gemm_dma<128, 64, 2, 2, 2, 1>(b, st);    // 48 KB: 3 workgroups / CU
     if (variant == 15) return launch_gemm_dma<64, 64, 2, 2, 2, 2>(b, st);     // 2 k-tiles per barrier, 2-stage ring (64 KB)

@@ -176,7 +176,10 @@ class ConvPlan:
                 return 0
             # measured (scripts/bench_conv.py): the 2-stage ring (32 KB LDS, 5 workgroups / CU) wins on the large-M
             # layers, the 3-stage ring on the small-M ones (layer4) where fewer workgroups exist to hide latency
-            return 17 if a.M >= 20000 else 11
+            if a.M >= 20000:
+                # N <= 64 (layer1: 52 % of the FLOPs): 128x64 tiles with the next tile's DMAs issued between MFMA groups
+                return 22 if a.N <= 64 else 17
+            return 11
         if variant >= 11 and not a.tap_tab:
             return 0
         return variant
