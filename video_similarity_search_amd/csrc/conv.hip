@@ -609,16 +609,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
 // dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][n][tap*Cs + c]
 __global__ void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, int Kp, int Cs, int C,
                                   int ntaps, float* __restrict__ dW) {
+  // threads walk the slab in its own (n, k) order: the S reads per element are coalesced; the single write per
+  // element scatters into the reference layout
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t tot = (int64_t)N * C * ntaps;
+  const int64_t tot = (int64_t)N * Kp;
   if (e >= tot) return;
-  const int tap = (int)(e % ntaps);
-  const int c = (int)((e / ntaps) % C);
-  const int n = (int)(e / ((int64_t)ntaps * C));
-  const int64_t src = (int64_t)n * Kp + tap * Cs + c;
+  const int k = (int)(e % Kp);
+  const int n = (int)(e / Kp);
+  const int tap = k / Cs, c = k % Cs;
+  if (tap >= ntaps || c >= C) return;
   float a = 0.f;
-  for (int s = 0; s < S; ++s) a += slab[(int64_t)s * N * Kp + src];
-  dW[e] = a;
+  for (int s = 0; s < S; ++s) a += slab[(int64_t)s * tot + e];
+  dW[((int64_t)n * C + c) * ntaps + tap] = a;
 }
 
 // ---- weight packing -------------------------------------------------------------------------
@@ -773,7 +775,7 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
     conv_wgrad_kernel<1><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
   }
   SLIC_LAUNCH_CHECK();
-  const int64_t tot = (int64_t)a->N * C * ntaps;
+  const int64_t tot = (int64_t)a->N * Kp;
   conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
