@@ -46,7 +46,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
     gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy.double())
     plan = ConvPlan(C, N, k, s, p, dims, "cuda")
     xd, wd_ = _ndhwc(x, plan.Cs).cuda(), w.cuda().contiguous()
-    for variant in (0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22):
+    for variant in (0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24):
         z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
         got = z.cpu().permute(0, 4, 1, 2, 3)
         tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6

@@ -315,11 +315,16 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
   // never touch the vmcnt queue the DMAs are counted on
   const __attribute__((address_space(4))) i32x4* tapc = (const __attribute__((address_space(4))) i32x4*)p.tab;
   // issue the (AL + BL) DMAs of k-tile kt into the LDS tile at float offset `toff`
+  // A k-tile index past the end (kt >= nk) issues the same number of DMAs with every offset out of range: zeros land
+  // in a ring stage nobody reads (or that a dummy stage multiplies as 0 * 0), so the main loop has no conditional
+  // around its DMA or MFMA groups — the accumulators then stay in AGPRs for the whole loop.
   auto issue = [&](int kt, int toff) {
-    const int tap = kt / tiles_per_tap;                      // wave-uniform -> scalar loads of the tap record
-    const int cb = (kt - tap * tiles_per_tap) << 5;          // channel base inside the tap
+    const bool live = kt < nk;
+    const int ktc = live ? kt : 0;
+    const int tap = ktc / tiles_per_tap;                     // wave-uniform -> scalar loads of the tap record
+    const int cb = (ktc - tap * tiles_per_tap) << 5;         // channel base inside the tap
     const i32x4 e = tapc[tap];                               // {src delta, tap mask, weight base, -}: s_load (lgkmcnt queue)
-    const unsigned tm = (unsigned)e.y;
+    const unsigned tm = live ? (unsigned)e.y : 0xFFFFFFFFu;  // an all-ones tap mask fails every row's bounds test
     const unsigned dlt = (unsigned)(e.x + cb) * 4u;
     const unsigned wc = (unsigned)(e.z + cb) * 4u;
     float* As = lds + toff;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-      const unsigned off = woff[i] == OOB ? OOB : woff[i] + wc;
+      const unsigned off = (woff[i] == OOB || !live) ? OOB : woff[i] + wc;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bs + (8 * wave + 32 * i) * 32),
                                                16, (int)off, 0, 0, 0);
     }
@@ -377,16 +382,16 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
   };
   // ILV: the next stage's DMAs (and their address math) are issued BETWEEN the MFMA groups of the current tile instead of
   // in front of them, so a wave's matrix pipe is not idle while it computes addresses (matters at 1-2 waves / SIMD)
-  auto compute_ilv = [&](int toff, bool do_issue, int ktn, int toffn) {
+  auto compute_ilv = [&](int toff, int ktn, int toffn) {
     const float* Ab = lds + toff;
     const float* Bb = Ab + BM * 32;
-    unsigned tm = 0xFFFFFFFFu, dlt = 0, wc = 0;
-    if (do_issue) {
-      const int tap = ktn / tiles_per_tap;
-      const int cb = (ktn - tap * tiles_per_tap) << 5;
-      const i32x4 e = tapc[tap];
-      tm = (unsigned)e.y; dlt = (unsigned)(e.x + cb) * 4u; wc = (unsigned)(e.z + cb) * 4u;
-    }
+    const bool live = ktn < nk;
+    const int ktc = live ? ktn : 0;
+    const int tap = ktc / tiles_per_tap;
+    const int cb = (ktc - tap * tiles_per_tap) << 5;
+    const i32x4 e = tapc[tap];
+    const unsigned tm = live ? (unsigned)e.y : 0xFFFFFFFFu;
+    const unsigned dlt = (unsigned)(e.x + cb) * 4u, wc = (unsigned)(e.z + cb) * 4u;
     float* Asn = lds + toffn;
     float* Bsn = Asn + BM * 32;
     f32x4 a[2][TM], b[2][TN];
@@ -411,18 +416,16 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
-      if (do_issue) {
 #pragma unroll
-        for (int d = q * NPER; d < (q + 1) * NPER && d < AL + BL; ++d) {
-          if (d < AL) {
-            const unsigned off = ((rmask[d] & tm) == tm) ? aoff[d] + dlt : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(Asn + (8 * wave + 32 * d) * 32),
-                                                     16, (int)off, 0, 0, 0);
-          } else {
-            const unsigned off = woff[d - AL] == OOB ? OOB : woff[d - AL] + wc;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bsn + (8 * wave + 32 * (d - AL)) * 32),
-                                                     16, (int)off, 0, 0, 0);
-          }
+      for (int d = q * NPER; d < (q + 1) * NPER && d < AL + BL; ++d) {
+        if (d < AL) {
+          const unsigned off = ((rmask[d] & tm) == tm) ? aoff[d] + dlt : OOB;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(Asn + (8 * wave + 32 * d) * 32),
+                                                   16, (int)off, 0, 0, 0);
+        } else {
+          const unsigned off = (woff[d - AL] == OOB || !live) ? OOB : woff[d - AL] + wc;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bsn + (8 * wave + 32 * (d - AL)) * 32),
+                                                   16, (int)off, 0, 0, 0);
         }
       }
     }
@@ -432,38 +435,28 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t)
 #pragma unroll
-    for (int u = 0; u < KT; ++u)
-      if (t * KT + u < nk) issue(t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
-  constexpr int PER_STAGE = KT * (AL + BL);                  // DMA instructions per stage per wave (a ragged last stage
-                                                             // issues fewer: the counted waits below stay conservative)
+    for (int u = 0; u < KT; ++u) issue(t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
+  constexpr int PER_STAGE = KT * (AL + BL);                  // DMA instructions per stage per wave, always exactly this many
+  // Branch-free steady state: the trip count is rounded up to whole rings; stages past the end multiply zeros.
   for (int s0 = 0; s0 < ns; s0 += STAGES) {
 #pragma unroll
     for (int sidx = 0; sidx < STAGES; ++sidx) {              // unrolled: ring stages are compile-time, so the compiler can
       const int sg = s0 + sidx;                               // see that the ds_reads and the in-flight DMAs never alias
-      if (sg < ns) {
-        // stage sg has landed once only the DMAs of the younger in-flight stages are outstanding
-        const int younger = min(STAGES - 2, ns - 1 - sg);
-        const bool ragged = (nk % KT) != 0 && sg + younger == ns - 1;   // the youngest stage is the short one
-        if (younger >= 2 && !ragged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_STAGE) : "memory");
-        else if (younger >= 1 && !ragged) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STAGE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // every wave's part of stage sg is in LDS; the previous stage is free
-        if constexpr (ILV && KT == 1) {
-          compute_ilv(sidx * STAGE_FLOATS, sg + STAGES - 1 < ns, sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
-        } else {
-          if (sg + STAGES - 1 < ns) {
+      // stage sg has landed once only the DMAs of the STAGES - 2 younger in-flight stages are outstanding
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
+      __builtin_amdgcn_s_barrier();        // every wave's part of stage sg is in LDS; the previous stage is free
+      if constexpr (ILV && KT == 1) {
+        compute_ilv(sidx * STAGE_FLOATS, sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
+      } else {
 #pragma unroll
-            for (int u = 0; u < KT; ++u)
-              if ((sg + STAGES - 1) * KT + u < nk)
-                issue((sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
-          }
+        for (int u = 0; u < KT; ++u)
+          issue((sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
 #pragma unroll
-          for (int u = 0; u < KT; ++u)
-            if (sg * KT + u < nk) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
-        }
+        for (int u = 0; u < KT; ++u) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing all-zero DMAs must land before LDS is reused
   __syncthreads();
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
@@ -606,6 +599,168 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
   }
 }
 
+// The same contraction with both operand tiles moved HBM -> LDS by the DMA path (buffer_load ... lds): no staging
+// registers, no ds_writes, a STAGES-deep ring with counted vmcnt waits.  A wave's DMA instruction covers 4 rows x 64
+// floats (lane-linear 16-byte slots), which IS the [32 m][64] tile layout, so no swizzle is needed.
+template <int G, int STAGES>
+__global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs p, const float* __restrict__ dy,
+                                                             int ldy, unsigned dy_bytes, float* __restrict__ slab,
+                                                             int m_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int SUB = 32 * 64;                       // one [32 m][64] sub-tile
+  constexpr int STAGE_FLOATS = (G + 1) * SUB;        // G sub-tiles of X and one of dY
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave >> 1, wn = wave & 1;
+  const int kc0 = blockIdx.x * (16 * G);
+  const int n0 = blockIdx.y * 64;
+  const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
+  int64_t mend = mbeg + m_per_split;
+  if (mend > p.M) mend = p.M;
+  const int cq = tid & 15, srow = tid >> 4;
+  int ex[G];
+  bool cv[G];
+  int oa[G], ob[G], oc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int q = kc0 + g * 16 + cq;
+    const int4 e = q < p.nchunks ? ((const int4*)p.tab)[q] : make_int4(0, -1, 0, 0);
+    ex[g] = e.x * 4;
+    cv[g] = e.y >= 0;
+    oa[g] = (e.w & 255) - 128; ob[g] = ((e.w >> 8) & 255) - 128; oc[g] = ((e.w >> 16) & 255) - 128;
+  }
+  const bool nvalid = (n0 + cq * 4) < p.N;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  int rn[2], ra[2], rb[2], rc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    unsigned rr = (unsigned)(mbeg + srow + 16 * i);
+    rc[i] = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+    rb[i] = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+    ra[i] = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
+    rn[i] = (int)rr;
+  }
+  int st_c, st_b, st_a, st_n;
+  {
+    unsigned t = 32u;
+    st_c = (int)(t % (unsigned)p.Gc); t /= (unsigned)p.Gc;
+    st_b = (int)(t % (unsigned)p.Gb); t /= (unsigned)p.Gb;
+    st_a = (int)(t % (unsigned)p.Ga); t /= (unsigned)p.Ga;
+    st_n = (int)t;
+  }
+  // issue() is called for consecutive tiles 0, 1, 2, ...: the coordinates describe the tile about to be issued
+  auto issue = [&](int64_t t, int stage) {
+    float* base = lds + stage * STAGE_FLOATS;
+    const int64_t mt = mbeg + t * 32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = mt + srow + 16 * i;
+      const bool mv = m < mend;
+      const int a0 = ra[i] * p.sa, b0 = rb[i] * p.sb, c0 = rc[i] * p.sc;
+      const unsigned rbase = ((((unsigned)rn[i] * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const bool ok = mv && cv[g] && (unsigned)(a0 + oa[g]) < (unsigned)p.Ts &&
+                        (unsigned)(b0 + ob[g]) < (unsigned)p.Hs && (unsigned)(c0 + oc[g]) < (unsigned)p.Ws;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(base + g * SUB + (4 * wave + 16 * i) * 64),
+                                                 16, (int)(ok ? rbase + (unsigned)ex[g] : OOB), 0, 0, 0);
+      }
+      const unsigned yo = (mv && nvalid) ? (unsigned)(m * ldy + n0 + cq * 4) * 4u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(base + G * SUB + (4 * wave + 16 * i) * 64),
+                                               16, (int)yo, 0, 0, 0);
+    }
+    // step the row coordinates to the next tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rc[i] += st_c; const int c1 = rc[i] >= p.Gc; rc[i] -= c1 ? p.Gc : 0;
+      rb[i] += st_b + c1; const int c2 = rb[i] >= p.Gb; rb[i] -= c2 ? p.Gb : 0;
+      ra[i] += st_a + c2; const int c3 = ra[i] >= p.Ga; ra[i] -= c3 ? p.Ga : 0;
+      rn[i] += st_n + c3;
+    }
+  };
+  f32x16 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[g][v] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  const int nmt = (mend > mbeg) ? (int)((mend - mbeg + 31) / 32) : 0;
+  constexpr int PER_STAGE = 2 * (G + 1);                     // DMA instructions per stage per wave, always exactly this many:
+  // tiles past the slice's end (rows >= mend) are all-OOB DMAs that land zeros, so the steady state has no branch
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t) issue(t, t);
+  for (int s0 = 0; s0 < nmt; s0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {
+      const int sg = s0 + sidx;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(sg + STAGES - 1, (sidx + STAGES - 1) % STAGES);
+      const float* Xb = lds + sidx * STAGE_FLOATS + wk * 32 + r + h * 64;
+      const float* Yb = lds + sidx * STAGE_FLOATS + G * SUB + wn * 32 + r + h * 64;
+      // operands of two reduction steps per group (rows 4q + h and 4q + 2 + h), register double-buffered
+      float a[2][G][2], b[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        b[0][u] = Yb[(2 * u) * 64];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a[0][g][u] = Xb[g * SUB + (2 * u) * 64];
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+        if (q < 7) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            b[nxt][u] = Yb[(4 * (q + 1) + 2 * u) * 64];
+#pragma unroll
+            for (int g = 0; g < G; ++g) a[nxt][g][u] = Xb[g * SUB + (4 * (q + 1) + 2 * u) * 64];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][g][u], b[cur][u], acc[g], 0, 0, 0);
+        if (q < 7) __builtin_amdgcn_sched_group_barrier(0x100, G + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * G, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const int Kp = p.nchunks * 4;
+  float* out = slab + (int64_t)blockIdx.z * p.N * Kp;
+  const int n = n0 + wn * 32 + r;
+  if (n < p.N) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int kidx = (kc0 + g * 16) * 4 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (kidx < Kp) out[(int64_t)n * Kp + kidx] = acc[g][v];
+      }
+  }
+}
+
+template <int G, int STAGES>
+static int launch_wgrad_dma(const SlicConvArgs& a, const float* dy, int ldy, unsigned dyb, float* slab, int per, int S,
+                            hipStream_t st) {
+  const size_t lds = (size_t)STAGES * (G + 1) * 32 * 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<G, STAGES>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)slic_cdiv(a.nchunks, 16 * G), (unsigned)slic_cdiv(a.N, 64), (unsigned)S);
+  conv_wgrad_dma_kernel<G, STAGES><<<grid, dim3(256), lds, st>>>(a, dy, ldy, dyb, slab, per);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 // dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][n][tap*Cs + c]
 __global__ void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, int Kp, int Cs, int C,
                                   int ntaps, float* __restrict__ dW) {
@@ -701,8 +856,8 @@ static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
 }
 
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
-  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17 || variant == 20) return 64;
-  if (variant == 13 || variant == 14 || variant == 18 || variant == 19 || variant == 21 || variant == 22) return 128;
+  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17 || variant == 20 || variant == 23) return 64;
+  if (variant == 13 || variant == 14 || variant == 18 || variant == 19 || variant == 21 || variant == 22 || variant == 24) return 128;
   // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
   if (variant == 1) return 128;
   if (variant == 2) return 64;
@@ -718,7 +873,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   hipStream_t st = S_(stream);
-  if (variant >= 11 && variant <= 22) {
+  if (variant >= 11 && variant <= 24) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SlicConvArgs b = *a;
@@ -727,6 +882,8 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     if (variant == 12) return launch_gemm_dma<64, 64, 2, 2, 4>(b, st);
     if (variant == 13) return launch_gemm_dma<128, 64, 2, 2, 3>(b, st);
     if (variant == 17) return launch_gemm_dma<64, 64, 2, 2, 2, 1>(b, st);     // 2-stage ring (32 KB: 5 workgroups / CU)
+    if (variant == 23) return launch_gemm_dma<64, 128, 2, 2, 2, 1, true>(b, st);    // 64x128 tiles (N >= 128 layers), interleaved
+    if (variant == 24) return launch_gemm_dma<128, 64, 2, 2, 3, 1, true>(b, st);    // v22 with a 3-stage ring
     if (variant == 20) return launch_gemm_dma<64, 64, 2, 2, 2, 1, true>(b, st);     // v17 + DMA issue interleaved with the MFMAs
     if (variant == 21) return launch_gemm_dma<128, 128, 2, 2, 2, 1, true>(b, st);   // v18 + interleave
     if (variant == 22) return launch_gemm_dma<128, 64, 2, 2, 2, 1, true>(b, st);    // v19 + interleave
@@ -766,8 +923,17 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   const int64_t dyb = a->M * (int64_t)ldy * 4;
   SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad: dy larger than 4 GiB (split the batch)");
   const char* gv = getenv("SLIC_WGRAD_G");      // tuning knob (scripts/bench_conv.py); default picked below
-  const int G = gv ? atoi(gv) : 2;
-  if (G == 2) {
+  const int G = gv ? atoi(gv) : 12;   // default: LDS-DMA kernel, 128 x 64 output tile, 2-stage ring (3 workgroups / CU)
+  if (G >= 10) {            // LDS-DMA kernels: 1x = G 2, 2x = G 4, 3x = G 1; last digit = ring stages
+    int rc2;
+    if (G == 12) rc2 = launch_wgrad_dma<2, 2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 13) rc2 = launch_wgrad_dma<2, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 14) rc2 = launch_wgrad_dma<2, 4>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 22) rc2 = launch_wgrad_dma<4, 2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 23) rc2 = launch_wgrad_dma<4, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else rc2 = launch_wgrad_dma<1, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    if (rc2) return rc2;
+  } else if (G == 2) {
     dim3 grid((unsigned)slic_cdiv(a->nchunks, 32), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
     conv_wgrad_kernel<2><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
   } else {

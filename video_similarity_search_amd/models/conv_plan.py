@@ -176,9 +176,9 @@ class ConvPlan:
                 return 0
             # measured (scripts/bench_conv.py): the 2-stage ring (32 KB LDS, 5 workgroups / CU) wins on the large-M
             # layers, the 3-stage ring on the small-M ones (layer4) where fewer workgroups exist to hide latency
-            if a.M >= 20000:
-                # N <= 64 (layer1: 52 % of the FLOPs): 128x64 tiles with the next tile's DMAs issued between MFMA groups
-                return 22 if a.N <= 64 else 17
+            if a.M >= 100000:
+                # the next tile's DMAs are issued between MFMA groups; N <= 64 (layer1: 52 % of the FLOPs): 128x64 tiles
+                return 22 if a.N <= 64 else 20
             return 11
         if variant >= 11 and not a.tap_tab:
             return 0
@@ -234,7 +234,8 @@ class ConvPlan:
         if splits is None:
             # measured (scripts/bench_conv.py, WGONLY=1 sweep): 128 x 64 output tiles, ~3000 workgroups, but at
             # least 1024 positions per slice so the slabs of the small-M layers stay small
-            G = int(os.environ.get("SLIC_WGRAD_G", "2"))
+            G = int(os.environ.get("SLIC_WGRAD_G", "12"))
+            G = {12: 2, 13: 2, 14: 2, 22: 4, 23: 4, 33: 1}.get(G, G)      # LDS-DMA kernel codes -> k-groups per workgroup
             target = int(os.environ.get("SLIC_WGRAD_BLOCKS", "3072"))
             blocks = ((self.nchunks_fwd + 16 * G - 1) // (16 * G)) * ((self.N + 63) // 64)
             splits = max(1, min((target + blocks - 1) // blocks, (a.M + 1023) // 1024))
