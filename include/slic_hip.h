@@ -168,6 +168,9 @@ typedef struct SlicConvArgs {
   int dst_strided;         /* 0: dst row = m; 1: dst row = ((b*Da + ga*da+ea)*Db + gb*db+eb)*Dc + gc*dc+ec */
   int Da, Db, Dc, da, db, dc, ea, eb, ec;
   int relu;                /* clamp at 0 last */
+  const uint32_t* row_tab; /* optional [M][2] per-row records {byte offset of the row's source origin, 21-bit in-bounds mask}
+                              written by slic_conv_row_table; slic_conv_wgrad's LDS-DMA kernel then does no per-row
+                              coordinate arithmetic.  NULL: the kernel decodes rows itself */
 } SlicConvArgs;
 
 /* rows per workgroup of the tile slic_conv_gemm picks for (args, variant); variant 0 = auto,
@@ -181,6 +184,9 @@ int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);
 size_t slic_conv_wgrad_workspace_bytes(const SlicConvArgs* args, int splits);
 int slic_conv_wgrad(const SlicConvArgs* args, const float* dy, int ldy, int splits, int C, int ntaps,
                     float* dW, void* workspace, void* stream);
+/* row_tab[m] = {(((b*Ts + ga*sa)*Hs + gb*sb)*Ws + gc*sc)*Cs*4, bit (7*dim + o + 3) set iff coordinate + o is inside the
+ * source for o in -3..3} for the M rows of args' geometry (args->src etc. unused): 8 bytes per row. */
+int slic_conv_row_table(const SlicConvArgs* args, uint32_t* row_tab, void* stream);
 /* Wp[n][tap*Cs + c] = W[n][c][tap] (zero padded to Cs channels / Kp columns) — forward operand */
 int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp, float* Wp, void* stream);
 /* Wd[c][tap*N + n] = W[n][c][tap] (Cs rows, Kd columns) — data-gradient operand */

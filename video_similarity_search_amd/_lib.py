@@ -42,6 +42,7 @@ SIGNATURES = {
     "slic_conv_tile_m": (I, [P, I]),
     "slic_conv_gemm": (I, [P, I, P]),
     "slic_conv_wgrad_workspace_bytes": (c_size_t, [P, I]),
+    "slic_conv_row_table": (I, [P, P, P]),
     "slic_conv_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
     "slic_pack_weight_fwd": (I, [P, I, I, I, I, I, P, P]),
     "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
@@ -94,6 +95,7 @@ class SlicConvArgs(ctypes.Structure):
         ("dst_strided", I), ("Da", I), ("Db", I), ("Dc", I), ("da", I), ("db", I), ("dc", I),
         ("ea", I), ("eb", I), ("ec", I),
         ("relu", I),
+        ("row_tab", P),
     ]
 
 

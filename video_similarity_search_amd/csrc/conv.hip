@@ -26,6 +26,7 @@
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
                                               int wm, int wn, int r, int h, int tid) {
+  const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   // ---- epilogue
   const bool want_stats = p.stat_partial != nullptr;
@@ -107,7 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
         for (int w = 0; w < WM; ++w) t += red[w * BN + tid];
         if (!pass) bmean[tid] = t * inv_rows;
         const int n = n0 + tid;
-        if (n < p.N) p.stat_partial[((int64_t)blockIdx.x * 2 + pass) * p.N + n] = t;
+        if (n < p.N) p.stat_partial[(mblk * 2 + pass) * p.N + n] = t;
       }
       __syncthreads();
     }
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk (p ^ ((row >> 1) & 7)).
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p) {
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -274,7 +275,12 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
   static_assert(WM * WN == 4, "4 waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  // XCD-aware order: consecutive workgroup ids run on different XCDs (id % 8), so hand each XCD a contiguous range of
+  // row blocks — neighbouring rows (the taps' halo) are then re-read through the same L2
+  int mb = blockIdx.x;
+  if (xcd_remap) mb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int64_t m0 = (int64_t)mb * BM;
+  if (m0 >= p.M) return;
   const int n0 = blockIdx.y * BN;
   const int srow = tid >> 3;                                  // row inside each 32-row group
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);               // SOURCE chunk column of this lane (LDS slot = tid & 7)
@@ -602,22 +608,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
 // The same contraction with both operand tiles moved HBM -> LDS by the DMA path (buffer_load ... lds): no staging
 // registers, no ds_writes, a STAGES-deep ring with counted vmcnt waits.  A wave's DMA instruction covers 4 rows x 64
 // floats (lane-linear 16-byte slots), which IS the [32 m][64] tile layout, so no swizzle is needed.
-template <int G, int STAGES>
+//   ILV: the next tile's DMAs are issued one at a time between the MFMA groups of the tile being computed.
+//   RT:  per-row {source byte offset, in-bounds mask} records come from args.row_tab (slic_conv_row_table) instead of
+//        being decoded from the row index — the per-tile VALU work drops from ~110 to ~30 instructions, which is
+//        what bounded this kernel (measured: removing the address math alone gave +15 %).
+template <int G, int STAGES, bool ILV, bool RT>
 __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs p, const float* __restrict__ dy,
                                                              int ldy, unsigned dy_bytes, float* __restrict__ slab,
-                                                             int m_per_split) {
+                                                             int m_per_split, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(!RT || STAGES == 2, "row-table path: the counted waits assume a 2-stage ring");
   constexpr int SUB = 32 * 64;                       // one [32 m][64] sub-tile
   constexpr int STAGE_FLOATS = (G + 1) * SUB;        // G sub-tiles of X and one of dY
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave >> 1, wn = wave & 1;
-  const int kc0 = blockIdx.x * (16 * G);
-  const int n0 = blockIdx.y * 64;
-  const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
-  int64_t mend = mbeg + m_per_split;
-  if (mend > p.M) mend = p.M;
+  const int nx = (p.nchunks + 16 * G - 1) / (16 * G), ny = (p.N + 63) / 64;
+  const int L = blockIdx.x;
+  if (L >= nx * ny * nsplit) return;
+  const int bx = L % nx, by = (L / nx) % ny, bz = L / (nx * ny);
+  const int kc0 = bx * (16 * G);
+  const int n0 = by * 64;
+  const int mbeg = bz * m_per_split;
+  const int mend = min(mbeg + m_per_split, (int)p.M);
   const int cq = tid & 15, srow = tid >> 4;
   int ex[G];
+  unsigned tmk[G];                                   // tap mask of the chunk; all ones (never satisfied) for a padding chunk
   bool cv[G];
   int oa[G], ob[G], oc[G];
 #pragma unroll
@@ -626,57 +641,79 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
     const int4 e = q < p.nchunks ? ((const int4*)p.tab)[q] : make_int4(0, -1, 0, 0);
     ex[g] = e.x * 4;
     cv[g] = e.y >= 0;
+    tmk[g] = (unsigned)e.y;
     oa[g] = (e.w & 255) - 128; ob[g] = ((e.w >> 8) & 255) - 128; oc[g] = ((e.w >> 16) & 255) - 128;
   }
   const bool nvalid = (n0 + cq * 4) < p.N;
+  const unsigned ycol = (unsigned)(n0 + cq * 4) * 4u;
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
+  // ---- row state: either decoded coordinates stepped in mixed radix, or records prefetched from the row table
   int rn[2], ra[2], rb[2], rc[2];
+  int st_c = 0, st_b = 0, st_a = 0, st_n = 0;
+  uint2 rec[2], recn[2];                             // RT: records of the next tile to issue / the one after
+  const uint2* rtab = (const uint2*)p.row_tab;
+  auto load_rec = [&](int t, uint2 (&dst)[2]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    unsigned rr = (unsigned)(mbeg + srow + 16 * i);
-    rc[i] = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
-    rb[i] = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
-    ra[i] = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
-    rn[i] = (int)rr;
-  }
-  int st_c, st_b, st_a, st_n;
-  {
+    for (int i = 0; i < 2; ++i) {
+      const int m = mbeg + t * 32 + srow + 16 * i;
+      dst[i] = m < mend ? rtab[m] : make_uint2(0u, 0u);       // mask 0 fails every tap's test
+    }
+  };
+  if constexpr (RT) {
+    load_rec(0, rec);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned rr = (unsigned)(mbeg + srow + 16 * i);
+      rc[i] = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+      rb[i] = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+      ra[i] = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
+      rn[i] = (int)rr;
+    }
     unsigned t = 32u;
     st_c = (int)(t % (unsigned)p.Gc); t /= (unsigned)p.Gc;
     st_b = (int)(t % (unsigned)p.Gb); t /= (unsigned)p.Gb;
     st_a = (int)(t % (unsigned)p.Ga); t /= (unsigned)p.Ga;
     st_n = (int)t;
   }
-  // issue() is called for consecutive tiles 0, 1, 2, ...: the coordinates describe the tile about to be issued
-  auto issue = [&](int64_t t, int stage) {
+  // DMA `d` (of 2 * (G + 1)) of tile t into ring stage `stage`; tiles past the slice's end issue all-OOB DMAs (zeros)
+  auto issue_piece = [&](int t, int stage, int d) {
     float* base = lds + stage * STAGE_FLOATS;
-    const int64_t mt = mbeg + t * 32;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t m = mt + srow + 16 * i;
-      const bool mv = m < mend;
-      const int a0 = ra[i] * p.sa, b0 = rb[i] * p.sb, c0 = rc[i] * p.sc;
-      const unsigned rbase = ((((unsigned)rn[i] * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
+    const int i = d / (G + 1), g = d % (G + 1);
+    const int m = mbeg + t * 32 + srow + 16 * i;
+    const bool mv = m < mend;
+    if (g < G) {
+      unsigned off;
+      if constexpr (RT) {
+        off = ((rec[i].y & tmk[g]) == tmk[g]) ? rec[i].x + (unsigned)ex[g] : OOB;
+      } else {
+        const int a0 = ra[i] * p.sa, b0 = rb[i] * p.sb, c0 = rc[i] * p.sc;
+        const unsigned rbase = ((((unsigned)rn[i] * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
         const bool ok = mv && cv[g] && (unsigned)(a0 + oa[g]) < (unsigned)p.Ts &&
                         (unsigned)(b0 + ob[g]) < (unsigned)p.Hs && (unsigned)(c0 + oc[g]) < (unsigned)p.Ws;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(base + g * SUB + (4 * wave + 16 * i) * 64),
-                                                 16, (int)(ok ? rbase + (unsigned)ex[g] : OOB), 0, 0, 0);
+        off = ok ? rbase + (unsigned)ex[g] : OOB;
       }
-      const unsigned yo = (mv && nvalid) ? (unsigned)(m * ldy + n0 + cq * 4) * 4u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(base + g * SUB + (4 * wave + 16 * i) * 64),
+                                               16, (int)off, 0, 0, 0);
+    } else {
+      const unsigned yo = (mv && nvalid) ? (unsigned)m * (unsigned)(ldy * 4) + ycol : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(base + G * SUB + (4 * wave + 16 * i) * 64),
                                                16, (int)yo, 0, 0, 0);
     }
-    // step the row coordinates to the next tile
+  };
+  auto step = [&]() {               // advance to the next tile's rows
+    if constexpr (RT) {
+      rec[0] = recn[0]; rec[1] = recn[1];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      rc[i] += st_c; const int c1 = rc[i] >= p.Gc; rc[i] -= c1 ? p.Gc : 0;
-      rb[i] += st_b + c1; const int c2 = rb[i] >= p.Gb; rb[i] -= c2 ? p.Gb : 0;
-      ra[i] += st_a + c2; const int c3 = ra[i] >= p.Ga; ra[i] -= c3 ? p.Ga : 0;
-      rn[i] += st_n + c3;
+      for (int i = 0; i < 2; ++i) {
+        rc[i] += st_c; const int c1 = rc[i] >= p.Gc; rc[i] -= c1 ? p.Gc : 0;
+        rb[i] += st_b + c1; const int c2 = rb[i] >= p.Gb; rb[i] -= c2 ? p.Gb : 0;
+        ra[i] += st_a + c2; const int c3 = ra[i] >= p.Ga; ra[i] -= c3 ? p.Ga : 0;
+        rn[i] += st_n + c3;
+      }
     }
   };
   f32x16 acc[G];
@@ -685,18 +722,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[g][v] = 0.f;
   const int r = lane & 31, h = lane >> 5;
-  const int nmt = (mend > mbeg) ? (int)((mend - mbeg + 31) / 32) : 0;
-  constexpr int PER_STAGE = 2 * (G + 1);                     // DMA instructions per stage per wave, always exactly this many:
-  // tiles past the slice's end (rows >= mend) are all-OOB DMAs that land zeros, so the steady state has no branch
+  const int nmt = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
+  constexpr int NP = 2 * (G + 1);                            // DMA instructions per stage per wave, always exactly this many
+  constexpr int PER_STAGE = NP + (RT ? 2 : 0);               // + the two record loads, which sit on the same vmcnt queue
 #pragma unroll
-  for (int t = 0; t < STAGES - 1; ++t) issue(t, t);
+  for (int t = 0; t < STAGES - 1; ++t) {
+    if constexpr (RT) load_rec(t + 1, recn);
+#pragma unroll
+    for (int d = 0; d < NP; ++d) issue_piece(t, t, d);
+    step();
+  }
   for (int s0 = 0; s0 < nmt; s0 += STAGES) {
 #pragma unroll
     for (int sidx = 0; sidx < STAGES; ++sidx) {
       const int sg = s0 + sidx;
+      const int tn = sg + STAGES - 1, stn = (sidx + STAGES - 1) % STAGES;      // tile / ring stage to fill
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
       __builtin_amdgcn_s_barrier();
-      issue(sg + STAGES - 1, (sidx + STAGES - 1) % STAGES);
+      if constexpr (RT) load_rec(tn + 1, recn);
+      if constexpr (!ILV) {
+#pragma unroll
+        for (int d = 0; d < NP; ++d) issue_piece(tn, stn, d);
+        step();
+      }
       const float* Xb = lds + sidx * STAGE_FLOATS + wk * 32 + r + h * 64;
       const float* Yb = lds + sidx * STAGE_FLOATS + G * SUB + wn * 32 + r + h * 64;
       // operands of two reduction steps per group (rows 4q + h and 4q + 2 + h), register double-buffered
@@ -724,15 +772,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
 #pragma unroll
           for (int g = 0; g < G; ++g)
             acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][g][u], b[cur][u], acc[g], 0, 0, 0);
-        if (q < 7) __builtin_amdgcn_sched_group_barrier(0x100, G + 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * G, 0);
+        if constexpr (ILV) {
+          constexpr int PER = (NP + 6) / 7;                  // pieces spread over groups 0..6, step() in group 7
+#pragma unroll
+          for (int d = q * PER; d < (q + 1) * PER && d < NP; ++d) issue_piece(tn, stn, d);
+          if (q == 7) step();
+        } else {
+          if (q < 7) __builtin_amdgcn_sched_group_barrier(0x100, G + 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * G, 0);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int Kp = p.nchunks * 4;
-  float* out = slab + (int64_t)blockIdx.z * p.N * Kp;
+  float* out = slab + (int64_t)bz * p.N * Kp;
   const int n = n0 + wn * 32 + r;
   if (n < p.N) {
 #pragma unroll
@@ -745,20 +800,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
   }
 }
 
-template <int G, int STAGES>
+template <int G, int STAGES, bool ILV = false, bool RT = false>
 static int launch_wgrad_dma(const SlicConvArgs& a, const float* dy, int ldy, unsigned dyb, float* slab, int per, int S,
                             hipStream_t st) {
   const size_t lds = (size_t)STAGES * (G + 1) * 32 * 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<G, STAGES>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_dma_kernel<G, STAGES, ILV, RT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)slic_cdiv(a.nchunks, 16 * G), (unsigned)slic_cdiv(a.N, 64), (unsigned)S);
-  conv_wgrad_dma_kernel<G, STAGES><<<grid, dim3(256), lds, st>>>(a, dy, ldy, dyb, slab, per);
+  const int64_t total = slic_cdiv(a.nchunks, 16 * G) * slic_cdiv(a.N, 64) * S;
+  conv_wgrad_dma_kernel<G, STAGES, ILV, RT><<<dim3((unsigned)total), dim3(256), lds, st>>>(a, dy, ldy, dyb, slab, per, S);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+// row_tab[m] = {byte offset of row m's source origin, 21-bit in-bounds mask}  (see slic_conv_row_table)
+__global__ void conv_row_table_kernel(const SlicConvArgs p, uint2* __restrict__ row_tab) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.M) return;
+  unsigned rr = (unsigned)m;
+  const int gc = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
+  const int gb = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
+  const int ga = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
+  const int a0 = ga * p.sa, b0 = gb * p.sb, c0 = gc * p.sc;
+  unsigned mk = 0;
+#pragma unroll
+  for (int o = -3; o <= 3; ++o) {
+    mk |= ((unsigned)(a0 + o) < (unsigned)p.Ts ? 1u : 0u) << (o + 3);
+    mk |= ((unsigned)(b0 + o) < (unsigned)p.Hs ? 1u : 0u) << (7 + o + 3);
+    mk |= ((unsigned)(c0 + o) < (unsigned)p.Ws ? 1u : 0u) << (14 + o + 3);
+  }
+  row_tab[m] = make_uint2(((((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs) * 4u, mk);
 }
 
 // dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][n][tap*Cs + c]
@@ -849,8 +923,10 @@ static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)slic_cdiv(a.M, BM), (unsigned)slic_cdiv(a.N, BN));
-  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a);
+  static const int xcd = getenv("SLIC_CONV_XCD") ? atoi(getenv("SLIC_CONV_XCD")) : 1;
+  const unsigned gx = (unsigned)slic_cdiv(a.M, BM);
+  dim3 grid(xcd ? (gx + 7) / 8 * 8 : gx, (unsigned)slic_cdiv(a.N, BN));
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a, xcd);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -923,15 +999,21 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   const int64_t dyb = a->M * (int64_t)ldy * 4;
   SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad: dy larger than 4 GiB (split the batch)");
   const char* gv = getenv("SLIC_WGRAD_G");      // tuning knob (scripts/bench_conv.py); default picked below
-  const int G = gv ? atoi(gv) : 12;   // default: LDS-DMA kernel, 128 x 64 output tile, 2-stage ring (3 workgroups / CU)
-  if (G >= 10) {            // LDS-DMA kernels: 1x = G 2, 2x = G 4, 3x = G 1; last digit = ring stages
+  const int G = gv ? atoi(gv) : (a->row_tab ? 62 : 42);   // default: LDS-DMA kernel, 128 x 64 output tile, 2-stage ring, interleaved issue
+  if (G >= 10) {            // LDS-DMA kernels: tens digit = flavour, units digit = ring stages
     int rc2;
+    SLIC_REQUIRE(a->M < (int64_t)0x7FFFFFFF, "slic_conv_wgrad: M must fit 31 bits");
     if (G == 12) rc2 = launch_wgrad_dma<2, 2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
     else if (G == 13) rc2 = launch_wgrad_dma<2, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 14) rc2 = launch_wgrad_dma<2, 4>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
     else if (G == 22) rc2 = launch_wgrad_dma<4, 2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 23) rc2 = launch_wgrad_dma<4, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else rc2 = launch_wgrad_dma<1, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 42) rc2 = launch_wgrad_dma<2, 2, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 52) rc2 = launch_wgrad_dma<4, 2, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    else if (G == 62 || G == 72 || G == 82) {
+      SLIC_REQUIRE(a->row_tab, "slic_conv_wgrad: this kernel needs args->row_tab (slic_conv_row_table)");
+      if (G == 62) rc2 = launch_wgrad_dma<2, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+      else if (G == 72) rc2 = launch_wgrad_dma<2, 2, false, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+      else rc2 = launch_wgrad_dma<4, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+    } else rc2 = launch_wgrad_dma<1, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
     if (rc2) return rc2;
   } else if (G == 2) {
     dim3 grid((unsigned)slic_cdiv(a->nchunks, 32), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
@@ -943,6 +1025,15 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)a->N * Kp;
   conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, dW);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_conv_row_table(const SlicConvArgs* a, uint32_t* row_tab, void* stream) {
+  SLIC_REQUIRE(a && row_tab && a->M > 0 && a->M < (int64_t)0x7FFFFFFF && a->Ga > 0 && a->Gb > 0 && a->Gc > 0 && a->Cs > 0,
+               "slic_conv_row_table: bad args");
+  SLIC_REQUIRE(a->M % ((int64_t)a->Ga * a->Gb * a->Gc) == 0, "slic_conv_row_table: M is not a multiple of Ga*Gb*Gc");
+  conv_row_table_kernel<<<dim3((unsigned)slic_cdiv(a->M, 256)), dim3(256), 0, S_(stream)>>>(*a, (uint2*)row_tab);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -111,6 +111,7 @@ class ConvPlan:
                                            tab=torch.from_numpy(t).to(device), tap=tapt))
         self._wp = None
         self._wd = None
+        self._row_tabs = {}
         self.prof = None      # bench.py: list collecting (start, end) HIP event pairs around conv_gemm launches
 
     # ------------------------------------------------------------------ weights
@@ -227,6 +228,16 @@ class ConvPlan:
             self._launch(a, variant)
         return dx
 
+    def _row_table(self, a, B):
+        """per-row {source byte offset, in-bounds mask} records of the forward geometry at batch B (8 bytes / row),
+        built once on the device and kept with the plan"""
+        t = self._row_tabs.get(B)
+        if t is None:
+            t = torch.empty(a.M, 2, dtype=torch.int32, device=self.device)
+            call("slic_conv_row_table", ctypes.byref(a), ptr(t), stream())
+            self._row_tabs[B] = t
+        return t
+
     def wgrad(self, x, dz, B, dW, splits=None):
         """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
         lib = _lib.load()
@@ -234,11 +245,12 @@ class ConvPlan:
         if splits is None:
             # measured (scripts/bench_conv.py, WGONLY=1 sweep): 128 x 64 output tiles, ~3000 workgroups, but at
             # least 1024 positions per slice so the slabs of the small-M layers stay small
-            G = int(os.environ.get("SLIC_WGRAD_G", "12"))
-            G = {12: 2, 13: 2, 14: 2, 22: 4, 23: 4, 33: 1}.get(G, G)      # LDS-DMA kernel codes -> k-groups per workgroup
+            G = int(os.environ.get("SLIC_WGRAD_G", "62"))
+            G = {12: 2, 13: 2, 42: 2, 62: 2, 72: 2, 52: 4, 82: 4, 22: 4, 33: 1}.get(G, G)      # LDS-DMA kernel codes -> k-groups per workgroup
             target = int(os.environ.get("SLIC_WGRAD_BLOCKS", "3072"))
             blocks = ((self.nchunks_fwd + 16 * G - 1) // (16 * G)) * ((self.N + 63) // 64)
             splits = max(1, min((target + blocks - 1) // blocks, (a.M + 1023) // 1024))
+        a.row_tab = self._row_table(a, B).data_ptr()
         ws = _lib.workspace(lib.slic_conv_wgrad_workspace_bytes(ctypes.byref(a), splits), x.device, "wgrad")
         call("slic_conv_wgrad", ctypes.byref(a), ptr(dz), self.N, splits, self.C, self.ntaps, ptr(dW), ptr(ws), stream())
         return dW
