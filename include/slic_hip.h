@@ -100,12 +100,13 @@ int slic_kmeans_apply_relocation(const float* xfar, int ldf, const int32_t* old_
 
 /* _average_centers + _center_shift (_k_means_common.pyx:274-311): C_new = sums * (1/counts)
  * (empty clusters copy the biggest one, in sklearn's in-place order), shift[j] =
- * ||C_new_j - C_old_j||.  status (device double[4]) = { sum_j shift[j]^2, number of clusters with
+ * ||C_new_j - C_old_j||; cnorm_new (optional, [K]) = slic_kmeans_cnorm(C_new), so the next E-step needs no extra
+ * launch.  status (device double[4]) = { sum_j shift[j]^2, number of clusters with
  * counts == 0, *n_changed (or -1 if NULL), 0 } — the one word the host loop reads per iteration
  * (_kmeans.py:717-731).  C_new must not alias sums or C_old. */
 int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts, int K, int D,
-                         float* C_new, float* shift /* [K] */, const int32_t* n_changed,
-                         double* status, void* stream);
+                         float* C_new, float* shift /* [K] */, float* cnorm_new /* [K] or NULL */,
+                         const int32_t* n_changed, double* status, void* stream);
 
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
  * order) — X.mean(axis=0) and np.var(X, axis=0) of KMeans.fit / _tolerance

@@ -25,4 +25,4 @@ def tm(f, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 print(f"cnorm {tm(lambda: k.cnorm(C, cn)):.1f} us | assign {tm(lambda: k.assign(Xd, C, cn, lab, None, None)):.1f} us | "
-      f"accumulate {tm(lambda: k.accumulate(Xd, lab, K, sums, counts)):.1f} us | finalize {tm(lambda: k.finalize(C, sums, counts, Cn, shift, nch, status)):.1f} us")
+      f"accumulate {tm(lambda: k.accumulate(Xd, lab, K, sums, counts)):.1f} us | finalize {tm(lambda: k.finalize(C, sums, counts, Cn, shift, nch, status, cn)):.1f} us")

@@ -63,10 +63,12 @@ class OracleKernels:
         sums.copy_(torch.from_numpy(s))
         counts.copy_(torch.from_numpy(c))
 
-    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status):
+    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None):
         K, Dp = C_old.shape
         new, sh, tot = ok.finalize(_np(C_old), _np(sums).reshape(K, Dp), _np(counts))
         C_new.copy_(torch.from_numpy(new))
+        if cnorm_new is not None:
+            cnorm_new.copy_(torch.from_numpy(ok.row_sqnorm_chain(np.ascontiguousarray(new))))
         shift.copy_(torch.from_numpy(sh))
         status[0] = tot
         status[1] = float((_np(counts) == 0).sum())

@@ -71,10 +71,10 @@ class HipKernels:
         call("slic_kmeans_combine_shards", ptr(allpart), ptr(allpart[0, K * Dp:]), stride, W, K, Dp,
              ptr(sums), ptr(counts), stream())
 
-    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status):
+    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None):
         K, Dp = C_old.shape
         call("slic_kmeans_finalize", ptr(C_old), ptr(sums), ptr(counts), K, Dp, ptr(C_new), ptr(shift),
-             ptr(n_changed), ptr(status), stream())
+             ptr(cnorm_new), ptr(n_changed), ptr(status), stream())
 
     def dist_to_assigned(self, X, C, labels, dist):
         call("slic_kmeans_dist_to_assigned", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(C), C.stride(0),
@@ -239,7 +239,7 @@ class KMeans:
         on_gpu = Xc.is_cuda
         Cb = [C.contiguous().clone(), torch.empty_like(C), torch.empty_like(C)]          # iteration it: Cb[it%3] -> Cb[(it+1)%3]
         Lb = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in range(3)]      # labels of iteration it: Lb[it%3]
-        cnorm = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(2)]
+        cnorm = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(3)]        # norms of Cb[i]: written by finalize
         n_changed = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
         part = [torch.empty(K * Dp + K, dtype=torch.float32, device=dev) for _ in range(2)]   # [sums | counts]: the all-gather unit
         shift = torch.empty(K, dtype=torch.float32, device=dev)
@@ -260,15 +260,16 @@ class KMeans:
             sl = it & 1
             Cin, Cout = Cb[it % 3], Cb[(it + 1) % 3]
             lab, lab_old = Lb[it % 3], Lb[(it + 2) % 3]            # (it - 1) % 3
-            k.cnorm(Cin, cnorm[sl])
+            if it == 0:
+                k.cnorm(Cin, cnorm[0])                             # later norms come out of the previous finalize
             n_changed[sl].zero_()
-            k.assign(Xc, Cin, cnorm[sl], lab, lab_old, n_changed[sl])
+            k.assign(Xc, Cin, cnorm[it % 3], lab, lab_old, n_changed[sl])
             k.accumulate(Xc, lab, K, part[sl][: K * Dp], part[sl][K * Dp:])
             if self._sharded:
                 torch.distributed.all_gather_into_tensor(allpart[sl].view(-1), part[sl], group=self.process_group)
                 k.combine_shards(allpart[sl], K, Dp, gsums[sl], gcounts[sl])
                 torch.distributed.all_reduce(n_changed[sl], group=self.process_group)
-            k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl])
+            k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl], cnorm[(it + 1) % 3])
             host[sl].copy_(status[sl], non_blocking=True)
             if on_gpu:
                 ev[sl].record()
@@ -295,7 +296,8 @@ class KMeans:
                 sl = it & 1
                 if self._relocate(Xc, Cb[it % 3], Lb[it % 3], gsums[sl], gcounts[sl], int(n_empty)):
                     n_reloc += 1
-                    k.finalize(Cb[it % 3], gsums[sl], gcounts[sl], Cb[(it + 1) % 3], shift, n_changed[sl], status[sl])
+                    k.finalize(Cb[it % 3], gsums[sl], gcounts[sl], Cb[(it + 1) % 3], shift, n_changed[sl], status[sl],
+                               cnorm[(it + 1) % 3])
                     shift_tot = status[sl].cpu().tolist()[0]
                     if speculated:
                         launch(it + 1)
@@ -315,8 +317,10 @@ class KMeans:
         if not strict:
             # rerun the E-step so labels match the final centres (_kmeans.py:736-748); any buffer but `C`'s reader state
             out = Lb[(last + 1) % 3]
-            k.cnorm(C, cnorm[0])
-            k.assign(Xc, C, cnorm[0], out, None, None)
+            cn = cnorm[(last + 1) % 3] if self.max_iter > 0 else cnorm[0]
+            if self.max_iter <= 0:
+                k.cnorm(C, cn)
+            k.assign(Xc, C, cn, out, None, None)
             labels = out
         inertia = self._inertia(Xc, C, labels)
         res = dict(labels=labels, centers=C, inertia=inertia, n_iter=n_iter, strict=strict, n_relocations=n_reloc)

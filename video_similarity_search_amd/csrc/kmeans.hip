@@ -222,18 +222,25 @@ __global__ void km_block_hist(const int32_t* __restrict__ labels, int64_t N, int
   if (i < N) atomicAdd(&bc[(int64_t)blockIdx.x * K + labels[i]], 1);
 }
 
-// per cluster: exclusive scan over blocks (in place) and total count
-__global__ void km_scan_blocks(int32_t* __restrict__ bc, int nblk, int K,
-                               int32_t* __restrict__ cnt) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
-  int run = 0;
-  for (int b = 0; b < nblk; ++b) {
-    const int t = bc[(int64_t)b * K + j];
-    bc[(int64_t)b * K + j] = run;
-    run += t;
+// per cluster: exclusive scan over blocks (in place) and total count.  One wave per cluster: 64 blocks per step,
+// shuffle scan inside the step, running carry between steps (integer adds: order-free)
+__global__ __launch_bounds__(64) void km_scan_blocks(int32_t* __restrict__ bc, int nblk, int K,
+                                                     int32_t* __restrict__ cnt) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  int carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += 64) {
+    const int b = b0 + lane;
+    const int v = b < nblk ? bc[(int64_t)b * K + j] : 0;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(inc, d);
+      if (lane >= d) inc += u;
+    }
+    if (b < nblk) bc[(int64_t)b * K + j] = carry + inc - v;
+    carry += __shfl(inc, 63);
   }
-  cnt[j] = run;
+  if (lane == 0) cnt[j] = carry;
 }
 
 // exclusive scan of cnt over clusters (K is small: one workgroup, serial per 1024-chunk)
@@ -410,9 +417,17 @@ __global__ void km_apply_relocation(const float* __restrict__ xfar, int ldf,
   }
 }
 
-// _average_centers in sklearn's in-place j-ascending order + _center_shift
-__global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums, const float* __restrict__ counts, int K,
-                                                  int D, float* __restrict__ Cn) {
+// _average_centers in sklearn's in-place j-ascending order, _center_shift, and the next E-step's centre norms, one
+// workgroup per cluster.  The element-parallel parts (the new row, the squared differences per group of four) are
+// computed by all threads; the two order-defining chains run on one lane each from LDS:
+//   cnorm_new[j] = k-ascending fmaf chain of c.c                     (same chain as km_cnorm)
+//   shift[j]     = sqrt( sum over groups g of (d0^2 + d1^2 + d2^2 + d3^2)_g, g ascending, then the D % 4 tail )
+__global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums, const float* __restrict__ counts,
+                                                  const float* __restrict__ Co, int K, int D, float* __restrict__ Cn,
+                                                  float* __restrict__ shift, float* __restrict__ cnorm_new) {
+  extern __shared__ float km_avg_lds[];
+  float* row = km_avg_lds;                 // [D] the new centre
+  float* tg = km_avg_lds + D;              // [D / 4 + (D % 4)] group terms, then tail terms
   __shared__ float mv[128];
   __shared__ int mi[128];
   const int j = blockIdx.x, t = threadIdx.x;
@@ -436,27 +451,34 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
     src = mi[0];  // copy of the biggest cluster: averaged already iff it precedes j (sklearn's in-place loop order)
     alpha = (src < j && counts[src] > 0.0f) ? (float)(1.0 / (double)counts[src]) : 1.0f;
   }
-  for (int k = t; k < D; k += 128)
-    Cn[(int64_t)j * D + k] = sums[(int64_t)src * D + k] * alpha;
+  for (int k = t; k < D; k += 128) {
+    const float v = sums[(int64_t)src * D + k] * alpha;
+    Cn[(int64_t)j * D + k] = v;
+    row[k] = v;
+  }
+  __syncthreads();
+  const int ng = D / 4;
+  const float* b = Co + (int64_t)j * D;
+  for (int g = t; g < ng; g += 128) {
+    const int k = 4 * g;
+    const float d0 = row[k] - b[k], d1 = row[k + 1] - b[k + 1], d2 = row[k + 2] - b[k + 2], d3 = row[k + 3] - b[k + 3];
+    tg[g] = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  if (t < D - 4 * ng) { const float d = row[4 * ng + t] - b[4 * ng + t]; tg[ng + t] = d * d; }
+  __syncthreads();
+  if (t == 0 && cnorm_new) {
+    float acc = 0.f;
+    for (int k = 0; k < D; ++k) acc = fmaf(row[k], row[k], acc);
+    cnorm_new[j] = acc;
+  }
+  if (t == 64) {
+    float r = 0.f;
+    const int nt = ng + (D - 4 * ng);
+    for (int g = 0; g < nt; ++g) r += tg[g];
+    shift[j] = sqrtf(r);
+  }
 }
 
-__global__ void km_shift(const float* __restrict__ Co, const float* __restrict__ Cn, int K, int D,
-                         float* __restrict__ shift) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= K) return;
-  const float* a = Cn + (int64_t)j * D;
-  const float* b = Co + (int64_t)j * D;
-  float r = 0.f;
-  int k = 0;
-  for (; k + 4 <= D; k += 4) {
-    const float d0 = a[k] - b[k], d1 = a[k + 1] - b[k + 1], d2 = a[k + 2] - b[k + 2],
-                d3 = a[k + 3] - b[k + 3];
-    const float t = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
-    r += t;
-  }
-  for (; k < D; ++k) { const float d = a[k] - b[k]; r += d * d; }
-  shift[j] = sqrtf(r);
-}
 // status word: { sum_j shift_j^2, #empty clusters, n_changed, 0 }.  One workgroup; per-thread partials over a fixed
 // strided partition, then a fixed binary tree in LDS (deterministic).
 __global__ __launch_bounds__(256) void km_status(const float* __restrict__ shift, const float* __restrict__ counts, int K,
@@ -750,7 +772,7 @@ extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
   SLIC_HIP_CHECK(hipMemsetAsync(bc, 0, (size_t)nblk * K * 4, st));
   km_block_hist<<<dim3(nblk), dim3(KM_SB), 0, st>>>(labels, N, K, bc);
   SLIC_LAUNCH_CHECK();
-  km_scan_blocks<<<dim3((unsigned)slic_cdiv(K, 64)), dim3(64), 0, st>>>(bc, nblk, K, cnt);
+  km_scan_blocks<<<dim3(K), dim3(64), 0, st>>>(bc, nblk, K, cnt);
   SLIC_LAUNCH_CHECK();
   km_scan_clusters<<<dim3(1), dim3(1024), 0, st>>>(cnt, K, off, counts);
   SLIC_LAUNCH_CHECK();
@@ -814,15 +836,15 @@ extern "C" int slic_kmeans_apply_relocation(const float* xfar, int ldf, const in
 }
 
 extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts,
-                                    int K, int D, float* C_new, float* shift,
+                                    int K, int D, float* C_new, float* shift, float* cnorm_new,
                                     const int32_t* n_changed, double* status, void* stream) {
   SLIC_REQUIRE(C_old && sums && counts && C_new && shift && status && K > 0 && D > 0,
                "slic_kmeans_finalize: bad args");
   SLIC_REQUIRE(C_new != sums && C_new != C_old, "slic_kmeans_finalize: C_new must not alias");
+  SLIC_REQUIRE(D <= 8192, "slic_kmeans_finalize: D > 8192");
   hipStream_t st = S(stream);
-  km_average<<<dim3(K), dim3(128), 0, st>>>(sums, counts, K, D, C_new);
-  SLIC_LAUNCH_CHECK();
-  km_shift<<<dim3((unsigned)slic_cdiv(K, 64)), dim3(64), 0, st>>>(C_old, C_new, K, D, shift);
+  const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
+  km_average<<<dim3(K), dim3(128), lds, st>>>(sums, counts, C_old, K, D, C_new, shift, cnorm_new);
   SLIC_LAUNCH_CHECK();
   km_status<<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, status);
   SLIC_LAUNCH_CHECK();
