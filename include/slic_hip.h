@@ -61,6 +61,14 @@ int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, const float* C
                        const float* cnorm, int32_t* labels, const int32_t* labels_old,
                        int32_t* n_changed, float* best_score, void* workspace, void* stream);
 
+/* The same E-step on operands whose rows are already in the MFMA's LDS order — inside every group of eight k's,
+ * [k0 k2 k4 k6 | k1 k3 k5 k7] (slic_kmeans_permute_k8; the centres can come permuted out of slic_kmeans_finalize) — so
+ * both tiles go HBM -> LDS by DMA.  Same arithmetic, bit-identical labels; same workspace size. */
+int slic_kmeans_permute_k8(const float* X, int64_t N, int D, int ldx, float* Xp, int ldxp, void* stream);
+int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ldxp, const float* Cp, int K, int ldcp,
+                            const float* cnorm, int32_t* labels, const int32_t* labels_old,
+                            int32_t* n_changed, float* best_score, void* workspace, void* stream);
+
 /* M-step sums: sums[j,:] = sum of rows with label j, fp32, ASCENDING ROW ORDER (deterministic;
  * == sklearn's centers_new[label] += X[i] loop on one thread, _k_means_lloyd.pyx:215-218);
  * counts[j] = member count as float (weight_in_clusters). */
@@ -106,6 +114,7 @@ int slic_kmeans_apply_relocation(const float* xfar, int ldf, const int32_t* old_
  * (_kmeans.py:717-731).  C_new must not alias sums or C_old. */
 int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts, int K, int D,
                          float* C_new, float* shift /* [K] */, float* cnorm_new /* [K] or NULL */,
+                         float* C_new_perm /* [K][D] in slic_kmeans_permute_k8 order, or NULL */,
                          const int32_t* n_changed, double* status, void* stream);
 
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in

@@ -16,6 +16,8 @@ Multi-GPU: pass `process_group`; X is then this rank's contiguo
 (RCCL over xGMI) and added in rank order on every GPU, so all ranks hold bit-identical centres
 and the result equals the oracle run with n_shards = world size.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -60,6 +62,18 @@ class HipKernels:
         call("slic_kmeans_assign", ptr(X), N, Dp, X.stride(0), ptr(C), K, C.stride(0), ptr(cnorm), ptr(labels),
              ptr(labels_old), ptr(n_changed), None, ptr(ws), stream())
 
+    uses_perm = True       # E-step on k-permuted copies of X and the centres (LDS-DMA kernel)
+
+    def permute_k8(self, X, Xp):
+        call("slic_kmeans_permute_k8", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(Xp), Xp.stride(0), stream())
+
+    def assign_perm(self, Xp, Cp, cnorm, labels, labels_old, n_changed):
+        N, Dp = Xp.shape
+        K = Cp.shape[0]
+        ws = _lib.workspace(_lib.load().slic_kmeans_assign_workspace_bytes(N, K), Xp.device, "km_assign")
+        call("slic_kmeans_assign_perm", ptr(Xp), N, Dp, Xp.stride(0), ptr(Cp), K, Cp.stride(0), ptr(cnorm), ptr(labels),
+             ptr(labels_old), ptr(n_changed), None, ptr(ws), stream())
+
     def accumulate(self, X, labels, K, sums, counts):
         N, Dp = X.shape
         ws = _lib.workspace(_lib.load().slic_kmeans_accumulate_workspace_bytes(N, K), X.device, "km_accum")
@@ -71,10 +85,10 @@ class HipKernels:
         call("slic_kmeans_combine_shards", ptr(allpart), ptr(allpart[0, K * Dp:]), stride, W, K, Dp,
              ptr(sums), ptr(counts), stream())
 
-    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None):
+    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None, C_new_perm=None):
         K, Dp = C_old.shape
         call("slic_kmeans_finalize", ptr(C_old), ptr(sums), ptr(counts), K, Dp, ptr(C_new), ptr(shift),
-             ptr(cnorm_new), ptr(n_changed), ptr(status), stream())
+             ptr(cnorm_new), ptr(C_new_perm), ptr(n_changed), ptr(status), stream())
 
     def dist_to_assigned(self, X, C, labels, dist):
         call("slic_kmeans_dist_to_assigned", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(C), C.stride(0),
@@ -240,6 +254,12 @@ class KMeans:
         Cb = [C.contiguous().clone(), torch.empty_like(C), torch.empty_like(C)]          # iteration it: Cb[it%3] -> Cb[(it+1)%3]
         Lb = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in range(3)]      # labels of iteration it: Lb[it%3]
         cnorm = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(3)]        # norms of Cb[i]: written by finalize
+        perm = bool(getattr(k, "uses_perm", False)) and os.environ.get("SLIC_KM_PERM", "1") != "0"
+        if perm:
+            Xp = self._permuted(Xc)                                                        # once per fit, shared by the inits
+            Cp = [torch.empty_like(C) for _ in range(3)]                                   # permuted twins of Cb
+        else:
+            Cp = [None] * 3
         n_changed = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
         part = [torch.empty(K * Dp + K, dtype=torch.float32, device=dev) for _ in range(2)]   # [sums | counts]: the all-gather unit
         shift = torch.empty(K, dtype=torch.float32, device=dev)
@@ -261,15 +281,21 @@ class KMeans:
             Cin, Cout = Cb[it % 3], Cb[(it + 1) % 3]
             lab, lab_old = Lb[it % 3], Lb[(it + 2) % 3]            # (it - 1) % 3
             if it == 0:
-                k.cnorm(Cin, cnorm[0])                             # later norms come out of the previous finalize
+                k.cnorm(Cin, cnorm[0])                             # later norms / permuted centres come out of finalize
+                if perm:
+                    k.permute_k8(Cin, Cp[0])
             n_changed[sl].zero_()
-            k.assign(Xc, Cin, cnorm[it % 3], lab, lab_old, n_changed[sl])
+            if perm:
+                k.assign_perm(Xp, Cp[it % 3], cnorm[it % 3], lab, lab_old, n_changed[sl])
+            else:
+                k.assign(Xc, Cin, cnorm[it % 3], lab, lab_old, n_changed[sl])
             k.accumulate(Xc, lab, K, part[sl][: K * Dp], part[sl][K * Dp:])
             if self._sharded:
                 torch.distributed.all_gather_into_tensor(allpart[sl].view(-1), part[sl], group=self.process_group)
                 k.combine_shards(allpart[sl], K, Dp, gsums[sl], gcounts[sl])
                 torch.distributed.all_reduce(n_changed[sl], group=self.process_group)
-            k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl], cnorm[(it + 1) % 3])
+            k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl], cnorm[(it + 1) % 3],
+                       *((Cp[(it + 1) % 3],) if perm else ()))
             host[sl].copy_(status[sl], non_blocking=True)
             if on_gpu:
                 ev[sl].record()
@@ -297,7 +323,7 @@ class KMeans:
                 if self._relocate(Xc, Cb[it % 3], Lb[it % 3], gsums[sl], gcounts[sl], int(n_empty)):
                     n_reloc += 1
                     k.finalize(Cb[it % 3], gsums[sl], gcounts[sl], Cb[(it + 1) % 3], shift, n_changed[sl], status[sl],
-                               cnorm[(it + 1) % 3])
+                               cnorm[(it + 1) % 3], *((Cp[(it + 1) % 3],) if perm else ()))
                     shift_tot = status[sl].cpu().tolist()[0]
                     if speculated:
                         launch(it + 1)
@@ -320,13 +346,25 @@ class KMeans:
             cn = cnorm[(last + 1) % 3] if self.max_iter > 0 else cnorm[0]
             if self.max_iter <= 0:
                 k.cnorm(C, cn)
-            k.assign(Xc, C, cn, out, None, None)
+            if perm and self.max_iter > 0:
+                k.assign_perm(Xp, Cp[(last + 1) % 3], cn, out, None, None)
+            else:
+                k.assign(Xc, C, cn, out, None, None)
             labels = out
         inertia = self._inertia(Xc, C, labels)
         res = dict(labels=labels, centers=C, inertia=inertia, n_iter=n_iter, strict=strict, n_relocations=n_reloc)
         if trace is not None:
             res["trace"] = np.stack(trace) if trace else np.zeros((0, N), np.int32)
         return res
+
+    def _permuted(self, Xc):
+        """k-permuted copy of the (centred) data for the LDS-DMA E-step; cached while Xc is the same tensor"""
+        key = (Xc.data_ptr(), tuple(Xc.shape), Xc._version)
+        if getattr(self, "_perm_key", None) != key:
+            Xp = torch.empty_like(Xc)
+            self.k.permute_k8(Xc, Xp)
+            self._perm_key, self._perm_X = key, Xp
+        return self._perm_X
 
     def _inertia(self, Xc, C, labels):
         N = Xc.shape[0]

@@ -169,6 +169,134 @@ __global__ __launch_bounds__(256) void km_assign_partial(
   }
 }
 
+// The same E-step with both operand tiles moved HBM -> LDS by the DMA path (buffer_load ... lds; no staging registers,
+// no ds_writes, a STAGES-deep ring with counted vmcnt waits, branch-free steady state).  The DMA cannot de-interleave
+// k on the fly, so this kernel takes operands whose rows are ALREADY in the LDS image's order: inside every group of
+// eight k's, [k0 k2 k4 k6 | k1 k3 k5 k7]  (km_permute_k8: X once per fit, the centres by km_average).  The MFMA then sees
+// exactly the operand registers km_assign_partial builds, so scores and labels are bit-identical.
+template <int NCT, int STAGES>
+__global__ __launch_bounds__(256) void km_assign_dma(
+    const float* __restrict__ Xp, int64_t N, int D, int ldx, const float* __restrict__ Cp, int K,
+    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx) {
+  extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  constexpr int BC = NCT * 32;
+  constexpr int STAGE_FLOATS = (KM_BP + BC) * KM_BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t pblock = (int64_t)blockIdx.x * KM_BP;
+  const int cblock = blockIdx.y * BC;
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
+  // block-local buffer resources: offsets stay 32-bit whatever N is
+  const int64_t xrows = (N - pblock) < KM_BP ? (N - pblock) : KM_BP;
+  const int crows = (K - cblock) < BC ? (K - cblock) : BC;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Xp + pblock * (int64_t)ldx), 0, (int)(((xrows - 1) * (int64_t)ldx + D) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Cp + (int64_t)cblock * ldc), 0, (int)((((int64_t)crows - 1) * ldc + D) * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned xoff[4], coff[NCT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xoff[i] = (srow + 32 * i) < xrows ? ((unsigned)(srow + 32 * i) * (unsigned)ldx + cq * 4) * 4u : OOB;
+#pragma unroll
+  for (int i = 0; i < NCT; ++i) coff[i] = (srow + 32 * i) < crows ? ((unsigned)(srow + 32 * i) * (unsigned)ldc + cq * 4) * 4u : OOB;
+  const int klim = D - cq * 4;                                // this lane's chunk of k-tile kt is inside D iff 32 kt < klim
+  const int nk = (D + KM_BK - 1) / KM_BK;
+  auto issue = [&](int kt, int stage) {
+    float* Xs = km_lds + stage * STAGE_FLOATS;
+    float* Cs = Xs + KM_BP * KM_BK;
+    const bool kin = kt * KM_BK < klim;                       // false for every lane once kt >= nk: all-OOB (zero) DMAs
+    const unsigned kb = (unsigned)kt * (KM_BK * 4u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Xs + (8 * wave + 32 * i) * KM_BK),
+                                               16, (int)((kin && xoff[i] != OOB) ? xoff[i] + kb : OOB), 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NCT; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (__attribute__((address_space(3))) void*)(Cs + (8 * wave + 32 * i) * KM_BK),
+                                               16, (int)((kin && coff[i] != OOB) ? coff[i] + kb : OOB), 0, 0, 0);
+  };
+  f32x16 acc[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  auto compute = [&](int stage) {
+    const float* Xs = km_lds + stage * STAGE_FLOATS;
+    const float* Cs = Xs + KM_BP * KM_BK;
+    f32x4 b[2], a[2][NCT];
+    b[0] = *(const f32x4*)&Xs[km_off(32 * wave + r, h)];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) a[0][ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, h)];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int cur = q & 1, nxt = cur ^ 1;
+      if (q < 3) {
+        b[nxt] = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * (q + 1) + h)];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) a[nxt][ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, 2 * (q + 1) + h)];
+      }
+      // k order inside every accumulator: q ascending, t ascending, lane half 0 then 1 => k = 8q + 2t + h ascending
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct][t], b[cur][t], acc[ct], 0, 0, 0);
+      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NCT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCT, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  constexpr int PER_STAGE = 4 + NCT;
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t) issue(t, t);
+  // k-tiles past the end are all-zero DMAs and 0 * 0 MFMAs (exact no-ops on the accumulators): no branch in the loop
+  for (int s0 = 0; s0 < nk; s0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(s0 + sidx + STAGES - 1, (sidx + STAGES - 1) % STAGES);
+      compute(sidx);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float best = INFINITY;
+  int bidx = 0x7fffffff;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int c = cblock + ct * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      if (c < K) {
+        const float s = cnorm[c] - 2.0f * acc[ct][g];
+        if (s < best || (s == best && c < bidx)) { best = s; bidx = c; }
+      }
+    }
+  const float ob = __shfl_xor(best, 32);
+  const int oi = __shfl_xor(bidx, 32);
+  if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  const int64_t p = pblock + 32 * wave + r;
+  if (h == 0 && p < N) {
+    pscore[(int64_t)blockIdx.y * N + p] = best;
+    pidx[(int64_t)blockIdx.y * N + p] = bidx;
+  }
+}
+
+// out[i][8g + {0,1,2,3,4,5,6,7}] = in[i][8g + {0,2,4,6,1,3,5,7}]   (D % 8 == 0)
+__global__ void km_permute_k8(const float* __restrict__ X, int64_t N, int D8, int ldx, float* __restrict__ Xp, int ldxp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * D8) return;
+  const int64_t i = e / D8;
+  const int g = (int)(e % D8);
+  const f32x4 v0 = *(const f32x4*)(X + i * ldx + 8 * g), v1 = *(const f32x4*)(X + i * ldx + 8 * g + 4);
+  const f32x4 ev = {v0.x, v0.z, v1.x, v1.z}, od = {v0.y, v0.w, v1.y, v1.w};
+  *(f32x4*)(Xp + i * ldxp + 8 * g) = ev;
+  *(f32x4*)(Xp + i * ldxp + 8 * g + 4) = od;
+}
+
 // labels = argmin over the G centroid groups (groups ascending, strict '<' => first index wins)
 __global__ void km_combine(const float* __restrict__ pscore, const int32_t* __restrict__ pidx,
                            int G, int64_t N, int K, int32_t* __restrict__ labels,
@@ -424,7 +552,8 @@ __global__ void km_apply_relocation(const float* __restrict__ xfar, int ldf,
 //   shift[j]     = sqrt( sum over groups g of (d0^2 + d1^2 + d2^2 + d3^2)_g, g ascending, then the D % 4 tail )
 __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums, const float* __restrict__ counts,
                                                   const float* __restrict__ Co, int K, int D, float* __restrict__ Cn,
-                                                  float* __restrict__ shift, float* __restrict__ cnorm_new) {
+                                                  float* __restrict__ shift, float* __restrict__ cnorm_new,
+                                                  float* __restrict__ Cn_perm) {
   extern __shared__ float km_avg_lds[];
   float* row = km_avg_lds;                 // [D] the new centre
   float* tg = km_avg_lds + D;              // [D / 4 + (D % 4)] group terms, then tail terms
@@ -455,6 +584,7 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
     const float v = sums[(int64_t)src * D + k] * alpha;
     Cn[(int64_t)j * D + k] = v;
     row[k] = v;
+    if (Cn_perm) Cn_perm[(int64_t)j * D + (k & ~7) + ((k & 1) << 2) + ((k & 7) >> 1)] = v;   // km_permute_k8 order
   }
   __syncthreads();
   const int ng = D / 4;
@@ -749,6 +879,59 @@ extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, con
   return SLIC_OK;
 }
 
+template <int NCT, int STAGES>
+static int launch_assign_dma(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K, int ldc,
+                             const float* cnorm, float* pscore, int32_t* pidx, hipStream_t st) {
+  const size_t lds = (size_t)STAGES * (KM_BP + NCT * 32) * KM_BK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_dma<NCT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((unsigned)slic_cdiv(N, KM_BP), (unsigned)slic_cdiv(K, NCT * 32));
+  km_assign_dma<NCT, STAGES><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_permute_k8(const float* X, int64_t N, int D, int ldx, float* Xp, int ldxp, void* stream) {
+  SLIC_REQUIRE(X && Xp && X != Xp && N > 0 && D > 0 && D % 8 == 0 && ldx % 4 == 0 && ldxp % 4 == 0 && ldx >= D && ldxp >= D,
+               "slic_kmeans_permute_k8: need D %% 8 == 0 and 16-byte aligned rows");
+  const int64_t tot = N * (D / 8);
+  km_permute_k8<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S(stream)>>>(X, N, D / 8, ldx, Xp, ldxp);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K,
+                                       int ldc, const float* cnorm, int32_t* labels,
+                                       const int32_t* labels_old, int32_t* n_changed, float* best_score,
+                                       void* workspace, void* stream) {
+  SLIC_REQUIRE(Xp && Cp && cnorm && labels && workspace, "slic_kmeans_assign_perm: null pointer");
+  SLIC_REQUIRE(N > 0 && K > 0 && D > 0, "slic_kmeans_assign_perm: N=%lld K=%d D=%d", (long long)N, K, D);
+  SLIC_REQUIRE(D % 8 == 0 && ldx % 4 == 0 && ldc % 4 == 0 && ldx >= D && ldc >= D,
+               "slic_kmeans_assign_perm: need D %% 8 == 0 and 16-byte aligned rows (D=%d ldx=%d ldc=%d)", D, ldx, ldc);
+  SLIC_REQUIRE(((uintptr_t)Xp % 16) == 0 && ((uintptr_t)Cp % 16) == 0, "slic_kmeans_assign_perm: unaligned");
+  SLIC_REQUIRE((int64_t)KM_BP * ldx * 4 < (1ll << 31) && (int64_t)128 * ldc * 4 < (1ll << 31), "slic_kmeans_assign_perm: rows too long");
+  SLIC_REQUIRE(!labels_old || n_changed, "slic_kmeans_assign_perm: labels_old needs n_changed");
+  static const int mode = getenv("SLIC_KM_DMA") ? atoi(getenv("SLIC_KM_DMA")) : 22;     // NCT, ring stages
+  const int nct = mode / 10 == 4 ? 4 : 2;
+  const int G = (int)slic_cdiv(K, nct * 32);
+  SlicCarver w(workspace);
+  float* pscore = w.take<float>((size_t)slic_cdiv(K, 64) * N);
+  int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 64) * N);
+  hipStream_t st = S(stream);
+  int rc;
+  if (mode == 42) rc = launch_assign_dma<4, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  else if (mode == 43) rc = launch_assign_dma<4, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  else if (mode == 23) rc = launch_assign_dma<2, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  else rc = launch_assign_dma<2, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  if (rc) return rc;
+  km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, st>>>(pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
   const int64_t nblk = slic_cdiv(N, KM_SB);
   return slic_align_up((size_t)nblk * K * 4, 256) + 2 * slic_align_up((size_t)K * 4, 256) +
@@ -837,14 +1020,15 @@ extern "C" int slic_kmeans_apply_relocation(const float* xfar, int ldf, const in
 
 extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts,
                                     int K, int D, float* C_new, float* shift, float* cnorm_new,
-                                    const int32_t* n_changed, double* status, void* stream) {
+                                    float* C_new_perm, const int32_t* n_changed, double* status, void* stream) {
   SLIC_REQUIRE(C_old && sums && counts && C_new && shift && status && K > 0 && D > 0,
                "slic_kmeans_finalize: bad args");
   SLIC_REQUIRE(C_new != sums && C_new != C_old, "slic_kmeans_finalize: C_new must not alias");
   SLIC_REQUIRE(D <= 8192, "slic_kmeans_finalize: D > 8192");
+  SLIC_REQUIRE(!C_new_perm || D % 8 == 0, "slic_kmeans_finalize: C_new_perm needs D %% 8 == 0");
   hipStream_t st = S(stream);
   const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
-  km_average<<<dim3(K), dim3(128), lds, st>>>(sums, counts, C_old, K, D, C_new, shift, cnorm_new);
+  km_average<<<dim3(K), dim3(128), lds, st>>>(sums, counts, C_old, K, D, C_new, shift, cnorm_new, C_new_perm);
   SLIC_LAUNCH_CHECK();
   km_status<<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, status);
   SLIC_LAUNCH_CHECK();
