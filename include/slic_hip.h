@@ -178,6 +178,13 @@ typedef struct SlicConvArgs {
   int dst_strided;         /* 0: dst row = m; 1: dst row = ((b*Da + ga*da+ea)*Db + gb*db+eb)*Dc + gc*dc+ec */
   int Da, Db, Dc, da, db, dc, ea, eb, ec;
   int relu;                /* clamp at 0 last */
+  const float* mask_src;   /* optional, same addressing as dst: v = mask_src > 0 ? v : 0 after the addend (ReLU backward of the
+                              layer that consumes this gradient) */
+  const float* bwd_z;      /* optional, same addressing as dst: with bwd_mean / bwd_invstd ([N]) and bwd_partial, the epilogue
+                              also emits the BatchNorm-backward partial sums of the stored gradient v: */
+  const float* bwd_mean;
+  const float* bwd_invstd;
+  float* bwd_partial;      /* [ceil(M/tile_m)][2][N]: per workgroup (sum v, sum v * (bwd_z - mean) * invstd); NULL = off */
   const uint32_t* row_tab; /* optional [M][2] per-row records {byte offset of the row's source origin, 21-bit in-bounds mask}
                               written by slic_conv_row_table; slic_conv_wgrad's LDS-DMA kernel then does no per-row
                               coordinate arithmetic.  NULL: the kernel decodes rows itself */
@@ -230,6 +237,13 @@ int slic_bn_bwd_rows_per_partial(void);
 int slic_bn_bwd(const float* dy, const float* out, const float* z, const float* mean, const float* invstd,
                 const float* gamma, int64_t M, int C, float* g_out, float* dz, float* dgamma, float* dbeta,
                 void* workspace, void* stream);
+/* The second half of slic_bn_bwd when the producer of g (slic_conv_gemm with args->bwd_partial) already applied the
+ * ReLU mask and emitted the R x [2][C] partial sums: merges them in slab order (double), writes dgamma / dbeta and
+ * dz = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)). */
+size_t slic_bn_bwd_fused_workspace_bytes(int R, int C);
+int slic_bn_bwd_fused(const float* partial, int R, const float* g, const float* z, const float* mean,
+                      const float* invstd, const float* gamma, int64_t M, int C, float* dz, float* dgamma,
+                      float* dbeta, void* workspace, void* stream);
 /* AdaptiveAvgPool3d(1): y[b,c] = mean_s x[b,s,c]; backward dx = dy / S */
 int slic_avgpool_fwd(const float* x, int B, int S, int C, float* y, void* stream);
 int slic_avgpool_bwd(const float* dy, int B, int S, int C, float* dx, void* stream);

@@ -174,7 +174,12 @@ def test_tiny_encoder_train_step_vs_reference_golden(gpu, golden_dir):
     emb = m(x)
     loss, _ = OnlineTripletLoss(0.2, 'cosine')(emb, torch.arange(2).repeat(2).cuda(), sampling_strategy='noise_contrastive')
     opt.zero_grad()
+    from video_similarity_search_amd.models import resnet as _rn
+    c0 = dict(_rn.COUNTS)
     loss.backward()
+    # the ReLU-mask + BatchNorm-backward sums ride on the producing dgrad's epilogue for every conv BatchNorm except the
+    # three downsample ones and the last bn2 (fed by the pooling backward); bn_proj is a BatchNorm1d
+    assert _rn.COUNTS["bn_bwd_fused"] - c0["bn_bwd_fused"] == 16 and _rn.COUNTS["bn_bwd"] - c0["bn_bwd"] == 5
     np.testing.assert_allclose(emb.detach().cpu().numpy(), enc["train/emb"], atol=1e-4, rtol=0)
     assert abs(loss.item() - float(enc["train/loss"])) < 1e-4
     for k, p in m.named_parameters():

@@ -57,6 +57,8 @@ SIGNATURES = {
     "slic_bn_bwd_workspace_bytes": (c_size_t, [L, I, I]),
     "slic_bn_bwd_rows_per_partial": (I, []),
     "slic_bn_bwd": (I, [P, P, P, P, P, P, L, I, P, P, P, P, P, P]),
+    "slic_bn_bwd_fused_workspace_bytes": (c_size_t, [I, I]),
+    "slic_bn_bwd_fused": (I, [P, I, P, P, P, P, P, L, I, P, P, P, P, P]),
     "slic_avgpool_fwd": (I, [P, I, I, I, P, P]),
     "slic_avgpool_bwd": (I, [P, I, I, I, P, P]),
     "slic_colsum": (I, [P, L, I, P, P]),
@@ -97,6 +99,7 @@ class SlicConvArgs(ctypes.Structure):
         ("dst_strided", I), ("Da", I), ("Db", I), ("Dc", I), ("da", I), ("db", I), ("dc", I),
         ("ea", I), ("eb", I), ("ec", I),
         ("relu", I),
+        ("mask_src", P), ("bwd_z", P), ("bwd_mean", P), ("bwd_invstd", P), ("bwd_partial", P),
         ("row_tab", P),
     ]
 

@@ -336,6 +336,30 @@ extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, co
   return SLIC_OK;
 }
 
+extern "C" size_t slic_bn_bwd_fused_workspace_bytes(int R, int C) {
+  return 2 * slic_align_up((size_t)C * 8, 256) + slic_align_up(merge_ws_bytes(R, C), 256);
+}
+
+extern "C" int slic_bn_bwd_fused(const float* partial, int R, const float* g, const float* z, const float* mean,
+                                 const float* invstd, const float* gamma, int64_t M, int C, float* dz,
+                                 float* dgamma, float* dbeta, void* workspace, void* stream) {
+  SLIC_REQUIRE(partial && g && z && mean && invstd && gamma && dz && workspace && R > 0 && M > 0 && C > 0 && C % 4 == 0,
+               "slic_bn_bwd_fused: bad args (C %% 4 == 0)");
+  hipStream_t st = S_(stream);
+  SlicCarver w(workspace);                                   // same order as slic_bn_bwd_fused_workspace_bytes
+  double* ka = w.take<double>(C);
+  double* kb = w.take<double>(C);
+  void* mws = w.take<char>(merge_ws_bytes(R, C));
+  const double* tot = nullptr;
+  int rc = run_merge<false>(partial, R, 1, C, M, mws, st, &tot);
+  if (rc) return rc;
+  bn_bwd_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(tot, C, M, dgamma, dbeta, ka, kb);
+  SLIC_LAUNCH_CHECK();
+  bn_bwd_apply_kernel<<<dim3(ew_grid(M * (C / 4))), dim3(256), 0, st>>>(g, z, mean, invstd, gamma, ka, kb, M, C / 4, dz);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" size_t slic_bn_bwd_workspace_bytes(int64_t M, int C, int need_g_buffer) {
   const int R = (int)slic_cdiv(M, BNB_RB);
   size_t b = slic_align_up((size_t)R * 2 * C * 4, 256) + 2 * slic_align_up((size_t)C * 8, 256) +

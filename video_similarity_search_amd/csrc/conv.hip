@@ -47,6 +47,8 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
         roff[i][g] = m * (int64_t)p.ldo;
       }
     }
+  const bool want_bwd = p.bwd_partial != nullptr;
+  float bs1[TN], bs2[TN];          // BatchNorm-backward partials of the stored gradient (this lane's column)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WTN + j * 32 + r;
@@ -54,6 +56,9 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
     const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
     const float sc = (p.scale && nv) ? p.scale[n] : 1.f;
     const float sh = (p.shift && nv) ? p.shift[n] : 0.f;
+    const float bmu = (want_bwd && nv) ? p.bwd_mean[n] : 0.f;
+    const float bis = (want_bwd && nv) ? p.bwd_invstd[n] : 0.f;
+    bs1[j] = 0.f; bs2[j] = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -63,11 +68,42 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
           const int64_t off = roff[i][g] + n;
           float v = (acc[i][j][g] + bias) * sc + sh;
           if (p.addend) v += p.addend[off];
+          if (p.mask_src) v = p.mask_src[off] > 0.f ? v : 0.f;
           if (p.relu) v = fmaxf(v, 0.f);
           p.dst[off] = v;
+          if (want_bwd) {
+            const float xh = (p.bwd_z[off] - bmu) * bis;
+            bs1[j] += v;
+            bs2[j] += v * xh;
+          }
         }
       }
     }
+  }
+  if (want_bwd) {
+    // fixed reduction order: rows inside the lane (above), lane halves, waves along M, one slab row per workgroup
+    __syncthreads();
+    float* red1 = lds;               // [WM][BN]
+    float* red2 = lds + WM * BN;     // [WM][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * WTN + j * 32 + r;
+      const float a1 = bs1[j] + __shfl_xor(bs1[j], 32);
+      const float a2 = bs2[j] + __shfl_xor(bs2[j], 32);
+      if (h == 0) { red1[wm * BN + col] = a1; red2[wm * BN + col] = a2; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
+      const int n = n0 + tid;
+      if (n < p.N) {
+        p.bwd_partial[(mblk * 2 + 0) * p.N + n] = t1;
+        p.bwd_partial[(mblk * 2 + 1) * p.N + n] = t2;
+      }
+    }
+    __syncthreads();
   }
   if (want_stats) {
     // BatchNorm partials of v = acc + bias over this workgroup's valid rows, per channel:
@@ -948,6 +984,8 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(a->wgt && a->dst && a->ldw % 4 == 0 && a->ldo >= 1, "slic_conv_gemm: bad weight/dst");
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0, "slic_conv_gemm: wgt not 16-byte aligned");
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
+  SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
+               "slic_conv_gemm: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
   hipStream_t st = S_(stream);
   if (variant >= 11 && variant <= 24) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,

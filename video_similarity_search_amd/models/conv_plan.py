@@ -196,12 +196,17 @@ class ConvPlan:
         e1.record()
         self.prof.append((e0, e1))
 
-    def dgrad(self, dz, wd, B, addend=None, out=None, variant=0):
+    def dgrad(self, dz, wd, B, addend=None, out=None, variant=0, mask=None, bwd=None):
         """dz: [B, To, Ho, Wo, N] -> dx: [B, T, H, W, Cs] = conv_transpose(dz) (+ addend; addend may be `out`
-        itself: every element is read and written by the same lane)"""
+        itself: every element is read and written by the same lane).
+        mask (same shape as dx): dx = where(mask > 0, dx, 0) — the ReLU backward of the layer below, fused.
+        bwd = (z, mean, invstd) of that layer's BatchNorm: also returns the per-workgroup partial sums
+        (sum dx, sum dx * xhat) as a [R, 2, Cs] slab for slic_bn_bwd_fused -> returns (dx, partial)."""
+        lib = _lib.load()
         T, H, W = self.in_dims
         To, Ho, Wo = self.out_dims
         dx = out if out is not None else torch.empty((B, T, H, W, self.Cs), dtype=torch.float32, device=dz.device)
+        launches = []
         for dc in self.dgrad_classes:
             a = SlicConvArgs()
             a.src = dz.data_ptr()
@@ -212,6 +217,7 @@ class ConvPlan:
             a.tab = dc["tab"].data_ptr()
             a.tap_tab = dc["tap"].data_ptr() if dc["tap"] is not None else None
             a.addend = addend.data_ptr() if addend is not None else None
+            a.mask_src = mask.data_ptr() if mask is not None else None
             ga, gb, gc = dc["grid"]
             a.M = B * ga * gb * gc
             a.N = self.Cs
@@ -225,8 +231,22 @@ class ConvPlan:
             a.Da, a.Db, a.Dc = T, H, W
             a.da, a.db, a.dc = self.stride
             a.ea, a.eb, a.ec = dc["cls"]
+            launches.append(a)
+        part = None
+        if bwd is not None:
+            z, mean, invstd = bwd
+            assert z.shape == dx.shape and z.is_contiguous()
+            rows = [(a.M + lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant)) - 1)
+                    // lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant)) for a in launches]
+            part = torch.empty(sum(rows), 2, self.Cs, dtype=torch.float32, device=dz.device)
+            r0 = 0
+            for a, r in zip(launches, rows):
+                a.bwd_z, a.bwd_mean, a.bwd_invstd = z.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+                a.bwd_partial = part.data_ptr() + r0 * 2 * self.Cs * 4
+                r0 += r
+        for a in launches:
             self._launch(a, variant)
-        return dx
+        return dx if bwd is None else (dx, part)
 
     def _row_table(self, a, B):
         """per-row {source byte offset, in-bounds mask} records of the forward geometry at batch B (8 bytes / row),

@@ -13,6 +13,8 @@ libslic_hip.so (csrc/conv.hip, bn.hip), forward AND backward, exposed to autogra
 Function — NDHWC activations, fp32 MFMA gather-GEMM convs with fused BatchNorm statistics,
 deterministic reductions.  There is no PyTorch/CPU fallback path.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -60,6 +62,9 @@ class _Bn:
         self.mean = self.invstd = self.scale = self.shift = None
 
 
+COUNTS = {"bn_bwd": 0, "bn_bwd_fused": 0}     # launches by flavour (diagnostics / tests)
+
+
 class _Engine:
     """Execution plan of one ResNet at one input shape: conv plans (tables on the device), forward and backward
     passes written out layer by layer.  Mirrors ResNet.forward / BasicBlock.forward of the reference
@@ -98,6 +103,8 @@ class _Engine:
                 self.layer_blocks[-1].append((blk, p1, p2, pd))
                 dims = p2.out_dims
         self.final_dims = dims
+        self._live = {}        # si -> saved context of the segment's pending backward (set by _SegmentFn.forward)
+        self._prefused = {}    # si -> (data_ptr, shape, partial sums) of a gradient whose ReLU mask + BN sums are already done
         self.feat = self.blocks[-1][2].N
         if net.projection_head:
             self.fc1 = ConvPlan(net.fc1.in_features, net.fc1.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
@@ -134,6 +141,7 @@ class _Engine:
     @staticmethod
     def _bn_bwd(dy, out, z, bn, want_g):
         """returns (dz, g or None, dgamma, dbeta)"""
+        COUNTS["bn_bwd"] += 1
         lib = _lib.load()
         M = z.numel() // bn.C
         dz = torch.empty_like(z)
@@ -145,6 +153,22 @@ class _Engine:
         call("slic_bn_bwd", ptr(dy), ptr(out), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), M, bn.C,
              ptr(g), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
         return dz, g, dgamma, dbeta
+
+    @staticmethod
+    def _bn_bwd_fused(part, g, z, bn):
+        """second half of _bn_bwd when the dgrad that produced g already masked it and emitted the partial sums;
+        returns (dz, dgamma, dbeta)"""
+        COUNTS["bn_bwd_fused"] += 1
+        lib = _lib.load()
+        M = z.numel() // bn.C
+        R = part.shape[0]
+        dz = torch.empty_like(z)
+        dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        ws = _lib.workspace(lib.slic_bn_bwd_fused_workspace_bytes(R, bn.C), z.device, "bn_bwd_fused")
+        call("slic_bn_bwd_fused", ptr(part), R, ptr(g), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), M, bn.C,
+             ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+        return dz, dgamma, dbeta
 
     # ------------------------------------------------------------------ segments
     # The plan is cut into segments — stem | layer1 | layer2 | layer3 | layer4 | head — each exposed to autograd as its
@@ -266,31 +290,77 @@ class _Engine:
             call("slic_avgpool_bwd", ptr(dpool), B, S, self.feat, ptr(dx), stream())
             return dx, grads
         if si >= 1:
-            for (blk, p1, p2, pd), s in zip(reversed(self.layer_blocks[si - 1]), reversed(ctx["blocks"])):
+            blocks = list(zip(self.layer_blocks[si - 1], ctx["blocks"]))
+            fuse = os.environ.get("SLIC_BN_FUSE", "1") != "0"
+            pre = None          # (g, partial) when the previous dgrad already produced this block's masked gradient + sums
+            pf = self._prefused.pop(si, None)
+            if pf is not None and pf[0] == dout.data_ptr() and pf[1] == tuple(dout.shape):
+                pre = (dout, pf[2])
+            for bi in reversed(range(len(blocks))):
+                (blk, p1, p2, pd), s = blocks[bi]
                 # out = relu(bn2(conv2(a1)) + r)
-                dz2, g, dg2, db2 = self._bn_bwd(dout, s["out"], s["z2"], s["b2"], True)
+                if pre is not None:
+                    g, part = pre
+                    dz2, dg2, db2 = self._bn_bwd_fused(part, g, s["z2"], s["b2"])
+                    pre = None
+                else:
+                    dz2, g, dg2, db2 = self._bn_bwd(dout, s["out"], s["z2"], s["b2"], True)
                 grads[blk.bn2.weight], grads[blk.bn2.bias] = dg2, db2
                 grads[blk.conv2.weight] = p2.wgrad(s["a1"], dz2, B, new_like(blk.conv2.weight))
-                da1 = p2.dgrad(dz2, p2.pack_dgrad(blk.conv2.weight), B)
-                del dz2
-                # a1 = relu(bn1(conv1(x)))
-                dz1, _, dg1, db1 = self._bn_bwd(da1, s["a1"], s["z1"], s["b1"], False)
-                del da1
+                # a1 = relu(bn1(conv1(x))): the ReLU mask and the BatchNorm-backward sums ride on conv2's dgrad epilogue
+                b1 = s["b1"]
+                if fuse:
+                    g1, part1 = p2.dgrad(dz2, p2.pack_dgrad(blk.conv2.weight), B, mask=s["a1"], bwd=(s["z1"], b1.mean, b1.invstd))
+                    del dz2
+                    dz1, dg1, db1 = self._bn_bwd_fused(part1, g1, s["z1"], b1)
+                    del g1
+                else:
+                    da1 = p2.dgrad(dz2, p2.pack_dgrad(blk.conv2.weight), B)
+                    del dz2
+                    dz1, _, dg1, db1 = self._bn_bwd(da1, s["a1"], s["z1"], b1, False)
+                    del da1
                 grads[blk.bn1.weight], grads[blk.bn1.bias] = dg1, db1
                 grads[blk.conv1.weight] = p1.wgrad(s["x"], dz1, B, new_like(blk.conv1.weight))
+                # the layer below consumes dx through relu + BatchNorm (the previous block's bn2, or across the segment
+                # boundary the previous segment's last bn2 / the stem's bn1): fuse its mask and sums as well
+                below = None
+                if fuse and bi > 0:
+                    pb = blocks[bi - 1][1]
+                    below = (pb["out"], pb["z2"], pb["b2"])
+                elif fuse and bi == 0:
+                    prev = self._live.get(si - 1)
+                    if prev is not None and si - 1 == 0:
+                        below = (prev["a0"], prev["z0"], prev["bn0"])
+                    elif prev is not None:
+                        pb = prev["blocks"][-1]
+                        below = (pb["out"], pb["z2"], pb["b2"])
+                kw = {}
+                if below is not None:
+                    kw = dict(mask=below[0], bwd=(below[1], below[2].mean, below[2].invstd))
                 if pd is not None:
                     # r = bn_d(conv_d(x)): g is its upstream gradient
                     dzd, _, dgd, dbd = self._bn_bwd(g, None, s["zd"], s["bd"], False)
                     grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dgd, dbd
                     grads[blk.downsample[0].weight] = pd.wgrad(s["x"], dzd, B, new_like(blk.downsample[0].weight))
                     dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B)
-                    dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx)
+                    res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx, **kw)
                 else:
-                    dx = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=g)
-                dout = dx
+                    res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=g, **kw)
+                if below is not None and bi > 0:
+                    pre = res
+                    dout = None
+                elif below is not None:
+                    dout, part = res             # crosses the segment boundary through autograd: the sums travel beside it
+                    self._prefused[si - 1] = (dout.data_ptr(), tuple(dout.shape), part)
+                else:
+                    dout = res
             return dout, grads
         # stem: a0 = relu(bn1(conv1(x4))); the clip needs no gradient
-        dz0, _, dg0, db0 = self._bn_bwd(dout, ctx["a0"], ctx["z0"], ctx["bn0"], False)
+        pf = self._prefused.pop(0, None)
+        if pf is not None and pf[0] == dout.data_ptr() and pf[1] == tuple(dout.shape):
+            dz0, dg0, db0 = self._bn_bwd_fused(pf[2], dout, ctx["z0"], ctx["bn0"])
+        else:
+            dz0, _, dg0, db0 = self._bn_bwd(dout, ctx["a0"], ctx["z0"], ctx["bn0"], False)
         grads[net.bn1.weight], grads[net.bn1.bias] = dg0, db0
         grads[net.conv1.weight] = self.stem.wgrad(ctx["x4"], dz0, B, new_like(net.conv1.weight))
         return None, grads
@@ -309,6 +379,8 @@ class _Engine:
         """dy: [B, out_dim].  Returns {parameter: gradient} (reference layouts)."""
         grads = {}
         d = dy
+        self._live = dict(enumerate(ctxs))
+        self._prefused = {}
         for si in reversed(range(self.N_SEG)):
             d, g = self.seg_backward(si, ctxs[si], d)
             grads.update(g)
@@ -328,6 +400,8 @@ class _SegmentFn(torch.autograd.Function):
         elif si <= 4:
             saved["blocks"][-1]["out"] = out.detach()
         ctx.engine, ctx.si, ctx.saved, ctx.params = engine, si, saved, params
+        engine._live[si] = saved      # the segment above fuses this segment's last ReLU/BatchNorm backward into its dgrad
+        engine._prefused.pop(si, None)
         ctx.inp_grad = inp.requires_grad
         return out
 
@@ -335,6 +409,7 @@ class _SegmentFn(torch.autograd.Function):
     def backward(ctx, dout):
         dinp, grads = ctx.engine.seg_backward(ctx.si, ctx.saved, dout)
         ctx.saved = None
+        ctx.engine._live.pop(ctx.si, None)
         return (dinp if ctx.inp_grad else None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
