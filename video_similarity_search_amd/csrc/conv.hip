@@ -683,18 +683,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
   const bool nvalid = (n0 + cq * 4) < p.N;
   const unsigned ycol = (unsigned)(n0 + cq * 4) * 4u;
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+  // dY and the row table are range-checked against the END OF THIS SLICE: rows >= mend read as zeros / mask 0 with no
+  // compare and no branch in the loop
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)dy, 0, (int)min((unsigned)dy_bytes, (unsigned)mend * (unsigned)(ldy * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc((void*)p.row_tab, 0, RT ? mend * 8 : 0, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
   // ---- row state: either decoded coordinates stepped in mixed radix, or records prefetched from the row table
   int rn[2], ra[2], rb[2], rc[2];
   int st_c = 0, st_b = 0, st_a = 0, st_n = 0;
   uint2 rec[2], recn[2];                             // RT: records of the next tile to issue / the one after
-  const uint2* rtab = (const uint2*)p.row_tab;
   auto load_rec = [&](int t, uint2 (&dst)[2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = mbeg + t * 32 + srow + 16 * i;
-      dst[i] = m < mend ? rtab[m] : make_uint2(0u, 0u);       // mask 0 fails every tap's test
+      const int m = mbeg + t * 32 + srow + 16 * i;            // past the slice: {0, 0}, and mask 0 fails every tap's test
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_rt, m * 8, 0, 0);
+      dst[i] = make_uint2(v.x, v.y);
     }
   };
   if constexpr (RT) {
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(base + g * SUB + (4 * wave + 16 * i) * 64),
                                                16, (int)off, 0, 0, 0);
     } else {
-      const unsigned yo = (mv && nvalid) ? (unsigned)m * (unsigned)(ldy * 4) + ycol : OOB;
+      const unsigned yo = nvalid ? (unsigned)m * (unsigned)(ldy * 4) + ycol : OOB;   // rows >= mend: out of rs_dy's range
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(base + G * SUB + (4 * wave + 16 * i) * 64),
                                                16, (int)yo, 0, 0, 0);
     }
