@@ -14,29 +14,51 @@
 // coalesced across channels, MG serial steps — a 12544-row slab (layer1 at B = 32) takes 3 short launches
 // instead of one 12544-step serial loop.
 #define BN_MG 64
+#define BN_MQ 4     // a group's rows are split over BN_MQ sub-chains (threadIdx.y) that run concurrently, then merged in order
 template <typename Tin>
-__global__ void bn_merge_level(const Tin* __restrict__ in, int R, int64_t rows_in, int C, int64_t M,
-                               double* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64 * BN_MQ) void bn_merge_level(const Tin* __restrict__ in, int R, int64_t rows_in, int C,
+                                                             int64_t M, double* __restrict__ out) {
+  __shared__ double sh[BN_MQ][4][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int q = threadIdx.y;
   const int grp = blockIdx.y;
-  if (c >= C) return;
-  const int r0 = grp * BN_MG;
-  const int r1 = r0 + BN_MG < R ? r0 + BN_MG : R;
+  const int g0 = grp * BN_MG;
+  const int g1 = g0 + BN_MG < R ? g0 + BN_MG : R;
+  const int r0 = g0 + q * (BN_MG / BN_MQ);
+  const int r1 = r0 + BN_MG / BN_MQ < g1 ? r0 + BN_MG / BN_MQ : g1;
   double n = 0.0, mean = 0.0, m2 = 0.0, sum = 0.0;
-  for (int r = r0; r < r1; ++r) {
-    const int64_t left = M - (int64_t)r * rows_in;
-    const double nb = (double)(left < rows_in ? left : rows_in);
-    const double sb = (double)in[((int64_t)r * 2 + 0) * C + c];
-    const double mb = sb / nb;
-    const double d = mb - mean;
-    const double nn = n + nb;
-    m2 += (double)in[((int64_t)r * 2 + 1) * C + c] + d * d * n * nb / nn;
-    mean += d * nb / nn;
-    sum += sb;
-    n = nn;
+  if (c < C) {
+    for (int r = r0; r < r1; ++r) {
+      const int64_t left = M - (int64_t)r * rows_in;
+      const double nb = (double)(left < rows_in ? left : rows_in);
+      const double sb = (double)in[((int64_t)r * 2 + 0) * C + c];
+      const double mb = sb / nb;
+      const double d = mb - mean;
+      const double nn = n + nb;
+      m2 += (double)in[((int64_t)r * 2 + 1) * C + c] + d * d * n * nb / nn;
+      mean += d * nb / nn;
+      sum += sb;
+      n = nn;
+    }
   }
-  out[((int64_t)grp * 2 + 0) * C + c] = sum;
-  out[((int64_t)grp * 2 + 1) * C + c] = m2;
+  sh[q][0][threadIdx.x] = n; sh[q][1][threadIdx.x] = mean; sh[q][2][threadIdx.x] = m2; sh[q][3][threadIdx.x] = sum;
+  __syncthreads();
+  if (q == 0 && c < C) {
+#pragma unroll
+    for (int u = 1; u < BN_MQ; ++u) {
+      const double nb = sh[u][0][threadIdx.x];
+      if (nb > 0.0) {
+        const double d = sh[u][1][threadIdx.x] - mean;
+        const double nn = n + nb;
+        m2 += sh[u][2][threadIdx.x] + d * d * n * nb / nn;
+        mean += d * nb / nn;
+        sum += sh[u][3][threadIdx.x];
+        n = nn;
+      }
+    }
+    out[((int64_t)grp * 2 + 0) * C + c] = sum;
+    out[((int64_t)grp * 2 + 1) * C + c] = m2;
+  }
 }
 
 // scale = gamma*invstd, shift = beta - mean*scale; running stats: momentum update with the UNBIASED variance
@@ -65,21 +87,33 @@ __global__ void bn_finalize_last(const double* __restrict__ tot, int C, int64_t 
   }
 }
 
-// plain two-plane sums in double, groups of BN_MG slab rows in row order (BatchNorm backward partials)
+// plain two-plane sums in double, groups of BN_MG slab rows: BN_MQ concurrent sub-chains in row order, merged in order
 template <typename Tin>
-__global__ void sum_merge_level(const Tin* __restrict__ in, int R, int C, double* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64 * BN_MQ) void sum_merge_level(const Tin* __restrict__ in, int R, int C,
+                                                              double* __restrict__ out) {
+  __shared__ double sh[BN_MQ][2][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int q = threadIdx.y;
   const int grp = blockIdx.y;
-  if (c >= C) return;
-  const int r0 = grp * BN_MG;
-  const int r1 = r0 + BN_MG < R ? r0 + BN_MG : R;
+  const int g0 = grp * BN_MG;
+  const int g1 = g0 + BN_MG < R ? g0 + BN_MG : R;
+  const int r0 = g0 + q * (BN_MG / BN_MQ);
+  const int r1 = r0 + BN_MG / BN_MQ < g1 ? r0 + BN_MG / BN_MQ : g1;
   double a = 0.0, b = 0.0;
-  for (int r = r0; r < r1; ++r) {
-    a += (double)in[((int64_t)r * 2 + 0) * C + c];
-    b += (double)in[((int64_t)r * 2 + 1) * C + c];
+  if (c < C) {
+    for (int r = r0; r < r1; ++r) {
+      a += (double)in[((int64_t)r * 2 + 0) * C + c];
+      b += (double)in[((int64_t)r * 2 + 1) * C + c];
+    }
   }
-  out[((int64_t)grp * 2 + 0) * C + c] = a;
-  out[((int64_t)grp * 2 + 1) * C + c] = b;
+  sh[q][0][threadIdx.x] = a; sh[q][1][threadIdx.x] = b;
+  __syncthreads();
+  if (q == 0 && c < C) {
+#pragma unroll
+    for (int u = 1; u < BN_MQ; ++u) { a += sh[u][0][threadIdx.x]; b += sh[u][1][threadIdx.x]; }
+    out[((int64_t)grp * 2 + 0) * C + c] = a;
+    out[((int64_t)grp * 2 + 1) * C + c] = b;
+  }
 }
 
 // eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
@@ -248,7 +282,7 @@ static int run_merge(const float* partial, int R, int64_t rows, int C, int64_t M
   int cur = 0;
   int Rl = R;
   int64_t rows_l = rows;
-  dim3 blk(64);
+  dim3 blk(64, BN_MQ);
   {
     const int Ro = (int)slic_cdiv(Rl, BN_MG);
     dim3 grid((unsigned)slic_cdiv(C, 64), (unsigned)Ro);
