@@ -196,6 +196,11 @@ typedef struct SlicConvArgs {
 int slic_conv_tile_m(const SlicConvArgs* args, int variant);
 /* dst = epilogue(gather(src) x wgt^T): forward conv, data gradient, linear. */
 int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);
+/* The same GEMM with the K loop cut into `splits` ranges run by separate workgroups (small-M layers whose 64 x 64 tiles
+ * do not fill the chip): raw accumulators go to workspace[splits][M][N], a second launch sums them in split order and
+ * runs the epilogue.  Deterministic; variants 11 and 20 only; splits <= 1 forwards to slic_conv_gemm. */
+size_t slic_conv_gemm_splitk_workspace_bytes(const SlicConvArgs* args, int splits);
+int slic_conv_gemm_splitk(const SlicConvArgs* args, int variant, int splits, void* workspace, void* stream);
 /* dW[N][C][ntaps] (reference layout) = sum_m gather(src)[m, tap*Cs + c] * dy[m, n]; `splits` slices of
  * m reduced in fixed order.  args->wgt/dst unused. */
 size_t slic_conv_wgrad_workspace_bytes(const SlicConvArgs* args, int splits);

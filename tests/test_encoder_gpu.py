@@ -68,6 +68,57 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
     assert (dW3 - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
 
 
+@pytest.mark.parametrize("variant", [11, 20])
+def test_conv_splitk_matches_single_pass(gpu, monkeypatch, variant):
+    """split-K launch (raw slabs + finish pass) == the one-pass kernel: output, fused BN partials, ReLU/addend epilogue"""
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(5)
+    C, N, B, dims = 256, 128, 3, (2, 7, 7)            # 27 taps x 8 k-tiles = 216 k-tiles, 5 x 2 tiles of 64 x 64
+    plan = ConvPlan(C, N, (3, 3, 3), (1, 1, 1), (1, 1, 1), dims, "cuda")
+    x = torch.from_numpy(rng.standard_normal((B,) + dims + (C,)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((N, C, 3, 3, 3)) / np.sqrt(C * 27)).astype(np.float32)).cuda()
+    res = torch.from_numpy(rng.standard_normal((B,) + dims + (N,)).astype(np.float32)).cuda()
+    wp = plan.pack_fwd(w)
+    monkeypatch.setenv("SLIC_CONV_SPLIT_BLOCKS", "0")
+    z0, (p0, rows0) = plan.forward(x, wp, B, want_stats=True, variant=variant)
+    y0, _ = plan.forward(x, wp, B, addend=res, relu=True, variant=variant)
+    monkeypatch.setenv("SLIC_CONV_SPLIT_BLOCKS", "3000")
+    a = plan._fwd_args(x, B)
+    assert plan._splits(a, variant) >= 4
+    z1, (p1, rows1) = plan.forward(x, wp, B, want_stats=True, variant=variant)
+    y1, _ = plan.forward(x, wp, B, addend=res, relu=True, variant=variant)
+    assert rows0 == rows1
+    assert torch.allclose(z0, z1, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(p0, p1, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(y0, y1, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("stride", [(1, 1, 1), (2, 2, 2)])
+def test_dgrad_fused_mask_and_bn_backward_sums(gpu, stride):
+    """dgrad epilogue with mask_src / bwd_partial == dgrad, then where(mask > 0), then the column sums of g and g * xhat"""
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(11)
+    C, N, B, dims = 64, 64, 2, (4, 10, 10)
+    plan = ConvPlan(C, N, (3, 3, 3), stride, (1, 1, 1), dims, "cuda")
+    w = torch.from_numpy((rng.standard_normal((N, C, 3, 3, 3)) / np.sqrt(C * 27)).astype(np.float32)).cuda()
+    dy = torch.from_numpy(rng.standard_normal((B,) + plan.out_dims + (N,)).astype(np.float32)).cuda()
+    shp = (B,) + dims + (C,)
+    mask = torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda()
+    z = torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda()
+    add = torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda()
+    mean = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda()
+    invstd = torch.from_numpy((0.5 + rng.random(C)).astype(np.float32)).cuda()
+    wd = plan.pack_dgrad(w)
+    ref = plan.dgrad(dy, wd, B, addend=add)
+    ref = torch.where(mask > 0, ref, torch.zeros_like(ref))
+    g, part = plan.dgrad(dy, wd, B, addend=add, mask=mask, bwd=(z, mean, invstd))
+    assert torch.equal(g, ref)
+    s1 = ref.double().reshape(-1, C).sum(0)
+    s2 = (ref.double() * ((z.double() - mean.double()) * invstd.double())).reshape(-1, C).sum(0)
+    assert torch.allclose(part[:, 0].double().sum(0), s1, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(part[:, 1].double().sum(0), s2, atol=1e-3, rtol=1e-4)
+
+
 def test_conv_epilogue_affine_relu_addend(gpu):
     from video_similarity_search_amd.models.conv_plan import ConvPlan
     rng = np.random.default_rng(3)

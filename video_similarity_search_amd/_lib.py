@@ -43,6 +43,8 @@ SIGNATURES = {
     # conv / linear
     "slic_conv_tile_m": (I, [P, I]),
     "slic_conv_gemm": (I, [P, I, P]),
+    "slic_conv_gemm_splitk_workspace_bytes": (c_size_t, [P, I]),
+    "slic_conv_gemm_splitk": (I, [P, I, I, P, P]),
     "slic_conv_wgrad_workspace_bytes": (c_size_t, [P, I]),
     "slic_conv_row_table": (I, [P, P, P]),
     "slic_conv_wgrad": (I, [P, P, I, I, I, I, P, P, P]),

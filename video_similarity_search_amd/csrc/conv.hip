@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk (p ^ ((row >> 1) & 7)).
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap) {
+__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
+                                                            float* __restrict__ slab, const int kt_per_split) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -351,7 +352,11 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
     const int n = n0 + srow + 32 * i;
     woff[i] = n < p.N ? ((unsigned)n * (unsigned)p.ldw + cq * 4) * 4u : OOB;
   }
-  const int nk = p.nchunks >> 3;
+  // split-K: workgroup z of gridDim.z reduces k-tiles [kt0, nk) of the GEMM and writes raw accumulators to slab[z]
+  // (conv_splitk_finish sums the slabs in z order and runs the epilogue); one split (slab == NULL) covers everything
+  const int nk_all = p.nchunks >> 3;
+  const int kt0 = slab ? blockIdx.z * kt_per_split : 0;
+  const int nk = slab ? min(nk_all, kt0 + kt_per_split) : nk_all;     // END of this workgroup's k-tile range
   const int tiles_per_tap = p.Cs >> 5;
   // per-tap records are read through the constant address space with a wave-uniform index: scalar loads, which
   // never touch the vmcnt queue the DMAs are counted on
@@ -473,11 +478,11 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
     }
   };
   // prologue: STAGES - 1 stages (of KT k-tiles each) in flight
-  const int ns = (nk + KT - 1) / KT;                         // number of stages' worth of work
+  const int ns = (nk - kt0 + KT - 1) / KT;                   // number of stages' worth of work
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t)
 #pragma unroll
-    for (int u = 0; u < KT; ++u) issue(t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
+    for (int u = 0; u < KT; ++u) issue(kt0 + t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
   constexpr int PER_STAGE = KT * (AL + BL);                  // DMA instructions per stage per wave, always exactly this many
   // Branch-free steady state: the trip count is rounded up to whole rings; stages past the end multiply zeros.
   for (int s0 = 0; s0 < ns; s0 += STAGES) {
@@ -488,11 +493,11 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
       __builtin_amdgcn_s_barrier();        // every wave's part of stage sg is in LDS; the previous stage is free
       if constexpr (ILV && KT == 1) {
-        compute_ilv(sidx * STAGE_FLOATS, sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
+        compute_ilv(sidx * STAGE_FLOATS, kt0 + sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
       } else {
 #pragma unroll
         for (int u = 0; u < KT; ++u)
-          issue((sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
+          issue(kt0 + (sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
 #pragma unroll
         for (int u = 0; u < KT; ++u) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
       }
@@ -500,6 +505,50 @@ __global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing all-zero DMAs must land before LDS is reused
   __syncthreads();
+  if (slab) {
+    float* out = slab + (int64_t)blockIdx.z * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + r;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+          if (m < p.M && n < p.N) out[m * p.N + n] = acc[i][j][g];
+        }
+    }
+    return;
+  }
+  conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+}
+
+// second pass of a split-K launch: accumulators = sum over the S slabs in slab order, then the ordinary epilogue
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_splitk_finish(const SlicConvArgs p, const float* __restrict__ slab, const int S) {
+  __shared__ float lds[WM * BN * 2 + BN];
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + r;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        float a = 0.f;
+        if (m < p.M && n < p.N)
+          for (int z = 0; z < S; ++z) a += slab[((int64_t)z * p.M + m) * p.N + n];
+        acc[i][j][g] = a;
+      }
+  }
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
 }
 
@@ -956,7 +1005,7 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
+static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
   constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -966,8 +1015,24 @@ static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st) {
   }
   static const int xcd = getenv("SLIC_CONV_XCD") ? atoi(getenv("SLIC_CONV_XCD")) : 1;
   const unsigned gx = (unsigned)slic_cdiv(a.M, BM);
+  if (splits > 1) {
+    if constexpr (KT == 1) {
+      const int nk = a.nchunks >> 3;
+      const int per = (nk + splits - 1) / splits;
+      const int S = (nk + per - 1) / per;
+      dim3 grid(gx, (unsigned)slic_cdiv(a.N, BN), (unsigned)S);
+      conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a, 0, slab, per);
+      SLIC_LAUNCH_CHECK();
+      conv_splitk_finish<BM, BN, WM, WN><<<dim3(gx, (unsigned)slic_cdiv(a.N, BN)), dim3(256), 0, st>>>(a, slab, S);
+      SLIC_LAUNCH_CHECK();
+      return SLIC_OK;
+    } else {
+      slic_set_error("slic_conv_gemm_splitk: variant does not support split-K");
+      return SLIC_EINVAL;
+    }
+  }
   dim3 grid(xcd ? (gx + 7) / 8 * 8 : gx, (unsigned)slic_cdiv(a.N, BN));
-  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a, xcd);
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a, xcd, nullptr, 0);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1019,6 +1084,28 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     return launch_gemm<128, 64, 2, 2>(*a, st);
   }
   return launch_gemm<64, 64, 2, 2>(*a, st);
+}
+
+extern "C" size_t slic_conv_gemm_splitk_workspace_bytes(const SlicConvArgs* a, int splits) {
+  if (!a || splits < 1) return 0;
+  return slic_align_up((size_t)splits * a->M * a->N * sizeof(float), 256);
+}
+
+extern "C" int slic_conv_gemm_splitk(const SlicConvArgs* a, int variant, int splits, void* workspace, void* stream) {
+  if (splits <= 1) return slic_conv_gemm(a, variant, stream);
+  int rc = validate(a, "slic_conv_gemm_splitk");
+  if (rc) return rc;
+  SLIC_REQUIRE(a->wgt && a->dst && workspace && a->ldw % 4 == 0 && a->ldo >= 1, "slic_conv_gemm_splitk: bad weight/dst/workspace");
+  SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0 && a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm_splitk: bad wgt");
+  SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
+               "slic_conv_gemm_splitk: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
+  SLIC_REQUIRE(variant == 11 || variant == 20, "slic_conv_gemm_splitk: variants 11 and 20 (64 x 64 tiles) only");
+  SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
+               "slic_conv_gemm_splitk: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
+  SlicConvArgs b = *a;
+  b.tab = a->tap_tab;
+  if (variant == 11) return launch_gemm_dma<64, 64, 2, 2, 3>(b, S_(stream), splits, (float*)workspace);
+  return launch_gemm_dma<64, 64, 2, 2, 2, 1, true>(b, S_(stream), splits, (float*)workspace);
 }
 
 extern "C" size_t slic_conv_wgrad_workspace_bytes(const SlicConvArgs* a, int splits) {

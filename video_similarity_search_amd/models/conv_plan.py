@@ -180,19 +180,44 @@ class ConvPlan:
             if a.M >= 100000:
                 # the next tile's DMAs are issued between MFMA groups; N <= 64 (layer1: 52 % of the FLOPs): 128x64 tiles
                 return 22 if a.N <= 64 else 20
-            return 11
+            return int(os.environ.get("SLIC_CONV_SMALL_VARIANT", "20"))      # 64x64, 2-stage ring, interleaved DMA issue; split-K when few tiles
         if variant >= 11 and not a.tap_tab:
             return 0
         return variant
 
+    @staticmethod
+    def _splits(a, variant):
+        """split-K factor for the 64 x 64-tile variants: small-M layers (layer3/4 at B = 32, the parity classes of a
+        stride-2 dgrad) have too few tiles to fill 256 CUs x 3-5 workgroups evenly, so cut K until ~SPLIT_BLOCKS
+        workgroups exist, keeping at least SPLIT_MINKT k-tiles of 32 per workgroup"""
+        if variant not in (11, 20):
+            return 1
+        target = int(os.environ.get("SLIC_CONV_SPLIT_BLOCKS", "3000"))
+        min_kt = int(os.environ.get("SLIC_CONV_SPLIT_MINKT", "24"))
+        if target <= 0:
+            return 1
+        tiles = ((a.M + 63) // 64) * ((a.N + 63) // 64)
+        nk = a.nchunks // 8
+        if tiles * 2 > target:
+            return 1
+        s = min((target + tiles - 1) // tiles, nk // min_kt)
+        return s if s >= 4 else 1          # a 2-3 way split does not pay for the second launch
+
     def _launch(self, a, variant):
         variant = self._pick(a, variant)
+        splits = self._splits(a, variant)
+        if splits > 1:
+            lib = _lib.load()
+            ws = _lib.workspace(lib.slic_conv_gemm_splitk_workspace_bytes(ctypes.byref(a), splits), self.device, "splitk")
+            go = lambda: call("slic_conv_gemm_splitk", ctypes.byref(a), variant, splits, ptr(ws), stream())
+        else:
+            go = lambda: call("slic_conv_gemm", ctypes.byref(a), variant, stream())
         if self.prof is None:
-            call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+            go()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                      # torch's current stream == the stream the kernel is launched on
-        call("slic_conv_gemm", ctypes.byref(a), variant, stream())
+        go()
         e1.record()
         self.prof.append((e0, e1))
 
