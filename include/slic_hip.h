@@ -117,6 +117,17 @@ int slic_kmeans_finalize(const float* C_old, const float* sums, const float* cou
                          float* C_new_perm /* [K][D] in slic_kmeans_permute_k8 order, or NULL */,
                          const int32_t* n_changed, double* status, void* stream);
 
+/* One whole single-GPU Lloyd iteration enqueued by one call: *n_changed = 0; slic_kmeans_assign_perm(Xp, Cp_old,
+ * cnorm_old -> labels, n_changed vs labels_old); slic_kmeans_accumulate(X, labels -> sums, counts);
+ * slic_kmeans_finalize(-> C_new, Cp_new, cnorm_new, shift, status).  X / Xp share ldx; the centre matrices are dense
+ * [K][D].  (A sharded fit calls the three pieces itself, with the all-gather between the last two.) */
+size_t slic_kmeans_lloyd_step_workspace_bytes(int64_t N, int K);
+int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N, int D, int ldx, const float* C_old,
+                           const float* Cp_old, const float* cnorm_old, int K, int32_t* labels,
+                           const int32_t* labels_old, int32_t* n_changed, float* sums, float* counts,
+                           float* C_new, float* Cp_new, float* cnorm_new, float* shift, double* status,
+                           void* workspace, void* stream);
+
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
  * order) — X.mean(axis=0) and np.var(X, axis=0) of KMeans.fit / _tolerance
  * (_kmeans.py:1479-1481, 279-288). */

@@ -17,6 +17,7 @@ Multi-GPU: pass `process_group`; X is then this rank's contiguo
 and the result equals the oracle run with n_shards = world size.
 """
 import os
+import time
 
 import numpy as np
 import torch
@@ -73,6 +74,17 @@ class HipKernels:
         ws = _lib.workspace(_lib.load().slic_kmeans_assign_workspace_bytes(N, K), Xp.device, "km_assign")
         call("slic_kmeans_assign_perm", ptr(Xp), N, Dp, Xp.stride(0), ptr(Cp), K, Cp.stride(0), ptr(cnorm), ptr(labels),
              ptr(labels_old), ptr(n_changed), None, ptr(ws), stream())
+
+    def lloyd_step(self, X, Xp, C_old, Cp_old, cnorm_old, labels, labels_old, n_changed, sums, counts, C_new, Cp_new,
+                   cnorm_new, shift, status):
+        """one whole unsharded iteration in one foreign call (the Python loop is otherwise the bottleneck at ~0.6 ms)"""
+        N, Dp = X.shape
+        K = C_old.shape[0]
+        assert X.stride(0) == Xp.stride(0) and C_old.is_contiguous() and Cp_old.is_contiguous() and C_new.is_contiguous()
+        ws = _lib.workspace(_lib.load().slic_kmeans_lloyd_step_workspace_bytes(N, K), X.device, "km_step")
+        call("slic_kmeans_lloyd_step", ptr(X), ptr(Xp), N, Dp, X.stride(0), ptr(C_old), ptr(Cp_old), ptr(cnorm_old), K,
+             ptr(labels), ptr(labels_old), ptr(n_changed), ptr(sums), ptr(counts), ptr(C_new), ptr(Cp_new), ptr(cnorm_new),
+             ptr(shift), ptr(status), ptr(ws), stream())
 
     def accumulate(self, X, labels, K, sums, counts):
         N, Dp = X.shape
@@ -266,6 +278,8 @@ class KMeans:
         status = [torch.empty(4, dtype=torch.float64, device=dev) for _ in range(2)]
         host = [torch.empty(4, dtype=torch.float64).pin_memory() if on_gpu else torch.empty(4, dtype=torch.float64) for _ in range(2)]
         ev = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
+        done = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
+        side = self._side_stream(dev) if on_gpu else None
         if self._sharded:
             W = torch.distributed.get_world_size(self.process_group)
             allpart = [torch.empty(W, K * Dp + K, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -274,6 +288,18 @@ class KMeans:
         else:
             gsums = [p[: K * Dp] for p in part]
             gcounts = [p[K * Dp:] for p in part]
+
+        def read_back(sl):
+            if on_gpu:
+                # the 32-byte status read-back goes through a side stream: on the compute stream the D2H copy and its
+                # system-scope release would hold the next iteration's first kernel back by ~35 us
+                done[sl].record()
+                side.wait_event(done[sl])
+                with torch.cuda.stream(side):
+                    host[sl].copy_(status[sl], non_blocking=True)
+                ev[sl].record(side)
+            else:
+                host[sl].copy_(status[sl])
 
         def launch(it):
             """enqueue iteration `it` (E-step, M-step, averaging) and the async read-back of its status word"""
@@ -284,6 +310,11 @@ class KMeans:
                 k.cnorm(Cin, cnorm[0])                             # later norms / permuted centres come out of finalize
                 if perm:
                     k.permute_k8(Cin, Cp[0])
+            if perm and not self._sharded and hasattr(k, "lloyd_step"):
+                k.lloyd_step(Xc, Xp, Cin, Cp[it % 3], cnorm[it % 3], lab, lab_old, n_changed[sl], gsums[sl], gcounts[sl],
+                             Cout, Cp[(it + 1) % 3], cnorm[(it + 1) % 3], shift, status[sl])
+                read_back(sl)
+                return
             n_changed[sl].zero_()
             if perm:
                 k.assign_perm(Xp, Cp[it % 3], cnorm[it % 3], lab, lab_old, n_changed[sl])
@@ -296,9 +327,7 @@ class KMeans:
                 torch.distributed.all_reduce(n_changed[sl], group=self.process_group)
             k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl], cnorm[(it + 1) % 3],
                        *((Cp[(it + 1) % 3],) if perm else ()))
-            host[sl].copy_(status[sl], non_blocking=True)
-            if on_gpu:
-                ev[sl].record()
+            read_back(sl)
 
         def read(it):
             if on_gpu:
@@ -309,6 +338,9 @@ class KMeans:
         strict = False
         n_reloc = 0
         it = 0
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        t_loop = time.time()                                               # the Lloyd phase proper (SURVEY.md §8d metric 2)
         if self.max_iter > 0:
             launch(0)
         while it < self.max_iter:
@@ -337,6 +369,9 @@ class KMeans:
                     break
             it += 1
         n_iter = min(it + 1, self.max_iter)
+        if on_gpu:
+            torch.cuda.synchronize(dev)
+        self.lloyd_seconds_, self.lloyd_iters_ = time.time() - t_loop, n_iter      # assign + update + convergence test
         last = n_iter - 1                                              # last executed (and kept) iteration
         C = Cb[(last + 1) % 3] if self.max_iter > 0 else Cb[0]
         labels = Lb[last % 3] if self.max_iter > 0 else Lb[0]
@@ -356,6 +391,11 @@ class KMeans:
         if trace is not None:
             res["trace"] = np.stack(trace) if trace else np.zeros((0, N), np.int32)
         return res
+
+    def _side_stream(self, dev):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
 
     def _permuted(self, Xc):
         """k-permuted copy of the (centred) data for the LDS-DMA E-step; cached while Xc is the same tensor"""

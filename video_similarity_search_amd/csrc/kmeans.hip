@@ -344,10 +344,15 @@ __global__ void km_cnorm(const float* __restrict__ C, int K, int D, int ldc,
 // ---------------- M-step: stable counting sort by label, then per-cluster ordered sums --------
 #define KM_SB 1024  // rows per sort block (one workgroup)
 
-__global__ void km_block_hist(const int32_t* __restrict__ labels, int64_t N, int K,
-                              int32_t* __restrict__ bc /* [nblk][K], zeroed */) {
+__global__ __launch_bounds__(KM_SB) void km_block_hist(const int32_t* __restrict__ labels, int64_t N, int K,
+                                                       int32_t* __restrict__ bc /* [nblk][K], every entry written */) {
+  extern __shared__ int km_hist[];
+  for (int j = threadIdx.x; j < K; j += KM_SB) km_hist[j] = 0;
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * KM_SB + threadIdx.x;
-  if (i < N) atomicAdd(&bc[(int64_t)blockIdx.x * K + labels[i]], 1);
+  if (i < N) atomicAdd(&km_hist[labels[i]], 1);        // integer counts: order-free
+  __syncthreads();
+  for (int j = threadIdx.x; j < K; j += KM_SB) bc[(int64_t)blockIdx.x * K + j] = km_hist[j];
 }
 
 // per cluster: exclusive scan over blocks (in place) and total count.  One wave per cluster: 64 blocks per step,
@@ -371,12 +376,16 @@ __global__ __launch_bounds__(64) void km_scan_blocks(int32_t* __restrict__ bc, i
   if (lane == 0) cnt[j] = carry;
 }
 
-// exclusive scan of cnt over clusters (K is small: one workgroup, serial per 1024-chunk)
-__global__ void km_scan_clusters(const int32_t* __restrict__ cnt, int K,
-                                 int32_t* __restrict__ off, float* __restrict__ counts_f) {
-  __shared__ int part[1024];
+// order[off[l] + (rows with label l in earlier blocks) + (rank inside the block)] = row: a stable counting sort.
+// off = exclusive scan of cnt over clusters, recomputed per workgroup in LDS (K is small) instead of a launch of its own.
+__global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
+                         const int32_t* __restrict__ bc, const int32_t* __restrict__ cnt,
+                         int32_t* __restrict__ order) {
+  extern __shared__ int km_cl_off[];          // [K] exclusive scan of cnt
+  __shared__ int part[KM_SB];
+  __shared__ int lab[KM_SB];
   const int t = threadIdx.x;
-  const int per = (K + 1023) / 1024;
+  const int per = (K + KM_SB - 1) / KM_SB;
   int s = 0;
   for (int u = 0; u < per; ++u) {
     const int j = t * per + u;
@@ -384,27 +393,17 @@ __global__ void km_scan_clusters(const int32_t* __restrict__ cnt, int K,
   }
   part[t] = s;
   __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int u = 0; u < 1024; ++u) { const int v = part[u]; part[u] = run; run += v; }
+  for (int d = 1; d < KM_SB; d <<= 1) {     // inclusive Hillis-Steele scan of the per-thread sums
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
   }
-  __syncthreads();
-  int run = part[t];
+  int run = part[t] - s;
   for (int u = 0; u < per; ++u) {
     const int j = t * per + u;
-    if (j < K) {
-      off[j] = run;
-      run += cnt[j];
-      if (counts_f) counts_f[j] = (float)cnt[j];
-    }
+    if (j < K) { km_cl_off[j] = run; run += cnt[j]; }
   }
-}
-
-__global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
-                         const int32_t* __restrict__ bc, const int32_t* __restrict__ off,
-                         int32_t* __restrict__ order) {
-  __shared__ int lab[KM_SB];
-  const int t = threadIdx.x;
   const int64_t i = (int64_t)blockIdx.x * KM_SB + t;
   const int l = i < N ? labels[i] : -1;
   lab[t] = l;
@@ -412,19 +411,28 @@ __global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ la
   if (i >= N) return;
   int rank = 0;
   for (int u = 0; u < t; ++u) rank += (lab[u] == l);
-  order[off[l] + bc[(int64_t)blockIdx.x * K + l] + rank] = (int32_t)i;
+  order[km_cl_off[l] + bc[(int64_t)blockIdx.x * K + l] + rank] = (int32_t)i;
 }
 
 // sums[j, 4*c4 .. 4*c4+3] = sequential fp32 sum over the cluster's rows in ascending order
 __global__ __launch_bounds__(128) void km_accumulate(
     const float* __restrict__ X, int D, int ldx, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
-    float* __restrict__ sums) {
+    const int32_t* __restrict__ cnt, float* __restrict__ sums, float* __restrict__ counts_f) {
+  __shared__ int red[128];
   const int j = blockIdx.x;
   const int c4 = blockIdx.y * 128 + threadIdx.x;
-  if (c4 * 4 >= D) return;
+  int o = 0;                                           // off[j] = rows of clusters 0..j-1
+  for (int u = threadIdx.x; u < j; u += 128) o += cnt[u];
+  red[threadIdx.x] = o;
+  __syncthreads();
+  for (int d = 64; d > 0; d >>= 1) {
+    if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+    __syncthreads();
+  }
   const int n = cnt[j];
-  const int32_t* ord = order + off[j];
+  if (blockIdx.y == 0 && threadIdx.x == 0 && counts_f) counts_f[j] = (float)n;
+  if (c4 * 4 >= D) return;
+  const int32_t* ord = order + red[0];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   int m = 0;
   for (; m + 8 <= n; m += 8) {
@@ -949,19 +957,17 @@ extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
   SlicCarver w(workspace);
   int32_t* bc = w.take<int32_t>((size_t)nblk * K);
   int32_t* cnt = w.take<int32_t>(K);
-  int32_t* off = w.take<int32_t>(K);
+  (void)w.take<int32_t>(K);                  // (slot kept so the workspace size query stays valid)
   int32_t* order = w.take<int32_t>((size_t)N);
   hipStream_t st = S(stream);
-  SLIC_HIP_CHECK(hipMemsetAsync(bc, 0, (size_t)nblk * K * 4, st));
-  km_block_hist<<<dim3(nblk), dim3(KM_SB), 0, st>>>(labels, N, K, bc);
+  SLIC_REQUIRE(K <= 16384, "slic_kmeans_accumulate: K > 16384");
+  km_block_hist<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc);
   SLIC_LAUNCH_CHECK();
   km_scan_blocks<<<dim3(K), dim3(64), 0, st>>>(bc, nblk, K, cnt);
   SLIC_LAUNCH_CHECK();
-  km_scan_clusters<<<dim3(1), dim3(1024), 0, st>>>(cnt, K, off, counts);
+  km_place<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc, cnt, order);
   SLIC_LAUNCH_CHECK();
-  km_place<<<dim3(nblk), dim3(KM_SB), 0, st>>>(labels, N, K, bc, off, order);
-  SLIC_LAUNCH_CHECK();
-  km_accumulate<<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, off, cnt, sums);
+  km_accumulate<<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, cnt, sums, counts);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1033,6 +1039,29 @@ extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const
   km_status<<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, status);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+// One whole single-GPU Lloyd iteration in one call (the host loop then costs one foreign call per iteration):
+// zero n_changed, E-step on the permuted operands, ordered M-step sums, averaging + shift + next norms + status word.
+extern "C" size_t slic_kmeans_lloyd_step_workspace_bytes(int64_t N, int K) {
+  return slic_align_up(slic_kmeans_assign_workspace_bytes(N, K), 256) + slic_kmeans_accumulate_workspace_bytes(N, K);
+}
+
+extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N, int D, int ldx,
+                                      const float* C_old, const float* Cp_old, const float* cnorm_old, int K,
+                                      int32_t* labels, const int32_t* labels_old, int32_t* n_changed,
+                                      float* sums, float* counts, float* C_new, float* Cp_new, float* cnorm_new,
+                                      float* shift, double* status, void* workspace, void* stream) {
+  SLIC_REQUIRE(X && Xp && C_old && Cp_old && cnorm_old && labels && n_changed && sums && counts && C_new && Cp_new &&
+               cnorm_new && shift && status && workspace, "slic_kmeans_lloyd_step: null pointer");
+  char* ws = (char*)workspace;
+  void* ws2 = ws + slic_align_up(slic_kmeans_assign_workspace_bytes(N, K), 256);
+  SLIC_HIP_CHECK(hipMemsetAsync(n_changed, 0, sizeof(int32_t), S(stream)));
+  int rc = slic_kmeans_assign_perm(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream);
+  if (rc) return rc;
+  rc = slic_kmeans_accumulate(X, N, D, ldx, labels, K, sums, counts, ws2, stream);
+  if (rc) return rc;
+  return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, n_changed, status, stream);
 }
 
 extern "C" size_t slic_col_stats_workspace_bytes(int64_t N, int D) {
