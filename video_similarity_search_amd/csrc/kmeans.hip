@@ -174,41 +174,50 @@ __global__ __launch_bounds__(256) void km_assign_partial(
 // k on the fly, so this kernel takes operands whose rows are ALREADY in the LDS image's order: inside every group of
 // eight k's, [k0 k2 k4 k6 | k1 k3 k5 k7]  (km_permute_k8: X once per fit, the centres by km_average).  The MFMA then sees
 // exactly the operand registers km_assign_partial builds, so scores and labels are bit-identical.
-template <int NCT, int STAGES>
+// Tile = BP points x NCT*32 centroids; the four waves are WP x WC (points x centroids), WP = BP / 32, so a wave owns 32
+// points and NCT / WC centroid tiles.  <128, 2, 1>: 48 KB LDS, 3 workgroups / CU; <64, 2, 2>: 32 KB, 5 / CU — more,
+// shorter workgroups, which is what the N / 128 x K / 64 = 6256-tile grid of the 100k x 512 x 500 case wants
+// (6256 / 768 slots = 8.15 rounds -> 9; 12504 / 1280 = 9.8 -> 10).
+template <int BP, int NCT, int WC, int STAGES>
 __global__ __launch_bounds__(256) void km_assign_dma(
     const float* __restrict__ Xp, int64_t N, int D, int ldx, const float* __restrict__ Cp, int K,
     int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx) {
   extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  constexpr int WP = 4 / WC;
+  static_assert(BP == 32 * WP && NCT % WC == 0, "wave grid");
   constexpr int BC = NCT * 32;
-  constexpr int STAGE_FLOATS = (KM_BP + BC) * KM_BK;
+  constexpr int TC = NCT / WC;                               // centroid tiles per wave
+  constexpr int AL = BP / 32;
+  constexpr int STAGE_FLOATS = (BP + BC) * KM_BK;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t pblock = (int64_t)blockIdx.x * KM_BP;
+  const int wp = wave % WP, wc = wave / WP;
+  const int64_t pblock = (int64_t)blockIdx.x * BP;
   const int cblock = blockIdx.y * BC;
   const int srow = tid >> 3;
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
   // block-local buffer resources: offsets stay 32-bit whatever N is
-  const int64_t xrows = (N - pblock) < KM_BP ? (N - pblock) : KM_BP;
+  const int64_t xrows = (N - pblock) < BP ? (N - pblock) : BP;
   const int crows = (K - cblock) < BC ? (K - cblock) : BC;
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(Xp + pblock * (int64_t)ldx), 0, (int)(((xrows - 1) * (int64_t)ldx + D) * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(Cp + (int64_t)cblock * ldc), 0, (int)((((int64_t)crows - 1) * ldc + D) * 4), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
-  unsigned xoff[4], coff[NCT];
+  unsigned xoff[AL], coff[NCT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) xoff[i] = (srow + 32 * i) < xrows ? ((unsigned)(srow + 32 * i) * (unsigned)ldx + cq * 4) * 4u : OOB;
+  for (int i = 0; i < AL; ++i) xoff[i] = (srow + 32 * i) < xrows ? ((unsigned)(srow + 32 * i) * (unsigned)ldx + cq * 4) * 4u : OOB;
 #pragma unroll
   for (int i = 0; i < NCT; ++i) coff[i] = (srow + 32 * i) < crows ? ((unsigned)(srow + 32 * i) * (unsigned)ldc + cq * 4) * 4u : OOB;
   const int klim = D - cq * 4;                                // this lane's chunk of k-tile kt is inside D iff 32 kt < klim
   const int nk = (D + KM_BK - 1) / KM_BK;
   auto issue = [&](int kt, int stage) {
     float* Xs = km_lds + stage * STAGE_FLOATS;
-    float* Cs = Xs + KM_BP * KM_BK;
+    float* Cs = Xs + BP * KM_BK;
     const bool kin = kt * KM_BK < klim;                       // false for every lane once kt >= nk: all-OOB (zero) DMAs
     const unsigned kb = (unsigned)kt * (KM_BK * 4u);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AL; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Xs + (8 * wave + 32 * i) * KM_BK),
                                                16, (int)((kin && xoff[i] != OOB) ? xoff[i] + kb : OOB), 0, 0, 0);
 #pragma unroll
@@ -216,40 +225,40 @@ __global__ __launch_bounds__(256) void km_assign_dma(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (__attribute__((address_space(3))) void*)(Cs + (8 * wave + 32 * i) * KM_BK),
                                                16, (int)((kin && coff[i] != OOB) ? coff[i] + kb : OOB), 0, 0, 0);
   };
-  f32x16 acc[NCT];
+  f32x16 acc[TC];
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
+  for (int ct = 0; ct < TC; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
   const int r = lane & 31, h = lane >> 5;
   auto compute = [&](int stage) {
     const float* Xs = km_lds + stage * STAGE_FLOATS;
-    const float* Cs = Xs + KM_BP * KM_BK;
-    f32x4 b[2], a[2][NCT];
-    b[0] = *(const f32x4*)&Xs[km_off(32 * wave + r, h)];
+    const float* Cs = Xs + BP * KM_BK;
+    f32x4 b[2], a[2][TC];
+    b[0] = *(const f32x4*)&Xs[km_off(32 * wp + r, h)];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) a[0][ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, h)];
+    for (int ct = 0; ct < TC; ++ct) a[0][ct] = *(const f32x4*)&Cs[km_off(32 * (wc * TC + ct) + r, h)];
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
       if (q < 3) {
-        b[nxt] = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * (q + 1) + h)];
+        b[nxt] = *(const f32x4*)&Xs[km_off(32 * wp + r, 2 * (q + 1) + h)];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) a[nxt][ct] = *(const f32x4*)&Cs[km_off(32 * ct + r, 2 * (q + 1) + h)];
+        for (int ct = 0; ct < TC; ++ct) a[nxt][ct] = *(const f32x4*)&Cs[km_off(32 * (wc * TC + ct) + r, 2 * (q + 1) + h)];
       }
       // k order inside every accumulator: q ascending, t ascending, lane half 0 then 1 => k = 8q + 2t + h ascending
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
+        for (int ct = 0; ct < TC; ++ct)
           acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct][t], b[cur][t], acc[ct], 0, 0, 0);
-      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1 + NCT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCT, 0);
+      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1 + TC, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TC, 0);
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  constexpr int PER_STAGE = 4 + NCT;
+  constexpr int PER_STAGE = AL + NCT;
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t) issue(t, t);
   // k-tiles past the end are all-zero DMAs and 0 * 0 MFMAs (exact no-ops on the accumulators): no branch in the loop
@@ -266,10 +275,10 @@ __global__ __launch_bounds__(256) void km_assign_dma(
   float best = INFINITY;
   int bidx = 0x7fffffff;
 #pragma unroll
-  for (int ct = 0; ct < NCT; ++ct)
+  for (int ct = 0; ct < TC; ++ct)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-      const int c = cblock + ct * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      const int c = cblock + (wc * TC + ct) * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
       if (c < K) {
         const float s = cnorm[c] - 2.0f * acc[ct][g];
         if (s < best || (s == best && c < bidx)) { best = s; bidx = c; }
@@ -278,10 +287,11 @@ __global__ __launch_bounds__(256) void km_assign_dma(
   const float ob = __shfl_xor(best, 32);
   const int oi = __shfl_xor(bidx, 32);
   if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-  const int64_t p = pblock + 32 * wave + r;
+  const int64_t p = pblock + 32 * wp + r;
   if (h == 0 && p < N) {
-    pscore[(int64_t)blockIdx.y * N + p] = best;
-    pidx[(int64_t)blockIdx.y * N + p] = bidx;
+    const int64_t grp = (int64_t)blockIdx.y * WC + wc;       // partial lists are per wave-column of centroids, ascending
+    pscore[grp * N + p] = best;
+    pidx[grp * N + p] = bidx;
   }
 }
 
@@ -857,7 +867,7 @@ static int km_nct() {
 }
 
 extern "C" size_t slic_kmeans_assign_workspace_bytes(int64_t N, int K) {
-  const int64_t G = slic_cdiv(K, 64);          // sized for the smaller centroid block
+  const int64_t G = slic_cdiv(K, 32);          // sized for the finest partial lists (one per 32-centroid wave column)
   return 2 * slic_align_up((size_t)(G * N) * 4, 256);
 }
 
@@ -875,8 +885,8 @@ extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, con
   const int nct = km_nct();
   const int G = (int)slic_cdiv(K, nct * 32);
   SlicCarver w(workspace);
-  float* pscore = w.take<float>((size_t)slic_cdiv(K, 64) * N);
-  int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 64) * N);
+  float* pscore = w.take<float>((size_t)slic_cdiv(K, 32) * N);
+  int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 32) * N);
   dim3 grid((unsigned)slic_cdiv(N, KM_BP), (unsigned)G);
   if (nct == 2) km_assign_partial<2><<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
   else km_assign_partial<4><<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
@@ -887,17 +897,17 @@ extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, con
   return SLIC_OK;
 }
 
-template <int NCT, int STAGES>
+template <int BP, int NCT, int WC, int STAGES>
 static int launch_assign_dma(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K, int ldc,
                              const float* cnorm, float* pscore, int32_t* pidx, hipStream_t st) {
-  const size_t lds = (size_t)STAGES * (KM_BP + NCT * 32) * KM_BK * sizeof(float);
+  const size_t lds = (size_t)STAGES * (BP + NCT * 32) * KM_BK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_dma<NCT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_dma<BP, NCT, WC, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)slic_cdiv(N, KM_BP), (unsigned)slic_cdiv(K, NCT * 32));
-  km_assign_dma<NCT, STAGES><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+  dim3 grid((unsigned)slic_cdiv(N, BP), (unsigned)slic_cdiv(K, NCT * 32));
+  km_assign_dma<BP, NCT, WC, STAGES><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -922,18 +932,19 @@ extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ld
   SLIC_REQUIRE(((uintptr_t)Xp % 16) == 0 && ((uintptr_t)Cp % 16) == 0, "slic_kmeans_assign_perm: unaligned");
   SLIC_REQUIRE((int64_t)KM_BP * ldx * 4 < (1ll << 31) && (int64_t)128 * ldc * 4 < (1ll << 31), "slic_kmeans_assign_perm: rows too long");
   SLIC_REQUIRE(!labels_old || n_changed, "slic_kmeans_assign_perm: labels_old needs n_changed");
-  static const int mode = getenv("SLIC_KM_DMA") ? atoi(getenv("SLIC_KM_DMA")) : 22;     // NCT, ring stages
-  const int nct = mode / 10 == 4 ? 4 : 2;
-  const int G = (int)slic_cdiv(K, nct * 32);
+  // tile / ring: 22 = 128 pts x 64 centroids, 2 stages (measured best; a 64 x 64 tile with 2 x 2 waves fills the grid
+  // more evenly but loses the same few % inside the loop); 23 = 3 stages; 42 / 43 = 128 x 128
+  static const int mode = getenv("SLIC_KM_DMA") ? atoi(getenv("SLIC_KM_DMA")) : 22;
+  const int G = (int)slic_cdiv(K, (mode / 10 == 4 ? 4 : 2) * 32);
   SlicCarver w(workspace);
-  float* pscore = w.take<float>((size_t)slic_cdiv(K, 64) * N);
-  int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 64) * N);
+  float* pscore = w.take<float>((size_t)slic_cdiv(K, 32) * N);
+  int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 32) * N);
   hipStream_t st = S(stream);
   int rc;
-  if (mode == 42) rc = launch_assign_dma<4, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  else if (mode == 43) rc = launch_assign_dma<4, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  else if (mode == 23) rc = launch_assign_dma<2, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  else rc = launch_assign_dma<2, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  if (mode == 42) rc = launch_assign_dma<128, 4, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  else if (mode == 43) rc = launch_assign_dma<128, 4, 1, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  else if (mode == 23) rc = launch_assign_dma<128, 2, 1, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  else rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
   if (rc) return rc;
   km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, st>>>(pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
   SLIC_LAUNCH_CHECK();
