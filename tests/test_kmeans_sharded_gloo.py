@@ -41,6 +41,10 @@ def _worker(rank, world, port, case, out_dir):
         gl = du.all_gather([torch.from_numpy(km.labels_.astype(np.int64))])[0]
         assert abs(t.item() - (world + 1) / 2) < 1e-6 and du.get_world_size() == world
         assert du.is_master_proc() == (rank == 0)
+        # cluster-label hand-off as a broadcast (online_train.iterative_cluster_step)
+        from video_similarity_search_amd.online_train import broadcast_cluster_labels
+        got = broadcast_cluster_labels(gl.numpy() if rank == 0 else None, N, "cpu", rank == 0)
+        assert got.dtype == np.int32 and np.array_equal(got, gl.numpy())
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=km.labels_, centers=km.cluster_centers_, n_iter=km.n_iter_,
                  strict=km.strict_, inertia=km.inertia_, all_labels=gl.numpy(), nreloc=km.n_relocations_)
     finally:

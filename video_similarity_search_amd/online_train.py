@@ -221,5 +221,21 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
                 f.write('{}\n'.format(label))
         print('Saved cluster labels to', cluster_output_path)
     if cfg.NUM_GPUS > 1:
-        torch.distributed.barrier()
+        # besides the text file (kept for the reference's dataset code, which re-parses it on every
+        # rank), hand the labels to the other ranks as one int32 broadcast, so a caller can rebuild its sampler
+        # without touching the filesystem; the broadcast is also the barrier of online_train.py:662
+        cluster_labels = broadcast_cluster_labels(cluster_labels, len(eval_train_loader.dataset), device, is_master_proc)
     return cluster_labels, NMI
+
+
+def broadcast_cluster_labels(cluster_labels, n, device, is_master_proc, src=0):
+    """labels (np.ndarray[int] on the master, anything elsewhere) -> the same np.ndarray[int32] on every rank"""
+    import numpy as np
+    dev = device if device is not None else ("cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+    buf = torch.empty(n, dtype=torch.int32, device=dev)
+    if is_master_proc:
+        lab = np.asarray(cluster_labels, dtype=np.int32)
+        assert lab.shape == (n,), "one label per dataset item"
+        buf.copy_(torch.from_numpy(lab))
+    torch.distributed.broadcast(buf, src=src)
+    return buf.cpu().numpy()
