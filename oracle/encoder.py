@@ -10,6 +10,7 @@ functionally over a plain state_dict so that it needs nothing from /root/referen
   ntxent_loss          <- loss/triplet_loss.py:95-116 ('noise_contrastive') + pdist :429-437
   nce_average / nce_softmax_loss <- loss/NCE_loss.py:26-88, 341-352
   sgd_step             <- online_train.py:543 (SGD lr .1, momentum .5, no weight decay)
+  r3d_to_resnet_keys   <- models/r3d/r3d.py:126-187 (R3DNet = the same network under other key names)
 
 Pinned against the imported reference modules by tests/golden/make_goldens_encoder.py (goldens in
 tests/golden/encoder_tiny.npz, loss_ntxent.npz), checked by tests/test_oracle_encoder.py.
@@ -128,6 +129,31 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
     h = F.linear(x, sd["fc1.weight"], sd["fc1.bias"])
     h = F.relu(_bn(h, sd, "bn_proj", training))
     return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def r3d_to_resnet_keys(sd):
+    """state_dict of the reference's R3DNet (models/r3d/r3d.py:126-187) under the 3D-ResNet key names encoder_forward
+    walks: conv{L+1}.block1 -> layer{L}.0, conv{L+1}.blocks.i -> layer{L}.{i+1}, *.temporal_spatial_conv.weight -> *.weight,
+    downsampleconv / downsamplebn -> downsample.0 / downsample.1.  R3DNet.forward is then
+    encoder_forward(mapped, x, training, conv1_stride=(1, 2, 2), projection_head=False) (3x7x7 stem, padding (1, 3, 3))."""
+    out = {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if parts[0] in ("conv2", "conv3", "conv4", "conv5"):
+            li = int(parts[0][4:]) - 1
+            if parts[1] == "block1":
+                pre, rest = f"layer{li}.0", parts[2:]
+            else:
+                pre, rest = f"layer{li}.{int(parts[2]) + 1}", parts[3:]
+            rest = [r for r in rest if r != "temporal_spatial_conv"]
+            if rest[0] == "downsampleconv":
+                rest = ["downsample", "0"] + rest[1:]
+            elif rest[0] == "downsamplebn":
+                rest = ["downsample", "1"] + rest[1:]
+            out[".".join([pre] + rest)] = v
+        else:
+            out[".".join(p for p in parts if p != "temporal_spatial_conv")] = v
+    return out
 
 
 def cosine_similarity_rows(x, Y, eps=1e-8):

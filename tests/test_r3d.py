@@ -1,0 +1,80 @@
+"""R3DNet (the reference's alternate encoder, models/r3d/r3d.py): the oracle's key map + CPU restatement
+against the reference's golden outputs (CPU), and the HIP plan against the same goldens (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from r3d_weights import r3d_weights  # noqa: E402
+
+
+def _golden(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "r3d_tiny.npz")))
+
+
+def test_oracle_r3d_matches_reference_golden(golden_dir):
+    from oracle import encoder as oe
+    g = _golden(golden_dir)
+    sd = oe.to_torch(oe.r3d_to_resnet_keys(r3d_weights(np.random.default_rng(23))), requires_grad=True)
+    x = torch.from_numpy(g["x"])
+    emb = oe.encoder_forward(sd, x, training=True, projection_head=False)
+    loss = oe.ntxent_loss(emb)
+    loss.backward()
+    np.testing.assert_allclose(emb.detach().numpy(), g["train/emb"], atol=2e-5, rtol=1e-5)
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-5
+    raw = r3d_weights(np.random.default_rng(23))
+    mapped = oe.r3d_to_resnet_keys({k: k for k in raw})            # reference key -> oracle key
+    n = 0
+    for rk, okey in ((v, k) for k, v in mapped.items()):
+        if "gnorm/" + rk in g:
+            gr = sd[okey].grad.numpy().reshape(-1)
+            assert abs(np.linalg.norm(gr.astype(np.float64)) - float(g["gnorm/" + rk])) <= 2e-3 * float(g["gnorm/" + rk]) + 1e-6, rk
+            np.testing.assert_allclose(gr[:8], g["ghead/" + rk], atol=1e-5 + 2e-3 * np.abs(g["ghead/" + rk]).max(), rtol=0, err_msg=rk)
+            n += 1
+    assert n == 36                                                  # 12 convs + 12 BatchNorms x (gamma, beta)
+    with torch.no_grad():
+        ev = oe.encoder_forward(sd, x, training=False, projection_head=False)
+    np.testing.assert_allclose(ev.numpy(), g["eval/emb"], atol=5e-5, rtol=1e-4)
+
+
+def test_r3d_state_dict_names_match_reference():
+    from video_similarity_search_amd.models import R3DNet
+    m = R3DNet(layer_sizes=(1, 1, 1, 1))
+    ref = r3d_weights(np.random.default_rng(0))                     # key order/shapes verified against the reference by the generator
+    sd = m.state_dict()
+    assert list(sd) == list(ref)
+    assert all(tuple(sd[k].shape) == tuple(np.asarray(ref[k]).shape) for k in sd)
+    with pytest.raises(Exception):
+        m(torch.zeros(1, 3, 8, 32, 32))                             # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_r3d_hip_matches_reference_golden(gpu, golden_dir):
+    from video_similarity_search_amd.models import R3DNet
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    g = _golden(golden_dir)
+    m = R3DNet(layer_sizes=(1, 1, 1, 1))
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in r3d_weights(np.random.default_rng(23)).items()})
+    m = m.cuda().train()
+    x = torch.from_numpy(g["x"]).cuda()
+    emb = m(x)
+    loss, _ = OnlineTripletLoss(0.2, 'cosine')(emb, torch.arange(2).repeat(2).cuda(), sampling_strategy='noise_contrastive')
+    loss.backward()
+    np.testing.assert_allclose(emb.detach().cpu().numpy(), g["train/emb"], atol=1e-4, rtol=0)
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-4
+    for k, p in m.named_parameters():
+        gr = p.grad.cpu().numpy().reshape(-1)
+        ref_n = float(g["gnorm/" + k])
+        assert abs(np.linalg.norm(gr.astype(np.float64)) - ref_n) <= 5e-3 * ref_n + 1e-6, k
+        np.testing.assert_allclose(gr[:8], g["ghead/" + k], atol=1e-5 + 5e-3 * np.abs(g["ghead/" + k]).max(), rtol=0, err_msg=k)
+    sd = m.state_dict()
+    for k in sd:
+        if "after/" + k in g:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g["after/" + k], atol=1e-5, rtol=1e-4, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    np.testing.assert_allclose(ev.cpu().numpy(), g["eval/emb"], atol=5e-4, rtol=1e-3)

@@ -86,7 +86,7 @@ class _Engine:
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             self.layer_blocks.append([])
             for blk in layer:
-                if not isinstance(blk, BasicBlock):
+                if not all(hasattr(blk, a) for a in ("conv1", "bn1", "conv2", "bn2", "downsample")) or hasattr(blk, "conv3"):
                     raise NotImplementedError("Bottleneck depths (50+) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
                 p1 = ConvPlan(blk.conv1.in_channels, blk.conv1.out_channels, blk.conv1.kernel_size, blk.conv1.stride,
                               blk.conv1.padding, dims, device)
@@ -94,7 +94,7 @@ class _Engine:
                               blk.conv2.padding, p1.out_dims, device)
                 pd = None
                 if blk.downsample is not None:
-                    if not isinstance(blk.downsample, nn.Sequential):
+                    if not (hasattr(blk.downsample, "__getitem__") and len(blk.downsample) == 2):
                         raise NotImplementedError("shortcut_type 'A' is never selected by the shipped configs")
                     dc = blk.downsample[0]
                     pd = ConvPlan(dc.in_channels, dc.out_channels, dc.kernel_size, dc.stride, dc.padding, dims, device)
@@ -482,16 +482,20 @@ class ResNet(nn.Module):
             raise _lib.SlicError("ResNet.forward needs a gfx950 device tensor: the encoder has no CPU/PyTorch fallback")
         _lib.load()
         x = x.to(torch.float32)
-        eng = self._engine(x)
-        params = [p for p in self.parameters() if p.requires_grad]
-        if torch.is_grad_enabled() and self.training and params:
-            a = x
-            for si in range(eng.N_SEG):
-                a = _SegmentFn.apply(a, eng, si, True, *eng.seg_params(si))
-            return a
-        # eval-mode graph (BN frozen) is not needed by the SLIC loop (validation runs under no_grad): inference only
-        with torch.no_grad():
-            return eng.forward(x, training=self.training, save=False)[0]
+        return run_engine(self._engine(x), self, x)
+
+
+def run_engine(eng, module, x):
+    """drive one encoder through its engine: autograd segments in train mode, a plain inference pass otherwise"""
+    params = [p for p in module.parameters() if p.requires_grad]
+    if torch.is_grad_enabled() and module.training and params:
+        a = x
+        for si in range(eng.N_SEG):
+            a = _SegmentFn.apply(a, eng, si, True, *eng.seg_params(si))
+        return a
+    # eval-mode graph (BN frozen) is not needed by the SLIC loop (validation runs under no_grad): inference only
+    with torch.no_grad():
+        return eng.forward(x, training=module.training, save=False)[0]
 
 
 def generate_model(model_depth, **kwargs):
