@@ -28,26 +28,37 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
                                               int wm, int wn, int r, int h, int tid) {
   const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial)
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  // ---- epilogue
+  // ---- epilogue.  All tensor accesses are range-checked buffer ops with 32-bit byte offsets: a row past M, a column past
+  // N or an absent optional operand (resource of size 0) is an out-of-range access — loads return 0, stores are dropped —
+  // so the element loop has no branch and the compiler batches its loads.
   const bool want_stats = p.stat_partial != nullptr;
-  int64_t roff[TM][16];           // dst row offsets (elements), one decode per accumulator row
+  const bool want_bwd = p.bwd_partial != nullptr;
+  constexpr unsigned OOBE = 0xFFFFFF00u;
+  const int64_t dst_rows = p.dst_strided ? (p.M / ((int64_t)p.Ga * p.Gb * p.Gc)) * p.Da * p.Db * p.Dc : p.M;
+  const unsigned dst_bytes = (unsigned)(((dst_rows - 1) * (int64_t)p.ldo + p.N) * 4);
+  const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dst_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void*)p.addend, 0, p.addend ? dst_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_src, 0, p.mask_src ? dst_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bz = __builtin_amdgcn_make_buffer_rsrc((void*)p.bwd_z, 0, p.bwd_z ? dst_bytes : 0, 0x00020000);
+  const bool has_mask = p.mask_src != nullptr, do_relu = p.relu != 0;
+  unsigned roff[TM][16];          // dst row byte offsets, one decode per accumulator row; OOBE for rows past M
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (p.dst_strided && m < p.M) {
+      unsigned ro;
+      if (p.dst_strided) {
         unsigned q = (unsigned)m;
         const unsigned gc = q % (unsigned)p.Gc; q /= (unsigned)p.Gc;
         const unsigned gbb = q % (unsigned)p.Gb; q /= (unsigned)p.Gb;
         const unsigned gaa = q % (unsigned)p.Ga; q /= (unsigned)p.Ga;
-        roff[i][g] = ((((int64_t)q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc +
-                      gc * p.dc + p.ec) * (int64_t)p.ldo;
+        ro = ((((q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc + gc * p.dc + p.ec) * (unsigned)p.ldo) * 4u;
       } else {
-        roff[i][g] = m * (int64_t)p.ldo;
+        ro = (unsigned)m * (unsigned)(p.ldo * 4);
       }
+      roff[i][g] = m < p.M ? ro : OOBE;
     }
-  const bool want_bwd = p.bwd_partial != nullptr;
   float bs1[TN], bs2[TN];          // BatchNorm-backward partials of the stored gradient (this lane's column)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -63,20 +74,18 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        if (m < p.M && nv) {
-          const int64_t off = roff[i][g] + n;
-          float v = (acc[i][j][g] + bias) * sc + sh;
-          if (p.addend) v += p.addend[off];
-          if (p.mask_src) v = p.mask_src[off] > 0.f ? v : 0.f;
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.dst[off] = v;
-          if (want_bwd) {
-            const float xh = (p.bwd_z[off] - bmu) * bis;
-            bs1[j] += v;
-            bs2[j] += v * xh;
-          }
-        }
+        const bool ok = nv && roff[i][g] != OOBE;
+        const unsigned off = ok ? roff[i][g] + (unsigned)n * 4u : OOBE;
+        float v = (acc[i][j][g] + bias) * sc + sh;
+        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, off, 0, 0));
+        const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, off, 0, 0));
+        v = (has_mask && !(mk > 0.f)) ? 0.f : v;
+        v = do_relu ? fmaxf(v, 0.f) : v;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dst, off, 0, 0);
+        const float zz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bz, off, 0, 0));
+        const float vv = ok ? v : 0.f;
+        bs1[j] += vv;
+        bs2[j] += vv * ((zz - bmu) * bis);
       }
     }
   }
@@ -300,8 +309,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // two k-tiles in flight across ONE raw barrier per tile.  LDS image = the same [rows][32] swizzled layout: the
 // DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE chunk (p ^ ((row >> 1) & 7)).
 // ------------------------------------------------------------------------------------------
+// waves per SIMD the LDS footprint allows (one wave of each resident workgroup per SIMD): the register allocator is held to
+// that occupancy, or the epilogue's batched loads would cost the main loop a workgroup per CU
+constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT) {
+  const int lds = STAGES * KT * (BM + BN) * 128;
+  const int w = (160 * 1024) / lds;
+  return w > 5 ? 5 : (w < 1 ? 1 : w);
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-__global__ __launch_bounds__(256) void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT))))
+void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
                                                             float* __restrict__ slab, const int kt_per_split) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -984,6 +1002,10 @@ static int validate(const SlicConvArgs* a, const char* who) {
                "%s: bad shape", who);
   SLIC_REQUIRE(a->M % ((int64_t)a->Ga * a->Gb * a->Gc) == 0, "%s: M is not batch * grid", who);
   SLIC_REQUIRE(a->M < (1ll << 31), "%s: M >= 2^31 rows (split the batch)", who);
+  if (a->dst) {   // the epilogue addresses dst / addend / mask_src / bwd_z with 32-bit byte offsets
+    const int64_t rows = a->dst_strided ? (a->M / ((int64_t)a->Ga * a->Gb * a->Gc)) * a->Da * a->Db * a->Dc : a->M;
+    SLIC_REQUIRE(rows > 0 && rows * (int64_t)a->ldo * 4 < (int64_t)0xFFFFFF00u, "%s: dst larger than 4 GiB (split the batch)", who);
+  }
   SLIC_REQUIRE(((uintptr_t)a->src % 16) == 0, "%s: src not 16-byte aligned", who);
   SLIC_REQUIRE(a->src_bytes > 0 && a->src_bytes < 0xFFFFFF00u, "%s: src_bytes must be set and < 4 GiB (split the batch)", who);
   return SLIC_OK;
