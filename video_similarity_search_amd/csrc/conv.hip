@@ -562,8 +562,16 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const SlicConvArgs p, 
       for (int g = 0; g < 16; ++g) {
         const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
         float a = 0.f;
-        if (m < p.M && n < p.N)
-          for (int z = 0; z < S; ++z) a += slab[((int64_t)z * p.M + m) * p.N + n];
+        if (m < p.M && n < p.N) {
+          const float* sp = slab + m * p.N + n;
+          const int64_t zs = p.M * (int64_t)p.N;
+          int z = 0;
+          for (; z + 4 <= S; z += 4) {           // four loads in flight; the adds stay in slab order
+            const float s0 = sp[z * zs], s1 = sp[(z + 1) * zs], s2 = sp[(z + 2) * zs], s3 = sp[(z + 3) * zs];
+            a += s0; a += s1; a += s2; a += s3;
+          }
+          for (; z < S; ++z) a += sp[z * zs];
+        }
         acc[i][j][g] = a;
       }
   }
