@@ -1,0 +1,62 @@
+"""Post-process the rocprofv3 outputs of scripts/collect_profiles.sh into the files kept under profiles/.
+usage: collect_profiles.py <scratch dir> <out dir> <round tag>"""
+import csv, glob, json, os, sys
+
+scratch, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+KERNEL = "conv_gemm_dma_kernel<128, 64, 2, 2, 2, 1, true>"
+GRID = 12544 * 256                      # layer1 shape at B = 32: M = 1 605 632 rows / 128 per workgroup
+
+
+def find(sub, pat):
+    f = sorted(glob.glob(os.path.join(scratch, sub, "**", pat), recursive=True))
+    return f[0] if f else None
+
+
+def counter_mean(sub, name):
+    f = find(sub, "*counter_collection.csv")
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] == name and int(r.get("Grid_Size", r.get("Grid_Size_X", 0))) == GRID:
+            per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    v = list(per.values())
+    return sum(v) / len(v), len(v)
+
+
+def trace_mean(sub):
+    f = find(sub, "*kernel_trace.csv")
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f))
+         if KERNEL in r["Kernel_Name"] and int(r["Grid_Size_X"]) == GRID]
+    return sum(d) / len(d) / 1e6, len(d)
+
+
+def json_line(path):
+    for line in open(path):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
+
+os.makedirs(out, exist_ok=True)
+d = json_line(os.path.join(scratch, "default.log"))
+json.dump(d, open(os.path.join(out, f"{tag}_bench_default_run.json"), "w"), indent=1)
+p = json_line(os.path.join(scratch, "stats.log"))
+json.dump(p, open(os.path.join(out, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+ks = find("stats", "*kernel_stats.csv")
+open(os.path.join(out, f"{tag}_kernel_stats_bench_steps5.csv"), "w").write(open(ks).read())
+fetch, nf = counter_mean("pmc_fetch", "FETCH_SIZE")
+write, nw = counter_mean("pmc_write", "WRITE_SIZE")
+tr, nt = trace_mean("stats")
+res = {
+    "FETCH_SIZE_KB_mean": fetch, "FETCH_SIZE_launches": nf, "WRITE_SIZE_KB_mean": write, "WRITE_SIZE_launches": nw,
+    "note": f"{KERNEL.replace(', ', ',')} at the layer1 shape (grid 12544 x 256 threads: M=1605632, N=64, K=1728; B=32): 4 forward "
+            "launches (fused BN statistics) + 4 data-gradient launches (fused ReLU mask + BN-backward sums: they also read the "
+            "mask and z tensors) per step. Separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; each with --kernel-trace only) "
+            "over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary`. Units KiB. Per MI355X_MICROARCH.md §HBM, "
+            "gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced read, so hbm_bytes_per_launch = "
+            "(2*FETCH_SIZE + WRITE_SIZE)*1024. Algorithmic minimum: 0.82 GB (forward) / 1.64 GB (data gradient with mask and z).",
+    "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
+    "rocprof_trace_avg_ms": tr, "rocprof_trace_launches": nt,
+    "hip_event_avg_ms": p["roofline"]["ms_per_launch"],
+}
+json.dump(res, open(os.path.join(out, f"{tag}_pmc_conv_gemm_dma.json"), "w"), indent=1)
+print(json.dumps({k: res[k] for k in ("hbm_bytes_per_launch", "rocprof_trace_avg_ms", "hip_event_avg_ms")}), d["value"], p["value"])

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun -- 'bash scripts/collect_profiles.sh'): default bench, rocprofv3 kernel stats, two PMC passes.
+# Outputs land in gpurun_out/prof_r01/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r01 profiles r01` files them.
+set -u
+R="$(pwd)"
+S="$R/gpurun_out/prof_r01"
+rm -rf "$S"; mkdir -p "$S"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 python "$R/bench.py" > "$S/default.log" 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats" -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$S/stats.log" 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$S/pmc_fetch" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_fetch.log" 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$S/pmc_write" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_write.log" 2>&1 < /dev/null
+# keep the merge-back small: per-kernel csvs only
+find "$S" -name "*agent_info.csv" -delete
+du -sh "$S"; ls "$S"
+grep "^{" "$S/default.log" | cut -c1-200
