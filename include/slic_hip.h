@@ -150,6 +150,15 @@ size_t slic_kmeanspp_step_workspace_bytes(int64_t N, int T);
 int slic_kmeanspp_step(const float* X, int64_t N, int D, int ldx, const int32_t* cand, int T,
                        const float* closest, float* newdist, double* pot, void* workspace,
                        void* stream);
+/* k-means++ seeding (_kmeans_plusplus, _kmeans.py:174-277) as ONE enqueued sequence: centre 0 = row `first`; for
+ * c = 1..K-1: T candidates = searchsorted(cumsum(closest), uniforms[(c-1)*T + t] * current_pot) (clipped), squared distances
+ * of every row to them, min with closest, potentials in double, first-minimum candidate kept.  `uniforms` (device,
+ * [(K-1)*T] doubles in [0, 1)) are the host RNG's draws — the draws do not depend on the data, so the host never waits.
+ * idx_out (device, [K]) receives the chosen row indices. */
+size_t slic_kmeanspp_run_workspace_bytes(int64_t N, int T);
+int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int first, int K, int T, const double* uniforms,
+                      int32_t* idx_out, void* workspace, void* stream);
+
 /* inclusive prefix sum of v (float) in double, and searchsorted(cumsum, vals[t], 'left')
  * clipped to N-1  (stable_cumsum + np.searchsorted, _kmeans.py:243-248). */
 size_t slic_cumsum_search_workspace_bytes(int64_t N);

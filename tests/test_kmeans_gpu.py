@@ -171,3 +171,34 @@ def test_kmeanspp_helpers(gpu):
     exp = np.clip(np.searchsorted(cs, vals_h), None, N - 1)
     got = idx.cpu().numpy()
     assert np.all(np.abs(got - exp) <= 1), (got, exp)      # chunked double sums vs np.cumsum: boundary +-1
+
+
+def test_kmeanspp_run_matches_stepwise(gpu):
+    """the single-sequence k-means++ (slic_kmeanspp_run) picks the rows the stepwise host loop picks from the same
+    uniform draws (distances are summed in a different order, so the data is chosen without near-ties), and both follow
+    _kmeans_plusplus restated in float64 numpy"""
+    from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
+    rng = np.random.default_rng(21)
+    N, D, K = 6000, 64, 24
+    T = 2 + int(np.log(K))
+    cen = rng.standard_normal((K, D)) * 3
+    X = (cen[rng.integers(0, K, N)] + 0.3 * rng.standard_normal((N, D))).astype(np.float32)
+    u = rng.random((K - 1, T))
+    first = 1234
+    # float64 restatement (sklearn/cluster/_kmeans.py:174-277)
+    Xd64 = X.astype(np.float64)
+    closest = ((Xd64 - Xd64[first]) ** 2).sum(1)
+    ref = [first]
+    for c in range(1, K):
+        cand = np.clip(np.searchsorted(np.cumsum(closest), u[c - 1] * closest.sum()), None, N - 1)
+        d = np.minimum(((Xd64[None] - Xd64[cand][:, None]) ** 2).sum(-1), closest[None])
+        b = int(np.argmin(d.sum(1)))
+        closest = d[b]
+        ref.append(int(cand[b]))
+    k = HipKernels()
+    Xg = torch.from_numpy(X).cuda()
+    idx = torch.empty(K, dtype=torch.int32, device="cuda")
+    k.kpp_run(Xg, first, K, T, torch.from_numpy(u).cuda(), idx)
+    got = idx.cpu().numpy().tolist()
+    assert got[0] == first and len(set(got)) == K
+    assert got == ref

@@ -86,6 +86,12 @@ class HipKernels:
              ptr(labels), ptr(labels_old), ptr(n_changed), ptr(sums), ptr(counts), ptr(C_new), ptr(Cp_new), ptr(cnorm_new),
              ptr(shift), ptr(status), ptr(ws), stream())
 
+    def kpp_run(self, X, first, K, T, uniforms, idx_out):
+        N, Dp = X.shape
+        ws = _lib.workspace(_lib.load().slic_kmeanspp_run_workspace_bytes(N, T), X.device, "kpp_run")
+        call("slic_kmeanspp_run", ptr(X), N, Dp, X.stride(0), int(first), int(K), int(T), ptr(uniforms), ptr(idx_out), ptr(ws),
+             stream())
+
     def accumulate(self, X, labels, K, sums, counts):
         N, Dp = X.shape
         ws = _lib.workspace(_lib.load().slic_kmeans_accumulate_workspace_bytes(N, K), X.device, "km_accum")
@@ -496,6 +502,15 @@ class KMeans:
             return t.cpu().numpy()
 
         first = int(bcast(np.array([rs.choice(N, p=np.full(N, 1.0 / N))], np.int64))[0])
+        if hasattr(k, "kpp_run") and T <= 16 and os.environ.get("SLIC_KPP_RUN", "1") != "0":
+            # the RNG draws of the loop below do not depend on the data: draw them all now (same stream, same order),
+            # and let the device run the K - 1 steps back to back
+            u = bcast(rs.uniform(size=(K - 1, T))) if K > 1 else np.zeros((0, T))
+            ud = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)).to(dev)
+            idx_d = torch.empty(K, dtype=torch.int32, device=dev)
+            k.kpp_run(Xs, first, K, T, ud, idx_d)
+            self.init_indices_ = idx_d.cpu().numpy().astype(np.int64)
+            return Xs.index_select(0, idx_d.long()).contiguous()
         idx[0] = first
         cand[0] = first
         k.kpp_step(Xs, cand, 1, None, closest, pot)

@@ -850,6 +850,185 @@ __global__ void cs_search(const float* __restrict__ v, int64_t N, const double* 
   if (lane == 0) idx[t] = (int32_t)res;
 }
 
+// ---------------- k-means++ as one device-driven sequence (no host round trip per centre) ----------------------
+// Step c: (1) kpp_search: T candidates = searchsorted(cumsum(closest), u[c] * current_pot)  (2) kpp_dist_rows: squared
+// distances of every row to the T candidates, min with closest, per-256-row potentials  (3) kpp_select: potentials,
+// first-minimum candidate, its index into idx[c], and the inclusive scan of ITS per-256-row sums = the chunked cumsum
+// step c+1 searches.  `closest` is never copied: it is row `sel` of the previous step's newdist buffer (double-buffered).
+
+// one wave per row: the row is read as one contiguous run (16 B per lane), candidate rows sit in LDS.  A workgroup covers
+// KPP_CH = 64 rows (16 per wave, two rows in flight per wave): ~1600 workgroups at N = 100k, enough waves to hide the
+// row loads; its per-candidate sums are the chunk sums kpp_select scans and kpp_search walks.
+// The T (<= 16) per-lane partial sums of a row are reduced with a reduce-scatter butterfly: each xor step halves the
+// number of values a lane carries (the lane's address bit picks the half it keeps), so a row costs 10 (T <= 8) or 17
+// cross-lane moves instead of 6 T; candidate t's total ends up in lanes [8t, 8t+8) (T <= 8) or [4t, 4t+4).
+#define KPP_CH 64
+template <int TP>
+__device__ __forceinline__ float kpp_reduce_scatter(float (&v)[TP], int lane) {
+  int off = 32;
+#pragma unroll
+  for (int half = TP / 2; half >= 1; half >>= 1, off >>= 1) {
+    const bool up = (lane & off) != 0;
+#pragma unroll
+    for (int j = 0; j < half; ++j) {
+      const float keep = up ? v[j + half] : v[j];
+      const float send = up ? v[j] : v[j + half];
+      v[j] = keep + __shfl_xor(send, off);
+    }
+  }
+  float r = v[0];
+  for (; off >= 1; off >>= 1) r += __shfl_xor(r, off);
+  return r;
+}
+
+template <int TP>
+__global__ __launch_bounds__(256) void kpp_dist_rows(const float* __restrict__ X, int64_t N, int D, int ldx,
+                                                     const int32_t* __restrict__ cand, int T,
+                                                     const float* __restrict__ prev, const int32_t* __restrict__ sel,
+                                                     float* __restrict__ newdist, double* __restrict__ bpart) {
+  extern __shared__ float cs[];  // [T][D] candidate rows
+  __shared__ float res[TP][KPP_CH];
+  for (int e = threadIdx.x; e < T * D; e += blockDim.x) {
+    const int t = e / D, k = e - t * D;
+    cs[e] = X[(int64_t)cand[t] * ldx + k];
+  }
+  for (int e = threadIdx.x; e < TP * KPP_CH; e += blockDim.x) (&res[0][0])[e] = 0.f;
+  __syncthreads();
+  const float* closest = prev ? prev + (int64_t)(*sel) * N : nullptr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPW = KPP_CH / 4;
+  constexpr int GL = 64 / TP;                            // lanes per candidate group after the scatter steps
+  const int64_t base = (int64_t)blockIdx.x * KPP_CH + wave * RPW;
+  for (int rr = 0; rr < RPW; rr += 2) {                  // two rows in flight (four: register pressure costs more than it hides)
+    const int64_t i0 = base + rr, i1 = i0 + 1;
+    if (i0 >= N) break;                                  // wave-uniform
+    const bool two = i1 < N;
+    float a0[TP], a1[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) { a0[t] = 0.f; a1[t] = 0.f; }
+    const float* x0 = X + i0 * (int64_t)ldx;
+    const float* x1 = X + (two ? i1 : i0) * (int64_t)ldx;
+    for (int k0 = lane * 4; k0 < D; k0 += 256) {
+      const f32x4 u0 = *(const f32x4*)(x0 + k0);
+      const f32x4 u1 = *(const f32x4*)(x1 + k0);
+#pragma unroll
+      for (int t = 0; t < TP; ++t)
+        if (t < T) {
+          const f32x4 c = *(const f32x4*)(cs + t * D + k0);
+          float d;
+          d = u0.x - c.x; a0[t] = fmaf(d, d, a0[t]);
+          d = u0.y - c.y; a0[t] = fmaf(d, d, a0[t]);
+          d = u0.z - c.z; a0[t] = fmaf(d, d, a0[t]);
+          d = u0.w - c.w; a0[t] = fmaf(d, d, a0[t]);
+          d = u1.x - c.x; a1[t] = fmaf(d, d, a1[t]);
+          d = u1.y - c.y; a1[t] = fmaf(d, d, a1[t]);
+          d = u1.z - c.z; a1[t] = fmaf(d, d, a1[t]);
+          d = u1.w - c.w; a1[t] = fmaf(d, d, a1[t]);
+        }
+    }
+    const float r0 = kpp_reduce_scatter<TP>(a0, lane);
+    const float r1 = kpp_reduce_scatter<TP>(a1, lane);
+    if ((lane & (GL - 1)) == 0) {
+      res[lane / GL][wave * RPW + rr] = r0;
+      if (two) res[lane / GL][wave * RPW + rr + 1] = r1;
+    }
+  }
+  __syncthreads();
+  // wave w writes candidates w, w + 4, ...: row r = lane of the 64-row chunk, coalesced; chunk potentials in double
+  const int64_t i = (int64_t)blockIdx.x * KPP_CH + lane;
+  const float cl = (closest && i < N) ? closest[i] : INFINITY;
+  for (int t = wave; t < T; t += 4) {
+    const float m = fminf(res[t][lane], cl);
+    if (i < N) newdist[(int64_t)t * N + i] = m;
+    double v = i < N ? (double)m : 0.0;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) bpart[(int64_t)blockIdx.x * T + t] = v;
+  }
+}
+
+// one workgroup: pot[t] = sum_b bpart[b][t] (fixed strided partition + tree), sel = first minimum, idx_out = cand[sel],
+// csum[b] = inclusive scan over b of bpart[b][sel]
+__global__ __launch_bounds__(256) void kpp_select(const double* __restrict__ bpart, int64_t nblk, int T,
+                                                  const int32_t* __restrict__ cand, int32_t* __restrict__ sel,
+                                                  double* __restrict__ cur_pot, double* __restrict__ csum,
+                                                  int32_t* __restrict__ idx_out) {
+  __shared__ double sm[256];
+  __shared__ double pots[PP_TMAX];
+  __shared__ int s_sel;
+  const int i = threadIdx.x;
+  for (int t = 0; t < T; ++t) {
+    double a = 0.0;
+    for (int64_t b = i; b < nblk; b += 256) a += bpart[b * T + t];
+    sm[i] = a;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+      if (i < s2) sm[i] += sm[i + s2];
+      __syncthreads();
+    }
+    if (i == 0) pots[t] = sm[0];
+    __syncthreads();
+  }
+  if (i == 0) {
+    int b = 0;
+    for (int t = 1; t < T; ++t) if (pots[t] < pots[b]) b = t;          // np.argmin: first minimum
+    s_sel = b;
+    *sel = b;
+    *cur_pot = pots[b];
+    *idx_out = cand[b];
+  }
+  __syncthreads();
+  const int b = s_sel;
+  // inclusive scan of column b: every thread scans its own run of `per` consecutive chunks, one block-wide scan of the run
+  // totals, then the offsets are added back
+  const int64_t per = (nblk + 255) / 256;
+  const int64_t c0 = (int64_t)i * per, c1 = c0 + per < nblk ? c0 + per : nblk;
+  double run = 0.0;
+  for (int64_t c = c0; c < c1; ++c) run += bpart[c * T + b];
+  sm[i] = run;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const double u = i >= d ? sm[i - d] : 0.0;
+    __syncthreads();
+    sm[i] += u;
+    __syncthreads();
+  }
+  double a = sm[i] - run;                                 // exclusive offset of this thread's run
+  for (int64_t c = c0; c < c1; ++c) { a += bpart[c * T + b]; csum[c] = a; }
+}
+
+// one WAVE per query: x = u * (*cur_pot); searchsorted(cumsum(v), x, 'left') with the cumsum taken in KPP_CH-element
+// chunks (inclusive chunk sums csum, one element per lane inside the chunk) in double, clipped to N - 1
+__global__ void kpp_search(const float* __restrict__ prev, const int32_t* __restrict__ sel, int64_t N,
+                           const double* __restrict__ csum, int64_t nchunk, const double* __restrict__ u,
+                           const double* __restrict__ cur_pot, int T, int32_t* __restrict__ idx) {
+  static_assert(KPP_CH == 64, "one element per lane");
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float* v = prev + (int64_t)(*sel) * N;
+  const int lane = threadIdx.x & 63;
+  const double x = u[t] * (*cur_pot);
+  int64_t lo = 0, hi = nchunk;  // first chunk whose inclusive sum >= x
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (csum[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  int64_t res = N;
+  if (lo < nchunk) {
+    const double base = lo ? csum[lo - 1] : 0.0;
+    const int64_t e = lo * KPP_CH + lane;
+    const double part = e < N ? (double)v[e] : 0.0;
+    double run = base, incl = 0.0;
+    for (int l = 0; l < 64; ++l) {                       // sequential inclusive scan in lane order
+      run += __shfl(part, l);
+      if (l == lane) incl = run;
+    }
+    const unsigned long long m = __ballot(incl >= x && e < N);
+    res = m ? lo * KPP_CH + (__ffsll((long long)m) - 1) : ((lo + 1) * KPP_CH < N ? (lo + 1) * KPP_CH : N);
+  }
+  if (res > N - 1) res = N - 1;
+  if (lane == 0) idx[t] = (int32_t)res;
+}
+
 // ------------------------------------ C ABI ------------------------------------------------
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -1120,6 +1299,48 @@ extern "C" int slic_kmeanspp_step(const float* X, int64_t N, int D, int ldx, con
   SLIC_LAUNCH_CHECK();
   kpp_pot<<<dim3(T), dim3(256), 0, S(stream)>>>((const double*)workspace, nblk, T, pot);
   SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+// workspace: newdist [2][T][N] f32 | bpart [nblk][T] f64 | csum [nblk] f64 | cur_pot f64 | cand [T] i32 | sel i32
+extern "C" size_t slic_kmeanspp_run_workspace_bytes(int64_t N, int T) {
+  const int64_t nblk = slic_cdiv(N, KPP_CH);
+  return slic_align_up((size_t)2 * T * N * 4, 256) + slic_align_up((size_t)nblk * T * 8, 256) +
+         slic_align_up((size_t)nblk * 8, 256) + 256 + slic_align_up((size_t)T * 4, 256) + 256;
+}
+
+extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int first, int K, int T,
+                                 const double* uniforms, int32_t* idx_out, void* workspace, void* stream) {
+  SLIC_REQUIRE(X && uniforms && idx_out && workspace, "slic_kmeanspp_run: null pointer");
+  SLIC_REQUIRE(N > 0 && K > 0 && K <= N && first >= 0 && first < N && T >= 1 && T <= PP_TMAX && D % 4 == 0 && ldx % 4 == 0 &&
+               (size_t)T * D * 4 <= 48 * 1024, "slic_kmeanspp_run: need 1 <= T <= %d, D %% 4 == 0, T*D*4 <= 48 KiB", PP_TMAX);
+  hipStream_t st = S(stream);
+  const int64_t nblk = slic_cdiv(N, KPP_CH);
+  SlicCarver w(workspace);
+  float* nd = w.take<float>((size_t)2 * T * N);
+  double* bpart = w.take<double>((size_t)nblk * T);
+  double* csum = w.take<double>((size_t)nblk);
+  double* cur_pot = w.take<double>(1);
+  int32_t* cand = w.take<int32_t>(T);
+  int32_t* sel = w.take<int32_t>(1);
+  // centre 0: one candidate (the uniformly drawn row), no closest yet
+  SLIC_HIP_CHECK(hipMemcpyAsync(cand, &first, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)D * 4, st>>>(X, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart);
+  SLIC_LAUNCH_CHECK();
+  kpp_select<<<dim3(1), dim3(256), 0, st>>>(bpart, nblk, 1, cand, sel, cur_pot, csum, idx_out);
+  SLIC_LAUNCH_CHECK();
+  for (int c = 1; c < K; ++c) {
+    const float* prev = nd + (size_t)((c - 1) & 1) * T * N;
+    float* cur = nd + (size_t)(c & 1) * T * N;
+    kpp_search<<<dim3((unsigned)slic_cdiv(T, 4)), dim3(256), 0, st>>>(prev, sel, N, csum, nblk, uniforms + (size_t)(c - 1) * T,
+                                                                 cur_pot, T, cand);
+    SLIC_LAUNCH_CHECK();
+    if (T <= 8) kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
+    else kpp_dist_rows<16><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
+    SLIC_LAUNCH_CHECK();
+    kpp_select<<<dim3(1), dim3(256), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c);
+    SLIC_LAUNCH_CHECK();
+  }
   return SLIC_OK;
 }
 
