@@ -273,6 +273,25 @@ def main():
             net.train()
             res["secondary"]["extract"] = dict(metric="clips/sec R3D-18 eval-mode forward (embedding extraction), per GPU", value=B / dte,
                                                unit="clips/s", ms_per_batch=dte * 1e3, frac_of_fp32_mfma_roofline=B / dte * 85.17 / 1e3 / FP32_MFMA_PEAK_TFLOPS)
+            # the yaml input size of the shipped configs, 128 x 128 ("also report S = 128"): same step, 1.306x FLOPs
+            x128 = torch.from_numpy(np.random.default_rng(11 + rank).standard_normal((B, 3, 16, 128, 128)).astype(np.float32)).cuda()
+            xs = x
+            try:
+                x = x128                                    # step() closes over x
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.time()
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                dt128 = (time.time() - t1) / 3
+            finally:
+                x = xs
+            res["secondary"]["train_128"] = dict(metric="clips/sec R3D-18+NT-Xent training step at 3x16x128x128, per GPU", value=B / dt128,
+                                                 unit="clips/s", ms_per_step=dt128 * 1e3,
+                                                 frac_of_fp32_mfma_roofline=B / dt128 * GFLOP_PER_CLIP_TRAIN * (128 * 128) / (112 * 112) / 1e3 / FP32_MFMA_PEAK_TFLOPS)
+            del x128
             if world == 1:
                 # the reference-shaped clustering call end to end: KMeans(n_clusters=500, n_init=10) = 10 x (k-means++ + Lloyd, tol 1e-4)
                 from video_similarity_search_amd.clustering import fit_cluster
