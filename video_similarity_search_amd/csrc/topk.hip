@@ -8,9 +8,9 @@
 // Workgroup = 128 queries x one slice of the gallery, walked in 128-row tiles (same LDS staging as
 // kmeans.hip).  MFMA roles: A = gallery tile (rows), B = query tile (cols)  =>  lane (r, h) holds query r and
 // 16 gallery rows per accumulator; the h = 0 lane of each pair owns the query's running top-k (an unsorted
-// k-slot list in LDS + its current worst entry in registers) and also consumes its partner's 16 values.
-// A candidate replaces the worst slot and triggers a k-step rescan — O(k log(Ng/k)) times per query in
-// expectation, negligible next to the 64-cycle MFMAs.  Order: larger s first, ties -> lower gallery index.
+// k-slot binary heap in LDS, root = worst kept entry, mirrored in registers) and also consumes its partner's 16 values.
+// A candidate replaces the root and sifts down: O(log k) per insertion, O(k log(Ng/k)) insertions per query and slice in
+// expectation.  Order: larger s first, ties -> lower gallery index.
 // slic_topk_merge folds the per-slice lists into the final sorted [Nq, k].
 #include "common.h"
 #include <math.h>
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
   if (h == 0)
     for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
   float thr = -INFINITY;     // worst kept entry
-  int thr_i = INT_MAX, thr_slot = 0;
+  int thr_i = INT_MAX;
   const int q = q0 + 32 * wave + r;
 
   const int srow = tid >> 2, scp = tid & 3;
@@ -136,15 +136,25 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
           const bool cand = (h == 0) && (q < Nq) && (gi < gend) && !(self_mask && gi == q) &&
                             tk_better(s, gi, thr, thr_i);
           if (cand) {
-            myv[thr_slot * 32 + r] = s;
-            myi[thr_slot * 32 + r] = gi;
-            float w = INFINITY; int wi = -1, ws = 0;       // rescan for the new worst entry
-            for (int t = 0; t < k; ++t) {
-              const float tv = myv[t * 32 + r];
-              const int ti = myi[t * 32 + r];
-              if (tk_better(w, wi, tv, ti)) { w = tv; wi = ti; ws = t; }
+            // the list is a binary heap whose root (slot 0) is the WORST kept entry: the candidate replaces the root
+            // and sifts down (<= log2 k levels) instead of a k-step rescan for the new worst
+            int pos = 0;
+            for (;;) {
+              const int c1 = 2 * pos + 1, c2 = c1 + 1;
+              if (c1 >= k) break;
+              float cv = myv[c1 * 32 + r];
+              int ci = myi[c1 * 32 + r], cs = c1;
+              if (c2 < k) {
+                const float v2 = myv[c2 * 32 + r];
+                const int i2 = myi[c2 * 32 + r];
+                if (tk_better(cv, ci, v2, i2)) { cv = v2; ci = i2; cs = c2; }       // the worse child
+              }
+              if (!tk_better(s, gi, cv, ci)) break;                                    // candidate is not better: stays here
+              myv[pos * 32 + r] = cv; myi[pos * 32 + r] = ci;                          // worse child moves up
+              pos = cs;
             }
-            thr = w; thr_i = wi; thr_slot = ws;
+            myv[pos * 32 + r] = s; myi[pos * 32 + r] = gi;
+            thr = myv[r]; thr_i = myi[r];
           }
         }
       }
