@@ -19,6 +19,7 @@
 #define TK_BQ 128
 #define TK_BG 128
 #define TK_BK 32
+#define TK_PC 16   // pending candidates per query between heap drains
 
 __device__ __forceinline__ int tk_off(int row, int chunk) {
   return row * TK_BK + ((chunk ^ ((row >> 1) & 7)) << 2);
@@ -35,6 +36,8 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
   float* stage = lds;                                   // [2][2][128*32]
   float* lval = lds + 2 * 2 * TK_BQ * TK_BK;             // [4 waves][k][32]
   int* lidx = (int*)(lval + 4 * k * 32);
+  float* pval_l = (float*)(lidx + 4 * k * 32);          // [4 waves][TK_PC][32] pending candidates (value)
+  int* pidx_l = (int*)(pval_l + 4 * TK_PC * 32);        // [4 waves][TK_PC][32]              (gallery index)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * TK_BQ;
@@ -42,6 +45,9 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
   const int gend = min(gbeg + g_per_slice, Ng);
   float* myv = lval + wave * k * 32;
   int* myi = lidx + wave * k * 32;
+  float* pv = pval_l + wave * TK_PC * 32;
+  int* pi = pidx_l + wave * TK_PC * 32;
+  int pc = 0;                // this lane's pending count
   if (h == 0)
     for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
   float thr = -INFINITY;     // worst kept entry
@@ -122,22 +128,20 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
       if (kt + 1 < nk) lwrite(buf ^ 1);
       __syncthreads();
     }
-    // ---- top-k update: the h == 0 lane of a pair consumes both halves' values
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const float own = acc[ct][v];
-        const float oth = __shfl_xor(own, 32);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const float s = half ? oth : own;
-          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-          const bool cand = (h == 0) && (q < Nq) && (gi < gend) && !(self_mask && gi == q) &&
-                            tk_better(s, gi, thr, thr_i);
-          if (cand) {
+    // ---- top-k update: the h == 0 lane of a pair consumes both halves' values.  A value that beats the lane's current
+    // worst kept entry is only APPENDED to a small pending buffer (O(1), no dependent LDS chain); the buffers are drained
+    // into the heaps when one fills up and at the end of every tile, so the wave pays one sift round per pending entry
+    // of its busiest lane instead of one per element step in which any of its 32 queries has a candidate.
+    auto flush = [&]() {
+      for (int j = 0; j < TK_PC; ++j) {
+        const bool act = j < pc;
+        if (!__any(act)) break;
+        if (act) {
+          const float s = pv[j * 32 + r];
+          const int gi = pi[j * 32 + r];
+          if (tk_better(s, gi, thr, thr_i)) {              // the root may have improved since the append
             // the list is a binary heap whose root (slot 0) is the WORST kept entry: the candidate replaces the root
-            // and sifts down (<= log2 k levels) instead of a k-step rescan for the new worst
+            // and sifts down (<= log2 k levels)
             int pos = 0;
             for (;;) {
               const int c1 = 2 * pos + 1, c2 = c1 + 1;
@@ -158,6 +162,29 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
           }
         }
       }
+      pc = 0;
+    };
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float own = acc[ct][v];
+        const float oth = __shfl_xor(own, 32);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float s = half ? oth : own;
+          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+          const bool cand = (h == 0) && (q < Nq) && (gi < gend) && !(self_mask && gi == q) &&
+                            tk_better(s, gi, thr, thr_i);
+          if (cand) {
+            pv[pc * 32 + r] = s;
+            pi[pc * 32 + r] = gi;
+            ++pc;
+          }
+        }
+        if (__any(pc > TK_PC - 2)) flush();               // at most two appends per step: pc never exceeds TK_PC
+      }
+    flush();
   }
   if (h == 0 && q < Nq) {
     float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
@@ -166,31 +193,49 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
   }
 }
 
-// one thread per query: k rounds of selection over the slices' lists (best = larger s, ties -> lower index)
-__global__ void topk_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx, int slices,
-                                  int Nq, int k, int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+// one WAVE per query: the slices' lists (slices * k entries, unsorted) are spread over the lanes' registers (up to
+// TKM_PER per lane, else the tail is re-read from memory), then k rounds of: lane-local best -> wave arg-best by
+// shuffles -> the owner retires that entry.  Order: larger s first, ties -> lower gallery index.
+#define TKM_PER 32
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                                         int slices, int Nq, int k, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_dist) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Nq) return;
-  float last = INFINITY;
-  int last_i = -1;
+  const int lane = threadIdx.x & 63;
+  const int tot = slices * k;
+  float v[TKM_PER];
+  int ix[TKM_PER];
+#pragma unroll
+  for (int u = 0; u < TKM_PER; ++u) {
+    const int e = lane + 64 * u;                         // entry e = (slice e / k, slot e % k)
+    if (e < tot) {
+      const int sl = e / k, t = e - sl * k;
+      v[u] = pval[((int64_t)sl * Nq + q) * k + t];
+      ix[u] = pidx[((int64_t)sl * Nq + q) * k + t];
+    } else { v[u] = -INFINITY; ix[u] = INT_MAX; }
+  }
   for (int o = 0; o < k; ++o) {
-    float bs = -INFINITY;
-    int bi = INT_MAX;
-    for (int sl = 0; sl < slices; ++sl) {
-      const float* v = pval + ((int64_t)sl * Nq + q) * k;
-      const int32_t* ix = pidx + ((int64_t)sl * Nq + q) * k;
-      for (int t = 0; t < k; ++t) {
-        const float s = v[t];
-        const int i = ix[t];
-        // strictly after (last, last_i) in the order, and better than the current best
-        if (tk_better(last, last_i, s, i) && tk_better(s, i, bs, bi)) { bs = s; bi = i; }
-      }
+    float bs = -INFINITY; int bi = INT_MAX, bu = 0;
+#pragma unroll
+    for (int u = 0; u < TKM_PER; ++u)
+      if (tk_better(v[u], ix[u], bs, bi)) { bs = v[u]; bi = ix[u]; bu = u; }
+    float ws = bs; int wi = bi;
+    for (int d = 32; d > 0; d >>= 1) {
+      const float os = __shfl_xor(ws, d);
+      const int oi = __shfl_xor(wi, d);
+      if (tk_better(os, oi, ws, wi)) { ws = os; wi = oi; }
     }
-    out_idx[(int64_t)q * k + o] = bi == INT_MAX ? -1 : bi;
-    float d = 1.0f - bs;
-    d = fminf(fmaxf(d, 0.f), 2.f);
-    out_dist[(int64_t)q * k + o] = bi == INT_MAX ? INFINITY : d;
-    last = bs; last_i = bi;
+    if (wi == bi && ws == bs && bi != INT_MAX) {         // the owner retires the winner (indices are unique per query)
+#pragma unroll
+      for (int u = 0; u < TKM_PER; ++u) if (u == bu) { v[u] = -INFINITY; ix[u] = INT_MAX; }
+    }
+    if (lane == 0) {
+      out_idx[(int64_t)q * k + o] = wi == INT_MAX ? -1 : wi;
+      float d = 1.0f - ws;
+      d = fminf(fmaxf(d, 0.f), 2.f);
+      out_dist[(int64_t)q * k + o] = wi == INT_MAX ? INFINITY : d;
+    }
   }
 }
 
@@ -259,16 +304,18 @@ extern "C" int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, fl
   return SLIC_OK;
 }
 
-static int topk_slices(int Nq, int Ng) {
+static int topk_slices(int Nq, int Ng, int k) {
   const int qb = (int)slic_cdiv(Nq, TK_BQ);
   int s = (int)slic_cdiv(1024, qb);                 // aim at ~4 workgroups per CU
   const int maxs = (int)slic_cdiv(Ng, 4 * TK_BG);   // at least 4 gallery tiles per slice
   if (s > maxs) s = maxs;
+  const int cap = (64 * TKM_PER) / (k < 1 ? 1 : k); // the merge kernel holds slices * k entries in one wave's registers
+  if (s > cap) s = cap;
   return s < 1 ? 1 : s;
 }
 
 extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
-  return 2 * slic_align_up((size_t)topk_slices(Nq, Ng) * Nq * k * 4, 256);
+  return 2 * slic_align_up((size_t)topk_slices(Nq, Ng, k) * Nq * k * 4, 256);
 }
 
 // Qn, Gn: L2-normalised rows (slic_normalize_rows).  out_idx / out_dist: [Nq, k], ascending distance.
@@ -279,14 +326,14 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
                "slic_cosine_topk: need D %% 8 == 0, 1 <= k <= min(128, Ng) (Nq=%d Ng=%d D=%d k=%d)", Nq, Ng, D, k);
   SLIC_REQUIRE(((uintptr_t)Qn % 16) == 0 && ((uintptr_t)Gn % 16) == 0, "slic_cosine_topk: unaligned");
   hipStream_t st = S_(stream);
-  const int slices = topk_slices(Nq, Ng);
+  const int slices = topk_slices(Nq, Ng, k);
   int per = (int)slic_cdiv(Ng, slices);
   per = (int)slic_cdiv(per, TK_BG) * TK_BG;
   const int S = (int)slic_cdiv(Ng, per);
   SlicCarver w(workspace);
   float* pval = w.take<float>((size_t)slices * Nq * k);
   int32_t* pidx = w.take<int32_t>((size_t)slices * Nq * k);
-  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2) * sizeof(float);
+  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2 + 4 * TK_PC * 32 * 2) * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -295,7 +342,8 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pval, pidx);
   SLIC_LAUNCH_CHECK();
-  topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 64)), dim3(64), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
+  SLIC_REQUIRE((int64_t)S * k <= 64 * TKM_PER, "slic_cosine_topk: slices * k = %d exceeds the merge kernel's %d entries", S * k, 64 * TKM_PER);
+  topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
