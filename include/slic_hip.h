@@ -315,7 +315,7 @@ int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* ou
 int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, float* out, void* stream);
 /* for every row of Qn the k nearest rows of Gn by cosine distance clip(1 - q.g, 0, 2), ascending (ties -> lower
  * gallery index).  Qn/Gn: normalised, dense [N, D], D % 8 == 0.  self_mask != 0 skips j == i
- * (np.fill_diagonal(distance_matrix, inf), evaluate.py:221-222).  k <= 128. */
+ * (np.fill_diagonal(distance_matrix, inf), evaluate.py:221-222).  k <= 88 (the per-query lists live in LDS). */
 size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k);
 int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
                      int32_t* out_idx, float* out_dist, void* workspace, void* stream);

@@ -15,11 +15,13 @@
 #include "common.h"
 #include <math.h>
 #include <limits.h>
+#include <stdlib.h>
 
 #define TK_BQ 128
 #define TK_BG 128
 #define TK_BK 32
-#define TK_PC 16   // pending candidates per query between heap drains
+#define TK_PC_MAX 16   // pending candidates per query between heap drains (fewer when k leaves less LDS)
+#define TK_KMAX 88
 
 __device__ __forceinline__ int tk_off(int row, int chunk) {
   return row * TK_BK + ((chunk ^ ((row >> 1) & 7)) << 2);
@@ -31,7 +33,7 @@ __device__ __forceinline__ bool tk_better(float s, int i, float t, int ti) {
 
 __global__ __launch_bounds__(256) void topk_partial_kernel(
     const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
-    int g_per_slice, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */) {
+    int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* stage = lds;                                   // [2][2][128*32]
   float* lval = lds + 2 * 2 * TK_BQ * TK_BK;             // [4 waves][k][32]
@@ -193,6 +195,173 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
   }
 }
 
+// The same kernel with both operand tiles moved HBM -> LDS by the DMA path (buffer_load ... lds): a 2-stage ring that runs
+// CONTINUOUSLY over (gallery tile, k-tile) pairs — the first k-tile of the next gallery tile is already in flight while
+// the wave drains the current tile's scores into its heaps — counted vmcnt waits, one barrier per k-tile, no branch in the
+// k loop (k-tiles past D are all-zero DMAs).  Natural k order: lane half h of MFMA step t takes k = 8 qd + 4 h + t from
+// both operands, which is just another order of the same dot product.
+__global__ __launch_bounds__(256) void topk_partial_dma(
+    const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
+    int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int STAGE_FLOATS = (TK_BQ + TK_BG) * TK_BK;
+  float* lval = lds + 2 * STAGE_FLOATS;                  // [4 waves][k][32]
+  int* lidx = (int*)(lval + 4 * k * 32);
+  float* pval_l = (float*)(lidx + 4 * k * 32);          // [4 waves][TK_PC][32] pending candidates (value)
+  int* pidx_l = (int*)(pval_l + 4 * TK_PC * 32);        // [4 waves][TK_PC][32]              (gallery index)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * TK_BQ;
+  const int gbeg = blockIdx.y * g_per_slice;
+  const int gend = min(gbeg + g_per_slice, Ng);
+  float* myv = lval + wave * k * 32;
+  int* myi = lidx + wave * k * 32;
+  float* pv = pval_l + wave * TK_PC * 32;
+  int* pi = pidx_l + wave * TK_PC * 32;
+  int pc = 0;
+  if (h == 0)
+    for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
+  float thr = -INFINITY;     // worst kept entry (heap root)
+  int thr_i = INT_MAX;
+  const int q = q0 + 32 * wave + r;
+
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
+  const int qrows = min(TK_BQ, Nq - q0);
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Q + (int64_t)q0 * D), 0, (int)((int64_t)qrows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(G + (int64_t)gbeg * D), 0, (int)((int64_t)(gend - gbeg) * D * 4), 0x00020000);     // rows past the slice: zeros
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned qoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qoff[i] = ((unsigned)(srow + 32 * i) * (unsigned)D + cq * 4) * 4u;
+  const int klim = D - cq * 4;
+  const int nk = (D + TK_BK - 1) / TK_BK;
+  const int nkp = (nk + 1) & ~1;                              // k-tiles per gallery tile, rounded up to the ring length
+  const int ntile = (gend - gbeg + TK_BG - 1) / TK_BG;
+  // issue the DMAs of ring step (tile, kt) — kt may run into the zero padding, tile past the end is all out of range
+  auto issue = [&](int tile, int kt, int stage) {
+    float* Gs = lds + stage * STAGE_FLOATS;
+    float* Qs = Gs + TK_BG * TK_BK;
+    const bool kin = kt * TK_BK < klim && tile < ntile;
+    const unsigned kb = (unsigned)kt * (TK_BK * 4u);
+    const unsigned gb = (unsigned)tile * (unsigned)(TK_BG * D * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(Gs + (8 * wave + 32 * i) * TK_BK),
+                                               16, (int)(kin ? gb + qoff[i] + kb : OOB), 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_q, (__attribute__((address_space(3))) void*)(Qs + (8 * wave + 32 * i) * TK_BK),
+                                               16, (int)(kin ? qoff[i] + kb : OOB), 0, 0, 0);
+  };
+  f32x16 acc[4];
+  auto compute = [&](int stage) {
+    const float* Gs = lds + stage * STAGE_FLOATS;
+    const float* Qs = Gs + TK_BG * TK_BK;
+    f32x4 b[2], a[2][4];
+    b[0] = *(const f32x4*)&Qs[tk_off(32 * wave + r, h)];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) a[0][ct] = *(const f32x4*)&Gs[tk_off(32 * ct + r, h)];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int cur = qd & 1, nxt = cur ^ 1;
+      if (qd < 3) {
+        b[nxt] = *(const f32x4*)&Qs[tk_off(32 * wave + r, 2 * (qd + 1) + h)];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) a[nxt][ct] = *(const f32x4*)&Gs[tk_off(32 * ct + r, 2 * (qd + 1) + h)];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct][t], b[cur][t], acc[ct], 0, 0, 0);
+      if (qd < 3) __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto flush = [&]() {
+    for (int j = 0; j < TK_PC; ++j) {
+      const bool act = j < pc;
+      if (!__any(act)) break;
+      if (act) {
+        const float s = pv[j * 32 + r];
+        const int gi = pi[j * 32 + r];
+        if (tk_better(s, gi, thr, thr_i)) {
+          int pos = 0;
+          for (;;) {
+            const int c1 = 2 * pos + 1, c2 = c1 + 1;
+            if (c1 >= k) break;
+            float cv = myv[c1 * 32 + r];
+            int ci = myi[c1 * 32 + r], cs = c1;
+            if (c2 < k) {
+              const float v2 = myv[c2 * 32 + r];
+              const int i2 = myi[c2 * 32 + r];
+              if (tk_better(cv, ci, v2, i2)) { cv = v2; ci = i2; cs = c2; }
+            }
+            if (!tk_better(s, gi, cv, ci)) break;
+            myv[pos * 32 + r] = cv; myi[pos * 32 + r] = ci;
+            pos = cs;
+          }
+          myv[pos * 32 + r] = s; myi[pos * 32 + r] = gi;
+          thr = myv[r]; thr_i = myi[r];
+        }
+      }
+    }
+    pc = 0;
+  };
+  issue(0, 0, 0);
+  for (int tile = 0; tile < ntile; ++tile) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ct][v] = 0.f;
+    for (int s0 = 0; s0 < nkp; s0 += 2) {
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int kt = s0 + sidx;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool wrap = kt + 1 >= nkp;                       // the next ring step opens the next gallery tile
+        issue(wrap ? tile + 1 : tile, wrap ? 0 : kt + 1, sidx ^ 1);
+        compute(sidx);
+      }
+    }
+    const int g0 = gbeg + tile * TK_BG;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const float own = acc[ct][v];
+        const float oth = __shfl_xor(own, 32);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const float s = half ? oth : own;
+          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+          const bool cand = (h == 0) && (q < Nq) && (gi < gend) && !(self_mask && gi == q) &&
+                            tk_better(s, gi, thr, thr_i);
+          if (cand) {
+            pv[pc * 32 + r] = s;
+            pi[pc * 32 + r] = gi;
+            ++pc;
+          }
+        }
+        if (__any(pc > TK_PC - 2)) flush();
+      }
+    flush();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (h == 0 && q < Nq) {
+    float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
+    int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq + q) * k;
+    for (int s = 0; s < k; ++s) { ov[s] = myv[s * 32 + r]; oi[s] = myi[s * 32 + r]; }
+  }
+}
+
 // one WAVE per query: the slices' lists (slices * k entries, unsorted) are spread over the lanes' registers (up to
 // TKM_PER per lane, else the tail is re-read from memory), then k rounds of: lane-local best -> wave arg-best by
 // shuffles -> the owner retires that entry.  Order: larger s first, ties -> lower gallery index.
@@ -305,13 +474,26 @@ extern "C" int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, fl
 }
 
 static int topk_slices(int Nq, int Ng, int k) {
+  // The LDS lists allow ONE workgroup per CU, so the grid (query blocks x gallery slices) should be a whole number of
+  // 256-workgroup rounds: among the slice counts that give 3+ rounds (if the gallery allows), take the one that fills its
+  // last round best — e.g. 79 query blocks: 13 slices = 1027 workgroups = 4 rounds + 3 stragglers (80 %), 16 slices =
+  // 1264 = 4.94 rounds (99 %).
   const int qb = (int)slic_cdiv(Nq, TK_BQ);
-  int s = (int)slic_cdiv(1024, qb);                 // aim at ~4 workgroups per CU
-  const int maxs = (int)slic_cdiv(Ng, 4 * TK_BG);   // at least 4 gallery tiles per slice
-  if (s > maxs) s = maxs;
-  const int cap = (64 * TKM_PER) / (k < 1 ? 1 : k); // the merge kernel holds slices * k entries in one wave's registers
-  if (s > cap) s = cap;
-  return s < 1 ? 1 : s;
+  int maxs = (int)slic_cdiv(Ng, 4 * TK_BG);               // at least 4 gallery tiles per slice
+  const int cap = (64 * TKM_PER) / (k < 1 ? 1 : k);       // the merge kernel holds slices * k entries in one wave's registers
+  if (maxs > cap) maxs = cap;
+  if (maxs < 1) maxs = 1;
+  int lo = (int)slic_cdiv(3 * 256, qb);
+  if (lo > maxs) lo = maxs;
+  int hi = 2 * lo + 1 < maxs ? 2 * lo + 1 : maxs;
+  int best = lo;
+  double beff = -1.0;
+  for (int s = lo; s <= hi; ++s) {
+    const int64_t blocks = (int64_t)qb * s;
+    const double eff = (double)blocks / (double)(slic_cdiv(blocks, 256) * 256);
+    if (eff > beff + 0.01) { beff = eff; best = s; }
+  }
+  return best;
 }
 
 extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
@@ -322,8 +504,8 @@ extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
 extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
                                 int32_t* out_idx, float* out_dist, void* workspace, void* stream) {
   SLIC_REQUIRE(Qn && Gn && out_idx && out_dist && workspace, "slic_cosine_topk: null pointer");
-  SLIC_REQUIRE(Nq > 0 && Ng > 0 && D > 0 && D % 8 == 0 && k >= 1 && k <= 128 && k <= Ng,
-               "slic_cosine_topk: need D %% 8 == 0, 1 <= k <= min(128, Ng) (Nq=%d Ng=%d D=%d k=%d)", Nq, Ng, D, k);
+  SLIC_REQUIRE(Nq > 0 && Ng > 0 && D > 0 && D % 8 == 0 && k >= 1 && k <= TK_KMAX && k <= Ng,
+               "slic_cosine_topk: need D %% 8 == 0, 1 <= k <= min(%d, Ng) (Nq=%d Ng=%d D=%d k=%d)", TK_KMAX, Nq, Ng, D, k);
   SLIC_REQUIRE(((uintptr_t)Qn % 16) == 0 && ((uintptr_t)Gn % 16) == 0, "slic_cosine_topk: unaligned");
   hipStream_t st = S_(stream);
   const int slices = topk_slices(Nq, Ng, k);
@@ -333,14 +515,26 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   SlicCarver w(workspace);
   float* pval = w.take<float>((size_t)slices * Nq * k);
   int32_t* pidx = w.take<int32_t>((size_t)slices * Nq * k);
-  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2 + 4 * TK_PC * 32 * 2) * sizeof(float);
+  int pcap = (int)((160 * 1024 - (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2) * sizeof(float)) / (4 * 32 * 2 * sizeof(float)));
+  pcap = pcap > TK_PC_MAX ? TK_PC_MAX : (pcap & ~1);
+  SLIC_REQUIRE(pcap >= 4, "slic_cosine_topk: k = %d leaves no LDS for the pending buffers", k);
+  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2 + 4 * pcap * 32 * 2) * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
   dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
-  topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pval, pidx);
+  static const int use_dma = getenv("SLIC_TOPK_DMA") ? atoi(getenv("SLIC_TOPK_DMA")) : 1;
+  if (use_dma && (int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31)) {
+    static size_t lds_set2 = 0;
+    if (lds > lds_set2) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set2 = lds;
+    }
+    topk_partial_dma<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx);
+  } else
+  topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx);
   SLIC_LAUNCH_CHECK();
   SLIC_REQUIRE((int64_t)S * k <= 64 * TKM_PER, "slic_cosine_topk: slices * k = %d exceeds the merge kernel's %d entries", S * k, 64 * TKM_PER);
   topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
