@@ -222,9 +222,10 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   int pc = 0;
   if (h == 0)
     for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
-  float thr = -INFINITY;     // worst kept entry (heap root)
-  int thr_i = INT_MAX;
   const int q = q0 + 32 * wave + r;
+  const bool owner = h == 0 && q < Nq;                       // this lane keeps query q's list
+  float thr = owner ? -INFINITY : INFINITY;                  // worst kept entry (heap root); +inf: never a candidate
+  int thr_i = owner ? INT_MAX : -1;
 
   const int srow = tid >> 3;
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
@@ -292,20 +293,25 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
         const float s = pv[j * 32 + r];
         const int gi = pi[j * 32 + r];
         if (tk_better(s, gi, thr, thr_i)) {
+          // 4-ary heap, root (slot 0) = worst kept entry: the four children of a node are read together (one LDS round
+          // trip per level, log4 k levels), the worst of them moves up while it is worse than the candidate
           int pos = 0;
           for (;;) {
-            const int c1 = 2 * pos + 1, c2 = c1 + 1;
-            if (c1 >= k) break;
-            float cv = myv[c1 * 32 + r];
-            int ci = myi[c1 * 32 + r], cs = c1;
-            if (c2 < k) {
-              const float v2 = myv[c2 * 32 + r];
-              const int i2 = myi[c2 * 32 + r];
-              if (tk_better(cv, ci, v2, i2)) { cv = v2; ci = i2; cs = c2; }
+            const int c0 = 4 * pos + 1;
+            if (c0 >= k) break;
+            float cv[4]; int ci[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int c = c0 + u < k ? c0 + u : c0;          // clamp: a repeated child never wins over the original
+              cv[u] = myv[c * 32 + r]; ci[u] = myi[c * 32 + r];
             }
-            if (!tk_better(s, gi, cv, ci)) break;
-            myv[pos * 32 + r] = cv; myi[pos * 32 + r] = ci;
-            pos = cs;
+            float wv = cv[0]; int wi = ci[0], ws = c0;
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+              if (c0 + u < k && tk_better(wv, wi, cv[u], ci[u])) { wv = cv[u]; wi = ci[u]; ws = c0 + u; }
+            if (!tk_better(s, gi, wv, wi)) break;
+            myv[pos * 32 + r] = wv; myi[pos * 32 + r] = wi;
+            pos = ws;
           }
           myv[pos * 32 + r] = s; myi[pos * 32 + r] = gi;
           thr = myv[r]; thr_i = myi[r];
@@ -332,6 +338,20 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
       }
     }
     const int g0 = gbeg + tile * TK_BG;
+    // rare exclusions are applied to the scores up front (wave-uniform tests), so the per-element test below is one compare:
+    // gallery rows past the slice (last tile only) and the query itself (self_mask, only where the ranges meet)
+    const bool ragged = g0 + TK_BG > gend;
+    const bool selfhit = self_mask && g0 < q0 + 32 * wave + 32 && g0 + TK_BG > q0 + 32 * wave;
+    if (ragged || selfhit) {
+      const int qo = q0 + 32 * wave + r;                       // both halves of a lane pair serve query r
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (gi >= gend || (self_mask && gi == qo)) acc[ct][v] = -INFINITY;
+        }
+    }
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -341,13 +361,13 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const float s = half ? oth : own;
-          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-          const bool cand = (h == 0) && (q < Nq) && (gi < gend) && !(self_mask && gi == q) &&
-                            tk_better(s, gi, thr, thr_i);
-          if (cand) {
-            pv[pc * 32 + r] = s;
-            pi[pc * 32 + r] = gi;
-            ++pc;
+          if (s >= thr) {                                      // thr = +inf on lanes that own no list
+            const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+            if ((s > thr || gi < thr_i) && s > -INFINITY) {
+              pv[pc * 32 + r] = s;
+              pi[pc * 32 + r] = gi;
+              ++pc;
+            }
           }
         }
         if (__any(pc > TK_PC - 2)) flush();
