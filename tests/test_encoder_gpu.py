@@ -248,6 +248,32 @@ def test_tiny_encoder_train_step_vs_reference_golden(gpu, golden_dir):
     np.testing.assert_allclose(ev.cpu().numpy(), enc["eval/emb"], atol=5e-4, rtol=1e-3)
 
 
+def test_two_live_forward_passes_fused_equals_unfused(gpu, monkeypatch):
+    """Tripletnet-style use: two train-mode passes of the SAME module are alive when backward runs.  The BatchNorm-backward
+    fusion side channel is keyed by pass, so it must give the gradients of the unfused path (SLIC_BN_FUSE=0)."""
+    from video_similarity_search_amd.models import generate_model
+    kw = dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32)
+    rng = np.random.default_rng(3)
+    x1 = torch.from_numpy(rng.standard_normal((4, 3, 8, 32, 32)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((4, 3, 8, 32, 32)).astype(np.float32)).cuda()
+    torch.manual_seed(0)
+    m = generate_model(18, **kw).cuda().train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+
+    def grads(fuse):
+        monkeypatch.setenv("SLIC_BN_FUSE", fuse)
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        y1, y2 = m(x1), m(x2)
+        ((y1 * y2).sum() + (y1 ** 2).sum()).backward()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    g1, g0 = grads("1"), grads("0")
+    for k in g0:
+        ref = g0[k]
+        assert torch.allclose(g1[k], ref, atol=1e-5 + 2e-4 * ref.abs().max().item(), rtol=0), k
+
+
 def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
     """BASELINE config 1 shape (2 x 3 x 16 x 112 x 112) on the real R3D-18: eval and train-mode embeddings within
     1e-4 of the CPU oracle; one train step's loss and a few gradients"""

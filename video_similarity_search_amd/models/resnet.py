@@ -14,6 +14,7 @@ Function — NDHWC activations, fp32 MFMA gather-GEMM convs with fused BatchNorm
 deterministic reductions.  There is no PyTorch/CPU fallback path.
 """
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -103,8 +104,11 @@ class _Engine:
                 self.layer_blocks[-1].append((blk, p1, p2, pd))
                 dims = p2.out_dims
         self.final_dims = dims
-        self._live = {}        # si -> saved context of the segment's pending backward (set by _SegmentFn.forward)
-        self._prefused = {}    # si -> (data_ptr, shape, partial sums) of a gradient whose ReLU mask + BN sums are already done
+        # Side channel between the autograd nodes of ONE forward pass (keys carry the pass id, so several passes of the same
+        # module that are alive at once — Tripletnet's three, gradient accumulation — never see each other's tensors):
+        self._pass_id = 0
+        self._live = {}        # (pass, si) -> weakref to the saved context of that segment's pending backward
+        self._prefused = {}    # (pass, si) -> (data_ptr, shape, partial sums) of a gradient whose ReLU mask + BN sums are done
         self.feat = self.blocks[-1][2].N
         if net.projection_head:
             self.fc1 = ConvPlan(net.fc1.in_features, net.fc1.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
@@ -259,8 +263,13 @@ class _Engine:
             ctx.update(h1=h1, ah=ah, bnp=bnp)
         return y.view(B, -1), ctx
 
-    def seg_backward(self, si, ctx, dout):
-        """returns (gradient wrt the segment input or None, {parameter: gradient})"""
+    def _live_ctx(self, pid, si):
+        ref = self._live.get((pid, si))
+        holder = ref() if ref is not None else None
+        return holder.d if holder is not None else None
+
+    def seg_backward(self, si, ctx, dout, pid=None):
+        """returns (gradient wrt the segment input or None, {parameter: gradient}); pid = forward pass the context is from"""
         net = self.net
         grads = {}
         B = dout.shape[0]
@@ -326,7 +335,7 @@ class _Engine:
             blocks = list(zip(self.layer_blocks[si - 1], ctx["blocks"]))
             fuse = os.environ.get("SLIC_BN_FUSE", "1") != "0"
             pre = None          # (g, partial) when the previous dgrad already produced this block's masked gradient + sums
-            pf = self._prefused.pop(si, None)
+            pf = self._prefused.pop((pid, si), None)
             if pf is not None and pf[0] == dout.data_ptr() and pf[1] == tuple(dout.shape):
                 pre = (dout, pf[2])
             for bi in reversed(range(len(blocks))):
@@ -361,7 +370,7 @@ class _Engine:
                     pb = blocks[bi - 1][1]
                     below = (pb["out"], pb["z2"], pb["b2"])
                 elif fuse and bi == 0:
-                    prev = self._live.get(si - 1)
+                    prev = self._live_ctx(pid, si - 1)
                     if prev is not None and si - 1 == 0:
                         below = (prev["a0"], prev["z0"], prev["bn0"])
                     elif prev is not None:
@@ -384,13 +393,13 @@ class _Engine:
                     dout = None
                 elif below is not None:
                     dout, part = res             # crosses the segment boundary through autograd: the sums travel beside it
-                    self._prefused[si - 1] = (dout.data_ptr(), tuple(dout.shape), part)
+                    self._prefused[(pid, si - 1)] = (dout.data_ptr(), tuple(dout.shape), part)
                 else:
                     dout = res
             join()
             return dout, grads
         # stem: a0 = relu(bn1(conv1(x4))); the clip needs no gradient
-        pf = self._prefused.pop(0, None)
+        pf = self._prefused.pop((pid, 0), None)
         if pf is not None and pf[0] == dout.data_ptr() and pf[1] == tuple(dout.shape):
             dz0, dg0, db0 = self._bn_bwd_fused(pf[2], dout, ctx["z0"], ctx["bn0"])
         else:
@@ -414,12 +423,28 @@ class _Engine:
         """dy: [B, out_dim].  Returns {parameter: gradient} (reference layouts)."""
         grads = {}
         d = dy
-        self._live = dict(enumerate(ctxs))
-        self._prefused = {}
-        for si in reversed(range(self.N_SEG)):
-            d, g = self.seg_backward(si, ctxs[si], d)
-            grads.update(g)
+        self._pass_id += 1
+        pid = self._pass_id
+        holders = [_Saved(c) for c in ctxs]                # kept alive for the duration of this call
+        for si, hd in enumerate(holders):
+            self._live[(pid, si)] = weakref.ref(hd)
+        try:
+            for si in reversed(range(self.N_SEG)):
+                d, g = self.seg_backward(si, ctxs[si], d, pid)
+                grads.update(g)
+        finally:
+            for si in range(self.N_SEG):
+                self._live.pop((pid, si), None)
+                self._prefused.pop((pid, si), None)
         return grads
+
+
+class _Saved:
+    """weak-referenceable holder of a segment's saved context (dicts are not)"""
+    __slots__ = ("d", "__weakref__")
+
+    def __init__(self, d):
+        self.d = d
 
 
 class _SegmentFn(torch.autograd.Function):
@@ -435,16 +460,24 @@ class _SegmentFn(torch.autograd.Function):
         elif si <= 4:
             saved["blocks"][-1]["out"] = out.detach()
         ctx.engine, ctx.si, ctx.saved, ctx.params = engine, si, saved, params
-        engine._live[si] = saved      # the segment above fuses this segment's last ReLU/BatchNorm backward into its dgrad
-        engine._prefused.pop(si, None)
+        if si == 0:
+            engine._pass_id += 1
+            if len(engine._live) > 64:                     # drop entries of passes whose graphs were freed without a backward
+                for key in [k for k, ref in engine._live.items() if ref() is None]:
+                    engine._live.pop(key, None)
+                    engine._prefused.pop(key, None)
+        ctx.pid = engine._pass_id
+        ctx.holder = _Saved(saved)    # the segment above fuses this segment's last ReLU/BatchNorm backward into its dgrad
+        engine._live[(ctx.pid, si)] = weakref.ref(ctx.holder)
         ctx.inp_grad = inp.requires_grad
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        dinp, grads = ctx.engine.seg_backward(ctx.si, ctx.saved, dout)
+        dinp, grads = ctx.engine.seg_backward(ctx.si, ctx.saved, dout, ctx.pid)
         ctx.saved = None
-        ctx.engine._live.pop(ctx.si, None)
+        ctx.holder = None
+        ctx.engine._live.pop((ctx.pid, ctx.si), None)
         return (dinp if ctx.inp_grad else None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
