@@ -46,6 +46,14 @@ open(os.path.join(out, f"{tag}_kernel_stats_bench_steps5.csv"), "w").write(open(
 fetch, nf = counter_mean("pmc_fetch", "FETCH_SIZE")
 write, nw = counter_mean("pmc_write", "WRITE_SIZE")
 tr, nt = trace_mean("stats")
+sq = {}
+if find("pmc_sq", "*counter_collection.csv"):
+    for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                 "GRBM_GUI_ACTIVE"):
+        try:
+            sq[name] = counter_mean("pmc_sq", name)[0]
+        except Exception:
+            pass
 res = {
     "FETCH_SIZE_KB_mean": fetch, "FETCH_SIZE_launches": nf, "WRITE_SIZE_KB_mean": write, "WRITE_SIZE_launches": nw,
     "note": f"{KERNEL.replace(', ', ',')} at the layer1 shape (grid 12544 x 256 threads: M=1605632, N=64, K=1728; B=32): 4 forward "
@@ -57,6 +65,13 @@ res = {
     "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
     "rocprof_trace_avg_ms": tr, "rocprof_trace_launches": nt,
     "hip_event_avg_ms": p["roofline"]["ms_per_launch"],
+    "sq_counters_per_launch": sq,
 }
+if sq.get("SQ_VALU_MFMA_BUSY_CYCLES") and sq.get("GRBM_GUI_ACTIVE"):
+    # MFMA pipe busy cycles summed over the 1024 SIMDs / (elapsed cycles x 1024); GRBM_GUI_ACTIVE comes summed over the 8
+    # XCDs, so elapsed = GUI_ACTIVE / 8.  (The busy count equals 64 cycles x the launch's 86.7 M v_mfma_f32_32x32x2_f32.)
+    res["mfma_busy_fraction"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if sq.get("SQ_WAVE_CYCLES"):
+        res["wave_cycle_split"] = {k: sq[k] / sq["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in sq}
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_conv_gemm_dma.json"), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("hbm_bytes_per_launch", "rocprof_trace_avg_ms", "hip_event_avg_ms")}), d["value"], p["value"])

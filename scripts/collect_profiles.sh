@@ -10,6 +10,7 @@ timeout 600 python "$R/bench.py" > "$S/default.log" 2>&1 < /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats" -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$S/stats.log" 2>&1 < /dev/null
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$S/pmc_fetch" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_fetch.log" 2>&1 < /dev/null
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$S/pmc_write" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_write.log" 2>&1 < /dev/null
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$S/pmc_sq" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_sq.log" 2>&1 < /dev/null
 # keep the merge-back small: per-kernel csvs only
 find "$S" -name "*agent_info.csv" -delete
 du -sh "$S"; ls "$S"
