@@ -115,6 +115,8 @@ int slic_kmeans_apply_relocation(const float* xfar, int ldf, const int32_t* old_
 int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts, int K, int D,
                          float* C_new, float* shift /* [K] */, float* cnorm_new /* [K] or NULL */,
                          float* C_new_perm /* [K][D] in slic_kmeans_permute_k8 order, or NULL */,
+                         int spherical /* 1: C_new rows are L2-normalised means (spherical k-means,
+                                          clustering/cluster_masks.py:73-77 -> spherecluster) */,
                          const int32_t* n_changed, double* status, void* stream);
 
 /* One whole single-GPU Lloyd iteration enqueued by one call: *n_changed = 0; slic_kmeans_assign_perm(Xp, Cp_old,
@@ -125,8 +127,8 @@ size_t slic_kmeans_lloyd_step_workspace_bytes(int64_t N, int K);
 int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N, int D, int ldx, const float* C_old,
                            const float* Cp_old, const float* cnorm_old, int K, int32_t* labels,
                            const int32_t* labels_old, int32_t* n_changed, float* sums, float* counts,
-                           float* C_new, float* Cp_new, float* cnorm_new, float* shift, double* status,
-                           void* workspace, void* stream);
+                           float* C_new, float* Cp_new, float* cnorm_new, float* shift, int spherical,
+                           double* status, void* workspace, void* stream);
 
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
  * order) — X.mean(axis=0) and np.var(X, axis=0) of KMeans.fit / _tolerance

@@ -165,3 +165,36 @@ def kmeans_fit(X, init_list, max_iter=300, tol=1e-4, n_shards=1):
     best["centers"] = best["centers"] + mean
     best["tol_abs"] = tol_abs
     return best
+
+
+def spherical_lloyd(X, init, max_iter=300, tol=1e-4):
+    """PARITY UNPINNED.  spherecluster.SphericalKMeans (the package behind clustering/cluster_masks.py:73-77, pinned
+    nowhere in the reference and absent from this image) restated from its published algorithm
+    (_spherical_kmeans_single_lloyd): rows and initial centres L2-normalised, then repeat
+    { euclidean assignment; centres = normalize(cluster means); stop when ||centres - centres_old||^2 <= tol (as given,
+    not variance-scaled) }, a final relabelling if the last shift was non-zero.  float64 numpy; empty clusters keep a zero
+    centre until relocation, which the small test cases never hit.  Returns (labels, centres, n_iter)."""
+    X = np.asarray(X, np.float64)
+    X = X / np.linalg.norm(X, axis=1, keepdims=True)
+    C = np.asarray(init, np.float64)
+    K = C.shape[0]
+    n_iter, shift = 0, 1.0
+    labels = None
+    for it in range(max_iter):
+        d = (X * X).sum(1)[:, None] - 2.0 * X @ C.T + (C * C).sum(1)[None, :]
+        labels = d.argmin(1)
+        Cn = np.zeros_like(C)
+        np.add.at(Cn, labels, X)
+        cnt = np.bincount(labels, minlength=K).astype(np.float64)
+        Cn = Cn / np.maximum(cnt, 1)[:, None]
+        nrm = np.linalg.norm(Cn, axis=1, keepdims=True)
+        Cn = np.where(nrm > 0, Cn / np.where(nrm > 0, nrm, 1), Cn)
+        shift = float(((Cn - C) ** 2).sum())
+        C = Cn
+        n_iter = it + 1
+        if shift <= tol:
+            break
+    if shift > 0:
+        d = (X * X).sum(1)[:, None] - 2.0 * X @ C.T + (C * C).sum(1)[None, :]
+        labels = d.argmin(1)
+    return labels.astype(np.int32), C, n_iter

@@ -63,9 +63,19 @@ class OracleKernels:
         sums.copy_(torch.from_numpy(s))
         counts.copy_(torch.from_numpy(c))
 
-    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None):
+    def l2norm_rows(self, X, out):
+        x = _np(X).astype(np.float64)
+        out.copy_(torch.from_numpy((x / np.sqrt((x * x).sum(1, keepdims=True))).astype(np.float32)))
+
+    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None, spherical=False):
         K, Dp = C_old.shape
         new, sh, tot = ok.finalize(_np(C_old), _np(sums).reshape(K, Dp), _np(counts))
+        if spherical:
+            nrm = np.sqrt((new.astype(np.float32) ** 2).sum(1, keepdims=True, dtype=np.float32))
+            new = np.where(nrm > 0, new / np.where(nrm > 0, nrm, 1), new).astype(np.float32)
+            d = (new - _np(C_old)).astype(np.float64)
+            sh = np.sqrt((d * d).sum(1)).astype(np.float32)
+            tot = float((sh.astype(np.float64) ** 2).sum())
         C_new.copy_(torch.from_numpy(new))
         if cnorm_new is not None:
             cnorm_new.copy_(torch.from_numpy(ok.row_sqnorm_chain(np.ascontiguousarray(new))))

@@ -202,3 +202,33 @@ def test_kmeanspp_run_matches_stepwise(gpu):
     got = idx.cpu().numpy().tolist()
     assert got[0] == first and len(set(got)) == K
     assert got == ref
+
+
+def test_spherical_kmeans_matches_restatement(gpu):
+    """spherical k-means (clustering/cluster_masks.py:73-77).  Its oracle (spherecluster) is not
+    vendored, so parity is UNPINNED: the HIP path is checked against oracle.kmeans.spherical_lloyd (the published
+    algorithm in float64) from the same explicit unit-norm init, and against the definition's invariants."""
+    from oracle import kmeans as ok
+    from video_similarity_search_amd.clustering import KMeans, fit_cluster
+    rng = np.random.default_rng(31)
+    N, D, K = 4000, 64, 12
+    cen = rng.standard_normal((K, D))
+    cen /= np.linalg.norm(cen, axis=1, keepdims=True)
+    z = rng.integers(0, K, N)
+    X = (cen[z] + 0.25 * rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32) * rng.uniform(0.5, 3.0, (N, 1)).astype(np.float32)
+    Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+    # one seed per true cluster, from two mixed points each, so no cluster runs empty (relocation is not part of the restatement)
+    init = np.stack([Xn[np.flatnonzero(z == j)[:2]].sum(0) for j in range(K)])
+    init = (init / np.linalg.norm(init, axis=1, keepdims=True)).astype(np.float32)
+    perm = rng.permutation(K)
+    init = init[perm]
+    ref_labels, ref_C, ref_iter = ok.spherical_lloyd(X, init)
+    km = KMeans(n_clusters=K, init=init, n_init=1, spherical=True).fit(torch.from_numpy(X).cuda())
+    assert np.array_equal(km.labels_, ref_labels)
+    assert km.n_iter_ == ref_iter
+    np.testing.assert_allclose(km.cluster_centers_, ref_C, atol=2e-6, rtol=0)
+    np.testing.assert_allclose(np.linalg.norm(km.cluster_centers_, axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(km.labels_, (Xn @ km.cluster_centers_.T).argmax(1))          # nearest centre = largest cosine
+    labels = fit_cluster(torch.from_numpy(X), method="spherical_kmeans", k=K)
+    from sklearn.metrics import normalized_mutual_info_score as nmi
+    assert labels.shape == (N,) and nmi(labels, ref_labels) > 0.9

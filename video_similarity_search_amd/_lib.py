@@ -29,10 +29,10 @@ SIGNATURES = {
     "slic_sum_f32_to_f64": (I, [P, L, P, P, P]),
     "slic_kmeans_select_far": (I, [P, L, I, P, P, P]),
     "slic_kmeans_apply_relocation": (I, [P, I, P, P, I, I, P, P, P]),
-    "slic_kmeans_finalize": (I, [P, P, P, I, I, P, P, P, P, P, P, P]),
+    "slic_kmeans_finalize": (I, [P, P, P, I, I, P, P, P, P, I, P, P, P]),
     "slic_kmeans_permute_k8": (I, [P, L, I, I, P, I, P]),
     "slic_kmeans_lloyd_step_workspace_bytes": (c_size_t, [L, I]),
-    "slic_kmeans_lloyd_step": (I, [P, P, L, I, I, P, P, P, I, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "slic_kmeans_lloyd_step": (I, [P, P, L, I, I, P, P, P, I, P, P, P, P, P, P, P, P, P, I, P, P, P]),
     "slic_kmeans_assign_perm": (I, [P, L, I, I, P, I, I, P, P, P, P, P, P, P]),
     "slic_col_stats_workspace_bytes": (c_size_t, [L, I]),
     "slic_col_stats": (I, [P, L, I, I, P, P, P, P]),

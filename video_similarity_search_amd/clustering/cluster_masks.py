@@ -52,16 +52,24 @@ def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, fi
         print('Taking partition {} from finch'.format(PARTITION))
         print("Fitted " + str(n_clusters) + " clusters with " + str(method))
         return labels
-    if method != 'kmeans':
+    if method not in ('kmeans', 'spherical_kmeans'):
         raise NotImplementedError(
-            f"method={method!r}: 'kmeans' and 'finch' are on the MI355X hot path (SURVEY.md §8); the reference runs "
-            "the others on the host through sklearn")
-    print("k:", k)
+            f"method={method!r}: 'kmeans', 'spherical_kmeans' and 'finch' are on the MI355X hot path (SURVEY.md §8); the "
+            "reference runs the others on the host through sklearn")
     x = _to_device(embeddings)
-    if l2normalize:
-        x = preprocess_features_kmeans(x)
-    km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group,
-                random_state=random_state).fit(x)
+    if method == 'spherical_kmeans':
+        # cluster_masks.py:73-77: SphericalKMeans(n_clusters=k).fit(embeddings) (spherecluster: normalises the rows itself,
+        # n_init=10, k-means++, centres renormalised every iteration).  spherecluster is not vendored: parity unpinned.
+        print('clustering with spherical kmeans with k={}'.format(k))
+        print(tuple(x.shape))
+        km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group, random_state=random_state,
+                    spherical=True).fit(x)
+    else:
+        print("k:", k)
+        if l2normalize:
+            x = preprocess_features_kmeans(x)
+        km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group,
+                    random_state=random_state).fit(x)
     labels = km.labels_
     print(labels.shape)
     n_clusters = len(set(labels.tolist())) - (1 if -1 in labels else 0)

@@ -76,7 +76,7 @@ class HipKernels:
              ptr(labels_old), ptr(n_changed), None, ptr(ws), stream())
 
     def lloyd_step(self, X, Xp, C_old, Cp_old, cnorm_old, labels, labels_old, n_changed, sums, counts, C_new, Cp_new,
-                   cnorm_new, shift, status):
+                   cnorm_new, shift, status, spherical=False):
         """one whole unsharded iteration in one foreign call (the Python loop is otherwise the bottleneck at ~0.6 ms)"""
         N, Dp = X.shape
         K = C_old.shape[0]
@@ -84,7 +84,10 @@ class HipKernels:
         ws = _lib.workspace(_lib.load().slic_kmeans_lloyd_step_workspace_bytes(N, K), X.device, "km_step")
         call("slic_kmeans_lloyd_step", ptr(X), ptr(Xp), N, Dp, X.stride(0), ptr(C_old), ptr(Cp_old), ptr(cnorm_old), K,
              ptr(labels), ptr(labels_old), ptr(n_changed), ptr(sums), ptr(counts), ptr(C_new), ptr(Cp_new), ptr(cnorm_new),
-             ptr(shift), ptr(status), ptr(ws), stream())
+             ptr(shift), int(spherical), ptr(status), ptr(ws), stream())
+
+    def l2norm_rows(self, X, out):
+        call("slic_l2norm_rows", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(out), out.stride(0), stream())
 
     def kpp_run(self, X, first, K, T, uniforms, idx_out):
         N, Dp = X.shape
@@ -103,10 +106,10 @@ class HipKernels:
         call("slic_kmeans_combine_shards", ptr(allpart), ptr(allpart[0, K * Dp:]), stride, W, K, Dp,
              ptr(sums), ptr(counts), stream())
 
-    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None, C_new_perm=None):
+    def finalize(self, C_old, sums, counts, C_new, shift, n_changed, status, cnorm_new=None, C_new_perm=None, spherical=False):
         K, Dp = C_old.shape
         call("slic_kmeans_finalize", ptr(C_old), ptr(sums), ptr(counts), K, Dp, ptr(C_new), ptr(shift),
-             ptr(cnorm_new), ptr(C_new_perm), ptr(n_changed), ptr(status), stream())
+             ptr(cnorm_new), ptr(C_new_perm), int(spherical), ptr(n_changed), ptr(status), stream())
 
     def dist_to_assigned(self, X, C, labels, dist):
         call("slic_kmeans_dist_to_assigned", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(C), C.stride(0),
@@ -148,7 +151,7 @@ class KMeans:
     copied to the current device)."""
 
     def __init__(self, n_clusters, n_init=10, max_iter=300, tol=1e-4, init="k-means++", random_state=None,
-                 process_group=None, fixed_iters=False, trace=False, kernels=None):
+                 process_group=None, fixed_iters=False, trace=False, kernels=None, spherical=False):
         self.n_clusters = int(n_clusters)
         self.n_init = int(n_init)
         self.max_iter = int(max_iter)
@@ -158,6 +161,9 @@ class KMeans:
         self.process_group = process_group
         self.fixed_iters = bool(fixed_iters)   # throughput runs: skip the stopping tests
         self.trace = bool(trace)               # keep every iteration's labels (tests)
+        # spherical k-means (clustering/cluster_masks.py:73-77 -> spherecluster.SphericalKMeans): rows L2-normalised, no
+        # mean-centring, centres renormalised after every averaging, tol compared unscaled
+        self.spherical = bool(spherical)
         self.k = kernels if kernels is not None else HipKernels()
 
     # ------------------------------------------------------------------ helpers
@@ -210,14 +216,23 @@ class KMeans:
         else:
             self._row0, self._sizes, Ng = 0, np.array([N]), N
 
-        # X -= X.mean(axis=0)   (_kmeans.py:1479-1481)
-        cs = self._col_stats(X)
-        mean = (cs[0] / float(Ng)).astype(np.float32)
-        mean_d = torch.from_numpy(mean).to(dev)
-        Xc = torch.empty_like(X)
-        self.k.sub_rowvec(X, mean_d, Xc)
+        if self.spherical:
+            # SphericalKMeans.fit: X = normalize(X); the data is NOT centred and tol is used as given
+            mean = np.zeros(Dp, np.float32)
+            Xc = torch.empty_like(X)
+            self.k.l2norm_rows(X, Xc)
+            tol_abs = self.tol
+        else:
+            # X -= X.mean(axis=0)   (_kmeans.py:1479-1481)
+            cs = self._col_stats(X)
+            mean = (cs[0] / float(Ng)).astype(np.float32)
+            mean_d = torch.from_numpy(mean).to(dev)
+            Xc = torch.empty_like(X)
+            self.k.sub_rowvec(X, mean_d, Xc)
         # tol = mean(var(Xc, axis=0)) * tol   (_tolerance, _kmeans.py:279-288)
-        if self.tol == 0:
+        if self.spherical:
+            pass
+        elif self.tol == 0:
             tol_abs = 0.0
         else:
             cs2 = self._col_stats(Xc)
@@ -273,6 +288,7 @@ class KMeans:
         Lb = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in range(3)]      # labels of iteration it: Lb[it%3]
         cnorm = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(3)]        # norms of Cb[i]: written by finalize
         perm = bool(getattr(k, "uses_perm", False)) and os.environ.get("SLIC_KM_PERM", "1") != "0"
+        sph = dict(spherical=True) if self.spherical else {}
         if perm:
             Xp = self._permuted(Xc)                                                        # once per fit, shared by the inits
             Cp = [torch.empty_like(C) for _ in range(3)]                                   # permuted twins of Cb
@@ -318,7 +334,7 @@ class KMeans:
                     k.permute_k8(Cin, Cp[0])
             if perm and not self._sharded and hasattr(k, "lloyd_step"):
                 k.lloyd_step(Xc, Xp, Cin, Cp[it % 3], cnorm[it % 3], lab, lab_old, n_changed[sl], gsums[sl], gcounts[sl],
-                             Cout, Cp[(it + 1) % 3], cnorm[(it + 1) % 3], shift, status[sl])
+                             Cout, Cp[(it + 1) % 3], cnorm[(it + 1) % 3], shift, status[sl], **sph)
                 read_back(sl)
                 return
             n_changed[sl].zero_()
@@ -332,7 +348,7 @@ class KMeans:
                 k.combine_shards(allpart[sl], K, Dp, gsums[sl], gcounts[sl])
                 torch.distributed.all_reduce(n_changed[sl], group=self.process_group)
             k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl], cnorm[(it + 1) % 3],
-                       *((Cp[(it + 1) % 3],) if perm else ()))
+                       *((Cp[(it + 1) % 3],) if perm else ()), **sph)
             read_back(sl)
 
         def read(it):
@@ -361,7 +377,7 @@ class KMeans:
                 if self._relocate(Xc, Cb[it % 3], Lb[it % 3], gsums[sl], gcounts[sl], int(n_empty)):
                     n_reloc += 1
                     k.finalize(Cb[it % 3], gsums[sl], gcounts[sl], Cb[(it + 1) % 3], shift, n_changed[sl], status[sl],
-                               cnorm[(it + 1) % 3], *((Cp[(it + 1) % 3],) if perm else ()))
+                               cnorm[(it + 1) % 3], *((Cp[(it + 1) % 3],) if perm else ()), **sph)
                     shift_tot = status[sl].cpu().tolist()[0]
                     if speculated:
                         launch(it + 1)

@@ -571,7 +571,7 @@ __global__ void km_apply_relocation(const float* __restrict__ xfar, int ldf,
 __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums, const float* __restrict__ counts,
                                                   const float* __restrict__ Co, int K, int D, float* __restrict__ Cn,
                                                   float* __restrict__ shift, float* __restrict__ cnorm_new,
-                                                  float* __restrict__ Cn_perm) {
+                                                  float* __restrict__ Cn_perm, int spherical) {
   extern __shared__ float km_avg_lds[];
   float* row = km_avg_lds;                 // [D] the new centre
   float* tg = km_avg_lds + D;              // [D / 4 + (D % 4)] group terms, then tail terms
@@ -598,13 +598,29 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
     src = mi[0];  // copy of the biggest cluster: averaged already iff it precedes j (sklearn's in-place loop order)
     alpha = (src < j && counts[src] > 0.0f) ? (float)(1.0 / (double)counts[src]) : 1.0f;
   }
+  for (int k = t; k < D; k += 128) row[k] = sums[(int64_t)src * D + k] * alpha;
+  __syncthreads();
+  if (spherical) {
+    // spherical k-means: the new centre is the mean direction, sklearn.preprocessing.normalize(centers) — a zero row stays
+    float a = 0.f;
+    for (int k = t; k < D; k += 128) a = fmaf(row[k], row[k], a);
+    mv[t] = a;
+    __syncthreads();
+    for (int s2 = 64; s2 > 0; s2 >>= 1) {
+      if (t < s2) mv[t] += mv[t + s2];
+      __syncthreads();
+    }
+    const float nrm = sqrtf(mv[0]);
+    __syncthreads();
+    if (nrm > 0.f)
+      for (int k = t; k < D; k += 128) row[k] = row[k] / nrm;
+    __syncthreads();
+  }
   for (int k = t; k < D; k += 128) {
-    const float v = sums[(int64_t)src * D + k] * alpha;
+    const float v = row[k];
     Cn[(int64_t)j * D + k] = v;
-    row[k] = v;
     if (Cn_perm) Cn_perm[(int64_t)j * D + (k & ~7) + ((k & 1) << 2) + ((k & 7) >> 1)] = v;   // km_permute_k8 order
   }
-  __syncthreads();
   const int ng = D / 4;
   const float* b = Co + (int64_t)j * D;
   for (int g = t; g < ng; g += 128) {
@@ -1216,7 +1232,8 @@ extern "C" int slic_kmeans_apply_relocation(const float* xfar, int ldf, const in
 
 extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const float* counts,
                                     int K, int D, float* C_new, float* shift, float* cnorm_new,
-                                    float* C_new_perm, const int32_t* n_changed, double* status, void* stream) {
+                                    float* C_new_perm, int spherical, const int32_t* n_changed, double* status,
+                                    void* stream) {
   SLIC_REQUIRE(C_old && sums && counts && C_new && shift && status && K > 0 && D > 0,
                "slic_kmeans_finalize: bad args");
   SLIC_REQUIRE(C_new != sums && C_new != C_old, "slic_kmeans_finalize: C_new must not alias");
@@ -1224,7 +1241,7 @@ extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const
   SLIC_REQUIRE(!C_new_perm || D % 8 == 0, "slic_kmeans_finalize: C_new_perm needs D %% 8 == 0");
   hipStream_t st = S(stream);
   const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
-  km_average<<<dim3(K), dim3(128), lds, st>>>(sums, counts, C_old, K, D, C_new, shift, cnorm_new, C_new_perm);
+  km_average<<<dim3(K), dim3(128), lds, st>>>(sums, counts, C_old, K, D, C_new, shift, cnorm_new, C_new_perm, spherical);
   SLIC_LAUNCH_CHECK();
   km_status<<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, status);
   SLIC_LAUNCH_CHECK();
@@ -1241,7 +1258,7 @@ extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N
                                       const float* C_old, const float* Cp_old, const float* cnorm_old, int K,
                                       int32_t* labels, const int32_t* labels_old, int32_t* n_changed,
                                       float* sums, float* counts, float* C_new, float* Cp_new, float* cnorm_new,
-                                      float* shift, double* status, void* workspace, void* stream) {
+                                      float* shift, int spherical, double* status, void* workspace, void* stream) {
   SLIC_REQUIRE(X && Xp && C_old && Cp_old && cnorm_old && labels && n_changed && sums && counts && C_new && Cp_new &&
                cnorm_new && shift && status && workspace, "slic_kmeans_lloyd_step: null pointer");
   char* ws = (char*)workspace;
@@ -1251,7 +1268,7 @@ extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N
   if (rc) return rc;
   rc = slic_kmeans_accumulate(X, N, D, ldx, labels, K, sums, counts, ws2, stream);
   if (rc) return rc;
-  return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, n_changed, status, stream);
+  return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, spherical, n_changed, status, stream);
 }
 
 extern "C" size_t slic_col_stats_workspace_bytes(int64_t N, int D) {
