@@ -283,13 +283,14 @@ class _Engine:
             call("slic_colsum", ptr(d2), d2.shape[0], d2.shape[1], ptr(g), stream())
             return g
 
-        # Optional (SLIC_WGRAD_STREAM=1): weight gradients on a side stream.  They depend only on (saved activation, dz),
-        # nothing downstream in this segment depends on them, and they are MFMA-bound — so they overlap the HBM-bound
-        # BatchNorm passes and fill the partial last rounds of the data-gradient launches; the main stream joins before
-        # returning.  Measured +1.3 % clips/s (70.2 vs 71.2 ms / step).  Off by default: with two kernels sharing the
-        # CUs, per-launch durations (HIP events, rocprof) stop describing one kernel, and bench.py's roofline object is
-        # defined on exactly that.
-        side = self._side_stream() if os.environ.get("SLIC_WGRAD_STREAM", "0") == "1" else None
+        # Weight gradients on a side stream: they depend only on (saved activation, dz), nothing downstream in this segment
+        # depends on them, and they are MFMA-bound — so they overlap the HBM-bound BatchNorm passes and fill the partial
+        # last rounds of the data-gradient launches; the main stream joins before returning.  All segments: +1.3 % clips/s
+        # (70.2 vs 71.2 ms / step, SLIC_WGRAD_STREAM=1).  Default ("auto"): every segment EXCEPT layer1 — with two kernels
+        # sharing the CUs a per-launch duration (HIP events, rocprof) stops describing one kernel, and bench.py's roofline
+        # object is defined on layer1's launches, which therefore keep the GPU to themselves.  "0": off.
+        mode = os.environ.get("SLIC_WGRAD_STREAM", "auto")
+        side = self._side_stream() if (mode == "1" or (mode == "auto" and si != 1)) else None
         main = torch.cuda.current_stream()
 
         def wgrad_async(plan, x, dz, weight):
