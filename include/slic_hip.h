@@ -218,6 +218,9 @@ typedef struct SlicConvArgs {
 int slic_conv_tile_m(const SlicConvArgs* args, int variant);
 /* dst = epilogue(gather(src) x wgt^T): forward conv, data gradient, linear. */
 int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);
+/* n (<= 8) independent GEMMs with the same N in ONE launch (blockIdx.z picks the GEMM): the parity classes of a stride-2
+ * data gradient, whose K loops are too short (1-8 taps) to fill the chip one launch at a time.  Variants 20 and 22. */
+int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant, void* stream);
 /* The same GEMM with the K loop cut into `splits` ranges run by separate workgroups (small-M layers whose 64 x 64 tiles
  * do not fill the chip): raw accumulators go to workspace[splits][M][N], a second launch sums them in split order and
  * runs the epilogue.  Deterministic; variants 11 and 20 only; splits <= 1 forwards to slic_conv_gemm. */

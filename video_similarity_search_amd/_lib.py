@@ -47,6 +47,7 @@ SIGNATURES = {
     # conv / linear
     "slic_conv_tile_m": (I, [P, I]),
     "slic_conv_gemm": (I, [P, I, P]),
+    "slic_conv_gemm_multi": (I, [P, I, I, P]),
     "slic_conv_gemm_splitk_workspace_bytes": (c_size_t, [P, I]),
     "slic_conv_gemm_splitk": (I, [P, I, I, P, P]),
     "slic_conv_wgrad_workspace_bytes": (c_size_t, [P, I]),

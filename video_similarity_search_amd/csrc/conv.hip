@@ -317,11 +317,12 @@ constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT) {
   return w > 5 ? 5 : (w < 1 ? 1 : w);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT))))
-void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
-                                                            float* __restrict__ slab, const int kt_per_split) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// The kernel body, shared by the one-GEMM launch and the multi-GEMM launch (several SlicConvArgs in one grid: the parity
+// classes of a stride-2 data gradient).  (bxi, gdx, byi, bzi) stand for (blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z).
+template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV>
+__device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const int xcd_remap, float* __restrict__ slab,
+                                                   const int kt_per_split, float* lds, const int bxi, const int gdx,
+                                                   const int byi, const int bzi) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int AL = BM / 32, BL = BN / 32;
@@ -332,11 +333,11 @@ void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware order: consecutive workgroup ids run on different XCDs (id % 8), so hand each XCD a contiguous range of
   // row blocks — neighbouring rows (the taps' halo) are then re-read through the same L2
-  int mb = blockIdx.x;
-  if (xcd_remap) mb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  int mb = bxi;
+  if (xcd_remap) mb = (bxi & 7) * (gdx >> 3) + (bxi >> 3);
   const int64_t m0 = (int64_t)mb * BM;
   if (m0 >= p.M) return;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = byi * BN;
   const int srow = tid >> 3;                                  // row inside each 32-row group
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);               // SOURCE chunk column of this lane (LDS slot = tid & 7)
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
@@ -370,10 +371,10 @@ void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
     const int n = n0 + srow + 32 * i;
     woff[i] = n < p.N ? ((unsigned)n * (unsigned)p.ldw + cq * 4) * 4u : OOB;
   }
-  // split-K: workgroup z of gridDim.z reduces k-tiles [kt0, nk) of the GEMM and writes raw accumulators to slab[z]
+  // split-K: workgroup z of the grid's z dimension reduces k-tiles [kt0, nk) of the GEMM and writes raw accumulators to slab[z]
   // (conv_splitk_finish sums the slabs in z order and runs the epilogue); one split (slab == NULL) covers everything
   const int nk_all = p.nchunks >> 3;
-  const int kt0 = slab ? blockIdx.z * kt_per_split : 0;
+  const int kt0 = slab ? bzi * kt_per_split : 0;
   const int nk = slab ? min(nk_all, kt0 + kt_per_split) : nk_all;     // END of this workgroup's k-tile range
   const int tiles_per_tap = p.Cs >> 5;
   // per-tap records are read through the constant address space with a wave-uniform index: scalar loads, which
@@ -524,7 +525,7 @@ void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing all-zero DMAs must land before LDS is reused
   __syncthreads();
   if (slab) {
-    float* out = slab + (int64_t)blockIdx.z * p.M * p.N;
+    float* out = slab + (int64_t)bzi * p.M * p.N;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WTN + j * 32 + r;
@@ -539,6 +540,30 @@ void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap,
     return;
   }
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT))))
+void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap, float* __restrict__ slab, const int kt_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV>(p, xcd_remap, slab, kt_per_split, lds, blockIdx.x, gridDim.x, blockIdx.y,
+                                                      blockIdx.z);
+}
+
+// up to SLIC_CONV_MULTI_MAX independent GEMMs (same N, same tile) in one grid: blockIdx.z picks the GEMM
+#define SLIC_CONV_MULTI_MAX 8
+struct SlicConvArgsPack {
+  SlicConvArgs a[SLIC_CONV_MULTI_MAX];
+  int gx[SLIC_CONV_MULTI_MAX];     // row blocks of each GEMM (a multiple of 8 when the XCD order is on)
+};
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT))))
+void conv_gemm_dma_multi_kernel(const SlicConvArgsPack pk, const int xcd_remap) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int c = blockIdx.z;
+  const int gdx = pk.gx[c];
+  if ((int)blockIdx.x >= gdx) return;
+  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV>(pk.a[c], xcd_remap, nullptr, 0, lds, blockIdx.x, gdx, blockIdx.y, 0);
 }
 
 // second pass of a split-K launch: accumulators = sum over the S slabs in slab order, then the ordinary epilogue
@@ -1114,6 +1139,51 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     return launch_gemm<128, 64, 2, 2>(*a, st);
   }
   return launch_gemm<64, 64, 2, 2>(*a, st);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV>
+static int launch_gemm_dma_multi(const SlicConvArgs* a, int n, hipStream_t st) {
+  constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  static const int xcd = getenv("SLIC_CONV_XCD") ? atoi(getenv("SLIC_CONV_XCD")) : 1;
+  SlicConvArgsPack pk;
+  unsigned gmax = 0;
+  for (int i = 0; i < SLIC_CONV_MULTI_MAX; ++i) {
+    pk.a[i] = a[i < n ? i : 0];
+    pk.a[i].tab = a[i < n ? i : 0].tap_tab;
+    unsigned gx = i < n ? (unsigned)slic_cdiv(a[i].M, BM) : 0u;
+    if (xcd) gx = (gx + 7) / 8 * 8;
+    pk.gx[i] = (int)gx;
+    if (gx > gmax) gmax = gx;
+  }
+  dim3 grid(gmax, (unsigned)slic_cdiv(a[0].N, BN), (unsigned)n);
+  conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(pk, xcd);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant, void* stream) {
+  SLIC_REQUIRE(args && n >= 1 && n <= SLIC_CONV_MULTI_MAX, "slic_conv_gemm_multi: 1 <= n <= %d", SLIC_CONV_MULTI_MAX);
+  SLIC_REQUIRE(variant == 20 || variant == 22, "slic_conv_gemm_multi: variants 20 and 22 only");
+  for (int i = 0; i < n; ++i) {
+    const SlicConvArgs* a = args + i;
+    int rc = validate(a, "slic_conv_gemm_multi");
+    if (rc) return rc;
+    SLIC_REQUIRE(a->wgt && a->dst && a->ldw % 4 == 0 && a->ldo >= 1 && ((uintptr_t)a->wgt % 16) == 0 && a->wgt_bytes > 0 &&
+                 a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm_multi: bad weight/dst");
+    SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
+                 "slic_conv_gemm_multi: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
+    SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
+                 "slic_conv_gemm_multi: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
+    SLIC_REQUIRE(a->N == args[0].N, "slic_conv_gemm_multi: every GEMM must have the same N");
+  }
+  if (variant == 22) return launch_gemm_dma_multi<128, 64, 2, 2, 2, 1, true>(args, n, S_(stream));
+  return launch_gemm_dma_multi<64, 64, 2, 2, 2, 1, true>(args, n, S_(stream));
 }
 
 extern "C" size_t slic_conv_gemm_splitk_workspace_bytes(const SlicConvArgs* a, int splits) {
