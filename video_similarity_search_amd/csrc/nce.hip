@@ -43,12 +43,23 @@ __global__ __launch_bounds__(256) void nce_scores_bwd(const float* __restrict__ 
   for (int k0 = 0; k0 < D; k0 += 128) {
     const int k = k0 + l * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (k < D)
-      for (int j = sub; j < K1; j += 8) {
+    if (k < D) {
+      int j = sub;
+      for (; j + 24 < K1; j += 32) {                       // four gathers in flight; the adds stay j-ascending
+        const int64_t e = (int64_t)b * K1 + j;
+        const float g0 = dout[e], g1 = dout[e + 8], g2 = dout[e + 16], g3 = dout[e + 24];
+        const f32x4 r0 = *(const f32x4*)(bank + idx[e] * (int64_t)D + k);
+        const f32x4 r1 = *(const f32x4*)(bank + idx[e + 8] * (int64_t)D + k);
+        const f32x4 r2 = *(const f32x4*)(bank + idx[e + 16] * (int64_t)D + k);
+        const f32x4 r3 = *(const f32x4*)(bank + idx[e + 24] * (int64_t)D + k);
+        a += r0 * g0; a += r1 * g1; a += r2 * g2; a += r3 * g3;
+      }
+      for (; j < K1; j += 8) {
         const float g = dout[(int64_t)b * K1 + j];
         const f32x4 r = *(const f32x4*)(bank + idx[(int64_t)b * K1 + j] * (int64_t)D + k);
         a += r * g;
       }
+    }
     *(f32x4*)&red[sub][l * 4] = a;
     __syncthreads();
     if (threadIdx.x < 128 && k0 + threadIdx.x < D) {
