@@ -5,7 +5,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libslic_hip.so")
+LIB_PATH = os.environ.get("SLIC_LIB_PATH") or os.path.join(_HERE, "csrc", "libslic_hip.so")     # override: kernel experiments
 
 c_void_p, c_int, c_int64, c_size_t, c_float, c_double = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float, ctypes.c_double)
