@@ -15,9 +15,11 @@
 //   matrix pipe, not LDS or address math, is the limiter.  Accumulation is exact fp32 (k-ordered
 //   fma chain per accumulator); no reduced-precision path.
 //
-// Epilogue (fused): + bias, per-channel affine (eval-mode BN), ReLU, + addend (residual / gradient
-// accumulation), and per-workgroup BatchNorm partial sums (sum, sum of squares per channel) written
-// to a slab that bn.hip reduces in fixed order (deterministic train-mode statistics).
+// Epilogue (fused, branch-free buffer ops): + bias, per-channel affine (eval-mode BN), + addend (residual /
+// gradient accumulation), ReLU-backward mask of the consuming layer, ReLU, and per-workgroup BatchNorm
+// partials written to a slab that bn.hip merges in fixed order: forward (sum, sum (v - mean_wg)^2) or
+// backward (sum g, sum g * xhat).  Kernels: conv_gemm_dma_kernel (LDS-DMA ring; default), its multi-GEMM
+// and split-K forms, conv_gemm_kernel (register-staged; stem), conv_wgrad_dma_kernel (+ row table).
 #include "common.h"
 #include "conv_common.h"
 #ifndef SLIC_WG_ILVQ

@@ -9,9 +9,11 @@ The module tree only HOLDS parameters (torch's own Conv3d / BatchNorm / Linear o
 reference's init rules (:203-210) and its 129 state_dict keys hold by construction, and
 checkpoints written by models/model_utils.py:161-176 load unchanged).  forward() never calls those
 modules: the whole encoder runs as one hand-written execution plan over the HIP kernels of
-libslic_hip.so (csrc/conv.hip, bn.hip), forward AND backward, exposed to autograd as a single
-Function — NDHWC activations, fp32 MFMA gather-GEMM convs with fused BatchNorm statistics,
-deterministic reductions.  There is no PyTorch/CPU fallback path.
+libslic_hip.so (csrc/conv.hip, bn.hip), forward AND backward, exposed to autograd as six segment
+Functions (stem | layer1-4 | head, so DDP's bucketed all-reduce overlaps the earlier layers' backward)
+— NDHWC activations, fp32 MFMA gather-GEMM convs with fused BatchNorm statistics (forward) and fused
+ReLU-mask / BatchNorm-backward sums (data gradient), deterministic reductions.  There is no
+PyTorch/CPU fallback path.
 """
 import os
 import weakref
