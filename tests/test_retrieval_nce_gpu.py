@@ -65,6 +65,42 @@ def test_topk_shapes_vs_oracle(gpu, Nq, Ng, D, k):
     assert (idx.cpu().numpy() == ref).mean() > 0.99
 
 
+def test_retrieval_full_size_properties(gpu):
+    """BASELINE configs[4] size (10k x 512 queries vs 100k x 512 gallery, k = 50), checked through properties the size does
+    not change: per-query distances ascending, indices unique and in range, a random subset of queries equal to the exact
+    float64 top-k (ties aside), and hit counts of that subset equal to the oracle's."""
+    from oracle import retrieval as orr
+    from video_similarity_search_amd.evaluate import cosine_topk
+    rng = np.random.default_rng(5)
+    Nq, Ng, D, k = 10000, 100000, 512, 50
+    Q = rng.standard_normal((Nq, D)).astype(np.float32)
+    G = rng.standard_normal((Ng, D)).astype(np.float32)
+    idx, dist = cosine_topk(torch.from_numpy(Q).cuda(), torch.from_numpy(G).cuda(), k=k)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert idx.shape == (Nq, k) and dist.shape == (Nq, k)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    assert idx.min() >= 0 and idx.max() < Ng
+    srt = np.sort(idx, axis=1)
+    assert np.all(srt[:, 1:] != srt[:, :-1])                       # no duplicates inside a list
+    sub = rng.choice(Nq, 64, replace=False)
+    Gn = G.astype(np.float64); Gn /= np.linalg.norm(Gn, axis=1, keepdims=True)
+    Qs = Q[sub].astype(np.float64); Qs /= np.linalg.norm(Qs, axis=1, keepdims=True)
+    d = np.clip(1.0 - Qs @ Gn.T, 0.0, 2.0)
+    ref = np.argsort(d, axis=1, kind="stable")[:, :k]
+    for row, qi in enumerate(sub):
+        got = idx[qi]
+        if not np.array_equal(got, ref[row]):                       # only near-ties (fp32 vs fp64 scores) may swap
+            bad = np.flatnonzero(got != ref[row])
+            assert np.all(np.abs(d[row, got[bad]] - d[row, ref[row][bad]]) < 5e-6), qi
+        np.testing.assert_allclose(dist[qi], d[row, got], atol=5e-6)
+    labels_g = rng.integers(0, 101, Ng)
+    labels_q = rng.integers(0, 101, Nq)
+    for kk in (1, 5, 10, 20, 50):
+        hit_gpu = sum(int(labels_q[qi] in labels_g[idx[qi, :kk]]) for qi in sub)
+        hit_ref = sum(int(labels_q[qi] in labels_g[ref[row, :kk]]) for row, qi in enumerate(sub))
+        assert hit_gpu == hit_ref
+
+
 def test_nce_average_matches_reference_golden(gpu, golden_dir):
     from video_similarity_search_amd.loss import NCEAverage, NCESoftmaxLoss
     g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
