@@ -159,7 +159,11 @@ int slic_kmeanspp_step(const float* X, int64_t N, int D, int ldx, const int32_t*
  * idx_out (device, [K]) receives the chosen row indices. */
 size_t slic_kmeanspp_run_workspace_bytes(int64_t N, int T);
 int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int first, int K, int T, const double* uniforms,
-                      int32_t* idx_out, void* workspace, void* stream);
+                      int32_t* idx_out,
+                      const float* Xp /* optional: slic_kmeans_permute_k8(X), same ldx */,
+                      const float* xnorm /* optional: [N] squared row norms; with Xp the distances run on the matrix
+                                            pipe as |x|^2 + |c|^2 - 2 x.c (sklearn's euclidean_distances form) */,
+                      void* workspace, void* stream);
 
 /* inclusive prefix sum of v (float) in double, and searchsorted(cumsum, vals[t], 'left')
  * clipped to N-1  (stable_cumsum + np.searchsorted, _kmeans.py:243-248). */

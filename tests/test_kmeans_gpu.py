@@ -202,6 +202,13 @@ def test_kmeanspp_run_matches_stepwise(gpu):
     got = idx.cpu().numpy().tolist()
     assert got[0] == first and len(set(got)) == K
     assert got == ref
+    # matrix-pipe distances (|x|^2 + |c|^2 - 2 x.c on the k-permuted copy): same picks on this well-separated data
+    Xp, xn = torch.empty_like(Xg), torch.empty(N, device="cuda")
+    k.permute_k8(Xg, Xp)
+    k.cnorm(Xg, xn)
+    idx2 = torch.empty(K, dtype=torch.int32, device="cuda")
+    k.kpp_run(Xg, first, K, T, torch.from_numpy(u).cuda(), idx2, Xp, xn)
+    assert idx2.cpu().numpy().tolist() == ref
 
 
 def test_spherical_kmeans_matches_restatement(gpu):

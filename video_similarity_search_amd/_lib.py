@@ -39,7 +39,7 @@ SIGNATURES = {
     "slic_sub_rowvec": (I, [P, L, I, I, P, P, I, P]),
     "slic_l2norm_rows": (I, [P, L, I, I, P, I, P]),
     "slic_kmeanspp_run_workspace_bytes": (c_size_t, [L, I]),
-    "slic_kmeanspp_run": (I, [P, L, I, I, I, I, I, P, P, P, P]),
+    "slic_kmeanspp_run": (I, [P, L, I, I, I, I, I, P, P, P, P, P, P]),
     "slic_kmeanspp_step_workspace_bytes": (c_size_t, [L, I]),
     "slic_kmeanspp_step": (I, [P, L, I, I, P, I, P, P, P, P, P]),
     "slic_cumsum_search_workspace_bytes": (c_size_t, [L]),

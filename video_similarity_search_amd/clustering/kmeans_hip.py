@@ -89,11 +89,12 @@ class HipKernels:
     def l2norm_rows(self, X, out):
         call("slic_l2norm_rows", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(out), out.stride(0), stream())
 
-    def kpp_run(self, X, first, K, T, uniforms, idx_out):
+    def kpp_run(self, X, first, K, T, uniforms, idx_out, Xp=None, xnorm=None):
         N, Dp = X.shape
+        assert Xp is None or Xp.stride(0) == X.stride(0)
         ws = _lib.workspace(_lib.load().slic_kmeanspp_run_workspace_bytes(N, T), X.device, "kpp_run")
-        call("slic_kmeanspp_run", ptr(X), N, Dp, X.stride(0), int(first), int(K), int(T), ptr(uniforms), ptr(idx_out), ptr(ws),
-             stream())
+        call("slic_kmeanspp_run", ptr(X), N, Dp, X.stride(0), int(first), int(K), int(T), ptr(uniforms), ptr(idx_out),
+             ptr(Xp), ptr(xnorm), ptr(ws), stream())
 
     def accumulate(self, X, labels, K, sums, counts):
         N, Dp = X.shape
@@ -419,6 +420,15 @@ class KMeans:
             self._side = torch.cuda.Stream(device=dev)
         return self._side
 
+    def _row_norms(self, Xc):
+        """squared row norms of the (centred) data, cached like the permuted copy"""
+        key = (Xc.data_ptr(), tuple(Xc.shape), Xc._version)
+        if getattr(self, "_norm_key", None) != key:
+            xn = torch.empty(Xc.shape[0], dtype=torch.float32, device=Xc.device)
+            self.k.cnorm(Xc, xn)
+            self._norm_key, self._norm_X = key, xn
+        return self._norm_X
+
     def _permuted(self, Xc):
         """k-permuted copy of the (centred) data for the LDS-DMA E-step; cached while Xc is the same tensor"""
         key = (Xc.data_ptr(), tuple(Xc.shape), Xc._version)
@@ -524,7 +534,11 @@ class KMeans:
             u = bcast(rs.uniform(size=(K - 1, T))) if K > 1 else np.zeros((0, T))
             ud = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)).to(dev)
             idx_d = torch.empty(K, dtype=torch.int32, device=dev)
-            k.kpp_run(Xs, first, K, T, ud, idx_d)
+            Xp = xn = None
+            if getattr(k, "uses_perm", False) and os.environ.get("SLIC_KPP_MFMA", "1") != "0":
+                Xp = self._permuted(Xs)                      # the same permuted copy the E-step uses (cached per fit)
+                xn = self._row_norms(Xs)
+            k.kpp_run(Xs, first, K, T, ud, idx_d, Xp, xn)
             self.init_indices_ = idx_d.cpu().numpy().astype(np.int64)
             return Xs.index_select(0, idx_d.long()).contiguous()
         idx[0] = first

@@ -962,6 +962,101 @@ __global__ __launch_bounds__(256) void kpp_dist_rows(const float* __restrict__ X
   }
 }
 
+// The same distances on the matrix pipe: d(x, c) = |x|^2 + |c|^2 - 2 x.c  (sklearn's own formulation,
+// euclidean_distances with precomputed row norms), x.c by v_mfma_f32_32x32x2_f32 with A = the T (<= 16) candidate rows
+// padded to one 32-row tile and B = 128 points per workgroup, both DMA'd from the k-permuted copy of X (the candidates ARE
+// rows of it) through the 2-stage LDS ring of the E-step.  One pass over X per centre at HBM speed instead of a VALU loop.
+// A workgroup covers two KPP_CH = 64 row chunks (waves 0-1, waves 2-3).
+__global__ __launch_bounds__(256) void kpp_dist_mfma(const float* __restrict__ Xp, const float* __restrict__ xnorm, int64_t N,
+                                                     int D, int ldx, const int32_t* __restrict__ cand, int T,
+                                                     const float* __restrict__ prev, const int32_t* __restrict__ sel,
+                                                     float* __restrict__ newdist, double* __restrict__ bpart, int64_t nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  constexpr int BP = 128;
+  constexpr int STAGE_FLOATS = (BP + 32) * KM_BK;
+  __shared__ float cn[PP_TMAX];
+  __shared__ double wp[4][PP_TMAX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t pblock = (int64_t)blockIdx.x * BP;
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);
+  const int64_t xrows = (N - pblock) < BP ? (N - pblock) : BP;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Xp + pblock * (int64_t)ldx), 0, (int)(((xrows - 1) * (int64_t)ldx + D) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Xp, 0, (int)(((N - 1) * (int64_t)ldx + D) * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned xoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xoff[i] = (srow + 32 * i) < xrows ? ((unsigned)(srow + 32 * i) * (unsigned)ldx + cq * 4) * 4u : OOB;
+  const unsigned coff = srow < T ? ((unsigned)cand[srow] * (unsigned)ldx + cq * 4) * 4u : OOB;     // candidate row `srow`
+  if (tid < T) cn[tid] = xnorm[cand[tid]];
+  const int klim = D - cq * 4;
+  const int nk = (D + KM_BK - 1) / KM_BK;
+  auto issue = [&](int kt, int stage) {
+    float* Xs = km_lds + stage * STAGE_FLOATS;
+    float* Cs = Xs + BP * KM_BK;
+    const bool kin = kt * KM_BK < klim;
+    const unsigned kb = (unsigned)kt * (KM_BK * 4u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Xs + (8 * wave + 32 * i) * KM_BK),
+                                               16, (int)((kin && xoff[i] != OOB) ? xoff[i] + kb : OOB), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (__attribute__((address_space(3))) void*)(Cs + (8 * wave) * KM_BK),
+                                             16, (int)((kin && coff != OOB) ? coff + kb : OOB), 0, 0, 0);
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int PER_STAGE = 5;
+  issue(0, 0);
+  for (int s0 = 0; s0 < nk; s0 += 2) {
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(s0 + sidx + 1, sidx ^ 1);
+      const float* Xs = km_lds + sidx * STAGE_FLOATS;
+      const float* Cs = Xs + BP * KM_BK;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * q + h)];
+        const f32x4 a = *(const f32x4*)&Cs[km_off(r, 2 * q + h)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+      }
+    }
+  }
+  (void)PER_STAGE;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float* closest = prev ? prev + (int64_t)(*sel) * N : nullptr;
+  const int64_t i = pblock + 32 * wave + r;
+  const bool iv = i < N;
+  const float xn = iv ? xnorm[i] : 0.f;
+  const float cl = (closest && iv) ? closest[i] : INFINITY;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int t = (g & 3) + 8 * (g >> 2) + 4 * h;           // candidate row held in accumulator register g of this lane half
+    if (t < T) {                                             // uniform per (g, h)
+      const float d = fmaxf(xn + cn[t] - 2.0f * acc[g], 0.f);
+      const float m = fminf(d, cl);
+      if (iv) newdist[(int64_t)t * N + i] = m;
+      double v = iv ? (double)m : 0.0;
+      for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);     // over the 32 points of this wave (lane half keeps its t)
+      if (r == 0) wp[wave][t] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < T) {
+    const int64_t c0 = (int64_t)blockIdx.x * 2;
+    bpart[c0 * T + tid] = wp[0][tid] + wp[1][tid];
+    if (c0 + 1 < nchunk) bpart[(c0 + 1) * T + tid] = wp[2][tid] + wp[3][tid];
+  }
+}
+
 // one workgroup: pot[t] = sum_b bpart[b][t] (fixed strided partition + tree), sel = first minimum, idx_out = cand[sel],
 // csum[b] = inclusive scan over b of bpart[b][sel]
 __global__ __launch_bounds__(256) void kpp_select(const double* __restrict__ bpart, int64_t nblk, int T,
@@ -1327,7 +1422,8 @@ extern "C" size_t slic_kmeanspp_run_workspace_bytes(int64_t N, int T) {
 }
 
 extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int first, int K, int T,
-                                 const double* uniforms, int32_t* idx_out, void* workspace, void* stream) {
+                                 const double* uniforms, int32_t* idx_out, const float* Xp, const float* xnorm,
+                                 void* workspace, void* stream) {
   SLIC_REQUIRE(X && uniforms && idx_out && workspace, "slic_kmeanspp_run: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && K <= N && first >= 0 && first < N && T >= 1 && T <= PP_TMAX && D % 4 == 0 && ldx % 4 == 0 &&
                (size_t)T * D * 4 <= 48 * 1024, "slic_kmeanspp_run: need 1 <= T <= %d, D %% 4 == 0, T*D*4 <= 48 KiB", PP_TMAX);
@@ -1340,9 +1436,21 @@ extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int 
   double* cur_pot = w.take<double>(1);
   int32_t* cand = w.take<int32_t>(T);
   int32_t* sel = w.take<int32_t>(1);
+  // matrix-pipe distances when the caller has the k-permuted copy and the row norms (and 32-bit offsets reach every row)
+  const bool mfma = Xp && xnorm && D % 8 == 0 && (int64_t)N * ldx * 4 < (1ll << 31);
+  const size_t lds_m = (size_t)2 * (128 + 32) * KM_BK * sizeof(float);
+  if (mfma) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)kpp_dist_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+      attr_set = true;
+    }
+  }
+  const unsigned nblk_m = (unsigned)slic_cdiv(N, 128);
   // centre 0: one candidate (the uniformly drawn row), no closest yet
   SLIC_HIP_CHECK(hipMemcpyAsync(cand, &first, sizeof(int32_t), hipMemcpyHostToDevice, st));
-  kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)D * 4, st>>>(X, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart);
+  if (mfma) kpp_dist_mfma<<<dim3(nblk_m), dim3(256), lds_m, st>>>(Xp, xnorm, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart, nblk);
+  else kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)D * 4, st>>>(X, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart);
   SLIC_LAUNCH_CHECK();
   kpp_select<<<dim3(1), dim3(256), 0, st>>>(bpart, nblk, 1, cand, sel, cur_pot, csum, idx_out);
   SLIC_LAUNCH_CHECK();
@@ -1352,7 +1460,8 @@ extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int 
     kpp_search<<<dim3((unsigned)slic_cdiv(T, 4)), dim3(256), 0, st>>>(prev, sel, N, csum, nblk, uniforms + (size_t)(c - 1) * T,
                                                                  cur_pot, T, cand);
     SLIC_LAUNCH_CHECK();
-    if (T <= 8) kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
+    if (mfma) kpp_dist_mfma<<<dim3(nblk_m), dim3(256), lds_m, st>>>(Xp, xnorm, N, D, ldx, cand, T, prev, sel, cur, bpart, nblk);
+    else if (T <= 8) kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
     else kpp_dist_rows<16><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
     SLIC_LAUNCH_CHECK();
     kpp_select<<<dim3(1), dim3(256), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c);
