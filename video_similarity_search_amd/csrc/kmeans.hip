@@ -1057,28 +1057,25 @@ __global__ __launch_bounds__(256) void kpp_dist_mfma(const float* __restrict__ X
   }
 }
 
-// one workgroup: pot[t] = sum_b bpart[b][t] (fixed strided partition + tree), sel = first minimum, idx_out = cand[sel],
-// csum[b] = inclusive scan over b of bpart[b][sel]
-__global__ __launch_bounds__(256) void kpp_select(const double* __restrict__ bpart, int64_t nblk, int T,
-                                                  const int32_t* __restrict__ cand, int32_t* __restrict__ sel,
-                                                  double* __restrict__ cur_pot, double* __restrict__ csum,
-                                                  int32_t* __restrict__ idx_out) {
-  __shared__ double sm[256];
+// one workgroup of 16 waves: pot[t] = sum_b bpart[b][t] — wave t sums candidate t's column (lanes strided over the chunks,
+// then a fixed shuffle tree) — sel = first minimum, idx_out = cand[sel], csum[b] = inclusive scan over b of bpart[b][sel]
+// (per-thread runs, wave shuffle scans, one scan of the 16 wave totals).  Latency-bound: a handful of barriers in all.
+#define KPP_ST 1024
+__global__ __launch_bounds__(KPP_ST) void kpp_select(const double* __restrict__ bpart, int64_t nblk, int T,
+                                                     const int32_t* __restrict__ cand, int32_t* __restrict__ sel,
+                                                     double* __restrict__ cur_pot, double* __restrict__ csum,
+                                                     int32_t* __restrict__ idx_out) {
   __shared__ double pots[PP_TMAX];
+  __shared__ double wtot[KPP_ST / 64];
   __shared__ int s_sel;
-  const int i = threadIdx.x;
-  for (int t = 0; t < T; ++t) {
+  const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+  if (wave < T) {
     double a = 0.0;
-    for (int64_t b = i; b < nblk; b += 256) a += bpart[b * T + t];
-    sm[i] = a;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-      if (i < s2) sm[i] += sm[i + s2];
-      __syncthreads();
-    }
-    if (i == 0) pots[t] = sm[0];
-    __syncthreads();
+    for (int64_t b = lane; b < nblk; b += 64) a += bpart[b * T + wave];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) pots[wave] = a;
   }
+  __syncthreads();
   if (i == 0) {
     int b = 0;
     for (int t = 1; t < T; ++t) if (pots[t] < pots[b]) b = t;          // np.argmin: first minimum
@@ -1089,21 +1086,21 @@ __global__ __launch_bounds__(256) void kpp_select(const double* __restrict__ bpa
   }
   __syncthreads();
   const int b = s_sel;
-  // inclusive scan of column b: every thread scans its own run of `per` consecutive chunks, one block-wide scan of the run
-  // totals, then the offsets are added back
-  const int64_t per = (nblk + 255) / 256;
+  // inclusive scan of column b: thread i owns the run of `per` consecutive chunks [i * per, ...)
+  const int64_t per = (nblk + KPP_ST - 1) / KPP_ST;
   const int64_t c0 = (int64_t)i * per, c1 = c0 + per < nblk ? c0 + per : nblk;
   double run = 0.0;
   for (int64_t c = c0; c < c1; ++c) run += bpart[c * T + b];
-  sm[i] = run;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const double u = i >= d ? sm[i - d] : 0.0;
-    __syncthreads();
-    sm[i] += u;
-    __syncthreads();
+  double inc = run;                                                     // inclusive scan of the run totals inside the wave
+  for (int d = 1; d < 64; d <<= 1) {
+    const double u = __shfl_up(inc, d);
+    if (lane >= d) inc += u;
   }
-  double a = sm[i] - run;                                 // exclusive offset of this thread's run
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  double woff = 0.0;
+  for (int w = 0; w < wave; ++w) woff += wtot[w];                       // <= 15 adds, same order in every thread of the wave
+  double a = woff + inc - run;                                          // exclusive offset of this thread's run
   for (int64_t c = c0; c < c1; ++c) { a += bpart[c * T + b]; csum[c] = a; }
 }
 
@@ -1452,7 +1449,7 @@ extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int 
   if (mfma) kpp_dist_mfma<<<dim3(nblk_m), dim3(256), lds_m, st>>>(Xp, xnorm, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart, nblk);
   else kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)D * 4, st>>>(X, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart);
   SLIC_LAUNCH_CHECK();
-  kpp_select<<<dim3(1), dim3(256), 0, st>>>(bpart, nblk, 1, cand, sel, cur_pot, csum, idx_out);
+  kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, 1, cand, sel, cur_pot, csum, idx_out);
   SLIC_LAUNCH_CHECK();
   for (int c = 1; c < K; ++c) {
     const float* prev = nd + (size_t)((c - 1) & 1) * T * N;
@@ -1464,7 +1461,7 @@ extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int 
     else if (T <= 8) kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
     else kpp_dist_rows<16><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
     SLIC_LAUNCH_CHECK();
-    kpp_select<<<dim3(1), dim3(256), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c);
+    kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c);
     SLIC_LAUNCH_CHECK();
   }
   return SLIC_OK;
