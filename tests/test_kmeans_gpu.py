@@ -173,18 +173,18 @@ def test_kmeanspp_helpers(gpu):
     assert np.all(np.abs(got - exp) <= 1), (got, exp)      # chunked double sums vs np.cumsum: boundary +-1
 
 
-def test_kmeanspp_run_matches_stepwise(gpu):
+@pytest.mark.parametrize("N,D,K", [(6000, 64, 24), (1000, 40, 8), (333, 8, 5)])
+def test_kmeanspp_run_matches_stepwise(gpu, N, D, K):
     """the single-sequence k-means++ (slic_kmeanspp_run) picks the rows the stepwise host loop picks from the same
     uniform draws (distances are summed in a different order, so the data is chosen without near-ties), and both follow
     _kmeans_plusplus restated in float64 numpy"""
     from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
     rng = np.random.default_rng(21)
-    N, D, K = 6000, 64, 24
     T = 2 + int(np.log(K))
     cen = rng.standard_normal((K, D)) * 3
     X = (cen[rng.integers(0, K, N)] + 0.3 * rng.standard_normal((N, D))).astype(np.float32)
     u = rng.random((K - 1, T))
-    first = 1234
+    first = 1234 % N
     # float64 restatement (sklearn/cluster/_kmeans.py:174-277)
     Xd64 = X.astype(np.float64)
     closest = ((Xd64 - Xd64[first]) ** 2).sum(1)
