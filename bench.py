@@ -133,7 +133,7 @@ def kmeans_secondary(rank, world, pg, run_cpu):
     flops = 2.0 * n_loc * K * D
     out["roofline"] = dict(bound="mfma", achieved=flops / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
                            unit="TFLOP/s", frac=flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, traffic=None,
-                           kernel="km_assign_dma<2,2> (+ km_combine)", ms_per_launch=ms,
+                           kernel="km_assign_dma<128,2,1,2> (+ km_combine)", ms_per_launch=ms,
                            algorithmic_flops_per_launch=flops)
     if run_cpu:
         from oracle import kmeans as ok
