@@ -317,9 +317,18 @@ __global__ void km_combine(const float* __restrict__ pscore, const int32_t* __re
   if (i < N) {
     float best = pscore[i];
     int idx = pidx[i];
-    for (int g = 1; g < G; ++g) {
+    int g = 1;
+    for (; g + 4 <= G; g += 4) {                            // four groups' (score, index) loads in flight; compares stay g-ascending
+      float sv[4]; int iv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { sv[u] = pscore[(int64_t)(g + u) * N + i]; iv[u] = pidx[(int64_t)(g + u) * N + i]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (sv[u] < best) { best = sv[u]; idx = iv[u]; }
+    }
+    for (; g < G; ++g) {
       const float s = pscore[(int64_t)g * N + i];
-      if (s < best) { best = s; idx = pidx[(int64_t)g * N + i]; }
+      const int ii = pidx[(int64_t)g * N + i];
+      if (s < best) { best = s; idx = ii; }
     }
     if (idx < 0 || idx >= K) idx = 0;  // all-NaN row: sklearn's argmin also yields 0
     labels[i] = idx;
@@ -388,40 +397,64 @@ __global__ __launch_bounds__(64) void km_scan_blocks(int32_t* __restrict__ bc, i
 
 // order[off[l] + (rows with label l in earlier blocks) + (rank inside the block)] = row: a stable counting sort.
 // off = exclusive scan of cnt over clusters, recomputed per workgroup in LDS (K is small) instead of a launch of its own.
+// Rank inside the block = (same-label rows in earlier waves) + (same-label lanes below the row in its own wave).  In-wave:
+// the wave's distinct labels are peeled one ballot at a time (<= 64 rounds instead of an O(1024) scan per row); across
+// waves: per-wave label counts in LDS when they fit (use_wcnt: 16 x K ints), else a scan of the earlier waves' labels.
 __global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
                          const int32_t* __restrict__ bc, const int32_t* __restrict__ cnt,
-                         int32_t* __restrict__ order) {
-  extern __shared__ int km_cl_off[];          // [K] exclusive scan of cnt
-  __shared__ int part[KM_SB];
+                         int32_t* __restrict__ order, int use_wcnt) {
+  extern __shared__ int km_cl_off[];          // [K] exclusive scan of cnt, then [16][K] per-wave label counts
+  __shared__ int wtot[KM_SB / 64];
   __shared__ int lab[KM_SB];
-  const int t = threadIdx.x;
+  int* wcnt = km_cl_off + K;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // ---- cluster offsets: thread t owns clusters [t * per, ...); wave shuffle scan of the run totals, then the 16 wave totals
   const int per = (K + KM_SB - 1) / KM_SB;
   int s = 0;
   for (int u = 0; u < per; ++u) {
     const int j = t * per + u;
     if (j < K) s += cnt[j];
   }
-  part[t] = s;
-  __syncthreads();
-  for (int d = 1; d < KM_SB; d <<= 1) {     // inclusive Hillis-Steele scan of the per-thread sums
-    const int v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  int inc = s;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(inc, d);
+    if (lane >= d) inc += v;
   }
-  int run = part[t] - s;
+  if (lane == 63) wtot[wave] = inc;
+  if (use_wcnt)
+    for (int j = t; j < (KM_SB / 64) * K; j += KM_SB) wcnt[j] = 0;
+  __syncthreads();
+  int run = inc - s;
+  for (int w = 0; w < wave; ++w) run += wtot[w];
   for (int u = 0; u < per; ++u) {
     const int j = t * per + u;
     if (j < K) { km_cl_off[j] = run; run += cnt[j]; }
   }
+  // ---- ranks
   const int64_t i = (int64_t)blockIdx.x * KM_SB + t;
   const int l = i < N ? labels[i] : -1;
-  lab[t] = l;
+  int intra = 0;
+  unsigned long long todo = __ballot(l >= 0);
+  while (todo) {                                        // wave-uniform loop over the wave's distinct labels
+    const int leader = __ffsll((long long)todo) - 1;
+    const int ll = __shfl(l, leader);
+    const unsigned long long m = __ballot(l == ll);
+    if (l == ll) intra = __popcll(m & ((1ull << lane) - 1ull));
+    if (use_wcnt && lane == leader) wcnt[wave * K + ll] = __popcll(m);
+    todo &= ~m;
+  }
+  if (!use_wcnt) lab[t] = l;
   __syncthreads();
+  int earlier = 0;
+  if (l >= 0) {
+    if (use_wcnt) {
+      for (int w = 0; w < wave; ++w) earlier += wcnt[w * K + l];
+    } else {
+      for (int u = 0; u < (wave << 6); ++u) earlier += (lab[u] == l);
+    }
+  }
   if (i >= N) return;
-  int rank = 0;
-  for (int u = 0; u < t; ++u) rank += (lab[u] == l);
-  order[km_cl_off[l] + bc[(int64_t)blockIdx.x * K + l] + rank] = (int32_t)i;
+  order[km_cl_off[l] + bc[(int64_t)blockIdx.x * K + l] + earlier + intra] = (int32_t)i;
 }
 
 // sums[j, 4*c4 .. 4*c4+3] = sequential fp32 sum over the cluster's rows in ascending order
@@ -1263,7 +1296,16 @@ extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
   SLIC_LAUNCH_CHECK();
   km_scan_blocks<<<dim3(K), dim3(64), 0, st>>>(bc, nblk, K, cnt);
   SLIC_LAUNCH_CHECK();
-  km_place<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc, cnt, order);
+  const int use_wcnt = (size_t)K * 4 * (1 + KM_SB / 64) <= 96 * 1024;
+  const size_t lds_place = (size_t)K * 4 * (use_wcnt ? 1 + KM_SB / 64 : 1);
+  if (lds_place > 48 * 1024) {
+    static size_t lds_set = 0;
+    if (lds_place > lds_set) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_place, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_place));
+      lds_set = lds_place;
+    }
+  }
+  km_place<<<dim3(nblk), dim3(KM_SB), lds_place, st>>>(labels, N, K, bc, cnt, order, use_wcnt);
   SLIC_LAUNCH_CHECK();
   km_accumulate<<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, cnt, sums, counts);
   SLIC_LAUNCH_CHECK();
