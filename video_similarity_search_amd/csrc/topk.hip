@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
 // both operands, which is just another order of the same dot product.
 __global__ __launch_bounds__(256) void topk_partial_dma(
     const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
-    int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */) {
+    int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */,
+    int* __restrict__ gthr /* [Nq] order-preserving int image of a lower bound of query q's final k-th best score */) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int STAGE_FLOATS = (TK_BQ + TK_BG) * TK_BK;
   float* lval = lds + 2 * STAGE_FLOATS;                  // [4 waves][k][32]
@@ -352,6 +353,15 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
           if (gi >= gend || (self_mask && gi == qo)) acc[ct][v] = -INFINITY;
         }
     }
+    // Slices of the same query prune for each other: the k-th best score any slice holds is a lower bound of the final
+    // k-th best, so it is published (atomic max on an order-preserving int image) and every slice drops scores strictly
+    // below the best bound published so far.  Exact whatever the timing: a dropped score cannot be in the final top-k.
+    float gb = -INFINITY;
+    if (owner) {
+      const int gi_ = __builtin_nontemporal_load(gthr + q);
+      gb = __int_as_float(gi_ >= 0 ? gi_ : gi_ ^ 0x7FFFFFFF);
+    }
+    const float filt = fmaxf(thr, gb);                         // thr = +inf on lanes that own no list
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           const float s = half ? oth : own;
-          if (s >= thr) {                                      // thr = +inf on lanes that own no list
+          if (s >= filt) {
             const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
             if ((s > thr || gi < thr_i) && s > -INFINITY) {
               pv[pc * 32 + r] = s;
@@ -373,6 +383,10 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
         if (__any(pc > TK_PC - 2)) flush();
       }
     flush();
+    if (owner && thr > -INFINITY) {                            // the heap is full: its root bounds the final k-th best from below
+      const int b = __float_as_int(thr);
+      atomicMax(gthr + q, b >= 0 ? b : b ^ 0x7FFFFFFF);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (h == 0 && q < Nq) {
@@ -517,7 +531,7 @@ static int topk_slices(int Nq, int Ng, int k) {
 }
 
 extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
-  return 2 * slic_align_up((size_t)topk_slices(Nq, Ng, k) * Nq * k * 4, 256);
+  return 2 * slic_align_up((size_t)topk_slices(Nq, Ng, k) * Nq * k * 4, 256) + slic_align_up((size_t)Nq * 4, 256);
 }
 
 // Qn, Gn: L2-normalised rows (slic_normalize_rows).  out_idx / out_dist: [Nq, k], ascending distance.
@@ -552,7 +566,9 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       lds_set2 = lds;
     }
-    topk_partial_dma<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx);
+    int* gthr = w.take<int>((size_t)Nq);
+    SLIC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)gthr, (int)0x807FFFFF, (size_t)Nq, st));   // the image of -inf
+    topk_partial_dma<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
   } else
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx);
   SLIC_LAUNCH_CHECK();
