@@ -1003,23 +1003,54 @@ __global__ void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, 
 }
 
 // ---- weight packing -------------------------------------------------------------------------
-// forward:  Wp[n][tap*Cs + c] = W[n][c][tap]  (zero for c >= C and the K padding)
-__global__ void pack_w_fwd(const float* __restrict__ W, int N, int C, int ntaps, int Cs, int Kp,
-                           float* __restrict__ Wp) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)N * Kp) return;
-  const int k = (int)(e % Kp), n = (int)(e / Kp);
-  const int tap = k / Cs, c = k % Cs;
-  Wp[e] = (tap < ntaps && c < C) ? W[((int64_t)n * C + c) * ntaps + tap] : 0.f;
+// Both packers are [channels][taps] <-> [taps][channels] transposes of the reference layout W[n][c][tap]; they go through
+// an LDS tile so that the global reads are contiguous runs of W and the global writes contiguous runs of the operand
+// (the one-thread-per-output-element version read W with a stride of `ntaps` floats).
+// forward:  Wp[n][tap*Cs + c] = W[n][c][tap]  (zero for c >= C and the K padding).  Workgroup = (n, chunk of CH channels).
+__global__ __launch_bounds__(256) void pack_w_fwd(const float* __restrict__ W, int N, int C, int ntaps, int Cs, int Kp,
+                                                  int CH, float* __restrict__ Wp) {
+  extern __shared__ float pk_lds[];                        // [CH][ld], ld odd: conflict-free column reads
+  const int n = blockIdx.x, c0 = blockIdx.y * CH, t = threadIdx.x;
+  const int ld = ntaps | 1;
+  const int cw = min(CH, C - c0);                          // real channels in this chunk (may be <= 0: all padding)
+  const int chw = min(CH, Cs - c0);                        // channels of the operand in this chunk
+  for (int e = t; e < cw * ntaps; e += 256) {
+    const int cc = e / ntaps, tap = e - cc * ntaps;
+    pk_lds[cc * ld + tap] = W[((int64_t)n * C + c0) * ntaps + e];
+  }
+  __syncthreads();
+  for (int e = t; e < ntaps * chw; e += 256) {
+    const int tap = e / chw, cc = e - tap * chw;
+    Wp[(int64_t)n * Kp + tap * Cs + c0 + cc] = cc < cw ? pk_lds[cc * ld + tap] : 0.f;
+  }
+  if (blockIdx.y == 0)
+    for (int k = ntaps * Cs + t; k < Kp; k += 256) Wp[(int64_t)n * Kp + k] = 0.f;
 }
-// data gradient:  Wd[c][tap*N + n] = W[n][c][tap]   (rows = input channels, Cs rows, zero padded)
-__global__ void pack_w_dgrad(const float* __restrict__ W, int N, int C, int ntaps, int Cs, int Kd,
-                             float* __restrict__ Wd) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)Cs * Kd) return;
-  const int k = (int)(e % Kd), c = (int)(e / Kd);
-  const int tap = k / N, n = k % N;
-  Wd[e] = (tap < ntaps && c < C) ? W[((int64_t)n * C + c) * ntaps + tap] : 0.f;
+// data gradient:  Wd[c][tap*N + n] = W[n][c][tap]   (rows = input channels, Cs rows, zero padded).
+// Workgroup = (32 output channels n, CB input channels c): reads CB*ntaps contiguous floats per n, writes 32 consecutive n.
+__global__ __launch_bounds__(256) void pack_w_dgrad(const float* __restrict__ W, int N, int C, int ntaps, int Cs, int Kd,
+                                                    int CB, float* __restrict__ Wd) {
+  extern __shared__ float pk_lds[];                        // [32][ld]
+  const int n0 = blockIdx.x * 32, c0 = blockIdx.y * CB, t = threadIdx.x;
+  const int run = CB * ntaps;
+  const int ld = run | 1;
+  const int cw = min(CB, C - c0);                          // real channels (<= 0: padding rows)
+  const int cbw = min(CB, Cs - c0);
+  const int nw = min(32, N - n0);
+  const int rw = cw > 0 ? cw * ntaps : 0;
+  for (int e = t; e < nw * rw; e += 256) {
+    const int nn = e / rw, r = e - nn * rw;
+    pk_lds[nn * ld + r] = W[((int64_t)(n0 + nn) * C + c0) * ntaps + r];
+  }
+  __syncthreads();
+  for (int e = t; e < cbw * ntaps * 32; e += 256) {
+    const int nn = e & 31, q = e >> 5;                     // q = cc * ntaps + tap
+    const int cc = q / ntaps, tap = q - cc * ntaps;
+    if (nn < nw) Wd[(int64_t)(c0 + cc) * Kd + tap * N + n0 + nn] = cc < cw ? pk_lds[nn * ld + q] : 0.f;
+  }
+  if (blockIdx.x == 0)
+    for (int cc = 0; cc < cbw; ++cc)
+      for (int k = ntaps * N + t; k < Kd; k += 256) Wd[(int64_t)(c0 + cc) * Kd + k] = 0.f;
 }
 
 // ---- layout conversion ------------------------------------------------------------------------
@@ -1280,8 +1311,10 @@ extern "C" int slic_conv_row_table(const SlicConvArgs* a, uint32_t* row_tab, voi
 extern "C" int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp, float* Wp,
                                     void* stream) {
   SLIC_REQUIRE(W && Wp && N > 0 && C > 0 && ntaps > 0 && Cs >= C && Kp >= ntaps * Cs, "slic_pack_weight_fwd: bad args");
-  const int64_t tot = (int64_t)N * Kp;
-  pack_w_fwd<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(W, N, C, ntaps, Cs, Kp, Wp);
+  const int CH = Cs < 64 ? Cs : 64;
+  const size_t lds = (size_t)CH * (ntaps | 1) * sizeof(float);
+  SLIC_REQUIRE(lds <= 64 * 1024, "slic_pack_weight_fwd: %d taps x %d channels per tile exceeds 64 KiB of LDS", ntaps, CH);
+  pack_w_fwd<<<dim3((unsigned)N, (unsigned)slic_cdiv(Cs, CH)), dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kp, CH, Wp);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1289,8 +1322,14 @@ extern "C" int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int
 extern "C" int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int Kd, float* Wd,
                                       void* stream) {
   SLIC_REQUIRE(W && Wd && N > 0 && C > 0 && ntaps > 0 && Cs >= C && Kd >= ntaps * N, "slic_pack_weight_dgrad: bad args");
-  const int64_t tot = (int64_t)Cs * Kd;
-  pack_w_dgrad<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(W, N, C, ntaps, Cs, Kd, Wd);
+  int CB = 64 / ntaps;
+  CB = CB < 8 ? 8 : CB;
+  const int fit = 384 / ntaps;                             // 32 x CB x ntaps floats <= 48 KiB
+  if (CB > fit) CB = fit < 1 ? 1 : fit;
+  if (CB > Cs) CB = Cs;
+  const size_t lds = (size_t)32 * ((CB * ntaps) | 1) * sizeof(float);
+  SLIC_REQUIRE(lds <= 64 * 1024, "slic_pack_weight_dgrad: %d taps x %d channels per tile exceeds 64 KiB of LDS", ntaps, CB);
+  pack_w_dgrad<<<dim3((unsigned)slic_cdiv(N, 32), (unsigned)slic_cdiv(Cs, CB)), dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kd, CB, Wd);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
