@@ -2,7 +2,10 @@
 """
 bench.py — headline benchmark of the MI355X hot path (contract: the round driver).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one rank per GPU over RCCL — either already under `python -m torch.distributed.run --nproc-per-node N ...`
+        (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or typed plainly, in which case this process
+        starts that launcher as a child before touching the GPU and relays rank 0's JSON line.
 
 Step = one pass of the training hot path over one synthetic batch: R3D-18 (models/resnet.py depth 18, the SLIC
 encoder) forward + backward + NT-Xent ('noise_contrastive') + SGD(lr .1, momentum .5) on a
@@ -32,6 +35,10 @@ GFLOP_PER_CLIP_TRAIN = 248.9         # fwd 85.17 + bwd 163.7 (
 R3D18_KW = dict(hidden_layer=2048, out_dim=128, num_classes=101, n_input_channels=3, shortcut_type='B',
                 conv1_t_size=7, conv1_t_stride=1, no_max_pool=True, widen_factor=1.0, projection_head=True,
                 predict_temporal_ds=False, spatio_temporal_attention=False, classifier=False, dropout=None)
+
+
+class _Skip(Exception):
+    pass
 
 
 def log(*a):
@@ -78,8 +85,10 @@ def cpu_baseline_encoder(sd, seconds_budget=25.0):
 
 
 def kmeans_secondary(rank, world, pg, run_cpu):
-    """k-means Lloyd throughput at BASELINE configs[2]: 100k x 512, K = 500, rows sharded over the ranks, explicit init,
-    tol = 0, fixed 20 iterations: embeddings/s = N * iters / wall (assign + update + status sync + collective)"""
+    """k-means Lloyd throughput at BASELINE configs[2]: 100k x 512, K = 500, explicit init, tol = 0, fixed 20 iterations:
+    embeddings/s = N * iters / wall (assign + update + status sync + collective).  With a process group the rows are sharded
+    over the ranks ([sums | counts] all-gathered over RCCL + rank-ordered add per iteration); without one (plain N = 1) the
+    whole matrix is on the one GPU and an iteration is one fused foreign call."""
     from video_similarity_search_amd.clustering import KMeans
     N, D, K, iters = 100000, 512, 500, 20
     rng = np.random.default_rng(1)
@@ -106,10 +115,13 @@ def kmeans_secondary(rank, world, pg, run_cpu):
         tt = torch.tensor([dt, dt_fit], device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt, dt_fit = (float(v) for v in tt.tolist())
+    layout = ("rows sharded over the ranks of an RCCL group, centroid partials [K*D sums | K counts] all-gathered + added in rank order"
+              if pg is not None else "whole matrix on one GPU, no process group (one fused foreign call per iteration)")
+    flops_iter = 2.0 * N * K * D
     out = dict(metric="k-means embeddings/sec 100kx512 K=500", value=N * iters / dt, unit="embeddings/s",
                ms_per_iter=dt / iters * 1e3, iters=iters, n_gpus=world, whole_fit_seconds=dt_fit,
-               config=dict(workload="Lloyd, N=100000 D=512 K=500 fp32, explicit init, tol=0, 20 fixed iterations, "
-                                    "rows sharded over ranks, centroid partials all-gathered + ordered add"))
+               whole_iteration_frac_of_fp32_mfma=flops_iter / (dt / iters) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
+               config=dict(workload=f"Lloyd, N=100000 D=512 K=500 fp32, explicit init, tol=0, 20 fixed iterations; {layout}"))
     # E-step kernel alone (dominant kernel of this path): HIP events on the launch stream
     from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
     k = HipKernels()
@@ -139,12 +151,135 @@ def kmeans_secondary(rank, world, pg, run_cpu):
         from oracle import kmeans as ok
         mean = ok.col_mean(X)
         t0 = time.time()
-        r = ok.lloyd(X - mean, init - mean, max_iter=3, tol_abs=0.0, fixed_iters=True)
+        ok.lloyd(X - mean, init - mean, max_iter=3, tol_abs=0.0, fixed_iters=True)
         dtc = time.time() - t0
         out["cpu_baseline"] = dict(value=N * 4 / dtc, unit="embeddings/s", cores=ok.num_threads(), kind="port",
-                                   sample="oracle/kmeans_oracle.c (OpenMP) 3 Lloyd iterations + final E-step on the same "
-                                          f"100k x 512, K=500 data: {dtc:.2f} s")
+                                   sample="oracle/kmeans_oracle.c (OpenMP, bit-exact fmaf chains) 3 Lloyd iterations + final "
+                                          f"E-step on the same 100k x 512, K=500 data: {dtc:.2f} s")
+        try:
+            # sklearn.cluster.KMeans itself (third-party code the reference calls, cluster_masks.py:70-71),
+            # same explicit init, tol = 0, a few fixed iterations, on this host's cores
+            import warnings
+            from sklearn.cluster import KMeans as SkKMeans
+            from threadpoolctl import threadpool_info
+            it_sk = 5
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                SkKMeans(n_clusters=K, init=init, n_init=1, max_iter=1, tol=0.0, algorithm="lloyd").fit(X[:20000])   # warm-up
+                t0 = time.time()
+                sk = SkKMeans(n_clusters=K, init=init, n_init=1, max_iter=it_sk, tol=0.0, algorithm="lloyd").fit(X)
+                dts = time.time() - t0
+            nthr = max([int(i.get("num_threads", 1)) for i in threadpool_info()] + [1])
+            out["cpu_baseline_sklearn"] = dict(
+                value=N * sk.n_iter_ / dts, unit="embeddings/s", cores=nthr, kind="third-party",
+                sample=f"sklearn {__import__('sklearn').__version__} KMeans(init=ndarray, n_init=1, max_iter={it_sk}, tol=0, lloyd).fit on the "
+                       f"same data: {dts:.2f} s wall for {sk.n_iter_} iterations (incl. its centring and final E-step), os.cpu_count()={os.cpu_count()}")
+        except Exception as e:
+            out["cpu_baseline_sklearn"] = dict(error=repr(e))
     return out
+
+
+def _time_events(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def retrieval_secondary(run_cpu):
+    """BASELINE configs[4] (iic_retrieve_clips.py:275-314): 10k x 512 queries vs 100k x 512 gallery, cosine top-50, one GPU;
+    inputs resident in HBM; normalise + fused similarity/top-k + merge per call"""
+    from video_similarity_search_amd.evaluate import cosine_topk
+    Nq, Ng, D, k = 10000, 100000, 512, 50
+    rng = np.random.default_rng(5)
+    Qh = rng.standard_normal((Nq, D)).astype(np.float32)
+    Gh = rng.standard_normal((Ng, D)).astype(np.float32)
+    Q, G = torch.from_numpy(Qh).cuda(), torch.from_numpy(Gh).cuda()
+    t = _time_events(lambda: cosine_topk(Q, G, k=k), 5)
+    fl = 2.0 * Nq * Ng * D
+    out = dict(metric="retrieval queries/sec, 10k x 512 vs 100k x 512 cosine top-50", value=Nq / t, unit="queries/s",
+               ms=t * 1e3, roofline=dict(bound="mfma", achieved=fl / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                                         frac=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, traffic=None,
+                                         kernel="topk_partial_dma + topk_merge_kernel (whole call incl. row normalisation)",
+                                         algorithmic_flops_per_launch=fl))
+    if run_cpu:
+        # the reference's own arithmetic on the host (sklearn cosine_distances = normalise + GEMM; then top-k): NumPy
+        # Q^ G^T + argpartition + sort of the kept k, on a bounded sample of the queries
+        ns = 500
+        t0 = time.time()
+        qn = Qh[:ns] / np.linalg.norm(Qh[:ns], axis=1, keepdims=True)
+        gn = Gh / np.linalg.norm(Gh, axis=1, keepdims=True)
+        Dm = 1.0 - qn @ gn.T
+        idx = np.argpartition(Dm, k, axis=1)[:, :k]
+        part = np.take_along_axis(Dm, idx, axis=1)
+        idx = np.take_along_axis(idx, np.argsort(part, axis=1), axis=1)
+        dtc = time.time() - t0
+        gi = cosine_topk(Q[:ns], G, k=k)[0].cpu().numpy()
+        same = float(np.mean([len(set(a) & set(b)) / k for a, b in zip(gi, idx)]))
+        out["cpu_baseline"] = dict(value=ns / dtc, unit="queries/s", cores=os.cpu_count(), kind="port",
+                                   sample=f"NumPy normalise + sgemm + argpartition/sort top-{k}: {ns} of the 10k queries vs the full "
+                                          f"100k gallery in {dtc:.2f} s (gallery normalisation included once); top-{k} set overlap with the GPU result {same:.4f}")
+    return out
+
+
+def nce_secondary():
+    """SURVEY.md §8 A4 at B = 32, K = 1024, D = 128, n_data = 100k: NCEAverage + 2 x NCESoftmaxLoss forward + backward + bank update"""
+    from video_similarity_search_amd.loss.NCE_loss import NCEAverage, NCESoftmaxLoss
+    B, K, D, n_data = 32, 1024, 128, 100000
+    nce = NCEAverage(D, n_data, K).cuda()
+    crit = NCESoftmaxLoss().cuda()
+    l = torch.randn(B, D, device="cuda", requires_grad=True)
+    ab = torch.randn(B, D, device="cuda", requires_grad=True)
+    y = torch.randint(0, n_data, (B,), device="cuda")
+
+    def nce_step():
+        o1, o2 = nce(l, ab, y)
+        (crit(o1) + crit(o2)).backward()
+
+    t = _time_events(nce_step, 20)
+    bytes_alg = 2 * B * (K + 1) * D * 4 + 2 * B * D * 4 * 2
+    return dict(metric="memory-bank NCE step (fwd + bwd + bank update), B=32 K=1024 D=128", ms=t * 1e3,
+                roofline=dict(bound="hbm", achieved=bytes_alg / t / 1e9, peak=8000.0, unit="GB/s", frac=bytes_alg / t / 1e9 / 8000.0,
+                              traffic=None, algorithmic_bytes_per_step=bytes_alg,
+                              note="launch-bound: a handful of small kernels over 33.6 MB of gathered bank rows"))
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed plainly: start the N ranks as a CHILD `torch.distributed.run` (one process per GPU,
+    rendezvous on 127.0.0.1) and relay rank 0's JSON line.  Nothing in this parent has touched the GPU yet (importing torch
+    does not initialise HIP), and the parent never exec()s — it waits and exits with the child's code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("bench.py: launching", " ".join(cmd))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in p.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            log(out)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        log("bench.py: the ranks exited cleanly but rank 0 printed no JSON line")
+        rc = 3
+    return rc
 
 
 def main():
@@ -155,14 +290,18 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (16 anchors || 16 positives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="secondary = the k-means row only (tests)")
     ap.add_argument("--force-dist", action="store_true", help="init the process group / DDP / sharded k-means even at world size 1 (path test)")
+    ap.add_argument("--self-launch", action="store_true", help="go through the child torch.distributed.run launcher even for --gpus 1 (path test)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        log("bench.py: --gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.self_launch):
+        sys.exit(self_launch(args.gpus))
+    if args.gpus != world:
+        log(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     pg = None
@@ -231,13 +370,17 @@ def main():
     flops_launch = 2.0 * M * 64 * 1728
     ach = flops_launch / (ms_k * 1e-3) / 1e12
 
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_gemm_dma.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    # HBM traffic of the dominant kernel comes from PMC counters, which need rocprofv3 around the process: the value below is
+    # the one committed with the profile of the same command (profiles/), NOT measured in this run — `traffic` stays null
+    traffic_prof, traffic_src = None, None
+    for name in ("r02_pmc_conv_gemm_dma.json", "r01_pmc_conv_gemm_dma.json"):
+        pmc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pmc):
+            try:
+                traffic_prof, traffic_src = json.load(open(pmc)).get("hbm_bytes_per_launch"), "profiles/" + name
+                break
+            except Exception:
+                pass
 
     try:
         metric_name = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]     # the exact string of BASELINE.json
@@ -252,7 +395,8 @@ def main():
                                     f"{B} x 3x16x112x112 fp32 = {B//2} anchors || {B//2} positives; BASELINE configs[1]",
                            global_batch=world * B, parallelism=f"dp{world}", final_loss=lossv),
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                             frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=traffic,
+                             frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
+                             traffic_source=traffic_src,
                              kernel="conv_gemm_dma_kernel<128,64,2,2,2,1,true> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring, DMA issue interleaved with the MFMAs; fwd + dgrad of layer1)",
                              ms_per_launch=ms_k, launches_timed=len(ev), algorithmic_flops_per_launch=flops_launch,
                              whole_step_frac=(world * B * args.steps / dt) * GFLOP_PER_CLIP_TRAIN / 1e3 /
@@ -262,7 +406,16 @@ def main():
             res["secondary"] = kmeans_secondary(rank, world, pg, run_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         except Exception as e:                                    # never lose the headline line
             res["secondary"] = dict(error=repr(e))
+        run_cpu_rows = rank == 0 and world == 1 and not args.no_cpu_baseline
+        if not args.quick and rank == 0:
+            for key, fn in (("retrieval", lambda: retrieval_secondary(run_cpu_rows)), ("nce", nce_secondary)):
+                try:
+                    res["secondary"][key] = fn()
+                except Exception as e:
+                    res["secondary"][key] = dict(error=repr(e))
         try:
+            if args.quick:
+                raise _Skip()
             # embedding extraction (evaluate.py:146-205): eval-mode forward only, BN folded into the conv epilogue
             net.eval()
             with torch.no_grad():
@@ -310,6 +463,8 @@ def main():
                     fit_cluster(Xc, 'kmeans', k=500, l2normalize=True)
                 torch.cuda.synchronize()
                 res["secondary"]["fit_cluster_reference_call_seconds"] = time.time() - t1
+        except _Skip:
+            pass
         except Exception as e:
             res["secondary"]["extra_error"] = repr(e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

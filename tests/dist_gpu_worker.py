@@ -1,0 +1,186 @@
+"""Worker of tests/test_dist_gpu.py: one rank of an RCCL (backend "nccl") process group on real MI355X(s).
+Started by `python -m torch.distributed.run --nproc-per-node W tests/dist_gpu_worker.py <case> <out_dir>`; a
+one-rank group (W = 1) takes exactly the code paths of W > 1 (DDP reducer, all-gather of the centroid partials,
+rank-ordered combine, label all-gather), which is how a single-GPU box covers them.  Every case writes
+<out_dir>/<case>_r<rank>.npz; the parent test compares the ranks with each other and with the oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+TINY = dict(hidden_layer=64, out_dim=32, num_classes=101, n_input_channels=3, shortcut_type='B', conv1_t_size=7,
+            conv1_t_stride=1, no_max_pool=True, widen_factor=0.125, projection_head=True, predict_temporal_ds=False,
+            spatio_temporal_attention=False, classifier=False, dropout=None)
+
+
+def tiny_state_dict(seed=3):
+    """seeded tiny R3D-18 weights with the reference's init rules — built without the oracle so the worker is product-only"""
+    import contextlib
+    import io
+    from video_similarity_search_amd.models import generate_model
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = generate_model(18, **TINY)
+    return m, {k: v.clone() for k, v in m.state_dict().items()}
+
+
+def case_ddp(rank, world, out):
+    """DistributedDataParallel(model) step == the un-wrapped step followed by an explicit gradient mean over the ranks
+    (online_train.py:485-494): bit-equal for W = 1 and W = 2 (a two-term sum is order-free, /2 is exact)."""
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    m, sd0 = tiny_state_dict()
+    m = m.cuda().train()
+    rng = np.random.default_rng(100 + rank)                      # every rank its own clips
+    x = torch.from_numpy(rng.standard_normal((4, 3, 8, 32, 32)).astype(np.float32)).cuda()
+    labels = torch.arange(2).repeat(2).cuda()
+    crit = OnlineTripletLoss(0.2, 'cosine')
+
+    def run(model):
+        model.zero_grad(set_to_none=True)
+        loss, _ = crit(model(x), labels, sampling_strategy='noise_contrastive')
+        loss.backward()
+        return float(loss.item())
+
+    l_plain = run(m)
+    plain = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for g in plain.values():                                       # what DDP is specified to produce
+        dist.all_reduce(g)
+        g.div_(world)
+    m.load_state_dict(sd0)                                         # BN running stats back to the start
+    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[torch.cuda.current_device()])
+    l_ddp = run(ddp)
+    res = dict(l_plain=l_plain, l_ddp=l_ddp)
+    nbad = 0
+    worst = 0.0
+    for k, p in m.named_parameters():
+        same = torch.equal(p.grad, plain[k])
+        nbad += int(not same)
+        worst = max(worst, float((p.grad - plain[k]).abs().max().item()))
+        res["g/" + k] = p.grad.cpu().numpy()
+    res.update(n_params=len(plain), n_not_bit_equal=nbad, worst_abs=worst)
+    # one optimiser step under DDP keeps the replicas identical
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1, momentum=0.5)
+    opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    allw = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(allw, flat)
+    res["replicas_equal"] = all(torch.equal(allw[0], w) for w in allw)
+    np.savez(out, **res)
+
+
+def case_kmeans(rank, world, out):
+    """KMeans(process_group=WORLD) on the HIP kernels: rows sharded, [sums | counts] all-gathered over RCCL,
+    slic_kmeans_combine_shards, one n_changed all-reduce; explicit init (goldens) and the k-means++ branch"""
+    from video_similarity_search_amd.clustering.kmeans_hip import KMeans
+    res = {}
+    for name in ("clustered_empty", "d128", "unstructured"):
+        g = dict(np.load(os.path.join(HERE, "golden", f"kmeans_{name}.npz")))
+        X, init = g["X"], g["init"]
+        N = len(X)
+        per = (N + world - 1) // world
+        shard = torch.from_numpy(X[rank * per:(rank + 1) * per]).cuda()
+        km = KMeans(n_clusters=init.shape[0], init=init, n_init=1, process_group=dist.group.WORLD, trace=True).fit(shard)
+        lab = torch.from_numpy(km.labels_).cuda()
+        sizes = [min(per, N - r * per) for r in range(world)]
+        parts = [torch.empty(s, dtype=lab.dtype, device="cuda") for s in sizes]
+        dist.all_gather(parts, lab) if len(set(sizes)) == 1 else _all_gather_ragged(parts, lab, sizes)
+        res[f"{name}/labels"] = torch.cat(parts).cpu().numpy()
+        res[f"{name}/centers"] = km.cluster_centers_
+        res[f"{name}/n_iter"] = km.n_iter_
+        res[f"{name}/strict"] = km.strict_
+        res[f"{name}/inertia"] = km.inertia_
+        res[f"{name}/nreloc"] = km.n_relocations_
+        res[f"{name}/trace_local"] = km.trace_
+    # k-means++ (sklearn _kmeans.py:174-277) in a sharded run: all ranks must pick the same rows of the GLOBAL matrix
+    g = dict(np.load(os.path.join(HERE, "golden", "kmeans_d128.npz")))
+    X = g["X"]
+    N = len(X)
+    per = (N + world - 1) // world
+    shard = torch.from_numpy(X[rank * per:(rank + 1) * per]).cuda()
+    km = KMeans(n_clusters=12, n_init=2, random_state=5 + rank * 0, process_group=dist.group.WORLD).fit(shard)
+    res["kpp/init_indices"] = np.asarray(km.init_indices_)
+    res["kpp/labels_local"] = km.labels_
+    res["kpp/centers"] = km.cluster_centers_
+    res["kpp/inertia"] = km.inertia_
+    res["kpp/n_iter"] = km.n_iter_
+    np.savez(out, **res)
+
+
+def _all_gather_ragged(parts, t, sizes):
+    mx = max(sizes)
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[: t.numel()] = t
+    buf = [torch.empty_like(pad) for _ in sizes]
+    dist.all_gather(buf, pad)
+    for p, b, s in zip(parts, buf, sizes):
+        p.copy_(b[:s])
+
+
+class _EvalSet(torch.utils.data.Dataset):
+    """synthetic eval-mode dataset with the reference loader's item shape: (clip, target, info, index)"""
+
+    def __init__(self, n, seed=17):
+        rng = np.random.default_rng(seed)
+        self.x = rng.standard_normal((n, 3, 8, 32, 32)).astype(np.float32)
+        self.y = rng.integers(0, 5, n)
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        return torch.from_numpy(self.x[i]), int(self.y[i]), 0, i
+
+
+def case_pipeline(rank, world, out):
+    """BASELINE configs[2] as a pipeline (online_train.py:605-667): extract with each rank's shard resident on its GPU ->
+    sharded fit_cluster -> labels handed to every rank in dataset order -> vid_clusters.txt on rank 0.
+    The DistributedSampler shuffles and pads exactly like the reference's eval loader (datasets/data_loader.py:283)."""
+    import types
+    from video_similarity_search_amd.online_train import iterative_cluster_step
+    m, _ = tiny_state_dict(seed=11)
+    m = m.cuda()
+    n = 37                                                          # not a multiple of the batch or the world size
+    ds = _EvalSet(n)
+    sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, sampler=sampler, drop_last=False)
+    ns = types.SimpleNamespace
+    out_dir = os.path.dirname(out)
+    cfg = ns(NUM_GPUS=max(world, 2), OUTPUT_PATH=out_dir, DATASET=ns(POSITIVE_SAMPLING_P=0.2),
+             ITERCLUSTER=ns(METHOD='kmeans', K=4, L2_NORMALIZE=True, FINCH_PARTITION=0, ADAPTIVEP=False, SHARDED=True))
+    np.random.seed(1)
+    labels, nmi = iterative_cluster_step(None, cfg, m, loader, epoch=0, cuda=True, device="cuda", is_master_proc=(rank == 0))
+    res = dict(labels=np.asarray(labels), n=n)
+    # the same embeddings through the reference-shaped (gathered, rank-0) path for comparison
+    from video_similarity_search_amd.evaluate import evaluate
+    emb, tg, idxs = evaluate(m, loader, gather=True)
+    res.update(emb=emb.numpy(), idxs=np.asarray(idxs), targets=np.asarray(tg))
+    np.savez(out, **res)
+
+
+def case_launch(rank, world, out):
+    raise SystemExit("case_launch is driven by the test itself (misc.distributed_helper.launch_processes)")
+
+
+def main():
+    case, out_dir = sys.argv[1], sys.argv[2]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    try:
+        globals()["case_" + case](rank, world, os.path.join(out_dir, f"{case}_r{rank}.npz"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,28 +24,33 @@ def _to_device(embeddings):
     return embeddings.detach().to(device="cuda", dtype=torch.float32).contiguous()
 
 
-def preprocess_features_kmeans(data):
+def preprocess_features_kmeans(data, kernels=None):
     """row L2-normalise: data / torch.norm(data, dim=1, keepdim=True) (no epsilon), on the device.
     Returns a tensor on the device the data ended up on (CPU input is moved to the current GPU)."""
-    x = _to_device(data)
-    out = torch.empty_like(x)
-    N, D = x.shape
-    call("slic_l2norm_rows", ptr(x), N, D, x.stride(0), ptr(out), out.stride(0), stream())
+    if kernels is not None:                 # explicit kernel provider (see KMeans(kernels=...)): tests of the host logic
+        x = kernels.to_device(data)
+        out = torch.empty_like(x)
+        kernels.l2norm_rows(x, out)
+    else:
+        x = _to_device(data)
+        out = torch.empty_like(x)
+        N, D = x.shape
+        call("slic_l2norm_rows", ptr(x), N, D, x.stride(0), ptr(out), out.stride(0), stream())
     print('l2-normalized data')
     return out
 
 
 def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, finch_partition=0,
-                n_init=10, init='k-means++', process_group=None, random_state=None):
-    """Reference signature + keyword-only extras (n_init / init / process_group / random_state) that default
-    to the reference's behaviour: KMeans(n_clusters=k, n_init=10).fit(embeddings).labels_."""
+                n_init=10, init='k-means++', process_group=None, random_state=None, kernels=None):
+    """Reference signature + keyword-only extras (n_init / init / process_group / random_state / kernels) that default
+    to the reference's behaviour: KMeans(n_clusters=k, n_init=10).fit(embeddings).labels_.
+    process_group: `embeddings` is this rank's row shard (rank order == row order), the returned labels are this rank's."""
     assert (method in _METHODS)
     print("Clustering with {}...".format(method))
     if method == 'finch':
         # cluster_masks.py:79-86: FINCH(embeddings, distance='cosine'), take partition `finch_partition`
         from .finch import FINCH
-        emb = embeddings.detach().cpu().numpy() if torch.is_tensor(embeddings) else np.asarray(embeddings)
-        c, num_clust, req_c = FINCH(emb, distance='cosine')
+        c, num_clust, req_c = FINCH(embeddings, distance='cosine')      # rows go to (or stay on) the device once
         PARTITION = finch_partition
         labels = c[:, PARTITION]
         n_clusters = num_clust[PARTITION]
@@ -56,20 +61,20 @@ def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, fi
         raise NotImplementedError(
             f"method={method!r}: 'kmeans', 'spherical_kmeans' and 'finch' are on the MI355X hot path (SURVEY.md §8); the "
             "reference runs the others on the host through sklearn")
-    x = _to_device(embeddings)
+    x = _to_device(embeddings) if kernels is None else kernels.to_device(embeddings)
     if method == 'spherical_kmeans':
         # cluster_masks.py:73-77: SphericalKMeans(n_clusters=k).fit(embeddings) (spherecluster: normalises the rows itself,
         # n_init=10, k-means++, centres renormalised every iteration).  spherecluster is not vendored: parity unpinned.
         print('clustering with spherical kmeans with k={}'.format(k))
         print(tuple(x.shape))
         km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group, random_state=random_state,
-                    spherical=True).fit(x)
+                    spherical=True, kernels=kernels).fit(x)
     else:
         print("k:", k)
         if l2normalize:
-            x = preprocess_features_kmeans(x)
+            x = preprocess_features_kmeans(x, kernels)
         km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group,
-                    random_state=random_state).fit(x)
+                    random_state=random_state, kernels=kernels).fit(x)
     labels = km.labels_
     print(labels.shape)
     n_clusters = len(set(labels.tolist())) - (1 if -1 in labels else 0)

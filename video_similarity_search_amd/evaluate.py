@@ -202,22 +202,31 @@ def topk_retrieval(args=None, X_train=None, y_train=None, X_test=None, y_test=No
 # ------------------------------------------------------------------------------------------------
 def evaluate(model, data_loader, device=None, is_master_proc=True, gather=True):
     """evaluate.py:146-205: eval-mode encoder over a loader of (input [b,3,T,S,S], targets [b], info, indexes [b]),
-    no grad; per batch the (embedding, label, index) triples are all-gathered across ranks (misc/distributed_helper)
-    and moved to the host, exactly the reference's return contract: (Tensor[N,D] cpu, list[int], list[int])."""
+    no grad.  gather=True is the reference's return contract — per batch the (embedding, label, index) triples are
+    all-gathered across ranks (misc/distributed_helper) and moved to the host: (Tensor[N',D] cpu, list[int], list[int]).
+    gather=False (SURVEY.md §8e row 1) keeps THIS rank's rows resident on its GPU: no collective, no per-batch D2H;
+    returns (Tensor[n_local, D] on the device, list[int], list[int]) for the sharded k-means / retrieval to consume."""
     from .misc import distributed_helper as du_helper
     model.eval()
     embedding, vid_info, idxs = [], [], []
     world = du_helper.get_world_size()
+    dev = torch.device("cuda") if device is None else torch.device(device)
     with torch.no_grad():
         for batch in data_loader:
             inp, targets, _info, indexes = batch
-            inp = inp.cuda(non_blocking=True)
+            inp = inp.to(dev, non_blocking=True)
             embedd = model(inp)
             if isinstance(embedd, tuple):
                 embedd = embedd[0]
-            targets = torch.as_tensor(targets).cuda()
-            indexes = torch.as_tensor(indexes).cuda()
-            if world > 1 and gather:
+            embedd = embedd.flatten(1)
+            if not gather:
+                embedding.append(embedd.detach())
+                vid_info.extend(torch.as_tensor(targets).tolist())
+                idxs.extend(torch.as_tensor(indexes).tolist())
+                continue
+            targets = torch.as_tensor(targets).to(dev)
+            indexes = torch.as_tensor(indexes).to(dev)
+            if world > 1:
                 embedd, targets, indexes = du_helper.all_gather([embedd, targets, indexes])
             embedding.append(embedd.detach().cpu())
             vid_info.extend(targets.cpu().tolist())
@@ -226,14 +235,17 @@ def evaluate(model, data_loader, device=None, is_master_proc=True, gather=True):
 
 
 def get_embeddings_and_labels(args, cfg, model, cuda, device, data_loader, split='val', is_master_proc=True,
-                              load_pkl=False, save_pkl=False):
-    """evaluate.py:310-350 (same positional signature; the optional pkl cache uses torch.save/torch.load)"""
+                              load_pkl=False, save_pkl=False, gather=True):
+    """evaluate.py:310-350 (same positional signature; the optional pkl cache uses torch.save/torch.load).
+    gather=False: this rank's shard stays on its GPU (see evaluate); the pkl cache then holds per-rank files."""
     out_dir = getattr(cfg, "OUTPUT_PATH", None) if cfg is not None else None
-    names = [f"{split}_embeddings.pkl", f"{split}_labels.pkl", f"{split}_idxs.pkl"]
+    tag = split if gather else "{}_rank{}".format(split, torch.distributed.get_rank() if torch.distributed.is_initialized() else 0)
+    names = [f"{tag}_embeddings.pkl", f"{tag}_labels.pkl", f"{tag}_idxs.pkl"]
     if load_pkl and out_dir and all(os.path.exists(os.path.join(out_dir, n)) for n in names):
-        return tuple(torch.load(os.path.join(out_dir, n)) for n in names)
-    embeddings, labels, idxs = evaluate(model, data_loader, device=device, is_master_proc=is_master_proc)
-    if save_pkl and out_dir and is_master_proc:
-        for n, v in zip(names, (embeddings, labels, idxs)):
+        emb, labels, idxs = (torch.load(os.path.join(out_dir, n)) for n in names)
+        return (emb if gather else emb.cuda()), labels, idxs
+    embeddings, labels, idxs = evaluate(model, data_loader, device=device, is_master_proc=is_master_proc, gather=gather)
+    if save_pkl and out_dir and (is_master_proc or not gather):
+        for n, v in zip(names, (embeddings.cpu(), labels, idxs)):
             torch.save(v, os.path.join(out_dir, n))
     return embeddings, labels, idxs

@@ -179,26 +179,85 @@ def _append_log(cfg, name, line):
         f.write(line)
 
 
+def _dataset_order(n, idxs, cluster_labels):
+    """cluster assignments in the unshuffled order of the dataset (online_train.py:649-651): slot idxs[i] <- label i, later
+    duplicates (DistributedSampler padding) overwrite earlier ones; slots the loader never produced (drop_last) stay -1"""
+    import numpy as np
+    order = np.full(n, -1, dtype=np.int32)
+    idxs = np.asarray(idxs, dtype=np.int64).reshape(-1)
+    lab = np.asarray(cluster_labels).reshape(-1).astype(np.int32)
+    if len(idxs) != len(lab):
+        raise ValueError("one dataset index per clustered row: {} vs {}".format(len(idxs), len(lab)))
+    if len(idxs) and (idxs.min() < 0 or idxs.max() >= n):
+        raise ValueError("dataset index outside [0, {})".format(n))
+    order[idxs] = lab               # numpy assigns in order: the last duplicate wins, like the reference's loop
+    return order
+
+
+def _cluster_sharded(cfg):
+    """the sharded route of SURVEY.md §8e (configs[2]): every rank keeps its rows, k-means runs over the process group"""
+    return (cfg.NUM_GPUS > 1 and torch.distributed.is_available() and torch.distributed.is_initialized()
+            and cfg.ITERCLUSTER.METHOD in ('kmeans', 'spherical_kmeans') and bool(getattr(cfg.ITERCLUSTER, "SHARDED", True)))
+
+
 def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=True, device=None, is_master_proc=True):
-    """online_train.py:605-662: embeddings of the whole train set -> fit_cluster -> NMI/AMI logs ->
-    vid_clusters.txt in the dataset's unshuffled order -> barrier.  Returns (cluster_labels, NMI or None)."""
+    """online_train.py:605-662: embeddings of the whole train set -> fit_cluster -> NMI/AMI logs -> vid_clusters.txt in
+    the dataset's unshuffled order -> barrier.
+
+    Returns (labels, NMI or None): labels = np.int32 [len(dataset)] in DATASET order (the content of vid_clusters.txt,
+    -1 where the eval loader produced no row, e.g. drop_last), identical on every rank.
+
+    NUM_GPUS > 1 with k-means (cfg.ITERCLUSTER.SHARDED, default on): the extraction keeps each rank's [N/W, D] rows on
+    its GPU (no per-batch all_gather + D2H, evaluate.py:189-193), fit_cluster runs row-sharded over the process group
+    (one [K*D + K] all-gather per Lloyd iteration over RCCL), and the only other exchange is one int32 all-gather of
+    (label, dataset index, true label).  FINCH — and SHARDED = False — keep the reference's shape: gather to every rank,
+    cluster on rank 0, and the dataset-ordered labels are broadcast (which is also the barrier of :662)."""
+    import numpy as np
     from .clustering.cluster_masks import fit_cluster
     from .evaluate import get_embeddings_and_labels
+    n_data = len(eval_train_loader.dataset)
+    sharded = _cluster_sharded(cfg)
     if is_master_proc:
         print('\n=> Computing embeddings')
     start_time = time.time()
     embeddings, true_labels, idxs = get_embeddings_and_labels(args, cfg, encoder, cuda, device, eval_train_loader,
-                                                              split='train', is_master_proc=is_master_proc)
+                                                              split='train', is_master_proc=is_master_proc,
+                                                              gather=not sharded)
     if is_master_proc:
         print('Time to get embeddings: {:.2f}s'.format(time.time() - start_time))
-    cluster_labels, NMI = None, None
-    if is_master_proc:
+    order, NMI = None, None
+    err = None
+    if sharded:
+        if is_master_proc:
+            print('\n=> Clustering')
+            print('embeddings shape (this rank)', tuple(embeddings.shape))
+        start_time = time.time()
+        pg = torch.distributed.group.WORLD
+        local = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
+                            getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0), process_group=pg,
+                            kernels=getattr(cfg.ITERCLUSTER, "KMEANS_KERNELS", None))
+        trip = torch.from_numpy(np.stack([np.asarray(local, np.int32), np.asarray(idxs, np.int32),
+                                          np.asarray(true_labels, np.int32)])).to(embeddings.device)
+        cluster_labels, idxs, true_labels = (a.reshape(-1) for a in _all_gather_rows(trip, pg))
+        if is_master_proc:
+            print('Time to cluster: {:.2f}s'.format(time.time() - start_time))
+        order = _dataset_order(n_data, idxs, cluster_labels)       # every rank holds all triples: no broadcast needed
+    elif is_master_proc:
         print('\n=> Clustering')
         start_time = time.time()
         print('embeddings shape', embeddings.size())
-        cluster_labels = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
-                                     getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0))
-        print('Time to cluster: {:.2f}s'.format(time.time() - start_time))
+        try:
+            cluster_labels = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
+                                         getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0),
+                                         **({"kernels": cfg.ITERCLUSTER.KMEANS_KERNELS}
+                                            if getattr(cfg.ITERCLUSTER, "KMEANS_KERNELS", None) is not None else {}))
+            print('Time to cluster: {:.2f}s'.format(time.time() - start_time))
+            order = _dataset_order(n_data, idxs, cluster_labels)
+        except Exception as e:              # the other ranks are about to enter a collective: tell them instead of hanging them
+            if cfg.NUM_GPUS <= 1:
+                raise
+            err = e
+    if is_master_proc and order is not None:
         try:                                     # O(N) contingency-table metrics stay on the host (SURVEY.md §8f #3)
             from sklearn.metrics import adjusted_mutual_info_score, normalized_mutual_info_score
             NMI = normalized_mutual_info_score(true_labels, cluster_labels)
@@ -211,31 +270,66 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
                 cfg.DATASET.POSITIVE_SAMPLING_P = float(1.0 - NMI)
         except ImportError:
             pass
-        # cluster assignments in the unshuffled order of the dataset, one label per line (online_train.py:649-657)
-        order = [None] * len(eval_train_loader.dataset)
-        for i in range(len(cluster_labels)):
-            order[idxs[i]] = cluster_labels[i]
+        # one label per line, unshuffled dataset order (online_train.py:654-657); a slot the loader never produced is
+        # written as the reference writes it ('None')
         cluster_output_path = os.path.join(cfg.OUTPUT_PATH, 'vid_clusters.txt')
         with open(cluster_output_path, "w") as f:
             for label in order:
-                f.write('{}\n'.format(label))
+                f.write('{}\n'.format(label if label >= 0 else None))
         print('Saved cluster labels to', cluster_output_path)
-    if cfg.NUM_GPUS > 1:
+    if cfg.NUM_GPUS > 1 and not sharded:
         # SURVEY.md §8f #3: besides the text file (kept for the reference's dataset code, which re-parses it on every
         # rank), hand the labels to the other ranks as one int32 broadcast, so a caller can rebuild its sampler
         # without touching the filesystem; the broadcast is also the barrier of online_train.py:662
-        cluster_labels = broadcast_cluster_labels(cluster_labels, len(eval_train_loader.dataset), device, is_master_proc)
-    return cluster_labels, NMI
+        send = order if err is None else np.full(n_data, _FAILED, np.int32)
+        order = broadcast_cluster_labels(send, n_data, device, is_master_proc)
+        if err is not None:
+            raise err
+        if len(order) and order[0] == _FAILED:
+            raise RuntimeError("clustering failed on the master process")
+    elif sharded:
+        torch.distributed.barrier()          # the file is complete before any rank re-reads it (online_train.py:662)
+    return order, NMI
+
+
+_FAILED = -2          # first slot of the broadcast when the master could not produce labels
+
+
+def _all_gather_rows(t, pg):
+    """[r, n_local] int32 on every rank (n_local may differ) -> numpy [r, sum n_local], rank-major along the columns"""
+    import numpy as np
+    W = torch.distributed.get_world_size(pg)
+    n = torch.tensor([t.shape[1]], dtype=torch.int64, device=t.device)
+    sizes = torch.empty(W, dtype=torch.int64, device=t.device)
+    torch.distributed.all_gather_into_tensor(sizes, n, group=pg)
+    sizes = sizes.cpu().tolist()
+    mx = max(sizes)
+    pad = torch.zeros(t.shape[0], mx, dtype=t.dtype, device=t.device)
+    pad[:, : t.shape[1]] = t
+    out = torch.empty(W * pad.numel(), dtype=t.dtype, device=t.device)
+    torch.distributed.all_gather_into_tensor(out, pad.reshape(-1), group=pg)
+    out = out.view(W, t.shape[0], mx).cpu().numpy()
+    return np.concatenate([out[r, :, : sizes[r]] for r in range(W)], axis=1)
 
 
 def broadcast_cluster_labels(cluster_labels, n, device, is_master_proc, src=0):
-    """labels (np.ndarray[int] on the master, anything elsewhere) -> the same np.ndarray[int32] on every rank"""
+    """dataset-ordered labels (np.ndarray[int] of length n on the master, anything elsewhere) -> the same np.ndarray[int32]
+    on every rank.  The master validates BEFORE the collective and still takes part in it when its input is unusable
+    (first slot = -2), so a bad array cannot strand the other ranks inside dist.broadcast."""
     import numpy as np
     dev = device if device is not None else ("cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
     buf = torch.empty(n, dtype=torch.int32, device=dev)
+    bad = None
     if is_master_proc:
-        lab = np.asarray(cluster_labels, dtype=np.int32)
-        assert lab.shape == (n,), "one label per dataset item"
+        try:
+            lab = np.asarray(cluster_labels, dtype=np.int32).reshape(-1)
+            if lab.shape != (n,):
+                raise ValueError("one label per dataset item: got {} for a dataset of {}".format(lab.shape, n))
+        except (TypeError, ValueError) as e:
+            bad = e
+            lab = np.full(n, _FAILED, np.int32)
         buf.copy_(torch.from_numpy(lab))
     torch.distributed.broadcast(buf, src=src)
+    if bad is not None:
+        raise bad
     return buf.cpu().numpy()
