@@ -16,7 +16,7 @@
  *
  * Parity status: the reference holds NO test that pins k-means results, so
  * this oracle is pinned by golden vectors generated from sklearn 1.7.2 in the build
- * container (tests/golden/make_goldens.py -> tests/golden/kmeans_*.npz).
+ * container (tests/golden/make_goldens_kmeans.py -> tests/golden/kmeans_*.npz).
  *
  * Floating-point contract (what "bit-exact" means between this file and the HIP path):
  *   score(i,j) = cnorm[j] - 2*dot(x_i, c_j)            (sklearn: ||c||^2 - 2 x.c via sgemm)

@@ -236,16 +236,20 @@ def test_tiny_encoder_train_step_vs_reference_golden(gpu, golden_dir):
     for k, p in m.named_parameters():
         ref = enc["grad/" + k]
         assert p.grad is not None, k
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-5 + 2e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+        # every one of the 66 parameter tensors, max-norm relative to the tensor's largest gradient entry
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-6 + 5e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
     opt.step()
     after = m.state_dict()
     for k in after:
         ref = enc["after/" + k]
-        np.testing.assert_allclose(after[k].cpu().numpy(), ref, atol=1e-5 + 1e-3 * np.abs(ref).max(), rtol=0, err_msg=k)
+        np.testing.assert_allclose(after[k].cpu().numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=k)
+    # eval-mode forward as a FORWARD check: on the reference's own post-step weights and running statistics (not on the
+    # weights this GPU's step produced, which would fold one step of fp32 drift into the comparison)
+    _load_into(m, {k[6:]: v for k, v in enc.items() if k.startswith("after/")})
     m.eval()
     with torch.no_grad():
         ev = m(x)
-    np.testing.assert_allclose(ev.cpu().numpy(), enc["eval/emb"], atol=5e-4, rtol=1e-3)
+    np.testing.assert_allclose(ev.cpu().numpy(), enc["eval/emb"], atol=1e-4, rtol=0)
 
 
 def test_two_live_forward_passes_fused_equals_unfused(gpu, monkeypatch):
@@ -275,18 +279,26 @@ def test_two_live_forward_passes_fused_equals_unfused(gpu, monkeypatch):
 
 
 def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
-    """BASELINE config 1 shape (2 x 3 x 16 x 112 x 112) on the real R3D-18: eval and train-mode embeddings within
-    1e-4 of the CPU oracle; one train step's loss and a few gradients"""
+    """the real R3D-18 at 4 x 3 x 16 x 112 x 112 (BASELINE configs[0]'s clip shape; B = 4 so that the train-mode
+    BatchNorm1d of the projection head normalises over four samples, a well-posed fp32 problem — at B = 2 its output is
+    +-gamma/sqrt(1 + 4 eps/d^2), ill-conditioned in d): eval and train-mode embeddings and the loss within 1e-4 of the CPU
+    oracle, gradients of eight tensors spread over the depth"""
     from oracle import encoder as oe
     from video_similarity_search_amd.models import generate_model
     from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
     rng = np.random.default_rng(7)
     sd = oe.make_state_dict(rng)
-    x = rng.standard_normal((2, 3, 16, 112, 112)).astype(np.float32)
+    x = rng.standard_normal((4, 3, 16, 112, 112)).astype(np.float32)
     m = generate_model(18, **R3D18_KW)
     _load_into(m, sd)
     m = m.cuda()
     xt = torch.from_numpy(x)
+    # eval mode first (initial running statistics on both sides): a pure forward check
+    m.eval()
+    with torch.no_grad():
+        ev = m(xt.cuda()).cpu()
+        ev_ref = oe.encoder_forward(oe.to_torch(sd), xt, training=False)
+    assert (ev - ev_ref).abs().max().item() <= 1e-4 * max(1.0, ev_ref.abs().max().item())
     tsd = oe.to_torch(sd, requires_grad=True)
     emb_ref = oe.encoder_forward(tsd, xt, training=True)
     loss_ref = oe.ntxent_loss(emb_ref)
@@ -297,39 +309,21 @@ def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
     emb = m(xt.cuda())
     loss = ntxent_loss(emb)
     loss.backward()
-    # train mode at B = 2 puts BatchNorm1d over TWO samples in the head: outputs are +-gamma/sqrt(1 + 4 eps/d^2),
-    # ill-conditioned in d = h[0] - h[1].  Judge both fp32 implementations against an fp64 run of the oracle:
-    # the HIP path must be within 1e-4, or as close to fp64 as the fp32 CPU oracle is (x3).
-    t64 = oe.to_torch(sd, dtype=torch.float64)
-    with torch.no_grad():
-        emb64 = oe.encoder_forward(t64, xt.double(), training=True)
-    err_gpu = (emb.detach().cpu().double() - emb64).abs().max().item()
-    err_cpu = (emb_ref.detach().double() - emb64).abs().max().item()
-    assert err_gpu <= max(1e-4, 3 * err_cpu), (err_gpu, err_cpu)
+    assert (emb.detach().cpu() - emb_ref.detach()).abs().max().item() <= 1e-4
     assert abs(loss.item() - loss_ref.item()) <= 1e-4
     pd = dict(m.named_parameters())
     t64g = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
     l64 = oe.ntxent_loss(oe.encoder_forward(t64g, xt.double(), training=True))
     g64 = dict(zip(names, torch.autograd.grad(l64, [t64g[k] for k in names])))
-    # Gradients below the head pass through ~20 ReLUs whose masks flip for pre-activations within fp32 noise of
-    # zero; the fp32 CPU oracle itself is 1e-3..1e-2 (max-norm) away from fp64 there (scripts/diag_grads.py).
-    # Tight bar where the chain is short, loose (bug-catching) bar in relative L2 further down.
-    tight = {"layer4.1.conv2.weight", "fc1.weight", "fc2.bias", "bn_proj.bias"}
+    # Gradients are judged against an fp64 run of the oracle, in max-norm relative to the tensor's largest entry: 1e-3, or
+    # twice the fp32 CPU oracle's own distance from fp64 where that is larger (below the head the chain passes ~20 ReLUs
+    # whose masks flip for pre-activations within fp32 noise of zero — scripts/diag_grads.py)
     for k in names:
         ref = g64[k]
-        d_gpu = pd[k].grad.cpu().double() - ref
-        d_cpu = gref[k].double() - ref
-        if k in tight:
-            assert d_gpu.abs().max().item() <= max(1e-3 * ref.abs().max().item(), 3 * d_cpu.abs().max().item()), k
-        else:
-            l2 = (d_gpu.norm() / ref.norm()).item()
-            assert l2 <= max(3e-2, 5 * (d_cpu.norm() / ref.norm()).item()), (k, l2)
-    # eval mode (running stats after the one update on both sides)
-    m.eval()
-    with torch.no_grad():
-        ev = m(xt.cuda()).cpu()
-        ev_ref = oe.encoder_forward({k: v.detach() for k, v in tsd.items()}, xt, training=False)
-    assert (ev - ev_ref).abs().max().item() <= 1e-4 * max(1.0, ev_ref.abs().max().item())
+        scale = ref.abs().max().item()
+        d_gpu = (pd[k].grad.cpu().double() - ref).abs().max().item() / scale
+        d_cpu = (gref[k].double() - ref).abs().max().item() / scale
+        assert d_gpu <= max(1e-3, 2 * d_cpu), (k, d_gpu, d_cpu)
 
 
 def test_tripletnet_surface(gpu):
@@ -374,3 +368,49 @@ def test_tiny_encoder_ragged_sizes_vs_oracle(gpu, shape):
     for k, ref in zip(names, g64):
         l2 = ((pd[k].grad.cpu().double() - ref).norm() / ref.norm().clamp_min(1e-12)).item()
         assert l2 < 3e-2, (k, l2)
+
+
+def test_bench_configuration_properties_b32(gpu, monkeypatch):
+    """BASELINE configs[1] itself — 32 x 3 x 16 x 112 x 112, the R3D-18 of bench.py — through size-independent properties:
+    finite outputs; the loss does not depend on the execution knobs (fused vs separate BatchNorm backward, side-stream vs
+    in-order weight gradients); two identical steps give bit-identical gradients (every reduction in the step has a fixed
+    order: no atomics on the gradient path)"""
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    import contextlib
+    import io
+    torch.manual_seed(7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = generate_model(18, **R3D18_KW).cuda().train()
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.from_numpy(np.random.default_rng(7).standard_normal((32, 3, 16, 112, 112)).astype(np.float32)).cuda()
+
+    def run(**env):
+        for k in ("SLIC_BN_FUSE", "SLIC_WGRAD_STREAM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        emb = m(x)
+        loss = ntxent_loss(emb)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.item()), emb.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    l0, e0, g0 = run()
+    assert np.isfinite(l0) and torch.isfinite(e0).all() and all(torch.isfinite(g).all() for g in g0.values())
+    assert e0.shape == (32, 128) and len(g0) == 66
+    l1, e1, g1 = run()
+    assert l1 == l0 and torch.equal(e1, e0)
+    notsame = [k for k in g0 if not torch.equal(g0[k], g1[k])]
+    assert not notsame, notsame                                           # bit-identical across two runs
+    l2, e2, g2 = run(SLIC_WGRAD_STREAM="0")                               # same kernels, one stream: still bit-identical
+    assert l2 == l0 and not [k for k in g0 if not torch.equal(g0[k], g2[k])]
+    l3, e3, g3 = run(SLIC_BN_FUSE="0")                                    # different summation structure in BN backward: close
+    assert l3 == l0 and torch.equal(e3, e0)
+    for k in g0:
+        ref = g0[k]
+        assert (g3[k] - ref).abs().max().item() <= 1e-5 + 2e-4 * ref.abs().max().item(), k
+    # running statistics moved exactly once per forward
+    assert int(m.bn1.num_batches_tracked.item()) == int(sd0["bn1.num_batches_tracked"].item()) + 1

@@ -76,7 +76,6 @@ def test_fit_matches_oracle_and_golden(gpu, golden_dir, name):
     assert np.array_equal(km.labels_, r["labels"])
     assert np.array_equal(km.labels_, g["labels"])           # and the sklearn golden itself
     assert km.labels_.dtype == np.int32
-    assert np.array_equal((km.cluster_centers_ - mean).astype(np.float32).view(np.uint32) * 0, 0 * r["centers"].view(np.uint32))
     np.testing.assert_allclose(km.cluster_centers_, r["centers"] + mean, rtol=0, atol=0)
     assert km.inertia_ == pytest.approx(r["inertia"], rel=1e-12)
     if name == "clustered_empty":

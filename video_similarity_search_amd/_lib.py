@@ -173,10 +173,24 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="default"):
-    """grow-only per-(device, tag) scratch buffer (the C ABI never allocates)"""
-    key = (str(device), tag)
+    """grow-only scratch buffer per (device, tag, CURRENT STREAM) — the C ABI never allocates.  Keyed by stream so that
+    growing a buffer never frees memory another stream's queued kernel may still read: within one stream the caching
+    allocator's reuse is ordered behind the kernels already queued there; across streams it is not."""
+    key = (str(device), tag, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+MAX_BUFFER_BYTES = 0xFFFFFF00       # buffer resources carry a 32-bit byte range (SlicConvArgs.src_bytes / wgt_bytes)
+
+
+def u32_bytes(t, what):
+    """byte size of a tensor for a uint32 range field; raises instead of wrapping modulo 2^32 (a wrapped range would make
+    the range-checked buffer loads return zeros past it, silently)"""
+    n = t.numel() * t.element_size()
+    if n >= MAX_BUFFER_BYTES:
+        raise SlicError(f"{what}: {n} bytes does not fit the 32-bit buffer range of one launch — split the batch")
+    return n

@@ -116,7 +116,7 @@ def get_distance_matrix(x_embeddings, y_embeddings=None, dist_metric='cosine'):
         sh = torch.full((Np,), 1.0, device=x.device)
         a = SlicConvArgs()
         a.src, a.wgt, a.dst, a.tab = xn.data_ptr(), yn.data_ptr(), out.data_ptr(), tabd.data_ptr()
-        a.src_bytes, a.wgt_bytes = xn.numel() * 4, yn.numel() * 4
+        a.src_bytes, a.wgt_bytes = _lib.u32_bytes(xn, 'x_embeddings'), _lib.u32_bytes(yn, 'y_embeddings')
         a.scale, a.shift, a.relu = sc.data_ptr(), sh.data_ptr(), 1
         a.M, a.N, a.nchunks = Nx, Ny, Dp // 4
         a.Cs, a.Ts, a.Hs, a.Ws = Dp, 1, 1, 1

@@ -133,7 +133,7 @@ class ConvPlan:
         T, H, W = self.in_dims
         To, Ho, Wo = self.out_dims
         a.src = x.data_ptr()
-        a.src_bytes = x.numel() * 4
+        a.src_bytes = _lib.u32_bytes(x, 'conv source')
         a.tab = self.tab_fwd.data_ptr()
         a.tap_tab = self.tap_fwd.data_ptr() if self.tap_fwd is not None else None
         a.M = B * To * Ho * Wo
@@ -152,7 +152,7 @@ class ConvPlan:
         a = self._fwd_args(x, B)
         z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
         a.wgt = wp.data_ptr()
-        a.wgt_bytes = wp.numel() * 4
+        a.wgt_bytes = _lib.u32_bytes(wp, 'packed weights')
         a.dst = z.data_ptr()
         a.bias = bias.data_ptr() if bias is not None else None
         a.scale = scale.data_ptr() if scale is not None else None
@@ -235,9 +235,9 @@ class ConvPlan:
         for dc in self.dgrad_classes:
             a = SlicConvArgs()
             a.src = dz.data_ptr()
-            a.src_bytes = dz.numel() * 4
+            a.src_bytes = _lib.u32_bytes(dz, 'dgrad source')
             a.wgt = wd.data_ptr()
-            a.wgt_bytes = wd.numel() * 4
+            a.wgt_bytes = _lib.u32_bytes(wd, 'packed weights')
             a.dst = dx.data_ptr()
             a.tab = dc["tab"].data_ptr()
             a.tap_tab = dc["tap"].data_ptr() if dc["tap"] is not None else None

@@ -477,6 +477,9 @@ class _SegmentFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.saved is None:
+            raise RuntimeError("the encoder's saved activations are released by its first backward pass: a second backward "
+                               "through the same forward (retain_graph=True) is not supported — run the forward again")
         dinp, grads = ctx.engine.seg_backward(ctx.si, ctx.saved, dout, ctx.pid)
         ctx.saved = None
         ctx.holder = None
@@ -556,6 +559,22 @@ class ResNet(nn.Module):
         return run_engine(self._engine(x), self, x)
 
 
+class _InferenceFn(torch.autograd.Function):
+    """an inference pass recorded in a live autograd graph: forward works, backward refuses loudly.  The reference can
+    back-propagate through an eval-mode encoder (BatchNorm frozen on its running statistics); the SLIC loop never does
+    (validation and extraction run under no_grad), so that backward is not built — but it must not fail obscurely or
+    silently train only the layers stacked on top of the encoder."""
+
+    @staticmethod
+    def forward(ctx, x, eng, training, *params):
+        return eng.forward(x, training=training, save=False)[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        raise NotImplementedError("backward through an eval-mode (or fully frozen) encoder is not implemented on the HIP path: "
+                                  "call .train() for a training step, or run inference under torch.no_grad()")
+
+
 def run_engine(eng, module, x):
     """drive one encoder through its engine: autograd segments in train mode, a plain inference pass otherwise"""
     params = [p for p in module.parameters() if p.requires_grad]
@@ -564,7 +583,8 @@ def run_engine(eng, module, x):
         for si in range(eng.N_SEG):
             a = _SegmentFn.apply(a, eng, si, True, *eng.seg_params(si))
         return a
-    # eval-mode graph (BN frozen) is not needed by the SLIC loop (validation runs under no_grad): inference only
+    if torch.is_grad_enabled() and (params or x.requires_grad):
+        return _InferenceFn.apply(x, eng, module.training, *params)      # usable forward, loud backward
     with torch.no_grad():
         return eng.forward(x, training=module.training, save=False)[0]
 
