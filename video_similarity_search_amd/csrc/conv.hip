@@ -25,22 +25,78 @@
 #ifndef SLIC_WG_ILVQ
 #define SLIC_WG_ILVQ 7   // same for the weight gradient's eight MFMA groups per tile
 #endif
+#ifndef SLIC_PRIO_EDGE
+#define SLIC_PRIO_EDGE 3 // wave priority of the gather-GEMM's prologue and epilogue (the k loop runs at 0)
+#endif
 #ifndef SLIC_ILVQ
 #define SLIC_ILVQ 2      // MFMA groups (of 4 per k-tile) over which the next tile's DMAs are spread (4 -> 2: +0.6 % on the step: the DMAs get half a tile more lead)
 #endif
 #include <stdlib.h>
 
-// Shared epilogue of the gather-GEMM kernels: bias / affine / addend / ReLU store + deterministic BatchNorm partials.
+// In-kernel time stamps (MI355X_MICROARCH.md, 'In-kernel stamps'): ONLY in the diagnostic build scripts/stamps_conv.py makes
+// (-DSLIC_STAMPS, a separate library under csrc/_exp/); in the shipped library the macro is empty and no stamp executes.
+#ifdef SLIC_STAMPS
+__device__ unsigned long long* slic_stamps_buf = nullptr;     // [workgroups][8], memory no other code reads
+extern "C" int slic_debug_set_stamps(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(slic_stamps_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define SLIC_STAMP(wg, slot)                                                                              \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && slic_stamps_buf) slic_stamps_buf[(size_t)(wg) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define SLIC_STAMP_ID(wg)                                                                                 \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && slic_stamps_buf)                                                             \
+      slic_stamps_buf[(size_t)(wg) * 8] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); \
+  } while (0)
+#else
+#define SLIC_STAMP(wg, slot)
+#define SLIC_STAMP_ID(wg)
+#endif
+
+// Shared epilogue of the gather-GEMM kernels: bias / affine / addend / mask / ReLU store + deterministic BatchNorm partials.
+//
+// The accumulators leave the registers through an LDS image of the output tile ([BM][BN] floats, row-major), so that every
+// global access of the epilogue is a 16-byte-per-lane buffer op on a contiguous run of a dst row (CPR = BN / 4 lanes cover one
+// row: 256-byte runs for BN = 64) — the MFMA accumulator layout itself (a lane owns ONE column, 16 scattered rows) would
+// make each of them a 4-byte access in 128-byte pieces, four times the instruction count for the store and for each of the
+// addend / mask / bwd_z loads.  Thread t owns chunk cq = t % CPR of rows rr + RPP * pass (RPP = 256 / CPR rows per pass).
+// All tensor accesses are range-checked buffer ops with 32-bit byte offsets: a row past M, a chunk past N (N % 4 == 0) or an
+// absent optional operand (resource of size 0) is an out-of-range access — loads return 0, stores are dropped.
+// Reductions have a fixed order: rows ascending inside a thread, then the RPP row groups ascending, one slab row per workgroup.
+constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * (1024 / BN) * BN + BN; }
+
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
                                               int wm, int wn, int r, int h, int tid) {
-  const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial)
+  const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial / bwd_partial)
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  // ---- epilogue.  All tensor accesses are range-checked buffer ops with 32-bit byte offsets: a row past M, a column past
-  // N or an absent optional operand (resource of size 0) is an out-of-range access — loads return 0, stores are dropped —
-  // so the element loop has no branch and the compiler batches its loads.
+  constexpr int CPR = BN / 4;       // 16-byte chunks per tile row
+  constexpr int RPP = 256 / CPR;    // rows per pass of the 256 threads
+  constexpr int NPASS = BM / RPP;
+  static_assert(256 % CPR == 0 && BM % RPP == 0, "tile shape");
+  float* tile = lds;                       // [BM][BN]: acc + bias
+  float* red1 = lds + BM * BN;             // [RPP][BN]
+  float* red2 = red1 + RPP * BN;           // [RPP][BN]
+  float* bmean = red2 + RPP * BN;          // [BN]
   const bool want_stats = p.stat_partial != nullptr;
   const bool want_bwd = p.bwd_partial != nullptr;
+  // ---- 1. registers -> LDS image (the k-loop's ring is dead: every caller has drained its DMAs and passed a barrier)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * WTN + j * 32 + r;
+    const int n = n0 + col;
+    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        tile[row * BN + col] = acc[i][j][g] + bias;
+      }
+  }
+  __syncthreads();
+  // ---- 2. row-major pass: thread = (row group rr, chunk cq)
   constexpr unsigned OOBE = 0xFFFFFF00u;
   const int64_t dst_rows = p.dst_strided ? (p.M / ((int64_t)p.Ga * p.Gb * p.Gc)) * p.Da * p.Db * p.Dc : p.M;
   const unsigned dst_bytes = (unsigned)(((dst_rows - 1) * (int64_t)p.ldo + p.N) * 4);
@@ -49,121 +105,102 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
   const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_src, 0, p.mask_src ? dst_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_bz = __builtin_amdgcn_make_buffer_rsrc((void*)p.bwd_z, 0, p.bwd_z ? dst_bytes : 0, 0x00020000);
   const bool has_mask = p.mask_src != nullptr, do_relu = p.relu != 0;
-  unsigned roff[TM][16];          // dst row byte offsets, one decode per accumulator row; OOBE for rows past M
+  const int cq = tid % CPR, rr = tid / CPR;
+  const int n = n0 + cq * 4;
+  const bool nv = n < p.N;                       // N % 4 == 0: a chunk is inside or outside as a whole
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bmu = sh, bis = sh;
+  if (nv) {
+    if (p.scale) sc = *(const f32x4*)(p.scale + n);
+    if (p.shift) sh = *(const f32x4*)(p.shift + n);
+    if (want_bwd) { bmu = *(const f32x4*)(p.bwd_mean + n); bis = *(const f32x4*)(p.bwd_invstd + n); }
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, fs = s1;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-      unsigned ro;
-      if (p.dst_strided) {
-        unsigned q = (unsigned)m;
-        const unsigned gc = q % (unsigned)p.Gc; q /= (unsigned)p.Gc;
-        const unsigned gbb = q % (unsigned)p.Gb; q /= (unsigned)p.Gb;
-        const unsigned gaa = q % (unsigned)p.Ga; q /= (unsigned)p.Ga;
-        ro = ((((q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc + gc * p.dc + p.ec) * (unsigned)p.ldo) * 4u;
-      } else {
-        ro = (unsigned)m * (unsigned)(p.ldo * 4);
-      }
-      roff[i][g] = m < p.M ? ro : OOBE;
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int row = ps * RPP + rr;
+    const int64_t m = m0 + row;
+    const bool ok = nv && m < p.M;
+    unsigned ro;
+    if (p.dst_strided) {
+      unsigned q = (unsigned)m;
+      const unsigned gc = q % (unsigned)p.Gc; q /= (unsigned)p.Gc;
+      const unsigned gbb = q % (unsigned)p.Gb; q /= (unsigned)p.Gb;
+      const unsigned gaa = q % (unsigned)p.Ga; q /= (unsigned)p.Ga;
+      ro = ((((q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc + gc * p.dc + p.ec) * (unsigned)p.ldo) * 4u;
+    } else {
+      ro = (unsigned)m * (unsigned)(p.ldo * 4);
     }
-  float bs1[TN], bs2[TN];          // BatchNorm-backward partials of the stored gradient (this lane's column)
+    const unsigned off = ok ? ro + (unsigned)n * 4u : OOBE;
+    f32x4 v = *(const f32x4*)&tile[row * BN + cq * 4];
+    if (ok) fs += v;
+    v = v * sc + sh;
+    v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0));
+    const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_msk, off, 0, 0));
+    const f32x4 zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bz, off, 0, 0));
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WTN + j * 32 + r;
-    const bool nv = n < p.N;
-    const float bias = (p.bias && nv) ? p.bias[n] : 0.f;
-    const float sc = (p.scale && nv) ? p.scale[n] : 1.f;
-    const float sh = (p.shift && nv) ? p.shift[n] : 0.f;
-    const float bmu = (want_bwd && nv) ? p.bwd_mean[n] : 0.f;
-    const float bis = (want_bwd && nv) ? p.bwd_invstd[n] : 0.f;
-    bs1[j] = 0.f; bs2[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const bool ok = nv && roff[i][g] != OOBE;
-        const unsigned off = ok ? roff[i][g] + (unsigned)n * 4u : OOBE;
-        float v = (acc[i][j][g] + bias) * sc + sh;
-        v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, off, 0, 0));
-        const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_msk, off, 0, 0));
-        v = (has_mask && !(mk > 0.f)) ? 0.f : v;
-        v = do_relu ? fmaxf(v, 0.f) : v;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_dst, off, 0, 0);
-        const float zz = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bz, off, 0, 0));
-        const float vv = ok ? v : 0.f;
-        bs1[j] += vv;
-        bs2[j] += vv * ((zz - bmu) * bis);
-      }
+    for (int c = 0; c < 4; ++c) {
+      float x = v[c];
+      x = (has_mask && !(mk[c] > 0.f)) ? 0.f : x;
+      x = do_relu ? fmaxf(x, 0.f) : x;
+      v[c] = x;
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs_dst, off, 0, 0);
+    if (ok) {
+      s1 += v;
+      s2 += v * ((zz - bmu) * bis);
     }
   }
   if (want_bwd) {
-    // fixed reduction order: rows inside the lane (above), lane halves, waves along M, one slab row per workgroup
-    __syncthreads();
-    float* red1 = lds;               // [WM][BN]
-    float* red2 = lds + WM * BN;     // [WM][BN]
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = wn * WTN + j * 32 + r;
-      const float a1 = bs1[j] + __shfl_xor(bs1[j], 32);
-      const float a2 = bs2[j] + __shfl_xor(bs2[j], 32);
-      if (h == 0) { red1[wm * BN + col] = a1; red2[wm * BN + col] = a2; }
-    }
+    // BatchNorm-backward partials of the stored gradient: (sum v, sum v * xhat) per channel over this row block
+    *(f32x4*)&red1[rr * BN + cq * 4] = s1;
+    *(f32x4*)&red2[rr * BN + cq * 4] = s2;
     __syncthreads();
     if (tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
-      const int n = n0 + tid;
-      if (n < p.N) {
-        p.bwd_partial[(mblk * 2 + 0) * p.N + n] = t1;
-        p.bwd_partial[(mblk * 2 + 1) * p.N + n] = t2;
+      for (int w = 0; w < RPP; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
+      const int nn = n0 + tid;
+      if (nn < p.N) {
+        p.bwd_partial[(mblk * 2 + 0) * p.N + nn] = t1;
+        p.bwd_partial[(mblk * 2 + 1) * p.N + nn] = t2;
       }
     }
-    __syncthreads();
   }
   if (want_stats) {
     // BatchNorm partials of v = acc + bias over this workgroup's valid rows, per channel:
-    //   slab[blk][0][n] = sum v          slab[blk][1][n] = sum (v - mean_blk)^2   (two passes over registers,
+    //   slab[blk][0][n] = sum v          slab[blk][1][n] = sum (v - mean_blk)^2   (second pass over the LDS image,
     // so the variance never comes from E[x^2] - mean^2); bn_finalize merges workgroups with Chan's formula in double.
-    // Reduction order is fixed: lane halves -> waves along M -> one slab row per workgroup.
-    __syncthreads();
-    float* red = lds;             // [WM][BN]
-    float* bmean = lds + WM * BN; // [BN]
     const int64_t left = p.M - m0;
     const float inv_rows = 1.0f / (float)(left < BM ? left : BM);
+    *(f32x4*)&red1[rr * BN + cq * 4] = fs;
+    __syncthreads();
+    if (tid < BN) {
+      float t = 0.f;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+      for (int w = 0; w < RPP; ++w) t += red1[w * BN + tid];
+      bmean[tid] = t * inv_rows;
+      const int nn = n0 + tid;
+      if (nn < p.N) p.stat_partial[(mblk * 2 + 0) * p.N + nn] = t;
+    }
+    __syncthreads();
+    const f32x4 mu = *(const f32x4*)&bmean[cq * 4];
+    f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = wn * WTN + j * 32 + r;
-        const int n = n0 + col;
-        const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-        const float mu = pass ? bmean[col] : 0.f;
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int g = 0; g < 16; ++g) {
-            const int64_t m = m0 + wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-            if (m < p.M) {
-              const float v = acc[i][j][g] + bias;
-              a += pass ? (v - mu) * (v - mu) : v;
-            }
-          }
-        a += __shfl_xor(a, 32);
-        if (h == 0) red[wm * BN + col] = a;
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + rr;
+      if (m0 + row < p.M) {
+        const f32x4 d = *(const f32x4*)&tile[row * BN + cq * 4] - mu;
+        q2 += d * d;
       }
-      __syncthreads();
-      if (tid < BN) {
-        float t = 0.f;
+    }
+    *(f32x4*)&red2[rr * BN + cq * 4] = q2;
+    __syncthreads();
+    if (tid < BN) {
+      float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) t += red[w * BN + tid];
-        if (!pass) bmean[tid] = t * inv_rows;
-        const int n = n0 + tid;
-        if (n < p.N) p.stat_partial[(mblk * 2 + pass) * p.N + n] = t;
-      }
-      __syncthreads();
+      for (int w = 0; w < RPP; ++w) t += red2[w * BN + tid];
+      const int nn = n0 + tid;
+      if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
     }
   }
 }
@@ -320,7 +357,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // waves per SIMD the LDS footprint allows (one wave of each resident workgroup per SIMD): the register allocator is held to
 // that occupancy, or the epilogue's batched loads would cost the main loop a workgroup per CU
 constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT) {
-  const int lds = STAGES * KT * (BM + BN) * 128;
+  const int ring = STAGES * KT * (BM + BN) * 128, epi = conv_epi_lds_floats(BM, BN) * 4;
+  const int lds = ring > epi ? ring : epi;
   const int w = (160 * 1024) / lds;
   return w > 5 ? 5 : (w < 1 ? 1 : w);
 }
@@ -346,6 +384,15 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   const int64_t m0 = (int64_t)mb * BM;
   if (m0 >= p.M) return;
   const int n0 = byi * BN;
+  [[maybe_unused]] const int stamp_wg = bxi + gdx * byi;
+  SLIC_STAMP_ID(stamp_wg);
+  SLIC_STAMP(stamp_wg, 1);
+  // A workgroup arrives on a CU whose other resident workgroups sit in their k loops: their waves are older and always have an
+  // MFMA waiting for the matrix pipe, and vector issue goes to the oldest wave first — measured with in-kernel stamps
+  // (scripts/stamps_conv.py), this prologue's few hundred VALU instructions then take 40-60 us (the k loop itself: ~120 us),
+  // during which the workgroup holds a residency slot and feeds the matrix pipe nothing.  Priority outranks age: run the
+  // prologue (and the epilogue) at raised priority, the k loop at the default.
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int srow = tid >> 3;                                  // row inside each 32-row group
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);               // SOURCE chunk column of this lane (LDS slot = tid & 7)
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
@@ -511,6 +558,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   for (int t = 0; t < STAGES - 1; ++t)
 #pragma unroll
     for (int u = 0; u < KT; ++u) issue(kt0 + t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
+  SLIC_STAMP(stamp_wg, 2);                                   // prologue DMAs issued
+#ifdef SLIC_STAMPS
+  unsigned long long stamp_wait_v = 0, stamp_wait_b = 0, stamp_loop0 = 0;
+#endif
+  __builtin_amdgcn_s_setprio(0);
   constexpr int PER_STAGE = KT * (AL + BL);                  // DMA instructions per stage per wave, always exactly this many
   // Branch-free steady state: the trip count is rounded up to whole rings; stages past the end multiply zeros.
   for (int s0 = 0; s0 < ns; s0 += STAGES) {
@@ -518,8 +570,19 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
     for (int sidx = 0; sidx < STAGES; ++sidx) {              // unrolled: ring stages are compile-time, so the compiler can
       const int sg = s0 + sidx;                               // see that the ds_reads and the in-flight DMAs never alias
       // stage sg has landed once only the DMAs of the STAGES - 2 younger in-flight stages are outstanding
+#ifdef SLIC_STAMPS
+      const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
+      const unsigned long long st_m = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+      stamp_wait_v += st_m - st_a;
+      stamp_wait_b += st_b - st_m;
+      if (sg == 0) { SLIC_STAMP(stamp_wg, 3); stamp_loop0 = st_b; }     // first k-tile landed
+#else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
       __builtin_amdgcn_s_barrier();        // every wave's part of stage sg is in LDS; the previous stage is free
+#endif
       if constexpr (ILV && KT == 1) {
         compute_ilv(sidx * STAGE_FLOATS, kt0 + sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
       } else {
@@ -533,6 +596,14 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing all-zero DMAs must land before LDS is reused
   __syncthreads();
+  SLIC_STAMP(stamp_wg, 4);                                   // k loop done
+#ifdef SLIC_STAMPS
+  if (threadIdx.x == 0 && slic_stamps_buf) {                 // cycles wave 0 spent at the counted vmcnt wait / at the barrier / in the loop
+    slic_stamps_buf[(size_t)stamp_wg * 8 + 6] = (stamp_wait_v << 32) | (stamp_wait_b & 0xFFFFFFFFull);
+    slic_stamps_buf[(size_t)stamp_wg * 8 + 7] = __builtin_amdgcn_s_memtime() - stamp_loop0;
+  }
+#endif
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   if (slab) {
     float* out = slab + (int64_t)bzi * p.M * p.N;
 #pragma unroll
@@ -549,6 +620,10 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
     return;
   }
   conv_epilogue<BM, BN, WM, WN, TM, TN>(p, acc, lds, m0, n0, wm, wn, r, h, tid);
+#ifdef SLIC_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // diagnostic build only: the stores have left the wave
+  SLIC_STAMP(stamp_wg, 5);
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
@@ -578,7 +653,7 @@ void conv_gemm_dma_multi_kernel(const SlicConvArgsPack pk, const int xcd_remap) 
 // second pass of a split-K launch: accumulators = sum over the S slabs in slab order, then the ordinary epilogue
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_splitk_finish(const SlicConvArgs p, const float* __restrict__ slab, const int S) {
-  __shared__ float lds[WM * BN * 2 + BN];
+  __shared__ __attribute__((aligned(16))) float lds[conv_epi_lds_floats(BM, BN)];
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1079,6 +1154,9 @@ static int validate(const SlicConvArgs* a, const char* who) {
     const int64_t rows = a->dst_strided ? (a->M / ((int64_t)a->Ga * a->Gb * a->Gc)) * a->Da * a->Db * a->Dc : a->M;
     SLIC_REQUIRE(rows > 0 && rows * (int64_t)a->ldo * 4 < (int64_t)0xFFFFFF00u, "%s: dst larger than 4 GiB (split the batch)", who);
   }
+  if (a->dst)     // the epilogue moves 16-byte chunks of dst rows
+    SLIC_REQUIRE(a->N % 4 == 0 && a->ldo % 4 == 0 && ((uintptr_t)a->dst % 16) == 0 && (!a->addend || ((uintptr_t)a->addend % 16) == 0),
+                 "%s: N and ldo must be multiples of 4 and dst / addend 16-byte aligned", who);
   SLIC_REQUIRE(((uintptr_t)a->src % 16) == 0, "%s: src not 16-byte aligned", who);
   SLIC_REQUIRE(a->src_bytes > 0 && a->src_bytes < 0xFFFFFF00u, "%s: src_bytes must be set and < 4 GiB (split the batch)", who);
   return SLIC_OK;
@@ -1086,7 +1164,8 @@ static int validate(const SlicConvArgs* a, const char* who) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  constexpr size_t ring = (size_t)2 * (BM + BN) * 32 * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>,
@@ -1101,7 +1180,8 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
 static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
-  constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV>,
@@ -1183,7 +1263,8 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
 
 template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV>
 static int launch_gemm_dma_multi(const SlicConvArgs* a, int n, hipStream_t st) {
-  constexpr size_t lds = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV>,

@@ -99,13 +99,13 @@ def get_distance_matrix(x_embeddings, y_embeddings=None, dist_metric='cosine'):
     x = _dev(x_embeddings)
     y = x if y_embeddings is None else _dev(y_embeddings)
     Nx, Ny, D = x.shape[0], y.shape[0], x.shape[1]
-    out = torch.empty(Nx, Ny, dtype=torch.float32, device=x.device)
+    Np = (Ny + 3) // 4 * 4                  # the GEMM epilogue stores 16-byte chunks: row stride and N are multiples of 4
     if dist_metric == 'cosine':
+        out = torch.empty(Nx, Np, dtype=torch.float32, device=x.device)[:, :Ny]
         # D = max(0, 1 - x_hat . y_hat): the gather-GEMM as a plain GEMM (1 tap) with scale -1, shift +1, ReLU
         Dp = (D + 31) // 32 * 32
         xn, yn = _normalize(x, Dp), (None if y_embeddings is None else _normalize(y, Dp))
         yn = xn if yn is None else yn
-        Np = (Ny + 3) // 4 * 4
         tab = np.zeros((Dp // 4, 4), np.int32)
         tab[:, 0] = np.arange(Dp // 4) * 4
         tab[:, 1] = (1 << 3) | (1 << 10) | (1 << 17)          # tap offset (0, 0, 0)
@@ -118,13 +118,14 @@ def get_distance_matrix(x_embeddings, y_embeddings=None, dist_metric='cosine'):
         a.src, a.wgt, a.dst, a.tab = xn.data_ptr(), yn.data_ptr(), out.data_ptr(), tabd.data_ptr()
         a.src_bytes, a.wgt_bytes = _lib.u32_bytes(xn, 'x_embeddings'), _lib.u32_bytes(yn, 'y_embeddings')
         a.scale, a.shift, a.relu = sc.data_ptr(), sh.data_ptr(), 1
-        a.M, a.N, a.nchunks = Nx, Ny, Dp // 4
+        a.M, a.N, a.nchunks = Nx, Np, Dp // 4       # columns Ny..Np-1: rows past yn's range read as zeros
         a.Cs, a.Ts, a.Hs, a.Ws = Dp, 1, 1, 1
         a.Ga = a.Gb = a.Gc = 1
         a.sa = a.sb = a.sc = 1
-        a.ldw, a.ldo = Dp, Ny
+        a.ldw, a.ldo = Dp, Np
         call("slic_conv_gemm", ctypes.byref(a), 0, stream())
     else:
+        out = torch.empty(Nx, Ny, dtype=torch.float32, device=x.device)
         call("slic_pairwise_euclidean", ptr(x), Nx, ptr(y), Ny, D, ptr(out), stream())
     distance_matrix = out.cpu().numpy()
     if y_embeddings is None:
