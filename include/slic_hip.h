@@ -214,6 +214,11 @@ typedef struct SlicConvArgs {
   const uint32_t* row_tab; /* optional [M][2] per-row records {byte offset of the row's source origin, 21-bit in-bounds mask}
                               written by slic_conv_row_table; slic_conv_wgrad's LDS-DMA kernel then does no per-row
                               coordinate arithmetic.  NULL: the kernel decodes rows itself */
+  int k_run_len;           /* 0: K = taps x Cs, one pixel per tap (Cs % 4 == 0).  > 0: "W-run" operand for few-channel inputs
+                              (the RGB stem): src is [B, Ts, Hs, Ws, Cs] with ANY Cs (3) and Ws already zero-padded along W; K is
+                              cut into runs of k_run_len floats (a multiple of 4) = k_run_px consecutive pixels x Cs channels of one
+                              (kt, kh) tap row, padded with zero-weight floats: 7 x 3 = 21 -> 24 instead of 7 x 4 = 28 */
+  int k_run_px;            /* real pixels (kw taps) per run; run r covers taps r * k_run_px ... (slic_conv_wgrad unpacks with it) */
 } SlicConvArgs;
 
 /* rows per workgroup of the tile slic_conv_gemm picks for (args, variant); variant 0 = auto,
@@ -240,10 +245,15 @@ int slic_conv_wgrad(const SlicConvArgs* args, const float* dy, int ldy, int spli
 int slic_conv_row_table(const SlicConvArgs* args, uint32_t* row_tab, void* stream);
 /* Wp[n][tap*Cs + c] = W[n][c][tap] (zero padded to Cs channels / Kp columns) — forward operand */
 int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp, float* Wp, void* stream);
+/* W-run operand (SlicConvArgs.k_run_len): Wp[n][run * run_len + px * C + c] = W[n][c][run * run_px + px], zero elsewhere */
+int slic_pack_weight_fwd_runs(const float* W, int N, int C, int ntaps, int run_len, int run_px, int Kp, float* Wp, void* stream);
 /* Wd[c][tap*N + n] = W[n][c][tap] (Cs rows, Kd columns) — data-gradient operand */
 int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int Kd, float* Wd, void* stream);
 /* [B, C, S] -> [B, S, Cp] with channels zero-padded to Cp (clip NCDHW -> NDHWC4, datasets/dataset_utils.py:104) */
 int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* y, void* stream);
+/* [B, C, R, W] -> [B, R, Wp, C] (R = T*H rows): column w lands at w + pad_left, the other columns are zero (Wp >= W + pad_left):
+ * the W-run stem operand */
+int slic_ncdhw_to_ndhwc_wpad(const float* x, int B, int C, int64_t R, int W, int pad_left, int Wp, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm3d/1d + ReLU + residual + global average pool (models/resnet.py:34-57,132-133,173,183,

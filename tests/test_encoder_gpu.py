@@ -23,7 +23,9 @@ def _ndhwc(x, Cs):
 
 CONV_CASES = [
     # C, N, kernel, stride, pad, B, (T, H, W)
-    (3, 8, (7, 7, 7), (1, 2, 2), (3, 3, 3), 2, (8, 20, 20)),
+    (3, 8, (7, 7, 7), (1, 2, 2), (3, 3, 3), 2, (8, 20, 20)),      # RGB stem: W-run operand (and the 4-channel-padded one)
+    (2, 8, (3, 7, 7), (1, 2, 2), (1, 3, 3), 2, (4, 13, 15)),      # R3DNet 'uv' stem, odd sizes
+    (3, 16, (3, 5, 3), (1, 1, 1), (1, 2, 1), 1, (3, 9, 11)),      # W-run with stride 1 and a 3-wide run (9 -> 12 floats)
     (8, 8, (3, 3, 3), (1, 1, 1), (1, 1, 1), 2, (4, 10, 10)),
     (8, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), 2, (8, 10, 10)),
     (8, 16, (1, 1, 1), (2, 2, 2), (0, 0, 0), 2, (8, 10, 10)),
@@ -44,8 +46,26 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
     y64 = F.conv3d(x64, w64, None, s, p)
     dy = torch.from_numpy(rng.standard_normal(tuple(y64.shape)).astype(np.float32))
     gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy.double())
-    plan = ConvPlan(C, N, k, s, p, dims, "cuda")
-    xd, wd_ = _ndhwc(x, plan.Cs).cuda(), w.cuda().contiguous()
+    wd_ = w.cuda().contiguous()
+    dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    if C % 4 != 0:
+        # few-channel input: the W-run operand ([B, T, H, W + 2 pad, C], K in runs of kw * C floats) — forward and weight gradient
+        wplan = ConvPlan(C, N, k, s, p, dims, "cuda")
+        assert wplan.wrun and wplan.Kp <= ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False).Kp
+        xs = wplan.make_source(x.cuda())
+        assert xs.shape[:3] == (B, dims[0], dims[1]) and xs.shape[3] >= dims[2] + 2 * p[2] and xs.shape[4] == C
+        for variant in (0, 1, 2):
+            z, (part, rows) = wplan.forward(xs, wplan.pack_fwd(wd_), B, want_stats=True, variant=variant)
+            got = z.cpu().permute(0, 4, 1, 2, 3)
+            tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6
+            assert (got - y64.float()).abs().max() <= tol * max(1.0, y64.abs().max().item()), f"W-run fwd variant {variant}"
+        for splits in (None, 3):
+            dWr = wplan.wgrad(xs, dyd, B, torch.empty_like(wd_), splits=splits).cpu()
+            assert (dWr - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item()), f"W-run wgrad splits={splits}"
+        with pytest.raises(Exception):
+            wplan.pack_dgrad(wd_)
+    plan = ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False)
+    xd = _ndhwc(x, plan.Cs).cuda()
     for variant in (0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24):
         z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
         got = z.cpu().permute(0, 4, 1, 2, 3)
@@ -58,7 +78,6 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
             blk = flat[rr * rows:(rr + 1) * rows]
             assert torch.allclose(part[rr, 0].double().cpu(), blk.sum(0), atol=1e-4, rtol=1e-4)
             assert torch.allclose(part[rr, 1].double().cpu(), ((blk - blk.mean(0)) ** 2).sum(0), atol=1e-4, rtol=1e-4)
-    dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
     for variant in (0, 11, 13):
         dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B, variant=variant).cpu()[..., :C].permute(0, 4, 1, 2, 3)
         assert (dx - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item()), f'dgrad variant {variant}'

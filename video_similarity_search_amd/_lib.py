@@ -54,8 +54,10 @@ SIGNATURES = {
     "slic_conv_row_table": (I, [P, P, P]),
     "slic_conv_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
     "slic_pack_weight_fwd": (I, [P, I, I, I, I, I, P, P]),
+    "slic_pack_weight_fwd_runs": (I, [P, I, I, I, I, I, I, P, P]),
     "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
     "slic_ncdhw_to_ndhwc": (I, [P, I, I, L, I, P, P]),
+    "slic_ncdhw_to_ndhwc_wpad": (I, [P, I, I, L, I, I, I, P, P]),
     # batch norm / pool
     "slic_bn_finalize_workspace_bytes": (c_size_t, [I, I]),
     "slic_bn_finalize": (I, [P, I, I, I, L, F, F, P, P, P, P, P, P, P, P, P, P]),
@@ -108,6 +110,7 @@ class SlicConvArgs(ctypes.Structure):
         ("relu", I),
         ("mask_src", P), ("bwd_z", P), ("bwd_mean", P), ("bwd_invstd", P), ("bwd_partial", P),
         ("row_tab", P),
+        ("k_run_len", I), ("k_run_px", I),
     ]
 
 

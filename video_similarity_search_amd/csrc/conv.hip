@@ -1060,9 +1060,11 @@ __global__ void conv_row_table_kernel(const SlicConvArgs p, uint2* __restrict__ 
   row_tab[m] = make_uint2(((((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs) * 4u, mk);
 }
 
-// dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][n][tap*Cs + c]
+// dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][n][k].  K is cut into runs of RL floats
+// holding PPR pixels (taps) x Cs channels: the ordinary operand has RL = Cs, PPR = 1 (k = tap * Cs + c); the W-run operand of the
+// RGB stem RL = 24, PPR = 7, Cs = 3.
 __global__ void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, int Kp, int Cs, int C,
-                                  int ntaps, float* __restrict__ dW) {
+                                  int ntaps, int RL, int PPR, float* __restrict__ dW) {
   // threads walk the slab in its own (n, k) order: the S reads per element are coalesced; the single write per
   // element scatters into the reference layout
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1070,8 +1072,10 @@ __global__ void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, 
   if (e >= tot) return;
   const int k = (int)(e % Kp);
   const int n = (int)(e / Kp);
-  const int tap = k / Cs, c = k % Cs;
-  if (tap >= ntaps || c >= C) return;
+  const int run = k / RL, rem = k - run * RL;
+  const int px = rem / Cs, c = rem - px * Cs;
+  const int tap = run * PPR + px;
+  if (px >= PPR || tap >= ntaps || c >= C) return;
   float a = 0.f;
   for (int s = 0; s < S; ++s) a += slab[(int64_t)s * tot + e];
   dW[((int64_t)n * C + c) * ntaps + tap] = a;
@@ -1100,6 +1104,16 @@ __global__ __launch_bounds__(256) void pack_w_fwd(const float* __restrict__ W, i
   }
   if (blockIdx.y == 0)
     for (int k = ntaps * Cs + t; k < Kp; k += 256) Wp[(int64_t)n * Kp + k] = 0.f;
+}
+// W-run operand (few-channel stem): Wp[n][run * RL + px * C + c] = W[n][c][run * PPR + px]; a few hundred KB, one thread per element
+__global__ void pack_w_fwd_runs(const float* __restrict__ W, int N, int C, int ntaps, int RL, int PPR, int Kp, float* __restrict__ Wp) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)N * Kp) return;
+  const int k = (int)(e % Kp), n = (int)(e / Kp);
+  const int run = k / RL, rem = k - run * RL;
+  const int px = rem / C, c = rem - px * C;
+  const int tap = run * PPR + px;
+  Wp[e] = (px < PPR && tap < ntaps) ? W[((int64_t)n * C + c) * ntaps + tap] : 0.f;
 }
 // data gradient:  Wd[c][tap*N + n] = W[n][c][tap]   (rows = input channels, Cs rows, zero padded).
 // Workgroup = (32 output channels n, CB input channels c): reads CB*ntaps contiguous floats per n, writes 32 consecutive n.
@@ -1139,12 +1153,28 @@ __global__ void ncdhw_to_ndhwc(const float* __restrict__ x, int B, int C, int64_
     y[e * Cp + c] = c < C ? x[(b * C + c) * S + s] : 0.f;
 }
 
+// NCDHW [B, C, R, W] -> [B, R, Wp, C]: rows of (T*H), `pad` zero columns on the left, zeros up to Wp on the right (the W-run stem operand)
+__global__ void ncdhw_to_ndhwc_wpad(const float* __restrict__ x, int B, int C, int64_t R, int W, int pad, int Wp, float* __restrict__ y) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (b, row, wp)
+  if (e >= (int64_t)B * R * Wp) return;
+  const int wp = (int)(e % Wp);
+  const int64_t br = e / Wp;
+  const int64_t b = br / R, row = br % R;
+  const int w = wp - pad;
+  const bool in = w >= 0 && w < W;
+  for (int c = 0; c < C; ++c) y[e * C + c] = in ? x[((b * C + c) * R + row) * W + w] : 0.f;
+}
+
 // ------------------------------------ C ABI ------------------------------------------------
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 
 static int validate(const SlicConvArgs* a, const char* who) {
   SLIC_REQUIRE(a && a->src && a->tab, "%s: null pointer", who);
-  SLIC_REQUIRE(a->Cs > 0 && a->Cs % 4 == 0, "%s: source channels must be a multiple of 4 (Cs=%d)", who, a->Cs);
+  if (a->k_run_len > 0)
+    SLIC_REQUIRE(a->Cs > 0 && a->k_run_len % 4 == 0 && a->k_run_px > 0 && a->k_run_px * a->Cs <= a->k_run_len && !a->tap_tab,
+                 "%s: W-run operand needs k_run_len %% 4 == 0, k_run_px * Cs <= k_run_len and no tap table", who);
+  else
+    SLIC_REQUIRE(a->Cs > 0 && a->Cs % 4 == 0, "%s: source channels must be a multiple of 4 (Cs=%d)", who, a->Cs);
   SLIC_REQUIRE(a->nchunks >= 0 && a->nchunks % 8 == 0, "%s: nchunks %% 8 != 0 (%d)", who, a->nchunks);
   SLIC_REQUIRE(a->M > 0 && a->N > 0 && a->Ga > 0 && a->Gb > 0 && a->Gc > 0 && a->Ts > 0 && a->Hs > 0 && a->Ws > 0,
                "%s: bad shape", who);
@@ -1340,7 +1370,8 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   if (rc) return rc;
   SLIC_REQUIRE(dy && dW && workspace && splits >= 1 && ldy % 4 == 0 && C > 0 && ntaps > 0 && a->N % 4 == 0,
                "slic_conv_wgrad: bad args (N %% 4 == 0 required)");
-  SLIC_REQUIRE(ntaps * a->Cs <= a->nchunks * 4, "slic_conv_wgrad: table shorter than ntaps*Cs");
+  const int RL = a->k_run_len > 0 ? a->k_run_len : a->Cs, PPR = a->k_run_len > 0 ? a->k_run_px : 1;
+  SLIC_REQUIRE((int64_t)slic_cdiv(ntaps, PPR) * RL <= (int64_t)a->nchunks * 4, "slic_conv_wgrad: table shorter than the taps");
   hipStream_t st = S_(stream);
   float* slab = (float*)workspace;
   int64_t per = slic_cdiv(a->M, splits);
@@ -1375,7 +1406,7 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   }
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)a->N * Kp;
-  conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, dW);
+  conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, RL, PPR, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1400,6 +1431,16 @@ extern "C" int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int
   return SLIC_OK;
 }
 
+extern "C" int slic_pack_weight_fwd_runs(const float* W, int N, int C, int ntaps, int run_len, int run_px, int Kp, float* Wp,
+                                         void* stream) {
+  SLIC_REQUIRE(W && Wp && N > 0 && C > 0 && ntaps > 0 && run_len > 0 && run_px > 0 && run_px * C <= run_len &&
+               (int64_t)slic_cdiv(ntaps, run_px) * run_len <= Kp, "slic_pack_weight_fwd_runs: bad args");
+  const int64_t tot = (int64_t)N * Kp;
+  pack_w_fwd_runs<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(W, N, C, ntaps, run_len, run_px, Kp, Wp);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int Kd, float* Wd,
                                       void* stream) {
   SLIC_REQUIRE(W && Wd && N > 0 && C > 0 && ntaps > 0 && Cs >= C && Kd >= ntaps * N, "slic_pack_weight_dgrad: bad args");
@@ -1419,6 +1460,14 @@ extern "C" int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int 
   SLIC_REQUIRE(x && y && B > 0 && C > 0 && S > 0 && Cp >= C, "slic_ncdhw_to_ndhwc: bad args");
   const int64_t tot = (int64_t)B * S;
   ncdhw_to_ndhwc<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(x, B, C, S, Cp, y);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_ncdhw_to_ndhwc_wpad(const float* x, int B, int C, int64_t R, int W, int pad_left, int Wp, float* y, void* stream) {
+  SLIC_REQUIRE(x && y && B > 0 && C > 0 && R > 0 && W > 0 && pad_left >= 0 && Wp >= W + pad_left, "slic_ncdhw_to_ndhwc_wpad: bad args");
+  const int64_t tot = (int64_t)B * R * Wp;
+  ncdhw_to_ndhwc_wpad<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(x, B, C, R, W, pad_left, Wp, y);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

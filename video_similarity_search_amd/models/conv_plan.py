@@ -36,7 +36,7 @@ def _tap_mask(oa, ob, oc):
 class ConvPlan:
     """One conv layer at one input size.  kernel/stride/pad are (t, h, w) triples."""
 
-    def __init__(self, C, N, kernel, stride, pad, in_dims, device):
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None):
         self.C, self.N = int(C), int(N)
         self.Cs = (self.C + 3) // 4 * 4
         self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
@@ -45,6 +45,16 @@ class ConvPlan:
         self.ntaps = int(np.prod(self.kernel))
         self.device = device
         assert self.N % 4 == 0, "output channels must be a multiple of 4"
+        # W-run operand (the RGB stem): with C = 3 padded to 4 channels a third of the K dimension is zeros (7^3 x 4 = 1372 for
+        # 1029 real MACs per output).  Instead keep the clip as [B, T, H, W + 2 pad_w, C] (zero columns in W, C un-padded): the
+        # kw taps of one (kt, kh) row are then ONE contiguous run of kw * C floats (21 -> padded to 24 with zero weights), in
+        # bounds along W by construction; K = kt * kh * 24 = 1176 (12.5 % padding instead of 33 %).
+        self.wrun = (self.C % 4 != 0 and self.kernel[2] * self.C <= 64) if wrun is None else bool(wrun)
+        if self.wrun:
+            self._init_wrun()
+            return
+        self.run_len = self.run_px = 0
+        self.src_dims = self.in_dims
         # ---- forward table: k = tap*Cs + c
         T, H, W = self.in_dims
         kt, kh, kw = self.kernel
@@ -114,14 +124,64 @@ class ConvPlan:
         self._row_tabs = {}
         self.prof = None      # bench.py: list collecting (start, end) HIP event pairs around conv_gemm launches
 
+    def _init_wrun(self):
+        T, H, W = self.in_dims
+        kt, kh, kw = self.kernel
+        self.Cs = self.C                                     # channels per pixel of the source tensor: not padded
+        self.run_px = kw
+        self.run_len = (kw * self.C + 3) // 4 * 4
+        # padded width: the conv's own zero columns, and enough on the right for the zero-weight tail of the last run of a row
+        need = (self.out_dims[2] - 1) * self.stride[2] * self.C + self.run_len
+        Wp = max(W + 2 * self.pad[2], (need + self.C - 1) // self.C)
+        self.src_dims = (T, H, Wp)                           # what the kernel sees: its w coordinate is already shifted by pad_w
+        cpr = self.run_len // 4                              # 16-byte chunks per run
+        nch = kt * kh * cpr
+        self.nchunks_fwd = _pad8(nch)
+        tab = np.zeros((self.nchunks_fwd, 4), np.int32)
+        tab[:, 1] = -1
+        q = np.arange(nch)
+        run, j = q // cpr, q % cpr
+        oa, ob = run // kh - self.pad[0], run % kh - self.pad[1]
+        assert max(self.pad[:2]) <= 3 and all(k - 1 - p <= 3 for k, p in zip(self.kernel[:2], self.pad[:2]))
+        tab[:nch, 0] = ((oa * H + ob) * Wp) * self.C + 4 * j
+        tab[:nch, 1] = (1 << (oa + 3)) | (1 << (7 + ob + 3)) | (1 << (14 + 0 + 3))
+        tab[:nch, 2] = q * 4
+        tab[:nch, 3] = (oa + 128) | ((ob + 128) << 8) | (128 << 16)
+        self.tab_fwd = torch.from_numpy(tab).to(self.device)
+        self.tap_fwd = None
+        self.Kp = self.nchunks_fwd * 4
+        self.dgrad_classes = []                              # the clip needs no gradient
+        self._wp = self._wd = None
+        self._row_tabs = {}
+        self.prof = None
+
+    def make_source(self, x):
+        """the operand layout of this plan from an NCDHW clip batch [B, C, T, H, W]"""
+        B, C, T, H, W = x.shape
+        assert C == self.C and (T, H, W) == self.in_dims
+        x = x.contiguous()
+        if self.wrun:
+            y = torch.empty((B,) + self.src_dims + (self.C,), dtype=torch.float32, device=x.device)
+            call("slic_ncdhw_to_ndhwc_wpad", ptr(x), B, C, T * H, W, self.pad[2], self.src_dims[2], ptr(y), stream())
+        else:
+            y = torch.empty(B, T, H, W, self.Cs, dtype=torch.float32, device=x.device)
+            call("slic_ncdhw_to_ndhwc", ptr(x), B, C, T * H * W, self.Cs, ptr(y), stream())
+        return y
+
     # ------------------------------------------------------------------ weights
     def pack_fwd(self, weight):
         if self._wp is None:
             self._wp = torch.empty(self.N, self.Kp, dtype=torch.float32, device=self.device)
-        call("slic_pack_weight_fwd", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kp, ptr(self._wp), stream())
+        if self.wrun:
+            call("slic_pack_weight_fwd_runs", ptr(weight), self.N, self.C, self.ntaps, self.run_len, self.run_px, self.Kp,
+                 ptr(self._wp), stream())
+        else:
+            call("slic_pack_weight_fwd", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kp, ptr(self._wp), stream())
         return self._wp
 
     def pack_dgrad(self, weight):
+        if self.wrun:
+            raise _lib.SlicError("the W-run operand serves forward and weight gradient only (the clip needs no gradient)")
         if self._wd is None:
             self._wd = torch.empty(self.Cs, self.Kd, dtype=torch.float32, device=self.device)
         call("slic_pack_weight_dgrad", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kd, ptr(self._wd), stream())
@@ -130,9 +190,11 @@ class ConvPlan:
     # ------------------------------------------------------------------ launches
     def _fwd_args(self, x, B):
         a = SlicConvArgs()
-        T, H, W = self.in_dims
+        T, H, W = self.src_dims
         To, Ho, Wo = self.out_dims
+        assert tuple(x.shape) == (B, T, H, W, self.Cs) and x.is_contiguous(), (tuple(x.shape), (B, T, H, W, self.Cs))
         a.src = x.data_ptr()
+        a.k_run_len, a.k_run_px = self.run_len, self.run_px
         a.src_bytes = _lib.u32_bytes(x, 'conv source')
         a.tab = self.tab_fwd.data_ptr()
         a.tap_tab = self.tap_fwd.data_ptr() if self.tap_fwd is not None else None

@@ -218,10 +218,7 @@ class _Engine:
         B = inp.shape[0]
         dev = inp.device
         if si == 0:
-            _, C, T, H, W = inp.shape
-            x = inp.contiguous()
-            x4 = torch.empty(B, T, H, W, self.stem.Cs, dtype=torch.float32, device=dev)
-            call("slic_ncdhw_to_ndhwc", ptr(x), B, C, T * H * W, self.stem.Cs, ptr(x4), stream())
+            x4 = self.stem.make_source(inp)          # NCDHW clip -> the stem plan's operand layout (W-run for RGB)
             z0, a, bn0 = self._conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True, training, B)
             return a, (dict(x4=x4, z0=z0, a0=a, bn0=bn0) if save else None)
         if si <= 4:
