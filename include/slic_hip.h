@@ -243,7 +243,8 @@ int slic_conv_wgrad(const SlicConvArgs* args, const float* dy, int ldy, int spli
 /* row_tab[m] = {(((b*Ts + ga*sa)*Hs + gb*sb)*Ws + gc*sc)*Cs*4, bit (7*dim + o + 3) set iff coordinate + o is inside the
  * source for o in -3..3} for the M rows of args' geometry (args->src etc. unused): 8 bytes per row. */
 int slic_conv_row_table(const SlicConvArgs* args, uint32_t* row_tab, void* stream);
-/* Wp[n][tap*Cs + c] = W[n][c][tap] (zero padded to Cs channels / Kp columns) — forward operand */
+/* Wp[n][tap*Cs + c] = W[n][c][tap] for c < C — forward operand.  The padding (channels C..Cs, columns ntaps*Cs..Kp) is NOT
+ * written: the caller zeroes the operand once when it allocates it (same for Wd below: rows C..Cs, columns ntaps*N..Kd). */
 int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp, float* Wp, void* stream);
 /* W-run operand (SlicConvArgs.k_run_len): Wp[n][run * run_len + px * C + c] = W[n][c][run * run_px + px], zero elsewhere */
 int slic_pack_weight_fwd_runs(const float* W, int N, int C, int ntaps, int run_len, int run_px, int Kp, float* Wp, void* stream);

@@ -39,7 +39,7 @@ for name, C, N, k, s, p, dims in SHAPES:
         t = timeit(lambda: plan.wgrad(x, dz, B, dW))
         print(f"{name.split()[0]}:{fl/t/1e9:.0f}", end=" ", flush=True)
         continue
-    for v in (22, 22, 24, 20, 11):
+    for v in (22, 30, 32, 20, 31):
         t = timeit(lambda: plan.forward(x, wp, B, want_stats=True, variant=v))
         line += f" fwd v{v} {fl/t/1e9:6.1f}"
     if C > 3:

@@ -66,7 +66,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
             wplan.pack_dgrad(wd_)
     plan = ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False)
     xd = _ndhwc(x, plan.Cs).cuda()
-    for variant in (0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24):
+    for variant in (0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 30, 31, 32):
         z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
         got = z.cpu().permute(0, 4, 1, 2, 3)
         tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6

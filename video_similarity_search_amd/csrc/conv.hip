@@ -63,8 +63,9 @@ extern "C" int slic_debug_set_stamps(unsigned long long* buf) {
 // addend / mask / bwd_z loads.  Thread t owns chunk cq = t % CPR of rows rr + RPP * pass (RPP = 256 / CPR rows per pass).
 // All tensor accesses are range-checked buffer ops with 32-bit byte offsets: a row past M, a chunk past N (N % 4 == 0) or an
 // absent optional operand (resource of size 0) is an out-of-range access — loads return 0, stores are dropped.
-// Reductions have a fixed order: rows ascending inside a thread, then the RPP row groups ascending, one slab row per workgroup.
-constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * (1024 / BN) * BN + BN; }
+// Reductions have a fixed order: rows ascending inside a thread, an xor butterfly over the row groups of a wave, then the four
+// waves ascending; one slab row per workgroup.
+constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * 4 * BN + BN; }
 
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
@@ -76,9 +77,22 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
   constexpr int NPASS = BM / RPP;
   static_assert(256 % CPR == 0 && BM % RPP == 0, "tile shape");
   float* tile = lds;                       // [BM][BN]: acc + bias
-  float* red1 = lds + BM * BN;             // [RPP][BN]
-  float* red2 = red1 + RPP * BN;           // [RPP][BN]
-  float* bmean = red2 + RPP * BN;          // [BN]
+  float* red1 = lds + BM * BN;             // [4 waves][BN]
+  float* red2 = red1 + 4 * BN;             // [4 waves][BN]
+  float* bmean = red2 + 4 * BN;            // [BN]
+  const int ewave = tid >> 6, elane = tid & 63;
+  // sum over the row groups a wave holds for one chunk column (lanes elane, elane ^ CPR, elane ^ 2 CPR, ...): every lane ends up
+  // with the same value, added in the same order
+  auto wave_rows_sum = [&](f32x4 v) {
+#pragma unroll
+    for (int off = CPR; off < 64; off <<= 1) {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = __shfl_xor(v[c], off);
+      v += o;
+    }
+    return v;
+  };
   const bool want_stats = p.stat_partial != nullptr;
   const bool want_bwd = p.bwd_partial != nullptr;
   // ---- 1. registers -> LDS image (the k-loop's ring is dead: every caller has drained its DMAs and passed a barrier)
@@ -152,13 +166,17 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
   }
   if (want_bwd) {
     // BatchNorm-backward partials of the stored gradient: (sum v, sum v * xhat) per channel over this row block
-    *(f32x4*)&red1[rr * BN + cq * 4] = s1;
-    *(f32x4*)&red2[rr * BN + cq * 4] = s2;
+    s1 = wave_rows_sum(s1);
+    s2 = wave_rows_sum(s2);
+    if (elane < CPR) {
+      *(f32x4*)&red1[ewave * BN + cq * 4] = s1;
+      *(f32x4*)&red2[ewave * BN + cq * 4] = s2;
+    }
     __syncthreads();
     if (tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < RPP; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
+      for (int w = 0; w < 4; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
       const int nn = n0 + tid;
       if (nn < p.N) {
         p.bwd_partial[(mblk * 2 + 0) * p.N + nn] = t1;
@@ -172,12 +190,14 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
     // so the variance never comes from E[x^2] - mean^2); bn_finalize merges workgroups with Chan's formula in double.
     const int64_t left = p.M - m0;
     const float inv_rows = 1.0f / (float)(left < BM ? left : BM);
-    *(f32x4*)&red1[rr * BN + cq * 4] = fs;
+    if (want_bwd) __syncthreads();             // red1 is still being read by the block above
+    fs = wave_rows_sum(fs);
+    if (elane < CPR) *(f32x4*)&red1[ewave * BN + cq * 4] = fs;
     __syncthreads();
     if (tid < BN) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < RPP; ++w) t += red1[w * BN + tid];
+      for (int w = 0; w < 4; ++w) t += red1[w * BN + tid];
       bmean[tid] = t * inv_rows;
       const int nn = n0 + tid;
       if (nn < p.N) p.stat_partial[(mblk * 2 + 0) * p.N + nn] = t;
@@ -193,12 +213,13 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
         q2 += d * d;
       }
     }
-    *(f32x4*)&red2[rr * BN + cq * 4] = q2;
+    q2 = wave_rows_sum(q2);
+    if (elane < CPR) *(f32x4*)&red2[ewave * BN + cq * 4] = q2;
     __syncthreads();
     if (tid < BN) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < RPP; ++w) t += red2[w * BN + tid];
+      for (int w = 0; w < 4; ++w) t += red2[w * BN + tid];
       const int nn = n0 + tid;
       if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
     }
@@ -356,23 +377,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // ------------------------------------------------------------------------------------------
 // waves per SIMD the LDS footprint allows (one wave of each resident workgroup per SIMD): the register allocator is held to
 // that occupancy, or the epilogue's batched loads would cost the main loop a workgroup per CU
-constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT) {
-  const int ring = STAGES * KT * (BM + BN) * 128, epi = conv_epi_lds_floats(BM, BN) * 4;
+constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT, int KD = 32) {
+  const int ring = STAGES * KT * (BM + BN) * KD * 4, epi = conv_epi_lds_floats(BM, BN) * 4;
   const int lds = ring > epi ? ring : epi;
   const int w = (160 * 1024) / lds;
-  return w > 5 ? 5 : (w < 1 ? 1 : w);
+  return w > 6 ? 6 : (w < 1 ? 1 : w);
 }
 
 // The kernel body, shared by the one-GEMM launch and the multi-GEMM launch (several SlicConvArgs in one grid: the parity
 // classes of a stride-2 data gradient).  (bxi, gdx, byi, bzi) stand for (blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z).
-template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV, int KD>
 __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const int xcd_remap, float* __restrict__ slab,
                                                    const int kt_per_split, float* lds, const int bxi, const int gdx,
                                                    const int byi, const int bzi) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int AL = BM / 32, BL = BN / 32;
-  constexpr int TILE_FLOATS = (BM + BN) * 32;                 // one k-tile (32 deep) of A and B
+  static_assert(KD == 32 || KD == 16, "k-tile depth");
+  constexpr int CPW = KD / 4;                                 // 16-byte chunks per LDS row
+  constexpr int RALL = 256 / CPW;                             // rows the 256 threads cover with one DMA instruction per wave
+  constexpr int AL = BM / RALL, BL = BN / RALL;               // DMA instructions per wave per k-tile
+  constexpr int NG = KD / 8;                                  // MFMA groups per k-tile (one ds_read_b128 per operand tile each)
+  constexpr int TILE_FLOATS = (BM + BN) * KD;                 // one k-tile (KD deep) of A and B
+  static_assert(BM % RALL == 0 && BN % RALL == 0, "tile rows per DMA pass");
   constexpr int STAGE_FLOATS = KT * TILE_FLOATS;              // a ring stage holds KT k-tiles: one barrier per KT tiles
   static_assert(WM * WN == 4, "4 waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,15 +419,15 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   // during which the workgroup holds a residency slot and feeds the matrix pipe nothing.  Priority outranks age: run the
   // prologue (and the epilogue) at raised priority, the k loop at the default.
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
-  const int srow = tid >> 3;                                  // row inside each 32-row group
-  const int cq = (tid & 7) ^ ((srow >> 1) & 7);               // SOURCE chunk column of this lane (LDS slot = tid & 7)
+  const int srow = tid / CPW;                                 // row inside each RALL-row group
+  const int cq = (tid % CPW) ^ lds_swz<KD>(srow);             // SOURCE chunk column of this lane (LDS slot = tid % CPW)
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
   unsigned aoff[AL], rmask[AL];
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
-    const int64_t m = m0 + srow + 32 * i;
+    const int64_t m = m0 + srow + RALL * i;
     aoff[i] = 0; rmask[i] = 0;
     if (m < p.M) {
       unsigned rr = (unsigned)m;
@@ -423,15 +449,15 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   unsigned woff[BL];
 #pragma unroll
   for (int i = 0; i < BL; ++i) {
-    const int n = n0 + srow + 32 * i;
+    const int n = n0 + srow + RALL * i;
     woff[i] = n < p.N ? ((unsigned)n * (unsigned)p.ldw + cq * 4) * 4u : OOB;
   }
   // split-K: workgroup z of the grid's z dimension reduces k-tiles [kt0, nk) of the GEMM and writes raw accumulators to slab[z]
   // (conv_splitk_finish sums the slabs in z order and runs the epilogue); one split (slab == NULL) covers everything
-  const int nk_all = p.nchunks >> 3;
+  const int nk_all = p.nchunks / CPW;
   const int kt0 = slab ? bzi * kt_per_split : 0;
   const int nk = slab ? min(nk_all, kt0 + kt_per_split) : nk_all;     // END of this workgroup's k-tile range
-  const int tiles_per_tap = p.Cs >> 5;
+  const int tiles_per_tap = p.Cs / KD;
   // per-tap records are read through the constant address space with a wave-uniform index: scalar loads, which
   // never touch the vmcnt queue the DMAs are counted on
   const __attribute__((address_space(4))) i32x4* tapc = (const __attribute__((address_space(4))) i32x4*)p.tab;
@@ -443,23 +469,23 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
     const bool live = kt < nk;
     const int ktc = live ? kt : 0;
     const int tap = ktc / tiles_per_tap;                     // wave-uniform -> scalar loads of the tap record
-    const int cb = (ktc - tap * tiles_per_tap) << 5;         // channel base inside the tap
+    const int cb = (ktc - tap * tiles_per_tap) * KD;         // channel base inside the tap
     const i32x4 e = tapc[tap];                               // {src delta, tap mask, weight base, -}: s_load (lgkmcnt queue)
     const unsigned tm = live ? (unsigned)e.y : 0xFFFFFFFFu;  // an all-ones tap mask fails every row's bounds test
     const unsigned dlt = (unsigned)(e.x + cb) * 4u;
     const unsigned wc = (unsigned)(e.z + cb) * 4u;
     float* As = lds + toff;
-    float* Bs = As + BM * 32;
+    float* Bs = As + BM * KD;
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
       const unsigned off = ((rmask[i] & tm) == tm) ? aoff[i] + dlt : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(As + (8 * wave + 32 * i) * 32),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(As + ((RALL / 4) * wave + RALL * i) * KD),
                                                16, (int)off, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
       const unsigned off = (woff[i] == OOB || !live) ? OOB : woff[i] + wc;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bs + (8 * wave + 32 * i) * 32),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bs + ((RALL / 4) * wave + RALL * i) * KD),
                                                16, (int)off, 0, 0, 0);
     }
   };
@@ -473,21 +499,21 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   const int r = lane & 31, h = lane >> 5;
   auto compute = [&](int toff) {
     const float* Ab = lds + toff;
-    const float* Bb = Ab + BM * 32;
+    const float* Bb = Ab + BM * KD;
     f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
+    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[lds_off<KD>(wm * WTM + i * 32 + r, h)];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
+    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[lds_off<KD>(wn * WTN + j * 32 + r, h)];
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NG; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
-      if (q < 3) {
+      if (q < NG - 1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
+        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[lds_off<KD>(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
+        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[lds_off<KD>(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -496,7 +522,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
-      if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      if (q < NG - 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -505,31 +531,31 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   // in front of them, so a wave's matrix pipe is not idle while it computes addresses (matters at 1-2 waves / SIMD)
   auto compute_ilv = [&](int toff, int ktn, int toffn) {
     const float* Ab = lds + toff;
-    const float* Bb = Ab + BM * 32;
+    const float* Bb = Ab + BM * KD;
     const bool live = ktn < nk;
     const int ktc = live ? ktn : 0;
     const int tap = ktc / tiles_per_tap;
-    const int cb = (ktc - tap * tiles_per_tap) << 5;
+    const int cb = (ktc - tap * tiles_per_tap) * KD;
     const i32x4 e = tapc[tap];
     const unsigned tm = live ? (unsigned)e.y : 0xFFFFFFFFu;
     const unsigned dlt = (unsigned)(e.x + cb) * 4u, wc = (unsigned)(e.z + cb) * 4u;
     float* Asn = lds + toffn;
-    float* Bsn = Asn + BM * 32;
+    float* Bsn = Asn + BM * KD;
     f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, h)];
+    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[lds_off<KD>(wm * WTM + i * 32 + r, h)];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, h)];
-    constexpr int ILVQ = SLIC_ILVQ;
+    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[lds_off<KD>(wn * WTN + j * 32 + r, h)];
+    constexpr int ILVQ = SLIC_ILVQ < NG ? SLIC_ILVQ : NG;
     constexpr int NPER = (AL + BL + ILVQ - 1) / ILVQ;   // DMAs per MFMA group: all issued within the first ILVQ groups
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NG; ++q) {
       const int cur = q & 1, nxt = cur ^ 1;
-      if (q < 3) {
+      if (q < NG - 1) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[cv_off(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
+        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[lds_off<KD>(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[cv_off(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
+        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[lds_off<KD>(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -542,11 +568,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
       for (int d = q * NPER; d < (q + 1) * NPER && d < AL + BL; ++d) {
         if (d < AL) {
           const unsigned off = ((rmask[d] & tm) == tm) ? aoff[d] + dlt : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(Asn + (8 * wave + 32 * d) * 32),
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(Asn + ((RALL / 4) * wave + RALL * d) * KD),
                                                    16, (int)off, 0, 0, 0);
         } else {
           const unsigned off = (woff[d - AL] == OOB || !live) ? OOB : woff[d - AL] + wc;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bsn + (8 * wave + 32 * (d - AL)) * 32),
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(Bsn + ((RALL / 4) * wave + RALL * (d - AL)) * KD),
                                                    16, (int)off, 0, 0, 0);
         }
       }
@@ -626,11 +652,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT))))
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false, int KD = 32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT, KD))))
 void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap, float* __restrict__ slab, const int kt_per_split) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV>(p, xcd_remap, slab, kt_per_split, lds, blockIdx.x, gridDim.x, blockIdx.y,
+  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV, KD>(p, xcd_remap, slab, kt_per_split, lds, blockIdx.x, gridDim.x, blockIdx.y,
                                                       blockIdx.z);
 }
 
@@ -640,14 +666,14 @@ struct SlicConvArgsPack {
   SlicConvArgs a[SLIC_CONV_MULTI_MAX];
   int gx[SLIC_CONV_MULTI_MAX];     // row blocks of each GEMM (a multiple of 8 when the XCD order is on)
 };
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT))))
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false, int KD = 32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT, KD))))
 void conv_gemm_dma_multi_kernel(const SlicConvArgsPack pk, const int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int c = blockIdx.z;
   const int gdx = pk.gx[c];
   if ((int)blockIdx.x >= gdx) return;
-  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV>(pk.a[c], xcd_remap, nullptr, 0, lds, blockIdx.x, gdx, blockIdx.y, 0);
+  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV, KD>(pk.a[c], xcd_remap, nullptr, 0, lds, blockIdx.x, gdx, blockIdx.y, 0);
 }
 
 // second pass of a split-K launch: accumulators = sum over the S slabs in slab order, then the ordinary epilogue
@@ -810,7 +836,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
     if (t + 1 < nmt) lwrite(buf ^ 1);
     __syncthreads();
   }
-  // slab[z][n][kidx]: rows of the accumulator = kidx, cols = n
+  // slab[z][kidx][n]: rows of the accumulator = kidx, cols = n — a lane owns a column, so 32 lanes write 32 consecutive floats
   const int Kp = p.nchunks * 4;
   float* out = slab + (int64_t)blockIdx.z * p.N * Kp;
   const int n = n0 + wn * 32 + r;
@@ -820,7 +846,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, c
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int kidx = (kc0 + g * 16) * 4 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (kidx < Kp) out[(int64_t)n * Kp + kidx] = acc[g][v];
+        if (kidx < Kp) out[(int64_t)kidx * p.N + n] = acc[g][v];
       }
   }
 }
@@ -1012,7 +1038,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int Kp = p.nchunks * 4;
-  float* out = slab + (int64_t)bz * p.N * Kp;
+  float* out = slab + (int64_t)bz * p.N * Kp;        // slab[z][kidx][n]
   const int n = n0 + wn * 32 + r;
   if (n < p.N) {
 #pragma unroll
@@ -1020,7 +1046,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int kidx = (kc0 + g * 16) * 4 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (kidx < Kp) out[(int64_t)n * Kp + kidx] = acc[g][v];
+        if (kidx < Kp) out[(int64_t)kidx * p.N + n] = acc[g][v];
       }
   }
 }
@@ -1060,50 +1086,116 @@ __global__ void conv_row_table_kernel(const SlicConvArgs p, uint2* __restrict__ 
   row_tab[m] = make_uint2(((((rr * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs) * 4u, mk);
 }
 
-// dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][n][k].  K is cut into runs of RL floats
-// holding PPR pixels (taps) x Cs channels: the ordinary operand has RL = Cs, PPR = 1 (k = tap * Cs + c); the W-run operand of the
-// RGB stem RL = 24, PPR = 7, Cs = 3.
-__global__ void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, int Kp, int Cs, int C,
-                                  int ntaps, int RL, int PPR, float* __restrict__ dW) {
-  // threads walk the slab in its own (n, k) order: the S reads per element are coalesced; the single write per
-  // element scatters into the reference layout
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t tot = (int64_t)N * Kp;
-  if (e >= tot) return;
-  const int k = (int)(e % Kp);
-  const int n = (int)(e / Kp);
-  const int run = k / RL, rem = k - run * RL;
-  const int px = rem / Cs, c = rem - px * Cs;
-  const int tap = run * PPR + px;
-  if (px >= PPR || tap >= ntaps || c >= C) return;
-  float a = 0.f;
-  for (int s = 0; s < S; ++s) a += slab[(int64_t)s * tot + e];
-  dW[((int64_t)n * C + c) * ntaps + tap] = a;
+// dW[n][c][tap] (reference layout, C = real channel count) = sum over splits of slab[s][k][n], splits added in slab order.
+// A thread owns four consecutive n of one k: 16-byte loads from each of the S slabs (four slabs in flight), then four
+// scattered 4-byte writes into the reference layout (one write per element against S reads).
+// K is cut into runs of RL floats holding PPR pixels (taps) x Cs channels: the ordinary operand has RL = Cs, PPR = 1
+// (k = tap * Cs + c); the W-run operand of the RGB stem RL = 24, PPR = 7, Cs = 3.
+template <bool RUNS>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce(const float* __restrict__ slab, int S, int N, int Kp, int Cs, int C,
+                                                         int ntaps, int RL, int PPR, float* __restrict__ dW) {
+  const int64_t e4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int N4 = N >> 2;
+  const int64_t tot4 = (int64_t)Kp * N4;
+  if (e4 >= tot4) return;
+  const int n0 = (int)(e4 % N4) * 4;
+  const int k = (int)(e4 / N4);
+  int tap, c;
+  if (RUNS) {
+    const int run = k / RL, rem = k - run * RL;
+    const int px = rem / Cs;
+    c = rem - px * Cs;
+    tap = run * PPR + px;
+    if (px >= PPR) return;
+  } else {
+    tap = k / Cs;
+    c = k - tap * Cs;
+  }
+  if (tap >= ntaps || c >= C) return;
+  const f32x4* sp = (const f32x4*)(slab + (int64_t)k * N + n0);
+  const int64_t zs = ((int64_t)N * Kp) >> 2;     // slab stride in f32x4 units
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  int z = 0;
+  for (; z + 4 <= S; z += 4) {
+    const f32x4 v0 = sp[z * zs], v1 = sp[(z + 1) * zs], v2 = sp[(z + 2) * zs], v3 = sp[(z + 3) * zs];
+    a += v0; a += v1; a += v2; a += v3;
+  }
+  for (; z < S; ++z) a += sp[z * zs];
+  float* d = dW + ((int64_t)n0 * C + c) * ntaps + tap;
+  const int64_t ns = (int64_t)C * ntaps;
+  d[0] = a.x; d[ns] = a.y; d[2 * ns] = a.z; d[3 * ns] = a.w;
 }
 
 // ---- weight packing -------------------------------------------------------------------------
-// Both packers are [channels][taps] <-> [taps][channels] transposes of the reference layout W[n][c][tap]; they go through
-// an LDS tile so that the global reads are contiguous runs of W and the global writes contiguous runs of the operand
-// (the one-thread-per-output-element version read W with a stride of `ntaps` floats).
-// forward:  Wp[n][tap*Cs + c] = W[n][c][tap]  (zero for c >= C and the K padding).  Workgroup = (n, chunk of CH channels).
-__global__ __launch_bounds__(256) void pack_w_fwd(const float* __restrict__ W, int N, int C, int ntaps, int Cs, int Kp,
+// Both packers re-order the reference layout W[n][c][tap] through an LDS tile so that global reads are contiguous runs of W and
+// global writes contiguous runs of the operand; the padding of the operands (channels C..Cs, columns past the last tap) is
+// written once, as zeros, when the plan allocates them — the packers only touch real elements.
+// forward:  Wp[n][tap*Cs + c] = W[n][c][tap].  Workgroup = (n, chunk of 64 channels); NT = compile-time tap count (0: generic),
+// so the index arithmetic divides by constants.
+template <int NT>
+__global__ __launch_bounds__(256) void pack_w_fwd(const float* __restrict__ W, int N, int C, int ntaps_rt, int Cs, int Kp,
                                                   int CH, float* __restrict__ Wp) {
   extern __shared__ float pk_lds[];                        // [CH][ld], ld odd: conflict-free column reads
+  const int ntaps = NT ? NT : ntaps_rt;
   const int n = blockIdx.x, c0 = blockIdx.y * CH, t = threadIdx.x;
   const int ld = ntaps | 1;
-  const int cw = min(CH, C - c0);                          // real channels in this chunk (may be <= 0: all padding)
-  const int chw = min(CH, Cs - c0);                        // channels of the operand in this chunk
+  const int cw = min(CH, C - c0);                          // real channels in this chunk
+  if (cw <= 0) return;
+  const float* src = W + ((int64_t)n * C + c0) * ntaps;
   for (int e = t; e < cw * ntaps; e += 256) {
     const int cc = e / ntaps, tap = e - cc * ntaps;
-    pk_lds[cc * ld + tap] = W[((int64_t)n * C + c0) * ntaps + e];
+    pk_lds[cc * ld + tap] = src[e];
   }
   __syncthreads();
-  for (int e = t; e < ntaps * chw; e += 256) {
-    const int tap = e / chw, cc = e - tap * chw;
-    Wp[(int64_t)n * Kp + tap * Cs + c0 + cc] = cc < cw ? pk_lds[cc * ld + tap] : 0.f;
+  float* dst = Wp + (int64_t)n * Kp + c0;
+  if (cw == 64) {
+    for (int e = t; e < ntaps * 64; e += 256) {
+      const int tap = e >> 6, cc = e & 63;
+      dst[tap * Cs + cc] = pk_lds[cc * ld + tap];
+    }
+  } else {
+    for (int e = t; e < ntaps * cw; e += 256) {
+      const int tap = e / cw, cc = e - tap * cw;
+      dst[tap * Cs + cc] = pk_lds[cc * ld + tap];
+    }
   }
-  if (blockIdx.y == 0)
-    for (int k = ntaps * Cs + t; k < Kp; k += 256) Wp[(int64_t)n * Kp + k] = 0.f;
+}
+// data gradient:  Wd[c][tap*N + n] = W[n][c][tap]: with r = c*ntaps + tap this is the 2-D transpose [N][R] -> [R][N] of W seen
+// as an N x R matrix (R = C*ntaps), rows of the result laid out with stride N inside a Wd row of Kd floats.  64 x 64 tiles,
+// 16-byte global accesses both ways (R % 4 == 0, N % 4 == 0), one division per output ROW.
+__global__ __launch_bounds__(256) void pack_w_dgrad(const float* __restrict__ W, int N, int R, int ntaps, int Kd,
+                                                    float* __restrict__ Wd) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, n0 = blockIdx.y * 64, t = threadIdx.x;
+  const int q = (t & 15) * 4, rowt = t >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int nn = rowt + 16 * i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n0 + nn < N && r0 + q < R) v = *(const f32x4*)(W + (int64_t)(n0 + nn) * R + r0 + q);
+    tile[nn][q] = v.x; tile[nn][q + 1] = v.y; tile[nn][q + 2] = v.z; tile[nn][q + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = rowt + 16 * i;
+    const int r = r0 + rr;
+    if (r < R && n0 + q < N) {
+      const int c = r / ntaps, tap = r - c * ntaps;
+      const f32x4 v = {tile[q][rr], tile[q + 1][rr], tile[q + 2][rr], tile[q + 3][rr]};
+      *(f32x4*)(Wd + (int64_t)c * Kd + (int64_t)tap * N + n0 + q) = v;
+    }
+  }
+}
+// the same for shapes whose rows are not 16-byte multiples (C % 4 != 0: never the case for a layer that needs a data gradient in
+// R3D-18 — its only few-channel layer is the stem): one thread per element
+__global__ void pack_w_dgrad_any(const float* __restrict__ W, int N, int C, int ntaps, int Kd, float* __restrict__ Wd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (c, tap, n), n fastest
+  if (e >= (int64_t)C * ntaps * N) return;
+  const int n = (int)(e % N);
+  const int64_t ct = e / N;
+  const int tap = (int)(ct % ntaps), c = (int)(ct / ntaps);
+  Wd[(int64_t)c * Kd + (int64_t)tap * N + n] = W[((int64_t)n * C + c) * ntaps + tap];
 }
 // W-run operand (few-channel stem): Wp[n][run * RL + px * C + c] = W[n][c][run * PPR + px]; a few hundred KB, one thread per element
 __global__ void pack_w_fwd_runs(const float* __restrict__ W, int N, int C, int ntaps, int RL, int PPR, int Kp, float* __restrict__ Wp) {
@@ -1208,13 +1300,13 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
   return SLIC_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false, int KD = 32>
 static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
-  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * KD * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1222,11 +1314,11 @@ static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st, int splits = 1
   const unsigned gx = (unsigned)slic_cdiv(a.M, BM);
   if (splits > 1) {
     if constexpr (KT == 1) {
-      const int nk = a.nchunks >> 3;
+      const int nk = a.nchunks / (KD / 4);
       const int per = (nk + splits - 1) / splits;
       const int S = (nk + per - 1) / per;
       dim3 grid(gx, (unsigned)slic_cdiv(a.N, BN), (unsigned)S);
-      conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a, 0, slab, per);
+      conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD><<<grid, dim3(256), lds, st>>>(a, 0, slab, per);
       SLIC_LAUNCH_CHECK();
       conv_splitk_finish<BM, BN, WM, WN><<<dim3(gx, (unsigned)slic_cdiv(a.N, BN)), dim3(256), 0, st>>>(a, slab, S);
       SLIC_LAUNCH_CHECK();
@@ -1237,14 +1329,14 @@ static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st, int splits = 1
     }
   }
   dim3 grid(xcd ? (gx + 7) / 8 * 8 : gx, (unsigned)slic_cdiv(a.N, BN));
-  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(a, xcd, nullptr, 0);
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD><<<grid, dim3(256), lds, st>>>(a, xcd, nullptr, 0);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
 
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
-  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17 || variant == 20 || variant == 23) return 64;
-  if (variant == 13 || variant == 14 || variant == 18 || variant == 19 || variant == 21 || variant == 22 || variant == 24) return 128;
+  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17 || variant == 20 || variant == 23 || variant == 31) return 64;
+  if (variant == 13 || variant == 14 || variant == 18 || variant == 19 || variant == 21 || variant == 22 || variant == 24 || variant == 30 || variant == 32) return 128;
   // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
   if (variant == 1) return 128;
   if (variant == 2) return 64;
@@ -1262,7 +1354,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                "slic_conv_gemm: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
   hipStream_t st = S_(stream);
-  if (variant >= 11 && variant <= 24) {
+  if (variant >= 11 && variant <= 32) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SlicConvArgs b = *a;
@@ -1276,6 +1368,9 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     if (variant == 20) return launch_gemm_dma<64, 64, 2, 2, 2, 1, true>(b, st);     // v17 + DMA issue interleaved with the MFMAs
     if (variant == 21) return launch_gemm_dma<128, 128, 2, 2, 2, 1, true>(b, st);   // v18 + interleave
     if (variant == 22) return launch_gemm_dma<128, 64, 2, 2, 2, 1, true>(b, st);    // v19 + interleave
+    if (variant == 30) return launch_gemm_dma<128, 64, 2, 2, 3, 1, true, 16>(b, st);   // 16-deep k-tiles, 3-stage ring: 36 KB, 4 workgroups / CU
+    if (variant == 31) return launch_gemm_dma<64, 64, 2, 2, 3, 1, true, 16>(b, st);    // 24 KB: 6 workgroups / CU
+    if (variant == 32) return launch_gemm_dma<128, 64, 2, 2, 4, 1, true, 16>(b, st);   // 4-stage ring: 48 KB, 3 workgroups / CU
     if (variant == 18) return launch_gemm_dma<128, 128, 2, 2, 2, 1>(b, st);   // 64 KB: 2 workgroups / CU, 64 acc regs
     if (variant == 19) return launch_gemm_dma<128, 64, 2, 2, 2, 1>(b, st);    // 48 KB: 3 workgroups / CU
     if (variant == 15) return launch_gemm_dma<64, 64, 2, 2, 2, 2>(b, st);     // 2 k-tiles per barrier, 2-stage ring (64 KB)
@@ -1291,13 +1386,13 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   return launch_gemm<64, 64, 2, 2>(*a, st);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV>
+template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV, int KD = 32>
 static int launch_gemm_dma_multi(const SlicConvArgs* a, int n, hipStream_t st) {
-  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * 32 * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * KD * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -1313,7 +1408,7 @@ static int launch_gemm_dma_multi(const SlicConvArgs* a, int n, hipStream_t st) {
     if (gx > gmax) gmax = gx;
   }
   dim3 grid(gmax, (unsigned)slic_cdiv(a[0].N, BN), (unsigned)n);
-  conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV><<<grid, dim3(256), lds, st>>>(pk, xcd);
+  conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD><<<grid, dim3(256), lds, st>>>(pk, xcd);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1406,7 +1501,10 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   }
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)a->N * Kp;
-  conv_wgrad_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, RL, PPR, dW);
+  if (a->k_run_len > 0)
+    conv_wgrad_reduce<true><<<dim3((unsigned)slic_cdiv(tot / 4, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, RL, PPR, dW);
+  else
+    conv_wgrad_reduce<false><<<dim3((unsigned)slic_cdiv(tot / 4, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, RL, PPR, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1423,10 +1521,14 @@ extern "C" int slic_conv_row_table(const SlicConvArgs* a, uint32_t* row_tab, voi
 extern "C" int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp, float* Wp,
                                     void* stream) {
   SLIC_REQUIRE(W && Wp && N > 0 && C > 0 && ntaps > 0 && Cs >= C && Kp >= ntaps * Cs, "slic_pack_weight_fwd: bad args");
-  const int CH = Cs < 64 ? Cs : 64;
+  int CH = 64;                                             // channels per tile: 64, fewer when the taps are many (48 KiB of LDS)
+  if ((size_t)CH * (ntaps | 1) * sizeof(float) > 48 * 1024) CH = (int)(12288 / (ntaps | 1));
+  SLIC_REQUIRE(CH >= 1, "slic_pack_weight_fwd: %d taps exceed the LDS tile", ntaps);
   const size_t lds = (size_t)CH * (ntaps | 1) * sizeof(float);
-  SLIC_REQUIRE(lds <= 64 * 1024, "slic_pack_weight_fwd: %d taps x %d channels per tile exceeds 64 KiB of LDS", ntaps, CH);
-  pack_w_fwd<<<dim3((unsigned)N, (unsigned)slic_cdiv(Cs, CH)), dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kp, CH, Wp);
+  const dim3 grid((unsigned)N, (unsigned)slic_cdiv(C, CH));
+  if (ntaps == 27) pack_w_fwd<27><<<grid, dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kp, CH, Wp);
+  else if (ntaps == 1) pack_w_fwd<1><<<grid, dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kp, CH, Wp);
+  else pack_w_fwd<0><<<grid, dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kp, CH, Wp);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1444,14 +1546,14 @@ extern "C" int slic_pack_weight_fwd_runs(const float* W, int N, int C, int ntaps
 extern "C" int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int Kd, float* Wd,
                                       void* stream) {
   SLIC_REQUIRE(W && Wd && N > 0 && C > 0 && ntaps > 0 && Cs >= C && Kd >= ntaps * N, "slic_pack_weight_dgrad: bad args");
-  int CB = 64 / ntaps;
-  CB = CB < 8 ? 8 : CB;
-  const int fit = 384 / ntaps;                             // 32 x CB x ntaps floats <= 48 KiB
-  if (CB > fit) CB = fit < 1 ? 1 : fit;
-  if (CB > Cs) CB = Cs;
-  const size_t lds = (size_t)32 * ((CB * ntaps) | 1) * sizeof(float);
-  SLIC_REQUIRE(lds <= 64 * 1024, "slic_pack_weight_dgrad: %d taps x %d channels per tile exceeds 64 KiB of LDS", ntaps, CB);
-  pack_w_dgrad<<<dim3((unsigned)slic_cdiv(N, 32), (unsigned)slic_cdiv(Cs, CB)), dim3(256), lds, S_(stream)>>>(W, N, C, ntaps, Cs, Kd, CB, Wd);
+  const int R = C * ntaps;
+  if (N % 4 != 0 || R % 4 != 0 || ((uintptr_t)W % 16) != 0 || ((uintptr_t)Wd % 16) != 0 || Kd % 4 != 0) {
+    const int64_t tot = (int64_t)R * N;
+    pack_w_dgrad_any<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(W, N, C, ntaps, Kd, Wd);
+    SLIC_LAUNCH_CHECK();
+    return SLIC_OK;
+  }
+  pack_w_dgrad<<<dim3((unsigned)slic_cdiv(R, 64), (unsigned)slic_cdiv(N, 64)), dim3(256), 0, S_(stream)>>>(W, N, R, ntaps, Kd, Wd);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -5,3 +5,11 @@
 __device__ __forceinline__ int cv_off(int row, int chunk) {
   return row * 32 + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
+
+// the same for a k-tile of KD floats per row (KD = 32: the function above; KD = 16: 64-byte rows, 4 chunks, and the chunk is
+// XORed with bits 2-3 of the row, so that the 16 rows of a ds_read_b128 lane group — distinct in (row & 3, (row >> 2) & 3) —
+// cover all 16 slots of a 256-byte bank row)
+template <int KD>
+__device__ __forceinline__ int lds_swz(int row) { return KD == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int KD>
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * KD + ((chunk ^ lds_swz<KD>(row)) << 2); }

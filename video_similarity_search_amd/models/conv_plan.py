@@ -170,8 +170,8 @@ class ConvPlan:
 
     # ------------------------------------------------------------------ weights
     def pack_fwd(self, weight):
-        if self._wp is None:
-            self._wp = torch.empty(self.N, self.Kp, dtype=torch.float32, device=self.device)
+        if self._wp is None:     # zeroed once: the packer writes real elements only, the padding stays zero
+            self._wp = torch.zeros(self.N, self.Kp, dtype=torch.float32, device=self.device)
         if self.wrun:
             call("slic_pack_weight_fwd_runs", ptr(weight), self.N, self.C, self.ntaps, self.run_len, self.run_px, self.Kp,
                  ptr(self._wp), stream())
@@ -183,7 +183,7 @@ class ConvPlan:
         if self.wrun:
             raise _lib.SlicError("the W-run operand serves forward and weight gradient only (the clip needs no gradient)")
         if self._wd is None:
-            self._wd = torch.empty(self.Cs, self.Kd, dtype=torch.float32, device=self.device)
+            self._wd = torch.zeros(self.Cs, self.Kd, dtype=torch.float32, device=self.device)
         call("slic_pack_weight_dgrad", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kd, ptr(self._wd), stream())
         return self._wd
 
@@ -241,7 +241,7 @@ class ConvPlan:
             # layers, the 3-stage ring on the small-M ones (layer4) where fewer workgroups exist to hide latency
             if a.M >= 100000:
                 # the next tile's DMAs are issued between MFMA groups; N <= 64 (layer1: 52 % of the FLOPs): 128x64 tiles
-                return 22 if a.N <= 64 else 20
+                return int(os.environ.get("SLIC_CONV_BIG_VARIANT", "22")) if a.N <= 64 else 20
             return int(os.environ.get("SLIC_CONV_SMALL_VARIANT", "20"))      # 64x64, 2-stage ring, interleaved DMA issue; split-K when few tiles
         if variant >= 11 and not a.tap_tab:
             return 0
@@ -332,6 +332,7 @@ class ConvPlan:
                 a.bwd_partial = part.data_ptr() + r0 * 2 * self.Cs * 4
                 r0 += r
         picks = [self._pick(a, variant) for a in launches]
+        picks = [22 if v == 30 else v for v in picks]          # the multi-GEMM launch exists for the 32-deep variants
         if (len(launches) > 1 and len(set(picks)) == 1 and picks[0] in (20, 22) and os.environ.get("SLIC_CONV_MULTI", "1") != "0"
                 and all(self._splits(a, picks[0]) == 1 for a in launches)):
             # the parity classes of a stride-2 layer as ONE launch: their K loops (1-8 taps) are too short to fill the chip
