@@ -323,8 +323,23 @@ int slic_margin_cos_bwd(const float* X, const float* Y, const float* Z, const fl
 int slic_triplet_select(const float* dist, const int64_t* labels, int n, const int32_t* anchors,
                         const int32_t* positives, int P, float margin, int mode, const float* u, int32_t* negatives,
                         void* stream);
+/* the same over a rectangular matrix dist[rows][ncols] (MemTripletLoss, loss/triplet_loss.py:9-81, 239-272: rows = the batch,
+ * columns = the queue): col_labels int64 [ncols], the pair's anchor row / anchor label / positive COLUMN; mode 3 =
+ * 'adapted_hard' (the reference's sampler returns nothing, so every pair takes the hardest-easy fallback). */
+int slic_triplet_select_cross(const float* dist, const int64_t* col_labels, int ncols, const int32_t* anchor_rows,
+                              const int64_t* anchor_labels, const int32_t* positive_cols, int P, float margin, int mode,
+                              const float* u, int32_t* negatives, void* stream);
 /* [n, n] distance matrix of the rows of V (loss/triplet_loss.py:429-437 pdist) */
 int slic_pdist(const float* V, int n, int D, float eps, int euclidean, float* out, void* stream);
+/* [nx, ny] distance matrix between the rows of X and Y (loss/triplet_loss.py:439-447 pdist_v2) */
+int slic_pdist2(const float* X, int nx, const float* Y, int ny, int D, float eps, int euclidean, float* out, void* stream);
+/* InfoNCE over gathered rows ('all_semi_hard', loss/triplet_loss.py:118-203): X [P, D] anchors, Y [P, NY, D] with row 0 the
+ * positive and rows 1..NY-1 the picked negatives (NY <= 8): loss = mean_i -log(e^{cos(x,y0)/T} / sum_j e^{cos(x,yj)/T}).
+ * state [P][18] floats is kept for the backward, which returns dX [P, D] and dY [P, NY, D] scaled by *gscale. */
+int slic_infonce_rows_fwd(const float* X, const float* Y, int P, int NY, int D, float temperature, float* state,
+                          float* rowloss, float* loss, void* stream);
+int slic_infonce_rows_bwd(const float* X, const float* Y, const float* state, int P, int NY, int D, float temperature,
+                          const float* gscale, float* dX, float* dY, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cosine top-k retrieval (iic_retrieve_clips.py:275-314 topk_retrieval; evaluate.py:208-231,287-307):

@@ -1,0 +1,76 @@
+"""
+Generates tests/golden/loss_variants.npz in the BUILD container by importing the reference's loss/triplet_loss.py
+(OnlineTripletLoss 'all_semi_hard' :118-203, MemTripletLoss :9-81) with the oracle-only .cuda() shim.
+    python tests/golden/make_goldens_loss_variants.py
+Inputs come from numpy's PCG64 so the GPU box regenerates nothing: everything needed is stored.
+"""
+import os
+import random
+import sys
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+import torch.nn as nn
+sys.path.insert(0, "/root/reference")
+torch.Tensor.cuda = lambda self, *a, **k: self              # oracle-only shim for hard-coded .cuda()
+nn.Module.cuda = lambda self, *a, **k: self
+from loss.triplet_loss import MemTripletLoss, OnlineTripletLoss, pdist      # noqa: E402  (the reference)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+rng = np.random.default_rng(41)
+out = {}
+
+# ---- all_semi_hard, deterministic regime: well-separated classes, tiny margin -> no pair has more than 5 candidates, so the
+# five negatives are the first five rows of the negatives list and Python's random only permutes them
+labs = np.repeat(np.arange(4), 6)[rng.permutation(24)]
+cen = rng.standard_normal((4, 128)).astype(np.float32) * 4
+E = (cen[labs] + 0.05 * rng.standard_normal((24, 128))).astype(np.float32)
+et = torch.from_numpy(E).requires_grad_(True)
+random.seed(3)
+l, n = OnlineTripletLoss(1e-4, 'cosine')(et, torch.from_numpy(labs.astype(np.int64)), sampling_strategy='all_semi_hard')
+l.backward()
+out.update(ash_det_E=E, ash_det_labels=labs.astype(np.int64), ash_det_margin=np.float32(1e-4), ash_det_loss=l.detach().numpy(),
+           ash_det_n=np.int64(n), ash_det_grad=et.grad.numpy().copy())
+print("all_semi_hard deterministic:", float(l), n)
+
+# ---- all_semi_hard, crowded regime: random embeddings, margin 0.2 -> dozens of candidates per pair; the reference's draw is
+# Python-RNG-bound, so the golden holds what is checkable: the per-pair candidate-list length L and the loss RANGE over seeds
+labs2 = rng.integers(0, 6, 40)
+E2 = rng.standard_normal((40, 128)).astype(np.float32)
+losses = []
+for seed in range(8):
+    random.seed(seed)
+    l2, n2 = OnlineTripletLoss(0.2, 'cosine')(torch.from_numpy(E2), torch.from_numpy(labs2.astype(np.int64)), sampling_strategy='all_semi_hard')
+    losses.append(float(l2))
+Dm = pdist(torch.from_numpy(E2), eps=0, dist_metric='cosine').numpy()
+Ls = []
+for lab in np.unique(labs2):
+    idx = np.nonzero(labs2 == lab)[0]
+    neg = np.nonzero(labs2 != lab)[0]
+    for i in range(len(idx)):
+        for j in range(i + 1, len(idx)):
+            a, p = idx[i], idx[j]
+            Ls.append(max(5, int(((Dm[a, p] + 0.2) - Dm[a, neg] > 0).sum())))
+out.update(ash_rand_E=E2, ash_rand_labels=labs2.astype(np.int64), ash_rand_margin=np.float32(0.2), ash_rand_losses=np.array(losses),
+           ash_rand_n=np.int64(n2), ash_rand_L=np.array(Ls, np.int64))
+print("all_semi_hard crowded: pairs", n2, "loss over seeds", min(losses), max(losses), "L", min(Ls), max(Ls))
+
+# ---- MemTripletLoss: three consecutive calls (the queue carries over), the two deterministic strategies
+for strat in ("adapted_hard", "fixed_semi_hard"):
+    torch.manual_seed(7)
+    m = MemTripletLoss(0.2, 'cosine')
+    out[f"mem_{strat}_queue0"] = m.queue.clone().numpy()
+    for it in range(3):
+        e = rng.standard_normal((8, 128)).astype(np.float32)
+        labs3 = (np.arange(4).repeat(2)[rng.permutation(8)] + (4 * it if it < 2 else 0)).astype(np.int64)   # call 3 reuses call 1's labels
+        et = torch.from_numpy(e).requires_grad_(True)
+        l3, n3 = m(et, torch.from_numpy(labs3), sampling_strategy=strat)
+        l3.backward()
+        out[f"mem_{strat}_E{it}"], out[f"mem_{strat}_labels{it}"] = e, labs3
+        out[f"mem_{strat}_loss{it}"], out[f"mem_{strat}_n{it}"] = l3.detach().numpy(), np.int64(n3)
+        out[f"mem_{strat}_grad{it}"] = et.grad.numpy().copy()
+    out[f"mem_{strat}_queue3"], out[f"mem_{strat}_label_q3"] = m.queue.numpy().copy(), m.label_q.numpy().copy()
+    out[f"mem_{strat}_ptr3"] = np.int64(int(m.queue_ptr))
+    print("MemTripletLoss", strat, [float(out[f"mem_{strat}_loss{i}"]) for i in range(3)], int(m.queue_ptr))
+np.savez_compressed(os.path.join(HERE, "loss_variants.npz"), **out)
+print("loss_variants goldens:", len(out))

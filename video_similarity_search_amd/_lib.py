@@ -79,7 +79,11 @@ SIGNATURES = {
     "slic_margin_cos_fwd": (I, [P, P, P, I, I, F, P, P, P, P]),
     "slic_margin_cos_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P]),
     "slic_triplet_select": (I, [P, P, I, P, P, I, F, I, P, P, P]),
+    "slic_triplet_select_cross": (I, [P, P, I, P, P, P, I, F, I, P, P, P]),
     "slic_pdist": (I, [P, I, I, F, I, P, P]),
+    "slic_pdist2": (I, [P, I, P, I, I, F, I, P, P]),
+    "slic_infonce_rows_fwd": (I, [P, P, I, I, I, F, P, P, P, P]),
+    "slic_infonce_rows_bwd": (I, [P, P, P, I, I, I, F, P, P, P, P]),
     # retrieval
     "slic_normalize_rows": (I, [P, L, I, I, P, P]),
     "slic_cosine_topk_workspace_bytes": (c_size_t, [I, I, I]),

@@ -165,6 +165,104 @@ __global__ void pdist_kernel(const float* __restrict__ V, int n, int D, float ep
   if (lane == 0) out[pair] = euclid ? sqrtf(a) : 1.0f - a / (fmaxf(sqrtf(b), 1e-8f) * fmaxf(sqrtf(c), 1e-8f));
 }
 
+// rectangular distance matrix (loss/triplet_loss.py:439-447 pdist_v2): one wave per (i, j)
+__global__ void pdist2_kernel(const float* __restrict__ X, int nx, const float* __restrict__ Y, int ny, int D, float eps,
+                              int euclid, float* __restrict__ out) {
+  const int64_t pair = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pair >= (int64_t)nx * ny) return;
+  const int i = (int)(pair / ny), j = (int)(pair % ny);
+  const int lane = threadIdx.x & 63;
+  const float* x = X + (int64_t)i * D;
+  const float* y = Y + (int64_t)j * D;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    if (euclid) { const float d = x[k] - y[k] + eps; a = fmaf(d, d, a); }
+    else { a = fmaf(x[k], y[k], a); b = fmaf(x[k], x[k], b); c = fmaf(y[k], y[k], c); }
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  if (lane == 0) out[pair] = euclid ? sqrtf(a) : 1.0f - a / (fmaxf(sqrtf(b), 1e-8f) * fmaxf(sqrtf(c), 1e-8f));
+}
+
+// InfoNCE over gathered rows — the 'all_semi_hard' branch of OnlineTripletLoss (loss/triplet_loss.py:118-203): per anchor row x
+// with NY rows y_0 (the positive), y_1 .. y_{NY-1} (the picked negatives):
+//   d_j = 1 - cos(x, y_j),  sim_j = exp((1 - d_j) / T),  loss = -log(sim_0 / (sum_{j >= 1} sim_j + sim_0)),  mean over the rows.
+// One wave per anchor row; the cosines and norms are kept for the backward.  NY <= 8.
+#define SLIC_INFONCE_MAXY 8
+__global__ void infonce_rows_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, int P, int NY, int D,
+                                        float inv_t, float* __restrict__ st /* [P][2 * MAXY + 2] */, float* __restrict__ rowloss) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= P) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = X + (int64_t)row * D;
+  const float* y = Y + (int64_t)row * NY * D;
+  float xy[SLIC_INFONCE_MAXY], yy[SLIC_INFONCE_MAXY], xx = 0.f;
+#pragma unroll
+  for (int j = 0; j < SLIC_INFONCE_MAXY; ++j) { xy[j] = 0.f; yy[j] = 0.f; }
+  for (int k = lane; k < D; k += 64) {
+    const float xv = x[k];
+    xx = fmaf(xv, xv, xx);
+#pragma unroll
+    for (int j = 0; j < SLIC_INFONCE_MAXY; ++j)
+      if (j < NY) { const float yv = y[(int64_t)j * D + k]; xy[j] = fmaf(xv, yv, xy[j]); yy[j] = fmaf(yv, yv, yy[j]); }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    xx += __shfl_xor(xx, o);
+#pragma unroll
+    for (int j = 0; j < SLIC_INFONCE_MAXY; ++j) { xy[j] += __shfl_xor(xy[j], o); yy[j] += __shfl_xor(yy[j], o); }
+  }
+  if (lane == 0) {
+    float* s = st + (int64_t)row * (2 * SLIC_INFONCE_MAXY + 2);
+    const float nx = fmaxf(sqrtf(xx), 1e-8f);
+    s[2 * SLIC_INFONCE_MAXY] = nx;
+    float sim0 = 0.f, an = 0.f;
+#pragma unroll
+    for (int j = 0; j < SLIC_INFONCE_MAXY; ++j)
+      if (j < NY) {
+        const float ny = fmaxf(sqrtf(yy[j]), 1e-8f);
+        const float c = xy[j] / (nx * ny);
+        const float d = 1.f - c;                        // the reference exponentiates (1 - dist) / T with dist = 1 - cos
+        const float e = expf((1.f - d) * inv_t);
+        s[j] = c; s[SLIC_INFONCE_MAXY + j] = ny;
+        if (j == 0) sim0 = e; else an += e;
+      }
+    s[2 * SLIC_INFONCE_MAXY + 1] = an + sim0;
+    rowloss[row] = -logf(sim0 / (an + sim0));
+  }
+}
+// d loss / d s_0 = -(1 - p_0), d loss / d s_j = p_j (p = softmax over the NY similarities s_j = cos_j / T); d cos(x,y)/dx as above
+__global__ void infonce_rows_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ st,
+                                        int P, int NY, int D, float inv_t, const float* __restrict__ gscale,
+                                        float* __restrict__ dX, float* __restrict__ dY) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= P) return;
+  const int lane = threadIdx.x & 63;
+  const float* s = st + (int64_t)row * (2 * SLIC_INFONCE_MAXY + 2);
+  const float nx = s[2 * SLIC_INFONCE_MAXY], Z = s[2 * SLIC_INFONCE_MAXY + 1];
+  const float g = (gscale ? *gscale : 1.f) / (float)P;
+  float w[SLIC_INFONCE_MAXY], c[SLIC_INFONCE_MAXY], ny[SLIC_INFONCE_MAXY];     // w_j = g * d loss / d cos_j
+#pragma unroll
+  for (int j = 0; j < SLIC_INFONCE_MAXY; ++j) {
+    c[j] = j < NY ? s[j] : 0.f;
+    ny[j] = j < NY ? s[SLIC_INFONCE_MAXY + j] : 1.f;
+    const float pj = j < NY ? expf((1.f - (1.f - c[j])) * inv_t) / Z : 0.f;
+    w[j] = g * inv_t * (j == 0 ? pj - 1.f : pj);
+  }
+  const float* x = X + (int64_t)row * D;
+  const float* y = Y + (int64_t)row * NY * D;
+  for (int k = lane; k < D; k += 64) {
+    const float xv = x[k];
+    float dx = 0.f;
+#pragma unroll
+    for (int j = 0; j < SLIC_INFONCE_MAXY; ++j)
+      if (j < NY) {
+        const float yv = y[(int64_t)j * D + k];
+        dx += w[j] * (yv / (nx * ny[j]) - c[j] * xv / (nx * nx));
+        dY[((int64_t)row * NY + j) * D + k] = w[j] * (xv / (nx * ny[j]) - c[j] * yv / (ny[j] * ny[j]));
+      }
+    dX[(int64_t)row * D + k] = dx;
+  }
+}
+
 // LLC / relative-speed margin term of triplet_train_epoch (online_train.py:317-332):
 //   d1 = 1 - cos(x, y), d2 = 1 - cos(x, z), MarginRankingLoss(margin)(d1, d2, target = -1) = mean(max(0, d1 - d2 + margin)).
 // One wave per row; row state (dots and norms) is kept for the backward.
@@ -221,15 +319,20 @@ __global__ void margin_cos_bwd_kernel(const float* __restrict__ X, const float* 
 // u[pair] in [0, 1) replaces Python's random.choice (rank floor(u * count) in ascending index order).
 // No semi-hard/hard negative -> hardest_easy_sampling (:350-351, 424-426): argmin of d(a, negatives) — and, exactly
 // like the reference, the POSITION in the negatives list is returned, not the row it stands for.
+//   mode 3 'adapted_hard'     : MemTripletLoss's default — the reference's adapted_hard_sampling has no return statement
+//                               (:408-421), so every pair takes the hardest-easy fallback
+// The matrix may be rectangular (MemTripletLoss: rows = the batch, columns = the queue): `labels` are the COLUMN labels, n the
+// column count = row stride, and the anchor's label comes from anc_label[pair] when given (else labels[anchor row]).
 __global__ void triplet_select_kernel(const float* __restrict__ Dm, const int64_t* __restrict__ labels, int n,
-                                      const int32_t* __restrict__ anc, const int32_t* __restrict__ pos, int P,
+                                      const int32_t* __restrict__ anc, const int64_t* __restrict__ anc_label,
+                                      const int32_t* __restrict__ pos, int P,
                                       float margin, int mode, const float* __restrict__ u,
                                       int32_t* __restrict__ neg) {
   const int pr = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (pr >= P) return;
   const int lane = threadIdx.x & 63;
   const int a = anc[pr];
-  const int64_t la = labels[a];
+  const int64_t la = anc_label ? anc_label[pr] : labels[a];
   const float thr = Dm[(int64_t)a * n + pos[pr]] + margin;
   const float* row = Dm + (int64_t)a * n;
   // pass 1: counts, argmax of loss / argmin of distance over the negatives (first index wins)
@@ -256,7 +359,9 @@ __global__ void triplet_select_kernel(const float* __restrict__ Dm, const int64_
   }
   int result = -1;
   const int want_set = mode == 0 ? cnt_neg : cnt_c;       // size of the set a rank is drawn from
-  if (mode == 2) {
+  if (mode == 3) {
+    // straight to the fallback
+  } else if (mode == 2) {
     if (cnt_c > 0) result = best_loss_j;
   } else if (want_set > 0) {
     int rsel = (int)(u[pr] * (float)want_set);
@@ -295,7 +400,18 @@ extern "C" int slic_triplet_select(const float* dist, const int64_t* labels, int
                                    int32_t* negatives, void* stream) {
   SLIC_REQUIRE(dist && labels && anchors && positives && negatives && n > 1 && P > 0 && mode >= 0 && mode <= 2 &&
                (mode == 2 || u), "slic_triplet_select: bad args");
-  triplet_select_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(dist, labels, n, anchors, positives, P, margin, mode, u, negatives);
+  triplet_select_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(dist, labels, n, anchors, nullptr, positives, P, margin, mode, u, negatives);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_triplet_select_cross(const float* dist, const int64_t* col_labels, int ncols, const int32_t* anchor_rows,
+                                         const int64_t* anchor_labels, const int32_t* positive_cols, int P, float margin,
+                                         int mode, const float* u, int32_t* negatives, void* stream) {
+  SLIC_REQUIRE(dist && col_labels && anchor_rows && anchor_labels && positive_cols && negatives && ncols > 0 && P > 0 &&
+               mode >= 0 && mode <= 3 && (mode >= 2 || u), "slic_triplet_select_cross: bad args");
+  triplet_select_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(dist, col_labels, ncols, anchor_rows, anchor_labels,
+                                                                                        positive_cols, P, margin, mode, u, negatives);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -323,6 +439,33 @@ extern "C" int slic_pair_distance(const float* X, const float* Y, int n, int D, 
                                   void* stream) {
   SLIC_REQUIRE(X && Y && out && n > 0 && D > 0, "slic_pair_distance: bad args");
   pair_distance_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, n, D, euclidean, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_pdist2(const float* X, int nx, const float* Y, int ny, int D, float eps, int euclidean, float* out,
+                           void* stream) {
+  SLIC_REQUIRE(X && Y && out && nx > 0 && ny > 0 && D > 0, "slic_pdist2: bad args");
+  pdist2_kernel<<<dim3((unsigned)slic_cdiv((int64_t)nx * ny, 4)), dim3(256), 0, S_(stream)>>>(X, nx, Y, ny, D, eps, euclidean, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_infonce_rows_fwd(const float* X, const float* Y, int P, int NY, int D, float temperature, float* state,
+                                     float* rowloss, float* loss, void* stream) {
+  SLIC_REQUIRE(X && Y && state && rowloss && loss && P > 0 && NY >= 2 && NY <= SLIC_INFONCE_MAXY && D > 0 && temperature > 0.f,
+               "slic_infonce_rows_fwd: bad args (2 <= NY <= %d)", SLIC_INFONCE_MAXY);
+  infonce_rows_fwd_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(X, Y, P, NY, D, 1.0f / temperature, state, rowloss);
+  SLIC_LAUNCH_CHECK();
+  mean_serial<<<dim3(1), dim3(64), 0, S_(stream)>>>(rowloss, P, loss);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_infonce_rows_bwd(const float* X, const float* Y, const float* state, int P, int NY, int D,
+                                     float temperature, const float* gscale, float* dX, float* dY, void* stream) {
+  SLIC_REQUIRE(X && Y && state && dX && dY && P > 0 && NY >= 2 && NY <= SLIC_INFONCE_MAXY && D > 0 && temperature > 0.f,
+               "slic_infonce_rows_bwd: bad args");
+  infonce_rows_bwd_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(X, Y, state, P, NY, D, 1.0f / temperature, gscale, dX, dY);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
