@@ -20,7 +20,7 @@
 #define TK_BQ 128
 #define TK_BG 128
 #define TK_BK 32
-#define TK_PC_MAX 16   // pending candidates per query between heap drains (fewer when k leaves less LDS)
+#define TK_PC_MAX 32   // pending candidates per lane between heap drains (fewer when k leaves less LDS)
 #define TK_KMAX 88
 
 __device__ __forceinline__ int tk_off(int row, int chunk) {
@@ -200,6 +200,13 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
 // the wave drains the current tile's scores into its heaps — counted vmcnt waits, one barrier per k-tile, no branch in the
 // k loop (k-tiles past D are all-zero DMAs).  Natural k order: lane half h of MFMA step t takes k = 8 qd + 4 h + t from
 // both operands, which is just another order of the same dot product.
+//
+// Draining a tile's 128 x 128 scores into the heaps (a third of the kernel's time when every element was shuffled to the list
+// owner and tested there): every lane — both halves of a pair — now tests its OWN 64 scores against the query's bound, a group
+// of GS at a time: one max over the group and ONE compare decide whether the group holds a candidate at all (after the first
+// tiles it rarely does); only then are the group's elements tested one by one and appended to the lane's own pending buffer.
+// The owner half drains its own and its partner's pending entries into the heap.
+template <int GS>
 __global__ __launch_bounds__(256) void topk_partial_dma(
     const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
     int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */,
@@ -208,8 +215,8 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   constexpr int STAGE_FLOATS = (TK_BQ + TK_BG) * TK_BK;
   float* lval = lds + 2 * STAGE_FLOATS;                  // [4 waves][k][32]
   int* lidx = (int*)(lval + 4 * k * 32);
-  float* pval_l = (float*)(lidx + 4 * k * 32);          // [4 waves][TK_PC][32] pending candidates (value)
-  int* pidx_l = (int*)(pval_l + 4 * TK_PC * 32);        // [4 waves][TK_PC][32]              (gallery index)
+  float* pval_l = (float*)(lidx + 4 * k * 32);          // [4 waves][TK_PC][64] pending candidates (value), one column per LANE
+  int* pidx_l = (int*)(pval_l + 4 * TK_PC * 64);        // [4 waves][TK_PC][64]              (gallery index)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -218,9 +225,9 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   const int gend = min(gbeg + g_per_slice, Ng);
   float* myv = lval + wave * k * 32;
   int* myi = lidx + wave * k * 32;
-  float* pv = pval_l + wave * TK_PC * 32;
-  int* pi = pidx_l + wave * TK_PC * 32;
-  int pc = 0;
+  float* pv = pval_l + wave * TK_PC * 64;
+  int* pi = pidx_l + wave * TK_PC * 64;
+  int pc = 0;                                                // this lane's pending count
   if (h == 0)
     for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
   const int q = q0 + 32 * wave + r;
@@ -287,12 +294,16 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
     __builtin_amdgcn_s_setprio(0);
   };
   auto flush = [&]() {
-    for (int j = 0; j < TK_PC; ++j) {
-      const bool act = j < pc;
+    const int pcp = __shfl_xor(pc, 32);                        // the partner half's count
+    const int tot = h == 0 ? pc + pcp : 0;                     // the owner drains its own entries, then its partner's
+    for (int j = 0; j < 2 * TK_PC; ++j) {
+      const bool act = j < tot;
       if (!__any(act)) break;
       if (act) {
-        const float s = pv[j * 32 + r];
-        const int gi = pi[j * 32 + r];
+        const int jj = j < pc ? j : j - pc;
+        const int col = j < pc ? lane : lane + 32;
+        const float s = pv[jj * 64 + col];
+        const int gi = pi[jj * 64 + col];
         if (tk_better(s, gi, thr, thr_i)) {
           // 4-ary heap, root (slot 0) = worst kept entry: the four children of a node are read together (one LDS round
           // trip per level, log4 k levels), the worst of them moves up while it is worse than the candidate
@@ -361,33 +372,41 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
       const int gi_ = __builtin_nontemporal_load(gthr + q);
       gb = __int_as_float(gi_ >= 0 ? gi_ : gi_ ^ 0x7FFFFFFF);
     }
-    const float filt = fmaxf(thr, gb);                         // thr = +inf on lanes that own no list
+    // the bound both halves of a pair test against: the owner's heap root (or the published bound); lanes of a query slot
+    // past Nq test against +inf
+    const float gbb = __shfl(gb, r);
+    float filt = fmaxf(__shfl(thr, r), gbb);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const float own = acc[ct][v];
-        const float oth = __shfl_xor(own, 32);
+      for (int v0 = 0; v0 < 16; v0 += GS) {
+        if (__any(pc > TK_PC - GS)) {                           // room for a whole group in every lane's pending buffer
+          flush();
+          filt = fmaxf(__shfl(thr, r), gbb);
+        }
+        float gm = acc[ct][v0];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const float s = half ? oth : own;
-          if (s >= filt) {
-            const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-            if ((s > thr || gi < thr_i) && s > -INFINITY) {
-              pv[pc * 32 + r] = s;
-              pi[pc * 32 + r] = gi;
+        for (int v = v0 + 1; v < v0 + GS; ++v) gm = fmaxf(gm, acc[ct][v]);
+        if (gm >= filt && gm > -INFINITY) {
+#pragma unroll
+          for (int v = v0; v < v0 + GS; ++v) {
+            const float sc = acc[ct][v];
+            if (sc >= filt && sc > -INFINITY) {                 // ties with the root are sorted out by the owner (index order)
+              pv[pc * 64 + lane] = sc;
+              pi[pc * 64 + lane] = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
               ++pc;
             }
           }
         }
-        if (__any(pc > TK_PC - 2)) flush();
       }
-    flush();
+    // no drain at the end of a tile: the pending entries ride along until a buffer runs short of a group's room (above) —
+    // a drain costs max-over-lanes rounds, and the fuller the buffers the closer that maximum is to the mean
     if (owner && thr > -INFINITY) {                            // the heap is full: its root bounds the final k-th best from below
       const int b = __float_as_int(thr);
       atomicMax(gthr + q, b >= 0 ? b : b ^ 0x7FFFFFFF);
     }
   }
+  flush();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (h == 0 && q < Nq) {
     float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
@@ -549,10 +568,11 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   SlicCarver w(workspace);
   float* pval = w.take<float>((size_t)slices * Nq * k);
   int32_t* pidx = w.take<int32_t>((size_t)slices * Nq * k);
-  int pcap = (int)((160 * 1024 - (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2) * sizeof(float)) / (4 * 32 * 2 * sizeof(float)));
-  pcap = pcap > TK_PC_MAX ? TK_PC_MAX : (pcap & ~1);
+  // pending buffers: one column per LANE (both halves of a pair collect candidates), pcap entries each
+  int pcap = (int)((160 * 1024 - (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2) * sizeof(float)) / (4 * 64 * 2 * sizeof(float)));
+  pcap = pcap > TK_PC_MAX ? TK_PC_MAX : pcap;
   SLIC_REQUIRE(pcap >= 4, "slic_cosine_topk: k = %d leaves no LDS for the pending buffers", k);
-  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2 + 4 * pcap * 32 * 2) * sizeof(float);
+  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2 + 4 * pcap * 64 * 2) * sizeof(float);
   static size_t lds_set = 0;
   if (lds > lds_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -563,12 +583,14 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   if (use_dma && (int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31)) {
     static size_t lds_set2 = 0;
     if (lds > lds_set2) {
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       lds_set2 = lds;
     }
     int* gthr = w.take<int>((size_t)Nq);
     SLIC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)gthr, (int)0x807FFFFF, (size_t)Nq, st));   // the image of -inf
-    topk_partial_dma<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    if (pcap >= 16) topk_partial_dma<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    else topk_partial_dma<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
   } else
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx);
   SLIC_LAUNCH_CHECK();
