@@ -27,6 +27,20 @@ __device__ __forceinline__ int tk_off(int row, int chunk) {
   return row * TK_BK + ((chunk ^ ((row >> 1) & 7)) << 2);
 }
 
+// (score, gallery index) as ONE 64-bit key whose unsigned order is the retrieval order — larger score first, ties -> lower
+// index: high word = the order-preserving image of the float, low word = ~index.  A heap step then costs one 8-byte LDS access
+// and one 64-bit compare per entry instead of two accesses and a three-way test.
+__device__ __forceinline__ unsigned long long tk_key(float s, int i) {
+  const unsigned u = __float_as_uint(s);
+  const unsigned o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)o << 32) | (unsigned)(~i);
+}
+__device__ __forceinline__ float tk_key_score(unsigned long long key) {
+  const unsigned o = (unsigned)(key >> 32);
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ int tk_key_index(unsigned long long key) { return (int)(~(unsigned)key); }
+
 __device__ __forceinline__ bool tk_better(float s, int i, float t, int ti) {
   return s > t || (s == t && i < ti);
 }
@@ -213,27 +227,27 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
     int* __restrict__ gthr /* [Nq] order-preserving int image of a lower bound of query q's final k-th best score */) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int STAGE_FLOATS = (TK_BQ + TK_BG) * TK_BK;
-  float* lval = lds + 2 * STAGE_FLOATS;                  // [4 waves][k][32]
-  int* lidx = (int*)(lval + 4 * k * 32);
-  float* pval_l = (float*)(lidx + 4 * k * 32);          // [4 waves][TK_PC][64] pending candidates (value), one column per LANE
-  int* pidx_l = (int*)(pval_l + 4 * TK_PC * 64);        // [4 waves][TK_PC][64]              (gallery index)
+  // heaps: [4 waves][kh][32] keys, kh = k rounded up to 4 m + 1 so that every node has four children (the padding holds the
+  // best possible key and is never picked as a node's worst child); pending candidates: [4 waves][TK_PC][64] keys, one column per LANE
+  const int kh = 1 + ((k + 2) / 4) * 4;
+  unsigned long long* heaps = (unsigned long long*)(lds + 2 * STAGE_FLOATS);
+  unsigned long long* pend = heaps + 4 * kh * 32;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int q0 = blockIdx.x * TK_BQ;
   const int gbeg = blockIdx.y * g_per_slice;
   const int gend = min(gbeg + g_per_slice, Ng);
-  float* myv = lval + wave * k * 32;
-  int* myi = lidx + wave * k * 32;
-  float* pv = pval_l + wave * TK_PC * 64;
-  int* pi = pidx_l + wave * TK_PC * 64;
+  unsigned long long* hp = heaps + wave * kh * 32;           // this wave's heaps, entry e of query r at hp[e * 32 + r]
+  unsigned long long* pq = pend + wave * TK_PC * 64;
   int pc = 0;                                                // this lane's pending count
+  const unsigned long long KEY_EMPTY = tk_key(-INFINITY, INT_MAX), KEY_PAD = ~0ull;
   if (h == 0)
-    for (int s = 0; s < k; ++s) { myv[s * 32 + r] = -INFINITY; myi[s * 32 + r] = INT_MAX; }
+    for (int s = 0; s < kh; ++s) hp[s * 32 + r] = s < k ? KEY_EMPTY : KEY_PAD;
   const int q = q0 + 32 * wave + r;
   const bool owner = h == 0 && q < Nq;                       // this lane keeps query q's list
-  float thr = owner ? -INFINITY : INFINITY;                  // worst kept entry (heap root); +inf: never a candidate
-  int thr_i = owner ? INT_MAX : -1;
+  unsigned long long root = KEY_EMPTY;                       // worst kept entry (heap root)
+  float thr = owner ? -INFINITY : INFINITY;                  // its score; +inf on lanes that own no list: never a candidate
 
   const int srow = tid >> 3;
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
@@ -301,36 +315,33 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
       if (!__any(act)) break;
       if (act) {
         const int jj = j < pc ? j : j - pc;
-        const int col = j < pc ? lane : lane + 32;
-        const float s = pv[jj * 64 + col];
-        const int gi = pi[jj * 64 + col];
-        if (tk_better(s, gi, thr, thr_i)) {
+        const unsigned long long cand = pq[jj * 64 + (j < pc ? lane : lane + 32)];
+        if (cand > root) {
           // 4-ary heap, root (slot 0) = worst kept entry: the four children of a node are read together (one LDS round
           // trip per level, log4 k levels), the worst of them moves up while it is worse than the candidate
           int pos = 0;
+          unsigned long long newroot = cand;
           for (;;) {
             const int c0 = 4 * pos + 1;
-            if (c0 >= k) break;
-            float cv[4]; int ci[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int c = c0 + u < k ? c0 + u : c0;          // clamp: a repeated child never wins over the original
-              cv[u] = myv[c * 32 + r]; ci[u] = myi[c * 32 + r];
-            }
-            float wv = cv[0]; int wi = ci[0], ws = c0;
-#pragma unroll
-            for (int u = 1; u < 4; ++u)
-              if (c0 + u < k && tk_better(wv, wi, cv[u], ci[u])) { wv = cv[u]; wi = ci[u]; ws = c0 + u; }
-            if (!tk_better(s, gi, wv, wi)) break;
-            myv[pos * 32 + r] = wv; myi[pos * 32 + r] = wi;
+            if (c0 >= kh) break;
+            const unsigned long long k0 = hp[c0 * 32 + r], k1 = hp[(c0 + 1) * 32 + r], k2 = hp[(c0 + 2) * 32 + r],
+                                     k3 = hp[(c0 + 3) * 32 + r];
+            unsigned long long w = k0; int ws = c0;
+            if (k1 < w) { w = k1; ws = c0 + 1; }
+            if (k2 < w) { w = k2; ws = c0 + 2; }
+            if (k3 < w) { w = k3; ws = c0 + 3; }
+            if (!(cand > w)) break;
+            hp[pos * 32 + r] = w;
+            if (pos == 0) newroot = w;
             pos = ws;
           }
-          myv[pos * 32 + r] = s; myi[pos * 32 + r] = gi;
-          thr = myv[r]; thr_i = myi[r];
+          hp[pos * 32 + r] = cand;
+          root = newroot;
         }
       }
     }
     pc = 0;
+    thr = owner ? tk_key_score(root) : INFINITY;
   };
   issue(0, 0, 0);
   for (int tile = 0; tile < ntile; ++tile) {
@@ -392,8 +403,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
           for (int v = v0; v < v0 + GS; ++v) {
             const float sc = acc[ct][v];
             if (sc >= filt && sc > -INFINITY) {                 // ties with the root are sorted out by the owner (index order)
-              pv[pc * 64 + lane] = sc;
-              pi[pc * 64 + lane] = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+              pq[pc * 64 + lane] = tk_key(sc, g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h);
               ++pc;
             }
           }
@@ -411,7 +421,11 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   if (h == 0 && q < Nq) {
     float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
     int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq + q) * k;
-    for (int s = 0; s < k; ++s) { ov[s] = myv[s * 32 + r]; oi[s] = myi[s * 32 + r]; }
+    for (int s = 0; s < k; ++s) {
+      const unsigned long long e = hp[s * 32 + r];
+      ov[s] = tk_key_score(e);
+      oi[s] = tk_key_index(e);
+    }
   }
 }
 
@@ -568,11 +582,13 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   SlicCarver w(workspace);
   float* pval = w.take<float>((size_t)slices * Nq * k);
   int32_t* pidx = w.take<int32_t>((size_t)slices * Nq * k);
-  // pending buffers: one column per LANE (both halves of a pair collect candidates), pcap entries each
-  int pcap = (int)((160 * 1024 - (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2) * sizeof(float)) / (4 * 64 * 2 * sizeof(float)));
+  // LDS: 2 ring stages + heaps [4][kh][32] keys (kh = k rounded up to 4 m + 1) + pending [4][pcap][64] keys, one column per LANE
+  const int kh = 1 + ((k + 2) / 4) * 4;
+  const size_t fixed = (size_t)2 * 2 * TK_BQ * TK_BK * sizeof(float) + (size_t)4 * kh * 32 * 8;
+  int pcap = (int)((160 * 1024 - fixed) / (4 * 64 * 8));
   pcap = pcap > TK_PC_MAX ? TK_PC_MAX : pcap;
-  SLIC_REQUIRE(pcap >= 4, "slic_cosine_topk: k = %d leaves no LDS for the pending buffers", k);
-  const size_t lds = (size_t)(2 * 2 * TK_BQ * TK_BK + 4 * k * 32 * 2 + 4 * pcap * 64 * 2) * sizeof(float);
+  SLIC_REQUIRE(pcap >= 2, "slic_cosine_topk: k = %d leaves no LDS for the pending buffers", k);
+  const size_t lds = fixed + (size_t)4 * pcap * 64 * 8;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -585,14 +601,16 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
     if (lds > lds_set2) {
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       lds_set2 = lds;
     }
     int* gthr = w.take<int>((size_t)Nq);
     SLIC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)gthr, (int)0x807FFFFF, (size_t)Nq, st));   // the image of -inf
     if (pcap >= 16) topk_partial_dma<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
-    else topk_partial_dma<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    else if (pcap >= 4) topk_partial_dma<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    else topk_partial_dma<2><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
   } else
-  topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx);
+  topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, (2 * pcap) & ~1, pval, pidx);
   SLIC_LAUNCH_CHECK();
   SLIC_REQUIRE((int64_t)S * k <= 64 * TKM_PER, "slic_cosine_topk: slices * k = %d exceeds the merge kernel's %d entries", S * k, 64 * TKM_PER);
   topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
