@@ -39,11 +39,11 @@ for name, C, N, k, s, p, dims in SHAPES:
         t = timeit(lambda: plan.wgrad(x, dz, B, dW))
         print(f"{name.split()[0]}:{fl/t/1e9:.0f}", end=" ", flush=True)
         continue
-    for v in (22, 30, 32, 20, 31):
+    for v in (22, 20):
         t = timeit(lambda: plan.forward(x, wp, B, want_stats=True, variant=v))
         line += f" fwd v{v} {fl/t/1e9:6.1f}"
     if C > 3:
-        for v in (2, 11, 17):
+        for v in (22, 20):
             t = timeit(lambda: plan.dgrad(dz, wd, B, variant=v))
             line += f" | dg v{v} {fl/t/1e9:6.1f}"
     t = timeit(lambda: plan.wgrad(x, dz, B, dW))

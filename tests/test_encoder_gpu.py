@@ -54,7 +54,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
         assert wplan.wrun and wplan.Kp <= ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False).Kp
         xs = wplan.make_source(x.cuda())
         assert xs.shape[:3] == (B, dims[0], dims[1]) and xs.shape[3] >= dims[2] + 2 * p[2] and xs.shape[4] == C
-        for variant in (0, 1, 2):
+        for variant in (0,):
             z, (part, rows) = wplan.forward(xs, wplan.pack_fwd(wd_), B, want_stats=True, variant=variant)
             got = z.cpu().permute(0, 4, 1, 2, 3)
             tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6
@@ -66,7 +66,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
             wplan.pack_dgrad(wd_)
     plan = ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False)
     xd = _ndhwc(x, plan.Cs).cuda()
-    for variant in (0, 1, 2, 3, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 30, 31, 32):
+    for variant in (0, 20, 22):
         z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
         got = z.cpu().permute(0, 4, 1, 2, 3)
         tol = 2e-6 * np.sqrt(C * np.prod(k)) + 1e-6
@@ -78,7 +78,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
             blk = flat[rr * rows:(rr + 1) * rows]
             assert torch.allclose(part[rr, 0].double().cpu(), blk.sum(0), atol=1e-4, rtol=1e-4)
             assert torch.allclose(part[rr, 1].double().cpu(), ((blk - blk.mean(0)) ** 2).sum(0), atol=1e-4, rtol=1e-4)
-    for variant in (0, 11, 13):
+    for variant in (0, 20, 22):
         dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B, variant=variant).cpu()[..., :C].permute(0, 4, 1, 2, 3)
         assert (dx - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item()), f'dgrad variant {variant}'
     dW = plan.wgrad(xd, dyd, B, torch.empty_like(wd_)).cpu()
@@ -87,7 +87,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
     assert (dW3 - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [11, 20])
+@pytest.mark.parametrize("variant", [20])
 def test_conv_splitk_matches_single_pass(gpu, monkeypatch, variant):
     """split-K launch (raw slabs + finish pass) == the one-pass kernel: output, fused BN partials, ReLU/addend epilogue"""
     from video_similarity_search_amd.models.conv_plan import ConvPlan

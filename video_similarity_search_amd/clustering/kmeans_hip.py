@@ -288,7 +288,7 @@ class KMeans:
         Cb = [C.contiguous().clone(), torch.empty_like(C), torch.empty_like(C)]          # iteration it: Cb[it%3] -> Cb[(it+1)%3]
         Lb = [torch.full((N,), -1, dtype=torch.int32, device=dev) for _ in range(3)]      # labels of iteration it: Lb[it%3]
         cnorm = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(3)]        # norms of Cb[i]: written by finalize
-        perm = bool(getattr(k, "uses_perm", False)) and os.environ.get("SLIC_KM_PERM", "1") != "0"
+        perm = bool(getattr(k, "uses_perm", False))
         sph = dict(spherical=True) if self.spherical else {}
         if perm:
             Xp = self._permuted(Xc)                                                        # once per fit, shared by the inits
@@ -528,14 +528,14 @@ class KMeans:
             return t.cpu().numpy()
 
         first = int(bcast(np.array([rs.choice(N, p=np.full(N, 1.0 / N))], np.int64))[0])
-        if hasattr(k, "kpp_run") and T <= 16 and os.environ.get("SLIC_KPP_RUN", "1") != "0":
+        if hasattr(k, "kpp_run") and T <= 16:
             # the RNG draws of the loop below do not depend on the data: draw them all now (same stream, same order),
             # and let the device run the K - 1 steps back to back
             u = bcast(rs.uniform(size=(K - 1, T))) if K > 1 else np.zeros((0, T))
             ud = torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)).to(dev)
             idx_d = torch.empty(K, dtype=torch.int32, device=dev)
             Xp = xn = None
-            if getattr(k, "uses_perm", False) and os.environ.get("SLIC_KPP_MFMA", "1") != "0":
+            if getattr(k, "uses_perm", False):
                 Xp = self._permuted(Xs)                      # the same permuted copy the E-step uses (cached per fit)
                 xn = self._row_norms(Xs)
             k.kpp_run(Xs, first, K, T, ud, idx_d, Xp, xn)

@@ -377,8 +377,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
 // ------------------------------------------------------------------------------------------
 // waves per SIMD the LDS footprint allows (one wave of each resident workgroup per SIMD): the register allocator is held to
 // that occupancy, or the epilogue's batched loads would cost the main loop a workgroup per CU
-constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT, int KD = 32) {
-  const int ring = STAGES * KT * (BM + BN) * KD * 4, epi = conv_epi_lds_floats(BM, BN) * 4;
+constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KD = 32) {
+  const int ring = STAGES * (BM + BN) * KD * 4, epi = conv_epi_lds_floats(BM, BN) * 4;
   const int lds = ring > epi ? ring : epi;
   const int w = (160 * 1024) / lds;
   return w > 6 ? 6 : (w < 1 ? 1 : w);
@@ -386,7 +386,7 @@ constexpr int conv_dma_waves(int BM, int BN, int STAGES, int KT, int KD = 32) {
 
 // The kernel body, shared by the one-GEMM launch and the multi-GEMM launch (several SlicConvArgs in one grid: the parity
 // classes of a stride-2 data gradient).  (bxi, gdx, byi, bzi) stand for (blockIdx.x, gridDim.x, blockIdx.y, blockIdx.z).
-template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV, int KD>
+template <int BM, int BN, int WM, int WN, int STAGES, int KD>
 __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const int xcd_remap, float* __restrict__ slab,
                                                    const int kt_per_split, float* lds, const int bxi, const int gdx,
                                                    const int byi, const int bzi) {
@@ -399,7 +399,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   constexpr int NG = KD / 8;                                  // MFMA groups per k-tile (one ds_read_b128 per operand tile each)
   constexpr int TILE_FLOATS = (BM + BN) * KD;                 // one k-tile (KD deep) of A and B
   static_assert(BM % RALL == 0 && BN % RALL == 0, "tile rows per DMA pass");
-  constexpr int STAGE_FLOATS = KT * TILE_FLOATS;              // a ring stage holds KT k-tiles: one barrier per KT tiles
+  constexpr int STAGE_FLOATS = TILE_FLOATS;                   // a ring stage holds one k-tile: one barrier per k-tile
   static_assert(WM * WN == 4, "4 waves");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -497,39 +497,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
   const int r = lane & 31, h = lane >> 5;
-  auto compute = [&](int toff) {
-    const float* Ab = lds + toff;
-    const float* Bb = Ab + BM * KD;
-    f32x4 a[2][TM], b[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) a[0][i] = *(const f32x4*)&Ab[lds_off<KD>(wm * WTM + i * 32 + r, h)];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b[0][j] = *(const f32x4*)&Bb[lds_off<KD>(wn * WTN + j * 32 + r, h)];
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int q = 0; q < NG; ++q) {
-      const int cur = q & 1, nxt = cur ^ 1;
-      if (q < NG - 1) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[nxt][i] = *(const f32x4*)&Ab[lds_off<KD>(wm * WTM + i * 32 + r, 2 * (q + 1) + h)];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[nxt][j] = *(const f32x4*)&Bb[lds_off<KD>(wn * WTN + j * 32 + r, 2 * (q + 1) + h)];
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][t], b[cur][j][t], acc[i][j], 0, 0, 0);
-      if (q < NG - 1) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
-    }
-    __builtin_amdgcn_s_setprio(0);
-  };
-  // ILV: the next stage's DMAs (and their address math) are issued BETWEEN the MFMA groups of the current tile instead of
+  // the next stage's DMAs (and their address math) are issued BETWEEN the MFMA groups of the current tile instead of
   // in front of them, so a wave's matrix pipe is not idle while it computes addresses (matters at 1-2 waves / SIMD)
-  auto compute_ilv = [&](int toff, int ktn, int toffn) {
+  auto compute_tile = [&](int toff, int ktn, int toffn) {
     const float* Ab = lds + toff;
     const float* Bb = Ab + BM * KD;
     const bool live = ktn < nk;
@@ -578,18 +548,16 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
       }
     }
   };
-  // prologue: STAGES - 1 stages (of KT k-tiles each) in flight
-  const int ns = (nk - kt0 + KT - 1) / KT;                   // number of stages' worth of work
+  // prologue: STAGES - 1 stages in flight
+  const int ns = nk - kt0;                                   // number of stages' worth of work
 #pragma unroll
-  for (int t = 0; t < STAGES - 1; ++t)
-#pragma unroll
-    for (int u = 0; u < KT; ++u) issue(kt0 + t * KT + u, t * STAGE_FLOATS + u * TILE_FLOATS);
+  for (int t = 0; t < STAGES - 1; ++t) issue(kt0 + t, t * STAGE_FLOATS);
   SLIC_STAMP(stamp_wg, 2);                                   // prologue DMAs issued
 #ifdef SLIC_STAMPS
   unsigned long long stamp_wait_v = 0, stamp_wait_b = 0, stamp_loop0 = 0;
 #endif
   __builtin_amdgcn_s_setprio(0);
-  constexpr int PER_STAGE = KT * (AL + BL);                  // DMA instructions per stage per wave, always exactly this many
+  constexpr int PER_STAGE = AL + BL;                         // DMA instructions per stage per wave, always exactly this many
   // Branch-free steady state: the trip count is rounded up to whole rings; stages past the end multiply zeros.
   for (int s0 = 0; s0 < ns; s0 += STAGES) {
 #pragma unroll
@@ -609,15 +577,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_STAGE) : "memory");
       __builtin_amdgcn_s_barrier();        // every wave's part of stage sg is in LDS; the previous stage is free
 #endif
-      if constexpr (ILV && KT == 1) {
-        compute_ilv(sidx * STAGE_FLOATS, kt0 + sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
-      } else {
-#pragma unroll
-        for (int u = 0; u < KT; ++u)
-          issue(kt0 + (sg + STAGES - 1) * KT + u, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS + u * TILE_FLOATS);
-#pragma unroll
-        for (int u = 0; u < KT; ++u) compute(sidx * STAGE_FLOATS + u * TILE_FLOATS);
-      }
+      compute_tile(sidx * STAGE_FLOATS, kt0 + sg + STAGES - 1, ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the trailing all-zero DMAs must land before LDS is reused
@@ -652,11 +612,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false, int KD = 32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT, KD))))
+template <int BM, int BN, int WM, int WN, int STAGES = 2, int KD = 32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KD))))
 void conv_gemm_dma_kernel(const SlicConvArgs p, const int xcd_remap, float* __restrict__ slab, const int kt_per_split) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV, KD>(p, xcd_remap, slab, kt_per_split, lds, blockIdx.x, gridDim.x, blockIdx.y,
+  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KD>(p, xcd_remap, slab, kt_per_split, lds, blockIdx.x, gridDim.x, blockIdx.y,
                                                       blockIdx.z);
 }
 
@@ -666,14 +626,14 @@ struct SlicConvArgsPack {
   SlicConvArgs a[SLIC_CONV_MULTI_MAX];
   int gx[SLIC_CONV_MULTI_MAX];     // row blocks of each GEMM (a multiple of 8 when the XCD order is on)
 };
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false, int KD = 32>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KT, KD))))
+template <int BM, int BN, int WM, int WN, int STAGES = 2, int KD = 32>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(conv_dma_waves(BM, BN, STAGES, KD))))
 void conv_gemm_dma_multi_kernel(const SlicConvArgsPack pk, const int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int c = blockIdx.z;
   const int gdx = pk.gx[c];
   if ((int)blockIdx.x >= gdx) return;
-  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KT, ILV, KD>(pk.a[c], xcd_remap, nullptr, 0, lds, blockIdx.x, gdx, blockIdx.y, 0);
+  conv_gemm_dma_body<BM, BN, WM, WN, STAGES, KD>(pk.a[c], xcd_remap, nullptr, 0, lds, blockIdx.x, gdx, blockIdx.y, 0);
 }
 
 // second pass of a split-K launch: accumulators = sum over the S slabs in slab order, then the ordinary epilogue
@@ -715,143 +675,11 @@ __global__ __launch_bounds__(256) void conv_splitk_finish(const SlicConvArgs p, 
 
 // ------------------------------------------------------------------------------------------
 // Weight gradient: dWp[n][kidx] = sum_m A[m][kidx] * dY[m][n]   (A = the forward's gathered rows).
-// Workgroup = 64 kidx x 64 n, waves 2 x 2 (32 x 32 each), reduction over a slice of m in chunks of
-// 32 positions.  Both LDS tiles are [32 m][64] (channel-contiguous, as they sit in HBM); the MFMA
-// operands are read with ds_read_b32 (lanes = 32 consecutive channels: conflict-free) — one read
-// per 64-cycle MFMA, far below the LDS rate.  Split over m: gridDim.z slabs, reduced (and unpacked
-// into the reference [N][Cin][taps] layout) by conv_wgrad_reduce in fixed order.
-// ------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const SlicConvArgs p, const float* __restrict__ dy,
-                                                         int ldy, unsigned dy_bytes, float* __restrict__ slab,
-                                                         int m_per_split) {
-  __shared__ __attribute__((aligned(16))) float Xs[2][G][32 * 64];
-  __shared__ __attribute__((aligned(16))) float Ys[2][32 * 64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave >> 1, wn = wave & 1;
-  const int kc0 = blockIdx.x * (16 * G);   // first 16-byte chunk of this workgroup's kidx range
-  const int n0 = blockIdx.y * 64;
-  const int64_t mbeg = (int64_t)blockIdx.z * m_per_split;
-  int64_t mend = mbeg + m_per_split;
-  if (mend > p.M) mend = p.M;
-
-  // staging: thread owns chunk column cq (16 chunks = 64 floats per row), rows srow, srow + 16
-  const int cq = tid & 15, srow = tid >> 4;
-  int4 e[G];
-  bool cv[G];
-  int oa[G], ob[G], oc[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int q = kc0 + g * 16 + cq;
-    e[g] = q < p.nchunks ? ((const int4*)p.tab)[q] : make_int4(0, -1, 0, 0);
-    cv[g] = e[g].y >= 0;
-    oa[g] = (e[g].w & 255) - 128; ob[g] = ((e[g].w >> 8) & 255) - 128; oc[g] = ((e[g].w >> 16) & 255) - 128;
-  }
-  const bool nvalid = (n0 + cq * 4) < p.N;
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFF00u;
-  i32x4 gx[G][2], gy[2];
-  // row coordinates advance by 32 positions per k'-tile: keep (batch, ga, gb, gc) of the thread's two rows and step
-  // them in mixed radix (a handful of compare/selects) instead of three integer divisions per row per tile
-  int rn[2], ra[2], rb[2], rc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    unsigned rr = (unsigned)(mbeg + srow + 16 * i);
-    rc[i] = (int)(rr % (unsigned)p.Gc); rr /= (unsigned)p.Gc;
-    rb[i] = (int)(rr % (unsigned)p.Gb); rr /= (unsigned)p.Gb;
-    ra[i] = (int)(rr % (unsigned)p.Ga); rr /= (unsigned)p.Ga;
-    rn[i] = (int)rr;
-  }
-  int st_c, st_b, st_a, st_n;      // 32 = ((st_n * Ga + st_a) * Gb + st_b) * Gc + st_c
-  {
-    unsigned t = 32u;
-    st_c = (int)(t % (unsigned)p.Gc); t /= (unsigned)p.Gc;
-    st_b = (int)(t % (unsigned)p.Gb); t /= (unsigned)p.Gb;
-    st_a = (int)(t % (unsigned)p.Ga); t /= (unsigned)p.Ga;
-    st_n = (int)t;
-  }
-  int64_t mcur = mbeg;             // first row of the tile the coordinates currently describe
-  auto gload = [&](int64_t mt) {
-    // gload is called with consecutive tiles (mbeg, mbeg + 32, ...): step the coordinates up to mt
-    while (mcur < mt) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        rc[i] += st_c; const int c1 = rc[i] >= p.Gc; rc[i] -= c1 ? p.Gc : 0;
-        rb[i] += st_b + c1; const int c2 = rb[i] >= p.Gb; rb[i] -= c2 ? p.Gb : 0;
-        ra[i] += st_a + c2; const int c3 = ra[i] >= p.Ga; ra[i] -= c3 ? p.Ga : 0;
-        rn[i] += st_n + c3;
-      }
-      mcur += 32;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t m = mt + srow + 16 * i;
-      const bool mv = m < mend;
-      const int a0 = ra[i] * p.sa, b0 = rb[i] * p.sb, c0 = rc[i] * p.sc;
-      const unsigned base = ((((unsigned)rn[i] * p.Ts + a0) * p.Hs + b0) * p.Ws + c0) * (unsigned)p.Cs * 4u;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const bool ok = mv && cv[g] && (unsigned)(a0 + oa[g]) < (unsigned)p.Ts &&
-                        (unsigned)(b0 + ob[g]) < (unsigned)p.Hs && (unsigned)(c0 + oc[g]) < (unsigned)p.Ws;
-        gx[g][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_src, (int)(ok ? base + (unsigned)e[g].x * 4u : OOB), 0, 0);
-      }
-      const unsigned yo = (mv && nvalid) ? (unsigned)(m * ldy + n0 + cq * 4) * 4u : OOB;
-      gy[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (int)yo, 0, 0);
-    }
-  };
-  auto lwrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = srow + 16 * i;
-#pragma unroll
-      for (int g = 0; g < G; ++g) *(i32x4*)&Xs[buf][g][row * 64 + cq * 4] = gx[g][i];
-      *(i32x4*)&Ys[buf][row * 64 + cq * 4] = gy[i];
-    }
-  };
-  f32x16 acc[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[g][v] = 0.f;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t nmt = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
-  if (nmt > 0) {
-    gload(mbeg);
-    lwrite(0);
-  }
-  __syncthreads();
-  for (int64_t t = 0; t < nmt; ++t) {
-    const int buf = (int)(t & 1);
-    if (t + 1 < nmt) gload(mbeg + (t + 1) * 32);
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float b = Ys[buf][(2 * s + h) * 64 + wn * 32 + r];
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float a = Xs[buf][g][(2 * s + h) * 64 + wk * 32 + r];
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
-      }
-    }
-    if (t + 1 < nmt) lwrite(buf ^ 1);
-    __syncthreads();
-  }
-  // slab[z][kidx][n]: rows of the accumulator = kidx, cols = n — a lane owns a column, so 32 lanes write 32 consecutive floats
-  const int Kp = p.nchunks * 4;
-  float* out = slab + (int64_t)blockIdx.z * p.N * Kp;
-  const int n = n0 + wn * 32 + r;
-  if (n < p.N) {
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int kidx = (kc0 + g * 16) * 4 + wk * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (kidx < Kp) out[(int64_t)kidx * p.N + n] = acc[g][v];
-      }
-  }
-}
-
-// The same contraction with both operand tiles moved HBM -> LDS by the DMA path (buffer_load ... lds): no staging
+// Workgroup = 128 kidx x 64 n (G = 2 sub-tiles of 64 kidx), waves 2 x 2, reduction over a slice of m in chunks of 32
+// positions.  Both LDS tiles are [32 m][64] (channel-contiguous, as they sit in HBM); the MFMA operands are read with
+// ds_read_b32 (lanes = 32 consecutive channels: conflict-free).  Split over m: slabs [slice][kidx][n], reduced (and unpacked
+// into the reference [N][Cin][taps] layout) by conv_wgrad_reduce in slice order.
+// Both operand tiles move HBM -> LDS by the DMA path (buffer_load ... lds): no staging
 // registers, no ds_writes, a STAGES-deep ring with counted vmcnt waits.  A wave's DMA instruction covers 4 rows x 64
 // floats (lane-linear 16-byte slots), which IS the [32 m][64] tile layout, so no swizzle is needed.
 //   ILV: the next tile's DMAs are issued one at a time between the MFMA groups of the tile being computed.
@@ -1300,49 +1128,42 @@ static int launch_gemm(const SlicConvArgs& a, hipStream_t st) {
   return SLIC_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT = 1, bool ILV = false, int KD = 32>
+template <int BM, int BN, int WM, int WN, int STAGES = 2, int KD = 32>
 static int launch_gemm_dma(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
-  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * KD * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * KD * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  static const int xcd = getenv("SLIC_CONV_XCD") ? atoi(getenv("SLIC_CONV_XCD")) : 1;
   const unsigned gx = (unsigned)slic_cdiv(a.M, BM);
   if (splits > 1) {
-    if constexpr (KT == 1) {
-      const int nk = a.nchunks / (KD / 4);
-      const int per = (nk + splits - 1) / splits;
-      const int S = (nk + per - 1) / per;
-      dim3 grid(gx, (unsigned)slic_cdiv(a.N, BN), (unsigned)S);
-      conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD><<<grid, dim3(256), lds, st>>>(a, 0, slab, per);
-      SLIC_LAUNCH_CHECK();
-      conv_splitk_finish<BM, BN, WM, WN><<<dim3(gx, (unsigned)slic_cdiv(a.N, BN)), dim3(256), 0, st>>>(a, slab, S);
-      SLIC_LAUNCH_CHECK();
-      return SLIC_OK;
-    } else {
-      slic_set_error("slic_conv_gemm_splitk: variant does not support split-K");
-      return SLIC_EINVAL;
-    }
+    const int nk = a.nchunks / (KD / 4);
+    const int per = (nk + splits - 1) / splits;
+    const int S = (nk + per - 1) / per;
+    dim3 grid(gx, (unsigned)slic_cdiv(a.N, BN), (unsigned)S);
+    conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KD><<<grid, dim3(256), lds, st>>>(a, 0, slab, per);
+    SLIC_LAUNCH_CHECK();
+    conv_splitk_finish<BM, BN, WM, WN><<<dim3(gx, (unsigned)slic_cdiv(a.N, BN)), dim3(256), 0, st>>>(a, slab, S);
+    SLIC_LAUNCH_CHECK();
+    return SLIC_OK;
   }
-  dim3 grid(xcd ? (gx + 7) / 8 * 8 : gx, (unsigned)slic_cdiv(a.N, BN));
-  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD><<<grid, dim3(256), lds, st>>>(a, xcd, nullptr, 0);
+  // XCD-aware order (see the kernel body): the grid is rounded up to a multiple of 8 row blocks
+  dim3 grid((gx + 7) / 8 * 8, (unsigned)slic_cdiv(a.N, BN));
+  conv_gemm_dma_kernel<BM, BN, WM, WN, STAGES, KD><<<grid, dim3(256), lds, st>>>(a, 1, nullptr, 0);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
 
+// Variants of the gather-GEMM (the tile sweeps that chose them are in DESIGN.md; the losers were removed from the library):
+//   0   register-staged 64 x 64 tiles — any source channel count (the W-run stem, tiny-channel layers, plain GEMMs)
+//   20  LDS-DMA ring, 64 x 64 tiles, 5 workgroups / CU   (source channels % 32 == 0)
+//   22  LDS-DMA ring, 128 x 64 tiles, 3 workgroups / CU  (N <= 64 and many rows: layer1)
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
-  if (variant == 11 || variant == 12 || variant == 15 || variant == 16 || variant == 17 || variant == 20 || variant == 23 || variant == 31) return 64;
-  if (variant == 13 || variant == 14 || variant == 18 || variant == 19 || variant == 21 || variant == 22 || variant == 24 || variant == 30 || variant == 32) return 128;
-  // rows per workgroup for the tile the dispatcher picks (callers size stat_partial with it)
-  if (variant == 1) return 128;
-  if (variant == 2) return 64;
-  if (variant == 3) return 256;
-  if (!a) return 128;
-  return 64;   // 64 x 64 tiles (5 workgroups / CU): measured fastest on every R3D-18 shape (scripts/bench_conv.py)
+  (void)a;
+  return variant == 22 ? 128 : 64;     // rows per workgroup (callers size stat_partial / bwd_partial with it)
 }
 
 extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) {
@@ -1353,50 +1174,30 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                "slic_conv_gemm: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
+  SLIC_REQUIRE(variant == 0 || variant == 20 || variant == 22, "slic_conv_gemm: variant must be 0, 20 or 22");
   hipStream_t st = S_(stream);
-  if (variant >= 11 && variant <= 32) {
+  if (variant != 0) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SlicConvArgs b = *a;
     b.tab = a->tap_tab;
-    if (variant == 11) return launch_gemm_dma<64, 64, 2, 2, 3>(b, st);
-    if (variant == 12) return launch_gemm_dma<64, 64, 2, 2, 4>(b, st);
-    if (variant == 13) return launch_gemm_dma<128, 64, 2, 2, 3>(b, st);
-    if (variant == 17) return launch_gemm_dma<64, 64, 2, 2, 2, 1>(b, st);     // 2-stage ring (32 KB: 5 workgroups / CU)
-    if (variant == 23) return launch_gemm_dma<64, 128, 2, 2, 2, 1, true>(b, st);    // 64x128 tiles (N >= 128 layers), interleaved
-    if (variant == 24) return launch_gemm_dma<128, 64, 2, 2, 3, 1, true>(b, st);    // v22 with a 3-stage ring
-    if (variant == 20) return launch_gemm_dma<64, 64, 2, 2, 2, 1, true>(b, st);     // v17 + DMA issue interleaved with the MFMAs
-    if (variant == 21) return launch_gemm_dma<128, 128, 2, 2, 2, 1, true>(b, st);   // v18 + interleave
-    if (variant == 22) return launch_gemm_dma<128, 64, 2, 2, 2, 1, true>(b, st);    // v19 + interleave
-    if (variant == 30) return launch_gemm_dma<128, 64, 2, 2, 3, 1, true, 16>(b, st);   // 16-deep k-tiles, 3-stage ring: 36 KB, 4 workgroups / CU
-    if (variant == 31) return launch_gemm_dma<64, 64, 2, 2, 3, 1, true, 16>(b, st);    // 24 KB: 6 workgroups / CU
-    if (variant == 32) return launch_gemm_dma<128, 64, 2, 2, 4, 1, true, 16>(b, st);   // 4-stage ring: 48 KB, 3 workgroups / CU
-    if (variant == 18) return launch_gemm_dma<128, 128, 2, 2, 2, 1>(b, st);   // 64 KB: 2 workgroups / CU, 64 acc regs
-    if (variant == 19) return launch_gemm_dma<128, 64, 2, 2, 2, 1>(b, st);    // 48 KB: 3 workgroups / CU
-    if (variant == 15) return launch_gemm_dma<64, 64, 2, 2, 2, 2>(b, st);     // 2 k-tiles per barrier, 2-stage ring (64 KB)
-    if (variant == 16) return launch_gemm_dma<64, 64, 2, 2, 3, 2>(b, st);     // 2 k-tiles per barrier, 3-stage ring (96 KB)
-    return launch_gemm_dma<128, 128, 2, 2, 3>(b, st);
-  }
-  const int bm = slic_conv_tile_m(a, variant);
-  if (bm == 256) return launch_gemm<256, 64, 4, 1>(*a, st);
-  if (bm == 128) {
-    if (a->N > 64) return launch_gemm<128, 128, 2, 2>(*a, st);
-    return launch_gemm<128, 64, 2, 2>(*a, st);
+    if (variant == 22) return launch_gemm_dma<128, 64, 2, 2>(b, st);
+    return launch_gemm_dma<64, 64, 2, 2>(b, st);
   }
   return launch_gemm<64, 64, 2, 2>(*a, st);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int KT, bool ILV, int KD = 32>
+template <int BM, int BN, int WM, int WN, int STAGES = 2, int KD = 32>
 static int launch_gemm_dma_multi(const SlicConvArgs* a, int n, hipStream_t st) {
-  constexpr size_t ring = (size_t)STAGES * KT * (BM + BN) * KD * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * (BM + BN) * KD * sizeof(float), epi = (size_t)conv_epi_lds_floats(BM, BN) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD>,
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KD>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  static const int xcd = getenv("SLIC_CONV_XCD") ? atoi(getenv("SLIC_CONV_XCD")) : 1;
+  constexpr int xcd = 1;
   SlicConvArgsPack pk;
   unsigned gmax = 0;
   for (int i = 0; i < SLIC_CONV_MULTI_MAX; ++i) {
@@ -1408,7 +1209,7 @@ static int launch_gemm_dma_multi(const SlicConvArgs* a, int n, hipStream_t st) {
     if (gx > gmax) gmax = gx;
   }
   dim3 grid(gmax, (unsigned)slic_cdiv(a[0].N, BN), (unsigned)n);
-  conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KT, ILV, KD><<<grid, dim3(256), lds, st>>>(pk, xcd);
+  conv_gemm_dma_multi_kernel<BM, BN, WM, WN, STAGES, KD><<<grid, dim3(256), lds, st>>>(pk, xcd);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1428,8 +1229,8 @@ extern "C" int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant
                  "slic_conv_gemm_multi: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
     SLIC_REQUIRE(a->N == args[0].N, "slic_conv_gemm_multi: every GEMM must have the same N");
   }
-  if (variant == 22) return launch_gemm_dma_multi<128, 64, 2, 2, 2, 1, true>(args, n, S_(stream));
-  return launch_gemm_dma_multi<64, 64, 2, 2, 2, 1, true>(args, n, S_(stream));
+  if (variant == 22) return launch_gemm_dma_multi<128, 64, 2, 2>(args, n, S_(stream));
+  return launch_gemm_dma_multi<64, 64, 2, 2>(args, n, S_(stream));
 }
 
 extern "C" size_t slic_conv_gemm_splitk_workspace_bytes(const SlicConvArgs* a, int splits) {
@@ -1445,13 +1246,12 @@ extern "C" int slic_conv_gemm_splitk(const SlicConvArgs* a, int variant, int spl
   SLIC_REQUIRE(((uintptr_t)a->wgt % 16) == 0 && a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm_splitk: bad wgt");
   SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                "slic_conv_gemm_splitk: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
-  SLIC_REQUIRE(variant == 11 || variant == 20, "slic_conv_gemm_splitk: variants 11 and 20 (64 x 64 tiles) only");
+  SLIC_REQUIRE(variant == 20, "slic_conv_gemm_splitk: variant 20 (64 x 64 tiles) only");
   SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                "slic_conv_gemm_splitk: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
   SlicConvArgs b = *a;
   b.tab = a->tap_tab;
-  if (variant == 11) return launch_gemm_dma<64, 64, 2, 2, 3>(b, S_(stream), splits, (float*)workspace);
-  return launch_gemm_dma<64, 64, 2, 2, 2, 1, true>(b, S_(stream), splits, (float*)workspace);
+  return launch_gemm_dma<64, 64, 2, 2>(b, S_(stream), splits, (float*)workspace);
 }
 
 extern "C" size_t slic_conv_wgrad_workspace_bytes(const SlicConvArgs* a, int splits) {
@@ -1475,30 +1275,12 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   const int Kp = a->nchunks * 4;
   const int64_t dyb = a->M * (int64_t)ldy * 4;
   SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad: dy larger than 4 GiB (split the batch)");
-  const char* gv = getenv("SLIC_WGRAD_G");      // tuning knob (scripts/bench_conv.py); default picked below
-  const int G = gv ? atoi(gv) : (a->row_tab ? 62 : 42);   // default: LDS-DMA kernel, 128 x 64 output tile, 2-stage ring, interleaved issue
-  if (G >= 10) {            // LDS-DMA kernels: tens digit = flavour, units digit = ring stages
-    int rc2;
-    SLIC_REQUIRE(a->M < (int64_t)0x7FFFFFFF, "slic_conv_wgrad: M must fit 31 bits");
-    if (G == 12) rc2 = launch_wgrad_dma<2, 2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 13) rc2 = launch_wgrad_dma<2, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 22) rc2 = launch_wgrad_dma<4, 2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 42) rc2 = launch_wgrad_dma<2, 2, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 52) rc2 = launch_wgrad_dma<4, 2, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    else if (G == 62 || G == 72 || G == 82) {
-      SLIC_REQUIRE(a->row_tab, "slic_conv_wgrad: this kernel needs args->row_tab (slic_conv_row_table)");
-      if (G == 62) rc2 = launch_wgrad_dma<2, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-      else if (G == 72) rc2 = launch_wgrad_dma<2, 2, false, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-      else rc2 = launch_wgrad_dma<4, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    } else rc2 = launch_wgrad_dma<1, 3>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-    if (rc2) return rc2;
-  } else if (G == 2) {
-    dim3 grid((unsigned)slic_cdiv(a->nchunks, 32), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
-    conv_wgrad_kernel<2><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
-  } else {
-    dim3 grid((unsigned)slic_cdiv(a->nchunks, 16), (unsigned)slic_cdiv(a->N, 64), (unsigned)S);
-    conv_wgrad_kernel<1><<<grid, dim3(256), 0, st>>>(*a, dy, ldy, (unsigned)dyb, slab, (int)per);
-  }
+  SLIC_REQUIRE(a->M < (int64_t)0x7FFFFFFF, "slic_conv_wgrad: M must fit 31 bits");
+  // LDS-DMA kernel, 128 x 64 output tile, 2-stage ring, interleaved issue; with args->row_tab the rows come from the table
+  int rc2;
+  if (a->row_tab) rc2 = launch_wgrad_dma<2, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+  else rc2 = launch_wgrad_dma<2, 2, true, false>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+  if (rc2) return rc2;
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)a->N * Kp;
   if (a->k_run_len > 0)

@@ -1180,11 +1180,7 @@ extern "C" int slic_kmeans_cnorm(const float* C, int K, int D, int ldc, float* c
   return SLIC_OK;
 }
 
-static int km_nct() {
-  const char* e = getenv("SLIC_KM_NCT");      // tuning knob: centroid tiles (of 32) per workgroup, 2 or 4
-  const int v = e ? atoi(e) : 4;
-  return v == 2 ? 2 : 4;
-}
+static int km_nct() { return 4; }     // centroid tiles (of 32) per workgroup of the natural-layout E-step (2 was slower)
 
 extern "C" size_t slic_kmeans_assign_workspace_bytes(int64_t N, int K) {
   const int64_t G = slic_cdiv(K, 32);          // sized for the finest partial lists (one per 32-centroid wave column)
@@ -1252,19 +1248,14 @@ extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ld
   SLIC_REQUIRE(((uintptr_t)Xp % 16) == 0 && ((uintptr_t)Cp % 16) == 0, "slic_kmeans_assign_perm: unaligned");
   SLIC_REQUIRE((int64_t)KM_BP * ldx * 4 < (1ll << 31) && (int64_t)128 * ldc * 4 < (1ll << 31), "slic_kmeans_assign_perm: rows too long");
   SLIC_REQUIRE(!labels_old || n_changed, "slic_kmeans_assign_perm: labels_old needs n_changed");
-  // tile / ring: 22 = 128 pts x 64 centroids, 2 stages (measured best; a 64 x 64 tile with 2 x 2 waves fills the grid
-  // more evenly but loses the same few % inside the loop); 23 = 3 stages; 42 / 43 = 128 x 128
-  static const int mode = getenv("SLIC_KM_DMA") ? atoi(getenv("SLIC_KM_DMA")) : 22;
-  const int G = (int)slic_cdiv(K, (mode / 10 == 4 ? 4 : 2) * 32);
+  // tile / ring: 128 points x 64 centroids, 2 stages (measured best: a 64 x 64 tile with 2 x 2 waves fills the grid more evenly
+  // but loses the same few % inside the loop; 3 stages and 128 x 128 tiles were slower)
+  const int G = (int)slic_cdiv(K, 64);
   SlicCarver w(workspace);
   float* pscore = w.take<float>((size_t)slic_cdiv(K, 32) * N);
   int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 32) * N);
   hipStream_t st = S(stream);
-  int rc;
-  if (mode == 42) rc = launch_assign_dma<128, 4, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  else if (mode == 43) rc = launch_assign_dma<128, 4, 1, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  else if (mode == 23) rc = launch_assign_dma<128, 2, 1, 3>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  else rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+  int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
   if (rc) return rc;
   km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, st>>>(pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
   SLIC_LAUNCH_CHECK();

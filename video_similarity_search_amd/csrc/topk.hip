@@ -595,8 +595,8 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
     lds_set = lds;
   }
   dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
-  static const int use_dma = getenv("SLIC_TOPK_DMA") ? atoi(getenv("SLIC_TOPK_DMA")) : 1;
-  if (use_dma && (int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31)) {
+  // LDS-DMA kernel unless a gallery slice exceeds the 32-bit byte range of one buffer resource (> 2 GiB: then the register-staged one)
+  if ((int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31)) {
     static size_t lds_set2 = 0;
     if (lds > lds_set2) {
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -232,37 +232,32 @@ class ConvPlan:
 
     @staticmethod
     def _pick(a, variant):
-        """variant 0 = auto: the LDS-DMA kernel (64x64 tiles, 2- or 3-stage ring) wherever a per-tap table exists
-        (source channels % 32 == 0), else the register-staged kernel (stem, tiny-channel layers)"""
-        if variant == 0:
-            if not a.tap_tab:
-                return 0
-            # measured (scripts/bench_conv.py): the 2-stage ring (32 KB LDS, 5 workgroups / CU) wins on the large-M
-            # layers, the 3-stage ring on the small-M ones (layer4) where fewer workgroups exist to hide latency
-            if a.M >= 100000:
-                # the next tile's DMAs are issued between MFMA groups; N <= 64 (layer1: 52 % of the FLOPs): 128x64 tiles
-                return int(os.environ.get("SLIC_CONV_BIG_VARIANT", "22")) if a.N <= 64 else 20
-            return int(os.environ.get("SLIC_CONV_SMALL_VARIANT", "20"))      # 64x64, 2-stage ring, interleaved DMA issue; split-K when few tiles
-        if variant >= 11 and not a.tap_tab:
+        """variant 0 = auto: the LDS-DMA kernel wherever a per-tap table exists (source channels % 32 == 0) — 128 x 64 tiles
+        for the tall N <= 64 layers (layer1: 52 % of the FLOPs), 64 x 64 tiles (5 workgroups / CU) otherwise — else the
+        register-staged kernel (W-run stem, tiny-channel layers).  Measured with scripts/bench_conv.py."""
+        if not a.tap_tab:
             return 0
+        if variant == 0:
+            return 22 if (a.M >= 100000 and a.N <= 64) else 20
         return variant
 
-    @staticmethod
-    def _splits(a, variant):
-        """split-K factor for the 64 x 64-tile variants: small-M layers (layer3/4 at B = 32, the parity classes of a
-        stride-2 dgrad) have too few tiles to fill 256 CUs x 3-5 workgroups evenly, so cut K until ~SPLIT_BLOCKS
-        workgroups exist, keeping at least SPLIT_MINKT k-tiles of 32 per workgroup"""
-        if variant not in (11, 20):
+    SPLIT_MIN_KTILES = 24      # k-tiles of 32 a split keeps at least
+
+    @classmethod
+    def _splits(cls, a, variant):
+        """split-K factor for the 64 x 64-tile variant: small-M layers (layer3/4 at B = 32, the parity classes of a
+        stride-2 dgrad) have too few tiles to fill 256 CUs x 5 workgroups evenly, so cut K until ~SLIC_CONV_SPLIT_BLOCKS
+        workgroups exist (0 = never split; tests switch it), keeping at least SPLIT_MIN_KTILES k-tiles per workgroup"""
+        if variant != 20:
             return 1
         target = int(os.environ.get("SLIC_CONV_SPLIT_BLOCKS", "3000"))
-        min_kt = int(os.environ.get("SLIC_CONV_SPLIT_MINKT", "24"))
         if target <= 0:
             return 1
         tiles = ((a.M + 63) // 64) * ((a.N + 63) // 64)
         nk = a.nchunks // 8
         if tiles * 2 > target:
             return 1
-        s = min((target + tiles - 1) // tiles, nk // min_kt)
+        s = min((target + tiles - 1) // tiles, nk // cls.SPLIT_MIN_KTILES)
         return s if s >= 4 else 1          # a 2-3 way split does not pay for the second launch
 
     def _launch(self, a, variant):
@@ -332,9 +327,7 @@ class ConvPlan:
                 a.bwd_partial = part.data_ptr() + r0 * 2 * self.Cs * 4
                 r0 += r
         picks = [self._pick(a, variant) for a in launches]
-        picks = [22 if v == 30 else v for v in picks]          # the multi-GEMM launch exists for the 32-deep variants
-        if (len(launches) > 1 and len(set(picks)) == 1 and picks[0] in (20, 22) and os.environ.get("SLIC_CONV_MULTI", "1") != "0"
-                and all(self._splits(a, picks[0]) == 1 for a in launches)):
+        if len(launches) > 1 and len(set(picks)) == 1 and picks[0] in (20, 22) and all(self._splits(a, picks[0]) == 1 for a in launches):
             # the parity classes of a stride-2 layer as ONE launch: their K loops (1-8 taps) are too short to fill the chip
             # one class at a time
             arr = (SlicConvArgs * len(launches))(*launches)
@@ -368,11 +361,8 @@ class ConvPlan:
         if splits is None:
             # measured (scripts/bench_conv.py, WGONLY=1 sweep): 128 x 64 output tiles, ~3000 workgroups, but at
             # least 1024 positions per slice so the slabs of the small-M layers stay small
-            G = int(os.environ.get("SLIC_WGRAD_G", "62"))
-            G = {12: 2, 13: 2, 42: 2, 62: 2, 72: 2, 52: 4, 82: 4, 22: 4, 33: 1}.get(G, G)      # LDS-DMA kernel codes -> k-groups per workgroup
-            target = int(os.environ.get("SLIC_WGRAD_BLOCKS", "3072"))
-            blocks = ((self.nchunks_fwd + 16 * G - 1) // (16 * G)) * ((self.N + 63) // 64)
-            splits = max(1, min((target + blocks - 1) // blocks, (a.M + 1023) // 1024))
+            blocks = ((self.nchunks_fwd + 31) // 32) * ((self.N + 63) // 64)
+            splits = max(1, min((3072 + blocks - 1) // blocks, (a.M + 1023) // 1024))
         a.row_tab = self._row_table(a, B).data_ptr()
         ws = _lib.workspace(lib.slic_conv_wgrad_workspace_bytes(ctypes.byref(a), splits), x.device, "wgrad")
         call("slic_conv_wgrad", ctypes.byref(a), ptr(dz), self.N, splits, self.C, self.ntaps, ptr(dW), ptr(ws), stream())
