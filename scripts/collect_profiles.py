@@ -3,7 +3,7 @@ usage: collect_profiles.py <scratch dir> <out dir> <round tag>"""
 import csv, glob, json, os, sys
 
 scratch, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNEL = "conv_gemm_dma_kernel<128, 64, 2, 2, 2, 1, true>"
+KERNEL = "conv_gemm_dma_kernel<128, 64, 2, 2, 2, 32>"
 GRID = 12544 * 256                      # layer1 shape at B = 32: M = 1 605 632 rows / 128 per workgroup
 
 
@@ -74,4 +74,14 @@ if sq.get("SQ_VALU_MFMA_BUSY_CYCLES") and sq.get("GRBM_GUI_ACTIVE"):
     if sq.get("SQ_WAVE_CYCLES"):
         res["wave_cycle_split"] = {k: sq[k] / sq["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in sq}
 json.dump(res, open(os.path.join(out, f"{tag}_pmc_conv_gemm_dma.json"), "w"), indent=1)
+for sub, name in (("stats_kmeans", "kmeans"), ("stats_rows", "rows"), ("stats_fit", "fit_cluster")):
+    f = find(sub, "*kernel_stats.csv")
+    if f:
+        open(os.path.join(out, f"{tag}_kernel_stats_{name}.csv"), "w").write(open(f).read())
+other = {}
+for log in ("rows.log", "topk_k.log", "conv_shapes.log", "epilogue_share.log"):
+    pth = os.path.join(scratch, log)
+    if os.path.exists(pth):
+        other[log[:-4]] = [l.rstrip() for l in open(pth) if l.strip() and "amdgpu.ids" not in l]
+json.dump(other, open(os.path.join(out, f"{tag}_other_rows.json"), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("hbm_bytes_per_launch", "rocprof_trace_avg_ms", "hip_event_avg_ms")}), d["value"], p["value"])

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash scripts/collect_profiles.sh'): default bench, rocprofv3 kernel stats, two PMC passes.
-# Outputs land in gpurun_out/prof_r01/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r01 profiles r01` files them.
+# Outputs land in gpurun_out/prof_r02/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r02 profiles r02` files them.
 set -u
 R="$(pwd)"
-S="$R/gpurun_out/prof_r01"
+S="$R/gpurun_out/prof_r02"
 rm -rf "$S"; mkdir -p "$S"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python "$R/bench.py" > "$S/default.log" 2>&1 < /dev/null
@@ -12,6 +12,16 @@ timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$S
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$S/pmc_write" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_write.log" 2>&1 < /dev/null
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$S/pmc_sq" -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > "$S/pmc_sq.log" 2>&1 < /dev/null
 # keep the merge-back small: per-kernel csvs only
+find "$S" -name "*agent_info.csv" -delete
+# the other rows: k-means Lloyd iterations, retrieval / NCE / NT-Xent, reference-shaped fit_cluster + FINCH
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats_kmeans" -- python "$R/scripts/bench_kmeans.py" > "$S/stats_kmeans.log" 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats_rows" -- python "$R/scripts/bench_rows.py" > "$S/stats_rows.log" 2>&1 < /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats_fit" -- python "$R/scripts/bench_fit_cluster.py" > "$S/stats_fit.log" 2>&1 < /dev/null
+timeout 300 python "$R/scripts/bench_rows.py" > "$S/rows.log" 2>&1 < /dev/null
+timeout 300 python "$R/scripts/bench_topk_k.py" > "$S/topk_k.log" 2>&1 < /dev/null
+timeout 300 python "$R/scripts/bench_conv.py" 32 > "$S/conv_shapes.log" 2>&1 < /dev/null
+timeout 300 python "$R/scripts/epilogue_share.py" 22 20 > "$S/epilogue_share.log" 2>&1 < /dev/null
+find "$S" -name "*kernel_trace.csv" -path "*stats_*" -delete
 find "$S" -name "*agent_info.csv" -delete
 du -sh "$S"; ls "$S"
 grep "^{" "$S/default.log" | cut -c1-200

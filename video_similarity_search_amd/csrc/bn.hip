@@ -9,8 +9,8 @@
 
 // Merging the per-workgroup BatchNorm partials.  A slab row r covers rows_in rows (the last one ragged) and holds
 // (sum, M2 = sum (x - mean_row)^2) per channel.  One level merges groups of MG consecutive slab rows with Chan's
-// pairwise update in double, in row order (deterministic); levels repeat until one row is left, then
-// bn_finalize_last turns it into mean / invstd / scale / shift (+ running stats).  Thread = (group, channel):
+// pairwise update in double, in row order (deterministic); levels repeat until at most BN_MG rows are left, then
+// bn_merge_final merges those and turns the result into mean / invstd / scale / shift (+ running stats).  Thread = (group, channel):
 // coalesced across channels, MG serial steps — a 12544-row slab (layer1 at B = 32) takes 3 short launches
 // instead of one 12544-step serial loop.
 #define BN_MG 64
@@ -61,29 +61,96 @@ __global__ __launch_bounds__(64 * BN_MQ) void bn_merge_level(const Tin* __restri
   }
 }
 
-// scale = gamma*invstd, shift = beta - mean*scale; running stats: momentum update with the UNBIASED variance
-// (torch semantics; models/resnet.py uses the defaults eps = 1e-5, momentum = 0.1).
-__global__ void bn_finalize_last(const double* __restrict__ tot, int C, int64_t M, float eps, float momentum,
-                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                 float* __restrict__ shift, float* __restrict__ running_mean,
-                                 float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mu = tot[c] / (double)M;
-  double var = tot[C + c] / (double)M;
-  if (var < 0.0) var = 0.0;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  mean[c] = (float)mu;
-  invstd[c] = is;
-  const float sc = g * is;
-  scale[c] = sc;
-  shift[c] = b - (float)mu * sc;
-  if (running_mean) {
-    const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+// Last merge level and the finalisation as ONE launch (R <= BN_MG rows left): the sub-chains of bn_merge_level, then
+// scale = gamma*invstd, shift = beta - mean*scale and the running-statistics update with the UNBIASED variance (torch semantics;
+// models/resnet.py uses the defaults eps = 1e-5, momentum = 0.1) — no trip through memory, no kernel boundary in between.
+template <typename Tin>
+__global__ __launch_bounds__(64 * BN_MQ) void bn_merge_final(const Tin* __restrict__ in, int R, int64_t rows_in, int C, int64_t M,
+                                                             float eps, float momentum, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ mean_o,
+                                                             float* __restrict__ invstd, float* __restrict__ scale,
+                                                             float* __restrict__ shift, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var) {
+  __shared__ double sh[BN_MQ][4][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int q = threadIdx.y;
+  const int r0 = q * (BN_MG / BN_MQ);
+  const int r1 = r0 + BN_MG / BN_MQ < R ? r0 + BN_MG / BN_MQ : R;
+  double n = 0.0, mean = 0.0, m2 = 0.0, sum = 0.0;
+  if (c < C) {
+    for (int r = r0; r < r1; ++r) {
+      const int64_t left = M - (int64_t)r * rows_in;
+      const double nb = (double)(left < rows_in ? left : rows_in);
+      const double sb = (double)in[((int64_t)r * 2 + 0) * C + c];
+      const double mb = sb / nb;
+      const double d = mb - mean;
+      const double nn = n + nb;
+      m2 += (double)in[((int64_t)r * 2 + 1) * C + c] + d * d * n * nb / nn;
+      mean += d * nb / nn;
+      sum += sb;
+      n = nn;
+    }
+  }
+  sh[q][0][threadIdx.x] = n; sh[q][1][threadIdx.x] = mean; sh[q][2][threadIdx.x] = m2; sh[q][3][threadIdx.x] = sum;
+  __syncthreads();
+  if (q == 0 && c < C) {
+#pragma unroll
+    for (int u = 1; u < BN_MQ; ++u) {
+      const double nb = sh[u][0][threadIdx.x];
+      if (nb > 0.0) {
+        const double d = sh[u][1][threadIdx.x] - mean;
+        const double nn = n + nb;
+        m2 += sh[u][2][threadIdx.x] + d * d * n * nb / nn;
+        mean += d * nb / nn;
+        sum += sh[u][3][threadIdx.x];
+        n = nn;
+      }
+    }
+    // finalise from (sum, m2)
+    const double mu = sum / (double)M;
+    double var = m2 / (double)M;
+    if (var < 0.0) var = 0.0;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean_o[c] = (float)mu;
+    invstd[c] = is;
+    const float sc = g * is;
+    scale[c] = sc;
+    shift[c] = b - (float)mu * sc;
+    if (running_mean) {
+      const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+// the backward twin: last sum level, then dgamma = s2, dbeta = s1 and ka = s1/M, kb = s2/M for pass 2
+template <typename Tin>
+__global__ __launch_bounds__(64 * BN_MQ) void sum_merge_final(const Tin* __restrict__ in, int R, int C, int64_t M,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              double* __restrict__ ka, double* __restrict__ kb) {
+  __shared__ double sh[BN_MQ][2][64];
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  const int q = threadIdx.y;
+  const int r0 = q * (BN_MG / BN_MQ);
+  const int r1 = r0 + BN_MG / BN_MQ < R ? r0 + BN_MG / BN_MQ : R;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int r = r0; r < r1; ++r) {
+      a += (double)in[((int64_t)r * 2 + 0) * C + c];
+      b += (double)in[((int64_t)r * 2 + 1) * C + c];
+    }
+  }
+  sh[q][0][threadIdx.x] = a; sh[q][1][threadIdx.x] = b;
+  __syncthreads();
+  if (q == 0 && c < C) {
+#pragma unroll
+    for (int u = 1; u < BN_MQ; ++u) { a += sh[u][0][threadIdx.x]; b += sh[u][1][threadIdx.x]; }
+    if (dbeta) dbeta[c] = (float)a;
+    if (dgamma) dgamma[c] = (float)b;
+    ka[c] = a / (double)M;
+    kb[c] = b / (double)M;
   }
 }
 
@@ -194,19 +261,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   }
 }
 
-// dgamma = s2, dbeta = s1 from the merged partials; ka = s1/M, kb = s2/M for pass 2
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ tot, int C, int64_t M,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       double* __restrict__ ka, double* __restrict__ kb) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double s1 = tot[c], s2 = tot[C + c];
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  ka[c] = s1 / (double)M;
-  kb[c] = s2 / (double)M;
-}
-
 // Backward pass 2: dz = gamma*invstd * (g - ka - xhat*kb).  The bracket cancels to ~(1 - xhat^2) of its terms
 // when a channel has few samples (BatchNorm1d over a small batch), so it is evaluated in double, like
 // torch's CPU kernel (accscalar = double), with the same fp32 xhat that pass 1 summed.
@@ -273,17 +327,19 @@ static size_t merge_ws_bytes(int R, int C) {
   const size_t rows1 = (size_t)slic_cdiv(R, BN_MG);
   return 2 * slic_align_up(rows1 * 2 * C * sizeof(double), 256);
 }
-// runs the levels; returns the pointer to the final [2][C] double row (inside ws)
+// runs the levels until at most BN_MG rows are left; *rows_out / *R_out / *src describe what the fused final kernel
+// (bn_merge_final / sum_merge_final) still has to merge: `partial` itself (float) when R <= BN_MG, else a double buffer
 template <bool CHAN>
 static int run_merge(const float* partial, int R, int64_t rows, int C, int64_t M, void* ws, hipStream_t st,
-                     const double** final_row) {
+                     const double** dsrc, int* R_out, int64_t* rows_out) {
   const size_t half = merge_ws_bytes(R, C) / 2;
   double* buf[2] = {(double*)ws, (double*)((char*)ws + half)};
   int cur = 0;
   int Rl = R;
   int64_t rows_l = rows;
   dim3 blk(64, BN_MQ);
-  {
+  *dsrc = nullptr;
+  if (Rl > BN_MG) {
     const int Ro = (int)slic_cdiv(Rl, BN_MG);
     dim3 grid((unsigned)slic_cdiv(C, 64), (unsigned)Ro);
     if (CHAN) bn_merge_level<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, buf[cur]);
@@ -291,18 +347,21 @@ static int run_merge(const float* partial, int R, int64_t rows, int C, int64_t M
     SLIC_LAUNCH_CHECK();
     Rl = Ro;
     rows_l *= BN_MG;
+    *dsrc = buf[cur];
+    while (Rl > BN_MG) {
+      const int Ro2 = (int)slic_cdiv(Rl, BN_MG);
+      dim3 grid2((unsigned)slic_cdiv(C, 64), (unsigned)Ro2);
+      if (CHAN) bn_merge_level<double><<<grid2, blk, 0, st>>>(buf[cur], Rl, rows_l, C, M, buf[cur ^ 1]);
+      else sum_merge_level<double><<<grid2, blk, 0, st>>>(buf[cur], Rl, C, buf[cur ^ 1]);
+      SLIC_LAUNCH_CHECK();
+      cur ^= 1;
+      Rl = Ro2;
+      rows_l *= BN_MG;
+      *dsrc = buf[cur];
+    }
   }
-  while (Rl > 1) {
-    const int Ro = (int)slic_cdiv(Rl, BN_MG);
-    dim3 grid((unsigned)slic_cdiv(C, 64), (unsigned)Ro);
-    if (CHAN) bn_merge_level<double><<<grid, blk, 0, st>>>(buf[cur], Rl, rows_l, C, M, buf[cur ^ 1]);
-    else sum_merge_level<double><<<grid, blk, 0, st>>>(buf[cur], Rl, C, buf[cur ^ 1]);
-    SLIC_LAUNCH_CHECK();
-    cur ^= 1;
-    Rl = Ro;
-    rows_l *= BN_MG;
-  }
-  *final_row = buf[cur];
+  *R_out = Rl;
+  *rows_out = rows_l;
   return SLIC_OK;
 }
 
@@ -316,11 +375,16 @@ extern "C" int slic_bn_finalize(const float* partial, int R, int rows, int C, in
                (int64_t)R * rows >= M && (int64_t)(R - 1) * rows < M, "slic_bn_finalize: bad args (R*rows must cover M)");
   SLIC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "slic_bn_finalize: running stats come in pairs");
   hipStream_t st = S_(stream);
-  const double* tot = nullptr;
-  int rc = run_merge<true>(partial, R, rows, C, M, workspace, st, &tot);
+  const double* dsrc = nullptr;
+  int Rl = 0;
+  int64_t rows_l = 0;
+  int rc = run_merge<true>(partial, R, rows, C, M, workspace, st, &dsrc, &Rl, &rows_l);
   if (rc) return rc;
-  bn_finalize_last<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(
-      tot, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var);
+  const dim3 grid((unsigned)slic_cdiv(C, 64)), blk(64, BN_MQ);
+  if (dsrc) bn_merge_final<double><<<grid, blk, 0, st>>>(dsrc, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
+                                                        running_mean, running_var);
+  else bn_merge_final<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
+                                                   running_mean, running_var);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -344,6 +408,21 @@ extern "C" int slic_bn_apply(const float* z, const float* scale, const float* sh
 
 extern "C" int slic_bn_bwd_rows_per_partial(void) { return BNB_RB; }
 
+// merge levels + the fused (last level, finalize) launch of the backward sums
+static int bwd_merge_finalize(const float* partial, int R, int64_t rows, int C, int64_t M, void* mws, hipStream_t st,
+                              float* dgamma, float* dbeta, double* ka, double* kb) {
+  const double* dsrc = nullptr;
+  int Rl = 0;
+  int64_t rows_l = 0;
+  int rc = run_merge<false>(partial, R, rows, C, M, mws, st, &dsrc, &Rl, &rows_l);
+  if (rc) return rc;
+  const dim3 grid((unsigned)slic_cdiv(C, 64)), blk(64, BN_MQ);
+  if (dsrc) sum_merge_final<double><<<grid, blk, 0, st>>>(dsrc, Rl, C, M, dgamma, dbeta, ka, kb);
+  else sum_merge_final<float><<<grid, blk, 0, st>>>(partial, Rl, C, M, dgamma, dbeta, ka, kb);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, const float* mean,
                            const float* invstd, const float* gamma, int64_t M, int C, float* g_out,
                            float* dz, float* dgamma, float* dbeta, void* workspace, void* stream) {
@@ -360,11 +439,8 @@ extern "C" int slic_bn_bwd(const float* dy, const float* out, const float* z, co
   if (!gbuf && out) gbuf = w.take<float>((size_t)M * C);     // masked gradient must be materialised for pass 2
   bn_bwd_reduce_kernel<<<dim3(R), dim3(256), 0, st>>>(dy, out, z, mean, invstd, M, C / 4, gbuf, partial);
   SLIC_LAUNCH_CHECK();
-  const double* tot = nullptr;
-  int rc = run_merge<false>(partial, R, BNB_RB, C, M, mws, st, &tot);
+  int rc = bwd_merge_finalize(partial, R, BNB_RB, C, M, mws, st, dgamma, dbeta, ka, kb);
   if (rc) return rc;
-  bn_bwd_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(tot, C, M, dgamma, dbeta, ka, kb);
-  SLIC_LAUNCH_CHECK();
   bn_bwd_apply_kernel<<<dim3(ew_grid(M * (C / 4))), dim3(256), 0, st>>>(gbuf ? gbuf : dy, z, mean, invstd, gamma, ka, kb, M, C / 4, dz);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
@@ -384,11 +460,8 @@ extern "C" int slic_bn_bwd_fused(const float* partial, int R, const float* g, co
   double* ka = w.take<double>(C);
   double* kb = w.take<double>(C);
   void* mws = w.take<char>(merge_ws_bytes(R, C));
-  const double* tot = nullptr;
-  int rc = run_merge<false>(partial, R, 1, C, M, mws, st, &tot);
+  int rc = bwd_merge_finalize(partial, R, 1, C, M, mws, st, dgamma, dbeta, ka, kb);
   if (rc) return rc;
-  bn_bwd_finalize_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, st>>>(tot, C, M, dgamma, dbeta, ka, kb);
-  SLIC_LAUNCH_CHECK();
   bn_bwd_apply_kernel<<<dim3(ew_grid(M * (C / 4))), dim3(256), 0, st>>>(g, z, mean, invstd, gamma, ka, kb, M, C / 4, dz);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;

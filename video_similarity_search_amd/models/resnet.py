@@ -134,7 +134,7 @@ class _Engine:
         call("slic_bn_finalize", ptr(part), part.shape[0], rows, bn.C, M, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias),
              ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var),
              ptr(ws), stream())
-        m.num_batches_tracked += 1
+        self._nbt.append(m.num_batches_tracked)        # counters of one segment are bumped by ONE fused add (seg_forward)
 
     def _bn_eval(self, bn):
         m = bn.mod
@@ -214,6 +214,14 @@ class _Engine:
     def seg_forward(self, si, inp, training, save):
         """returns (out, ctx).  Segment 0 takes the NCDHW clip batch; 1..4 take/return NDHWC activations;
         5 returns the [B, out_dim] (or [B, 512]) embedding."""
+        self._nbt = []
+        out = self._seg_forward(si, inp, training, save)
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)          # num_batches_tracked += 1 for every BatchNorm of the segment
+            self._nbt = []
+        return out
+
+    def _seg_forward(self, si, inp, training, save):
         net = self.net
         B = inp.shape[0]
         dev = inp.device
