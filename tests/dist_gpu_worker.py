@@ -164,6 +164,47 @@ def case_pipeline(rank, world, out):
     np.savez(out, **res)
 
 
+def case_step39(rank, world, out):
+    """BASELINE configs[3]'s per-GPU step at full size: the real R3D-18 under DistributedDataParallel, 13 anchors + 13 positives
+    + 13 second anchors of 3 x 16 x 112 x 112 through ONE forward, random_semi_hard mining + the LLC margin term, SGD —
+    driven by triplet_train_epoch (online_train.py:255-392) for two steps"""
+    import contextlib
+    import io
+    import types
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.online_train import triplet_train_epoch
+    kw = dict(TINY, widen_factor=1.0, hidden_layer=2048, out_dim=128)
+    torch.manual_seed(7)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = generate_model(18, **kw).cuda()
+    ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[torch.cuda.current_device()])
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1, momentum=0.5)
+    rng = np.random.default_rng(50 + rank)
+    b = 13
+    batches = []
+    for _ in range(2):
+        views = [torch.from_numpy(rng.standard_normal((b, 3, 16, 112, 112)).astype(np.float32)) for _ in range(3)]
+        batches.append((views, (torch.arange(b), torch.arange(b)), torch.arange(b)))
+
+    class Loader(list):
+        dataset = list(range(2 * b * world))
+
+    ns = types.SimpleNamespace
+    cfg = ns(LOSS=ns(LOCAL_LOCAL_CONTRAST=True, RELATIVE_SPEED_PERCEPTION=False, INTRA_NEGATIVE=False, DIST_METRIC='cosine',
+                     LOCAL_LOCAL_MARGIN=0.04, LOCAL_LOCAL_WEIGHT=1.0),
+             DATASET=ns(SAMPLING_STRATEGY='random_semi_hard'), NUM_GPUS=max(world, 2), TRAIN=ns(LOG_INTERVAL=1000),
+             OUTPUT_PATH=os.path.dirname(out))
+    w0 = m.conv1.weight.detach().clone()
+    with contextlib.redirect_stdout(io.StringIO()):
+        avg = triplet_train_epoch(Loader(batches), ddp, OnlineTripletLoss(0.2, 'cosine'), opt, 0, cfg, True, "cuda", rank == 0)
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    allw = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(allw, flat)
+    np.savez(out, avg=avg, finite=bool(torch.isfinite(flat).all()), moved=float((m.conv1.weight.detach() - w0).abs().max()),
+             replicas_equal=all(torch.equal(allw[0], w) for w in allw), nbt=int(m.bn1.num_batches_tracked))
+
+
 def case_launch(rank, world, out):
     raise SystemExit("case_launch is driven by the test itself (misc.distributed_helper.launch_processes)")
 

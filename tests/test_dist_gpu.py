@@ -127,6 +127,17 @@ def test_extract_sharded_cluster_pipeline(gpu, tmp_path, world):
     assert nmi(order, lab) > 0.99
 
 
+@pytest.mark.parametrize("world", _worlds())
+def test_configs3_full_size_ddp_step(gpu, tmp_path, world):
+    """BASELINE configs[3] per-GPU step (39 clips of 3x16x112x112 through one forward, random_semi_hard + LLC, DDP over RCCL):
+    two steps of triplet_train_epoch on the real R3D-18 — finite, weights moved, replicas identical, loss averaged over ranks"""
+    res = _run("step39", world, tmp_path, timeout=1500)
+    for r in res:
+        assert bool(r["finite"]) and float(r["moved"]) > 0 and bool(r["replicas_equal"]) and int(r["nbt"]) == 2
+        assert np.isfinite(float(r["avg"])) and float(r["avg"]) > 0
+    assert all(float(r["avg"]) == float(res[0]["avg"]) for r in res)        # the logged loss is the all-reduced mean
+
+
 def _launched(cmd_args, cfg):
     """func of launch_processes (online_train.py:787): runs in every spawned rank"""
     import torch.distributed as dist
