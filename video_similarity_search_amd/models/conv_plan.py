@@ -245,9 +245,11 @@ class ConvPlan:
 
     @classmethod
     def _splits(cls, a, variant):
-        """split-K factor for the 64 x 64-tile variant: small-M layers (layer3/4 at B = 32, the parity classes of a
-        stride-2 dgrad) have too few tiles to fill 256 CUs x 5 workgroups evenly, so cut K until ~SLIC_CONV_SPLIT_BLOCKS
-        workgroups exist (0 = never split; tests switch it), keeping at least SPLIT_MIN_KTILES k-tiles per workgroup"""
+        """split-K factor for the 64 x 64-tile variant: layer4 at B = 32 (392 tiles) and the like have too few tiles to keep
+        256 CUs x 5 workgroups busy, so cut K until ~SLIC_CONV_SPLIT_BLOCKS workgroups exist (0 = never split; tests switch
+        it), keeping at least SPLIT_MIN_KTILES k-tiles per workgroup.  Layer3's 1568 tiles gain from a 4-way split in isolation
+        (104 -> 117 TFLOP/s) but the whole step is 0.4 ms SLOWER with it (slab traffic + the finish pass's epilogue beside the
+        side-stream weight gradients; same-box A/B, scripts/ab_env.sh), so only launches with < target / 2 tiles are split."""
         if variant != 20:
             return 1
         target = int(os.environ.get("SLIC_CONV_SPLIT_BLOCKS", "3000"))
