@@ -72,5 +72,26 @@ for strat in ("adapted_hard", "fixed_semi_hard"):
     out[f"mem_{strat}_queue3"], out[f"mem_{strat}_label_q3"] = m.queue.numpy().copy(), m.label_q.numpy().copy()
     out[f"mem_{strat}_ptr3"] = np.int64(int(m.queue_ptr))
     print("MemTripletLoss", strat, [float(out[f"mem_{strat}_loss{i}"]) for i in range(3)], int(m.queue_ptr))
+# ---- memory-bank NCE without softmax (loss/NCE_loss.py:54-71) + NCECriterion (:312-337): two calls (Z fixed by the first)
+from loss.NCE_loss import NCEAverage, NCECriterion       # noqa: E402  (the reference)
+B, D, K, ndata = 8, 128, 64, 1000
+torch.manual_seed(9)
+nce = NCEAverage(D, ndata, K, 0.07, 0.5, use_softmax=False)
+out["nce0_memory_l"], out["nce0_memory_ab"] = nce.memory_l.clone().numpy(), nce.memory_ab.clone().numpy()
+crit = NCECriterion(ndata)
+for it in range(2):
+    l_f = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)), dim=1).requires_grad_(True)
+    ab_f = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)), dim=1).requires_grad_(True)
+    y = torch.from_numpy(rng.choice(ndata, B, replace=False).astype(np.int64))
+    idx = torch.from_numpy(rng.integers(0, ndata, (B, K + 1)).astype(np.int64))
+    idx[:, 0] = y
+    o_l, o_ab = nce(l_f, ab_f, y, idx.clone())
+    tot = crit(o_l) + crit(o_ab)
+    tot.backward()
+    out.update({f"nce0_l{it}": l_f.detach().numpy(), f"nce0_ab{it}": ab_f.detach().numpy(), f"nce0_y{it}": y.numpy(), f"nce0_idx{it}": idx.numpy(),
+                f"nce0_out_l{it}": o_l.detach().numpy(), f"nce0_out_ab{it}": o_ab.detach().numpy(), f"nce0_loss{it}": tot.detach().numpy(),
+                f"nce0_grad_l{it}": l_f.grad.numpy().copy(), f"nce0_grad_ab{it}": ab_f.grad.numpy().copy()})
+out["nce0_params"] = nce.params.detach().numpy().copy()
+print("NCE without softmax: Z", nce.params[2:4].tolist(), "loss", float(tot))
 np.savez_compressed(os.path.join(HERE, "loss_variants.npz"), **out)
 print("loss_variants goldens:", len(out))

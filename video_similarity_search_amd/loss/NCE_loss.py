@@ -5,8 +5,11 @@ Drop-in for the memory-bank NCE of the reference's loss/NCE_loss.py:
     AliasMethod(probs).draw(N)                                                                  <- :246-307
 Same buffers (`params`, `memory_l`, `memory_ab`), same cross-wiring (out_ab is scored against memory_l, out_l
 against memory_ab), bank rows detached, momentum update + renormalise under no_grad.  The gather+bmm, its
-backward, the bank update and the class-0 cross-entropy are HIP kernels (csrc/nce.hip); the
-use_softmax=False branch (Z normalisation constants) is not used by SLIC and raises.
+backward, the bank update and the class-0 cross-entropy are HIP kernels (csrc/nce.hip).
+The use_softmax=False branch (:54-71: out = exp(score / T / Z) with the constants Z_l / Z_ab fixed on the first call and
+kept in `params[2:4]`) and its NCECriterion (:312-337, Eq. 12 of the CMC paper) are not selected by SLIC
+(online_train.py:701-710 builds NCEAverage with the default and NCESoftmaxLoss); they are restated on top of the same
+score kernels — the exp / log over the [B, K+1] outputs are a few kilobytes of elementwise torch ops.
 """
 import math
 
@@ -96,9 +99,6 @@ class NCEAverage(nn.Module):
         self.multinomial.cuda()
         self.K = K
         self.use_softmax = use_softmax
-        if not use_softmax:
-            raise NotImplementedError("use_softmax=False (Z_l / Z_ab constants) is never selected by SLIC "
-                                      "(online_train.py:701-702 builds NCEAverage with the default)")
         self.register_buffer('params', torch.tensor([K, T, -1, -1, momentum]))
         stdv = 1. / math.sqrt(inputSize / 3)
         self.register_buffer('memory_l', torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
@@ -119,6 +119,20 @@ class NCEAverage(nn.Module):
         # out_ab scores ab against memory_l, out_l scores l against memory_ab (NCE_loss.py:41-48)
         out_ab = _BankScores.apply(ab, self.memory_l, idx, T)
         out_l = _BankScores.apply(l, self.memory_ab, idx, T)
+        if not self.use_softmax:
+            # NCE_loss.py:54-71.  The reference sets Z from the RAW dot products (before the division by T): mean * outputSize
+            outputSize = self.memory_l.size(0)
+            Z_l, Z_ab = self.params[2].item(), self.params[3].item()
+            if Z_l < 0:
+                self.params[2] = out_l.detach().mean() * T * outputSize
+                Z_l = self.params[2].item()
+                print("normalization constant Z_l is set to {:.1f}".format(Z_l))
+            if Z_ab < 0:
+                self.params[3] = out_ab.detach().mean() * T * outputSize
+                Z_ab = self.params[3].item()
+                print("normalization constant Z_ab is set to {:.1f}".format(Z_ab))
+            out_l = torch.exp(torch.div(out_l, Z_l))
+            out_ab = torch.exp(torch.div(out_ab, Z_ab))
         with torch.no_grad():   # update memory (NCE_loss.py:73-86)
             B, D = l.shape
             call("slic_nce_bank_update", ptr(self.memory_l), ptr(y), ptr(l.detach().contiguous().float()), B, D,
@@ -158,3 +172,23 @@ class NCESoftmaxLoss(nn.Module):
         bsz = x.shape[0]
         x = x.reshape(bsz, -1).contiguous().float()      # x.squeeze() of [B, K+1, 1]
         return _SoftmaxCE0.apply(x)
+
+
+class NCECriterion(nn.Module):
+    """Eq. (12) L_NCE of the CMC paper (loss/NCE_loss.py:312-337) on the use_softmax=False outputs [B, K+1, 1]:
+    -(sum_b log(P_pos / (P_pos + m Pn + eps)) + sum_{b,k} log(m Pn / (P_neg + m Pn + eps))) / B with Pn = 1 / n_data"""
+
+    def __init__(self, n_data):
+        super(NCECriterion, self).__init__()
+        self.n_data = n_data
+
+    def forward(self, x):
+        eps = 1e-7
+        bsz = x.shape[0]
+        m = x.size(1) - 1
+        Pn = 1 / float(self.n_data)
+        P_pos = x.select(1, 0)
+        log_D1 = torch.div(P_pos, P_pos.add(m * Pn + eps)).log_()
+        P_neg = x.narrow(1, 1, m)
+        log_D0 = torch.div(P_neg.clone().fill_(m * Pn), P_neg.add(m * Pn + eps)).log_()
+        return - (log_D1.sum(0) + log_D0.view(-1, 1).sum(0)) / bsz
