@@ -1,0 +1,17 @@
+"""six launches of the layer1 gather-GEMM (variant 22, forward geometry, plain store epilogue) for PMC passes"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from video_similarity_search_amd.models.conv_plan import ConvPlan
+from video_similarity_search_amd._lib import call, stream
+B = 32
+plan = ConvPlan(64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 56, 56), "cuda")
+x = torch.randn((B, 16, 56, 56, 64), device="cuda")
+w = torch.randn((64, 64, 3, 3, 3), device="cuda") * 0.05
+wp = plan.pack_fwd(w)
+z = torch.empty((B, 16, 56, 56, 64), device="cuda")
+a = plan._fwd_args(x, B)
+a.wgt, a.wgt_bytes, a.dst = wp.data_ptr(), wp.numel() * 4, z.data_ptr()
+for _ in range(6):
+    call("slic_conv_gemm", ctypes.byref(a), 22, stream())
+torch.cuda.synchronize()

@@ -458,6 +458,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   const int kt0 = slab ? bzi * kt_per_split : 0;
   const int nk = slab ? min(nk_all, kt0 + kt_per_split) : nk_all;     // END of this workgroup's k-tile range
   const int tiles_per_tap = p.Cs / KD;
+  // k-tile -> (tap, channel base): a shift and a mask when the tap holds a power-of-two number of k-tiles (every R3D-18 layer)
+  // instead of a wave-uniform division per k-tile per wave
+  const bool tpt_pow2 = (tiles_per_tap & (tiles_per_tap - 1)) == 0;
+  const int tpt_shift = 31 - __builtin_clz(tiles_per_tap);
+  auto tap_of = [&](int ktc) { return tpt_pow2 ? (ktc >> tpt_shift) : (ktc / tiles_per_tap); };
   // per-tap records are read through the constant address space with a wave-uniform index: scalar loads, which
   // never touch the vmcnt queue the DMAs are counted on
   const __attribute__((address_space(4))) i32x4* tapc = (const __attribute__((address_space(4))) i32x4*)p.tab;
@@ -468,7 +473,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   auto issue = [&](int kt, int toff) {
     const bool live = kt < nk;
     const int ktc = live ? kt : 0;
-    const int tap = ktc / tiles_per_tap;                     // wave-uniform -> scalar loads of the tap record
+    const int tap = tap_of(ktc);                             // wave-uniform -> scalar loads of the tap record
     const int cb = (ktc - tap * tiles_per_tap) * KD;         // channel base inside the tap
     const i32x4 e = tapc[tap];                               // {src delta, tap mask, weight base, -}: s_load (lgkmcnt queue)
     const unsigned tm = live ? (unsigned)e.y : 0xFFFFFFFFu;  // an all-ones tap mask fails every row's bounds test
@@ -504,7 +509,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
     const float* Bb = Ab + BM * KD;
     const bool live = ktn < nk;
     const int ktc = live ? ktn : 0;
-    const int tap = ktc / tiles_per_tap;
+    const int tap = tap_of(ktc);
     const int cb = (ktc - tap * tiles_per_tap) * KD;
     const i32x4 e = tapc[tap];
     const unsigned tm = live ? (unsigned)e.y : 0xFFFFFFFFu;
