@@ -220,11 +220,34 @@ __global__ __launch_bounds__(256) void topk_partial_kernel(
 // of GS at a time: one max over the group and ONE compare decide whether the group holds a candidate at all (after the first
 // tiles it rarely does); only then are the group's elements tested one by one and appended to the lane's own pending buffer.
 // The owner half drains its own and its partner's pending entries into the heap.
+#ifdef TK_COUNT
+__device__ unsigned long long tk_cnt[8];
+extern "C" int slic_debug_topk_counters(unsigned long long* out, int reset) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(tk_cnt), sizeof(tk_cnt));
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(tk_cnt), z, sizeof(z)); }
+  return 0;
+}
+// counters are kept in registers and added to the global ones once, at the end of the kernel (an atomic per event would sit
+// in front of the next vmcnt(0) and be measured itself)
+#define TKC(i, n) do { tkc_[i] += (unsigned long long)(n); } while (0)
+#define TKC_DECL unsigned long long tkc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define TKC_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; ++i_) if (tkc_[i_]) atomicAdd(&tk_cnt[i_], tkc_[i_]); } while (0)
+static __device__ inline unsigned long long tk_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#else
+#define TKC(i, n) do {} while (0)
+#define TKC_DECL
+#define TKC_FLUSH do {} while (0)
+#endif
 template <int GS>
 __global__ __launch_bounds__(256) void topk_partial_dma(
     const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
     int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */,
     int* __restrict__ gthr /* [Nq] order-preserving int image of a lower bound of query q's final k-th best score */) {
+  TKC_DECL
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int STAGE_FLOATS = (TK_BQ + TK_BG) * TK_BK;
   // heaps: [4 waves][kh][32] keys, kh = k rounded up to 4 m + 1 so that every node has four children (the padding holds the
@@ -240,6 +263,11 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   const int gend = min(gbeg + g_per_slice, Ng);
   unsigned long long* hp = heaps + wave * kh * 32;           // this wave's heaps, entry e of query r at hp[e * 32 + r]
   unsigned long long* pq = pend + wave * TK_PC * 64;
+  // drains are taken by all four waves TOGETHER: a wave that drains alone keeps the other three waiting at the next k-tile
+  // barrier, so four independent drains cost the workgroup four stalls.  wflag[tile & 1] is raised at the end of a tile by any
+  // wave whose pending buffers run short and read by everybody after the first barrier of the next tile.
+  int* wflag = (int*)(pend + 4 * TK_PC * 64);
+  if (tid < 2) wflag[tid] = 0;
   int pc = 0;                                                // this lane's pending count
   const unsigned long long KEY_EMPTY = tk_key(-INFINITY, INT_MAX), KEY_PAD = ~0ull;
   if (h == 0)
@@ -268,7 +296,11 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   auto issue = [&](int tile, int kt, int stage) {
     float* Gs = lds + stage * STAGE_FLOATS;
     float* Qs = Gs + TK_BG * TK_BK;
+#if defined(TK_ABL) && (TK_ABL & 1)
+    const bool kin = false;
+#else
     const bool kin = kt * TK_BK < klim && tile < ntile;
+#endif
     const unsigned kb = (unsigned)kt * (TK_BK * 4u);
     const unsigned gb = (unsigned)tile * (unsigned)(TK_BG * D * 4);
 #pragma unroll
@@ -281,6 +313,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
                                                16, (int)(kin ? qoff[i] + kb : OOB), 0, 0, 0);
   };
   f32x16 acc[4];
+  int gimg = (int)0x807FFFFF;                                  // order-preserving int image of -inf
   auto compute = [&](int stage) {
     const float* Gs = lds + stage * STAGE_FLOATS;
     const float* Qs = Gs + TK_BG * TK_BK;
@@ -310,13 +343,18 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   auto flush = [&]() {
     const int pcp = __shfl_xor(pc, 32);                        // the partner half's count
     const int tot = h == 0 ? pc + pcp : 0;                     // the owner drains its own entries, then its partner's
+    TKC(0, 1);
     for (int j = 0; j < 2 * TK_PC; ++j) {
       const bool act = j < tot;
       if (!__any(act)) break;
+      TKC(1, 1);
       if (act) {
         const int jj = j < pc ? j : j - pc;
         const unsigned long long cand = pq[jj * 64 + (j < pc ? lane : lane + 32)];
         if (cand > root) {
+#if defined(TK_COUNT) && TK_COUNT > 1
+          atomicAdd(&tk_cnt[5], 1ull);
+#endif
           // 4-ary heap, root (slot 0) = worst kept entry: the four children of a node are read together (one LDS round
           // trip per level, log4 k levels), the worst of them moves up while it is worse than the candidate
           int pos = 0;
@@ -342,9 +380,20 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
     }
     pc = 0;
     thr = owner ? tk_key_score(root) : INFINITY;
+    // slices of the same query prune for each other: the k-th best score any slice holds is a lower bound of the final k-th
+    // best, so a full heap publishes its root (atomic max on an order-preserving int image).  Published HERE, where the root
+    // changes — a drain is followed by a k-tile of matrix work, which hides the atomic's round trip; at the end of a tile it
+    // would sit right in front of the next k-tile's vmcnt(0).
+    if (owner && thr > -INFINITY) {
+      const int b = __float_as_int(thr);
+      atomicMax(gthr + q, b >= 0 ? b : b ^ 0x7FFFFFFF);
+    }
   };
   issue(0, 0, 0);
   for (int tile = 0; tile < ntile; ++tile) {
+#ifdef TK_COUNT
+    const unsigned long long ts0_ = tk_now();
+#endif
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -354,12 +403,26 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
       for (int sidx = 0; sidx < 2; ++sidx) {
         const int kt = s0 + sidx;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !(defined(TK_ABL) && (TK_ABL & 4))
         __builtin_amdgcn_s_barrier();
+#endif
         const bool wrap = kt + 1 >= nkp;                       // the next ring step opens the next gallery tile
         issue(wrap ? tile + 1 : tile, wrap ? 0 : kt + 1, sidx ^ 1);
+        // the best bound the other slices have published: asked for two k-tiles before the tile ends, so the round trip
+        // to memory is over by then (the vmcnt(0) of the last k-tile covers it)
+        if (s0 == nkp - 2 && sidx == 0 && owner) gimg = __builtin_nontemporal_load(gthr + q);
+        if (s0 == 0) {
+          if (sidx == 0) {
+            if (wflag[(tile + 1) & 1]) flush();                // raised at the end of the previous tile (0 before the first)
+          } else if (tid == 0) wflag[(tile + 1) & 1] = 0;      // everybody has read it: clear it for the tile after this one
+        }
         compute(sidx);
       }
     }
+#ifdef TK_COUNT
+    const unsigned long long ts1_ = tk_now();
+    TKC(6, ts1_ - ts0_);                                       // k loop (incl. a collective flush)
+#endif
     const int g0 = gbeg + tile * TK_BG;
     // rare exclusions are applied to the scores up front (wave-uniform tests), so the per-element test below is one compare:
     // gallery rows past the slice (last tile only) and the query itself (self_mask, only where the ranges meet)
@@ -378,13 +441,254 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
     // Slices of the same query prune for each other: the k-th best score any slice holds is a lower bound of the final
     // k-th best, so it is published (atomic max on an order-preserving int image) and every slice drops scores strictly
     // below the best bound published so far.  Exact whatever the timing: a dropped score cannot be in the final top-k.
-    float gb = -INFINITY;
-    if (owner) {
-      const int gi_ = __builtin_nontemporal_load(gthr + q);
-      gb = __int_as_float(gi_ >= 0 ? gi_ : gi_ ^ 0x7FFFFFFF);
-    }
+    const float gb = __int_as_float(gimg >= 0 ? gimg : gimg ^ 0x7FFFFFFF);
     // the bound both halves of a pair test against: the owner's heap root (or the published bound); lanes of a query slot
     // past Nq test against +inf
+    const float gbb = __shfl(gb, r);
+    float filt = fmaxf(__shfl(thr, r), gbb);
+#if defined(TK_ABL) && (TK_ABL & 2)
+    { float sm = 0.f;
+      for (int ct = 0; ct < 4; ++ct) for (int v = 0; v < 16; ++v) sm += acc[ct][v];
+      if (sm == 12345.678f) thr = sm;
+      filt = INFINITY; }
+#endif
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v0 = 0; v0 < 16; v0 += GS) {
+        if (__any(pc > TK_PC - GS)) {                           // room for a whole group in every lane's pending buffer
+          flush();
+          filt = fmaxf(__shfl(thr, r), gbb);
+        }
+        float gm = acc[ct][v0];
+#pragma unroll
+        for (int v = v0 + 1; v < v0 + GS; ++v) gm = fmaxf(gm, acc[ct][v]);
+        if (gm >= filt && gm > -INFINITY) {
+          TKC(2, 1);
+#pragma unroll
+          for (int v = v0; v < v0 + GS; ++v) {
+            const float sc = acc[ct][v];
+            if (sc >= filt && sc > -INFINITY) {                 // ties with the root are sorted out by the owner (index order)
+              TKC(3, 1);
+#if defined(TK_COUNT) && TK_COUNT > 1
+              atomicAdd(&tk_cnt[4], 1ull);
+#endif
+              pq[pc * 64 + lane] = tk_key(sc, g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h);
+              ++pc;
+            }
+          }
+        }
+      }
+    // no drain at the end of a tile: the pending entries ride along until a buffer runs short of room for two more groups —
+    // a drain costs max-over-lanes rounds, and the fuller the buffers the closer that maximum is to the mean
+    if (__any(pc > TK_PC - 2 * GS) && lane == 0) wflag[tile & 1] = 1;
+#ifdef TK_COUNT
+    TKC(7, tk_now() - ts1_);               // everything between two k loops
+#endif
+  }
+  flush();
+  TKC_FLUSH;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (h == 0 && q < Nq) {
+    float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
+    int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq + q) * k;
+    for (int s = 0; s < k; ++s) {
+      const unsigned long long e = hp[s * 32 + r];
+      ov[s] = tk_key_score(e);
+      oi[s] = tk_key_index(e);
+    }
+  }
+}
+
+// D <= 512: the QUERY operand lives in registers.  At one workgroup per CU (the lists fill the LDS) a SIMD holds a single wave,
+// so whatever a k-tile does before its first MFMA — wait for the DMA, barrier, issue the next DMA, fetch the first fragments
+// from LDS — leaves the matrix pipe idle (the 2-stage kernel above spends 20 % of its k loop that way).  Here
+//  * a wave's 32 queries x D are loaded once into NK * 16 registers per lane (NK = ceil(D / 32) k-tiles, unrolled, so every
+//    MFMA's B operand is a fixed register): no query DMA, no query LDS reads, half the DMA instructions;
+//  * the freed LDS makes the gallery ring 4 stages deep at the same footprint: the DMA of step s + 3 is issued at step s and
+//    waited for (counted vmcnt) at step s + 2 — two k-tiles in flight instead of one;
+//  * the barrier of step s publishes stage s + 1, so the last quarter of step s already fetches the first fragments of step
+//    s + 1: after the next barrier the MFMAs start at once.
+// Same k order inside every accumulator as topk_partial_dma, same scan / drain / bound logic: bit-identical lists.
+template <int NK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void topk_partial_qreg(
+    const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
+    int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */,
+    int* __restrict__ gthr) {
+  TKC_DECL
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(NK % 4 == 0, "a gallery tile is a whole number of ring turns");
+  constexpr int GS = 4;
+  constexpr int STAGE_FLOATS = TK_BG * TK_BK;                  // gallery rows only
+  const int kh = 1 + ((k + 2) / 4) * 4;
+  unsigned long long* heaps = (unsigned long long*)(lds + 4 * STAGE_FLOATS);
+  unsigned long long* pend = heaps + 4 * kh * 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * TK_BQ;
+  const int gbeg = blockIdx.y * g_per_slice;
+  const int gend = min(gbeg + g_per_slice, Ng);
+  unsigned long long* hp = heaps + wave * kh * 32;
+  unsigned long long* pq = pend + wave * TK_PC * 64;
+  int* wflag = (int*)(pend + 4 * TK_PC * 64);                  // collective drains, see topk_partial_dma
+  if (tid < 2) wflag[tid] = 0;
+  int pc = 0;
+  const unsigned long long KEY_EMPTY = tk_key(-INFINITY, INT_MAX), KEY_PAD = ~0ull;
+  if (h == 0)
+    for (int s = 0; s < kh; ++s) hp[s * 32 + r] = s < k ? KEY_EMPTY : KEY_PAD;
+  const int q = q0 + 32 * wave + r;
+  const bool owner = h == 0 && q < Nq;
+  unsigned long long root = KEY_EMPTY;
+  float thr = owner ? -INFINITY : INFINITY;
+
+  // lane (r, h) of MFMA step (kt, qd, t) multiplies by Q[q][32 kt + 8 qd + 4 h + t]
+  f32x4 qr[NK][4];
+  {
+    const float* qrow = Q + (int64_t)(q < Nq ? q : Nq - 1) * D;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int c = 32 * kt + 8 * qd + 4 * h;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        qr[kt][qd] = c < D ? *(const f32x4*)(qrow + c) : z;    // D % 8 == 0: a chunk is inside the row or past it
+      }
+  }
+
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(G + (int64_t)gbeg * D), 0, (int)((int64_t)(gend - gbeg) * D * 4), 0x00020000);     // rows past the slice: zeros
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned goff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) goff[i] = ((unsigned)(srow + 32 * i) * (unsigned)D + cq * 4) * 4u;
+  const int klim = D - cq * 4;
+  const int ntile = (gend - gbeg + TK_BG - 1) / TK_BG;
+  // the DMAs of ring step (tile, kt): k-tiles past D are all-zero, a tile past the end is all out of range
+  auto issue = [&](int tile, int kt, int stage) {
+    float* Gs = lds + stage * STAGE_FLOATS;
+    const bool kin = kt * TK_BK < klim && tile < ntile;
+    const unsigned kb = (unsigned)kt * (TK_BK * 4u);
+    const unsigned gb = (unsigned)tile * (unsigned)(TK_BG * D * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(Gs + (8 * wave + 32 * i) * TK_BK),
+                                               16, (int)(kin ? gb + goff[i] + kb : OOB), 0, 0, 0);
+  };
+  auto flush = [&]() {
+    const int pcp = __shfl_xor(pc, 32);                        // the partner half's count
+    const int tot = h == 0 ? pc + pcp : 0;                     // the owner drains its own entries, then its partner's
+    TKC(0, 1);
+    for (int j = 0; j < 2 * TK_PC; ++j) {
+      const bool act = j < tot;
+      if (!__any(act)) break;
+      TKC(1, 1);
+      if (act) {
+        const int jj = j < pc ? j : j - pc;
+        const unsigned long long cand = pq[jj * 64 + (j < pc ? lane : lane + 32)];
+        if (cand > root) {
+          int pos = 0;                                         // 4-ary heap, see topk_partial_dma
+          unsigned long long newroot = cand;
+          for (;;) {
+            const int c0 = 4 * pos + 1;
+            if (c0 >= kh) break;
+            const unsigned long long k0 = hp[c0 * 32 + r], k1 = hp[(c0 + 1) * 32 + r], k2 = hp[(c0 + 2) * 32 + r],
+                                     k3 = hp[(c0 + 3) * 32 + r];
+            unsigned long long w = k0; int ws = c0;
+            if (k1 < w) { w = k1; ws = c0 + 1; }
+            if (k2 < w) { w = k2; ws = c0 + 2; }
+            if (k3 < w) { w = k3; ws = c0 + 3; }
+            if (!(cand > w)) break;
+            hp[pos * 32 + r] = w;
+            if (pos == 0) newroot = w;
+            pos = ws;
+          }
+          hp[pos * 32 + r] = cand;
+          root = newroot;
+        }
+      }
+    }
+    pc = 0;
+    thr = owner ? tk_key_score(root) : INFINITY;
+    if (owner && thr > -INFINITY) {                            // publish the new root (see topk_partial_dma)
+      const int b = __float_as_int(thr);
+      atomicMax(gthr + q, b >= 0 ? b : b ^ 0x7FFFFFFF);
+    }
+  };
+  f32x16 acc[4];
+  f32x4 a[2][4];                                               // gallery fragments, double-buffered ACROSS k-tiles
+  int gimg = (int)0x807FFFFF;                                  // order-preserving int image of -inf
+  issue(0, 0, 0);
+  issue(NK > 1 ? 0 : 1, NK > 1 ? 1 : 0, 1);
+  issue(NK > 2 ? 0 : 1, NK > 2 ? 2 : 0, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // step 0 has landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) a[0][ct] = *(const f32x4*)&lds[tk_off(32 * ct + r, h)];
+  for (int tile = 0; tile < ntile; ++tile) {
+#ifdef TK_COUNT
+    const unsigned long long ts0_ = tk_now();
+#endif
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ct][v] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      // step s = (tile, kt) computes from stage kt & 3.  Outstanding here: the DMAs of steps s + 1 and s + 2 (4 each).
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // step s + 1 has landed (this wave's part of it)
+      __builtin_amdgcn_s_barrier();                            // ... everybody's; and stage (kt + 3) & 3 has been read by all
+      {
+        const int kn = kt + 3;                                  // step s + 3
+        issue(kn >= NK ? tile + 1 : tile, kn >= NK ? kn - NK : kn, kn & 3);
+      }
+      if (kt == 0) {
+        if (wflag[(tile + 1) & 1]) flush();                    // raised at the end of the previous tile (0 before the first)
+      } else if (kt == 1) {
+        if (tid == 0) wflag[(tile + 1) & 1] = 0;               // everybody has read it: clear it for the tile after this one
+      } else if (kt == NK - 2) {
+        if (owner) gimg = __builtin_nontemporal_load(gthr + q); // the other slices' best bound, needed when the tile ends
+      }
+      const float* Gs = lds + (kt & 3) * STAGE_FLOATS;
+      const float* Gn = lds + ((kt + 1) & 3) * STAGE_FLOATS;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int cur = qd & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          a[nxt][ct] = qd < 3 ? *(const f32x4*)&Gs[tk_off(32 * ct + r, 2 * (qd + 1) + h)]
+                              : *(const f32x4*)&Gn[tk_off(32 * ct + r, h)];       // first fragments of the next step
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct][t], qr[kt][qd][t], acc[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+#ifdef TK_COUNT
+    const unsigned long long ts1_ = tk_now();
+    TKC(6, ts1_ - ts0_);
+#endif
+    const int g0 = gbeg + tile * TK_BG;
+    const bool ragged = g0 + TK_BG > gend;
+    const bool selfhit = self_mask && g0 < q0 + 32 * wave + 32 && g0 + TK_BG > q0 + 32 * wave;
+    if (ragged || selfhit) {
+      const int qo = q0 + 32 * wave + r;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (gi >= gend || (self_mask && gi == qo)) acc[ct][v] = -INFINITY;
+        }
+    }
+    const float gb = __int_as_float(gimg >= 0 ? gimg : gimg ^ 0x7FFFFFFF);
     const float gbb = __shfl(gb, r);
     float filt = fmaxf(__shfl(thr, r), gbb);
 #pragma unroll
@@ -399,6 +703,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
 #pragma unroll
         for (int v = v0 + 1; v < v0 + GS; ++v) gm = fmaxf(gm, acc[ct][v]);
         if (gm >= filt && gm > -INFINITY) {
+          TKC(2, 1);
 #pragma unroll
           for (int v = v0; v < v0 + GS; ++v) {
             const float sc = acc[ct][v];
@@ -409,15 +714,14 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
           }
         }
       }
-    // no drain at the end of a tile: the pending entries ride along until a buffer runs short of a group's room (above) —
-    // a drain costs max-over-lanes rounds, and the fuller the buffers the closer that maximum is to the mean
-    if (owner && thr > -INFINITY) {                            // the heap is full: its root bounds the final k-th best from below
-      const int b = __float_as_int(thr);
-      atomicMax(gthr + q, b >= 0 ? b : b ^ 0x7FFFFFFF);
-    }
+    if (__any(pc > TK_PC - 2 * GS) && lane == 0) wflag[tile & 1] = 1;
+#ifdef TK_COUNT
+    TKC(7, tk_now() - ts1_);
+#endif
   }
   flush();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TKC_FLUSH;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
   if (h == 0 && q < Nq) {
     float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
     int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq + q) * k;
@@ -585,10 +889,10 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   // LDS: 2 ring stages + heaps [4][kh][32] keys (kh = k rounded up to 4 m + 1) + pending [4][pcap][64] keys, one column per LANE
   const int kh = 1 + ((k + 2) / 4) * 4;
   const size_t fixed = (size_t)2 * 2 * TK_BQ * TK_BK * sizeof(float) + (size_t)4 * kh * 32 * 8;
-  int pcap = (int)((160 * 1024 - fixed) / (4 * 64 * 8));
+  int pcap = (int)((160 * 1024 - 16 - fixed) / (4 * 64 * 8));
   pcap = pcap > TK_PC_MAX ? TK_PC_MAX : pcap;
   SLIC_REQUIRE(pcap >= 2, "slic_cosine_topk: k = %d leaves no LDS for the pending buffers", k);
-  const size_t lds = fixed + (size_t)4 * pcap * 64 * 8;
+  const size_t lds = fixed + (size_t)4 * pcap * 64 * 8 + 16;
   static size_t lds_set = 0;
   if (lds > lds_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -606,8 +910,26 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
     }
     int* gthr = w.take<int>((size_t)Nq);
     SLIC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)gthr, (int)0x807FFFFF, (size_t)Nq, st));   // the image of -inf
-    if (pcap >= 16) topk_partial_dma<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
-    else if (pcap >= 4) topk_partial_dma<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+#ifndef TK_NO_QREG
+    if (pcap >= 12 && D <= 512) {
+      static size_t lds_set3 = 0;
+      if (lds > lds_set3) {
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set3 = lds;
+      }
+      if (D > 256) topk_partial_qreg<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+      else if (D > 128) topk_partial_qreg<8><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+      else topk_partial_qreg<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    } else
+#endif
+#ifdef TK_FORCE_GS
+    if (true) topk_partial_dma<TK_FORCE_GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    else
+#endif
+    if (pcap >= 12) topk_partial_dma<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+    else if (pcap >= 400) topk_partial_dma<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
     else topk_partial_dma<2><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
   } else
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, (2 * pcap) & ~1, pval, pidx);
