@@ -35,3 +35,13 @@ for s, e, n, _ in sorted(win):
     cur_e = max(cur_e, e)
 idle.sort(reverse=True)
 print("  longest idle stretches (us, next kernel):", [(round(g / 1e3, 1), n[:40]) for g, n in idle[:6]])
+# waits of the main queue (gaps >= 20 us between its consecutive kernels): where it stands still for the side queue
+mainq = max(byq, key=lambda q: len(byq[q]))
+lst = byq[mainq]
+waits = [(lst[i + 1][0] - lst[i][1], lst[i][2][:36], lst[i + 1][2][:36]) for i in range(len(lst) - 1) if lst[i + 1][0] - lst[i][1] >= 20000]
+print(f"  main queue waits >= 20 us: {len(waits)} totalling {sum(w[0] for w in waits)/1e6:.2f} ms:", [(round(w[0] / 1e3), w[1], w[2]) for w in waits])
+# per phase: forward = up to the NT-Xent kernel, backward after it
+nt = [i for i, e in enumerate(win) if e[2].startswith("ntxent_fwd")]
+if nt:
+    tf = win[nt[0]][0]
+    print(f"  forward {(tf - t0)/1e6:.2f} ms, backward + optimizer {(t1 - tf)/1e6:.2f} ms")

@@ -44,6 +44,44 @@ def test_assign_scores_bit_exact(gpu, N, D, K):
     assert np.array_equal(lab, olab)
 
 
+def _assign_perm_gpu(X, C):
+    """the product E-step: k8-permuted operands -> slic_kmeans_assign_perm (km_assign_creg / km_assign_dma) -> km_combine"""
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd._lib import call, ptr, stream
+    N, D = X.shape
+    K = C.shape[0]
+    lib = _lib.load()
+    Xd, Cd = torch.from_numpy(X).cuda(), torch.from_numpy(C).cuda()
+    Xp, Cp = torch.empty_like(Xd), torch.empty_like(Cd)
+    call("slic_kmeans_permute_k8", ptr(Xd), N, D, D, ptr(Xp), D, stream())
+    call("slic_kmeans_permute_k8", ptr(Cd), K, D, D, ptr(Cp), D, stream())
+    cn = torch.empty(K, device="cuda")
+    call("slic_kmeans_cnorm", ptr(Cd), K, D, D, ptr(cn), stream())
+    lab = torch.empty(N, dtype=torch.int32, device="cuda")
+    best = torch.empty(N, dtype=torch.float32, device="cuda")
+    ws = torch.empty(lib.slic_kmeans_assign_workspace_bytes(N, K), dtype=torch.uint8, device="cuda")
+    call("slic_kmeans_assign_perm", ptr(Xp), N, D, D, ptr(Cp), K, D, ptr(cn), ptr(lab), None, None, ptr(best), ptr(ws), stream())
+    torch.cuda.synchronize()
+    return lab.cpu().numpy(), best.cpu().numpy()
+
+
+# centroids in registers with 16 / 8 / 4 k-tiles (D <= 512 / 256 / 128; ragged last tile, K not a multiple of 128 or 32),
+# and the shapes that fall back to the 128 x 64 tile kernel (few points, K far below a multiple of 128, D > 512)
+@pytest.mark.parametrize("N,D,K", [(40000, 512, 500), (33003, 200, 384), (70001, 128, 250), (2000, 512, 500),
+                                   (40000, 64, 130), (9000, 520, 500)])
+def test_assign_perm_scores_bit_exact(gpu, N, D, K):
+    from oracle import kmeans as ok
+    rng = np.random.default_rng(N + D + K)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    C = rng.standard_normal((K, D)).astype(np.float32)
+    C[K // 2] = C[3]                                                 # an exact tie: the lower index must win
+    lab, best = _assign_perm_gpu(X, C)
+    olab, obest, _ = ok.assign(X, C, with_scores=True)
+    assert np.array_equal(best.view(np.uint32), obest.view(np.uint32)), np.abs(best - obest).max()
+    assert np.array_equal(lab, olab)
+    assert not np.any(lab == K // 2)
+
+
 def test_assign_ties_first_index(gpu):
     X = np.ones((300, 16), np.float32)
     C = np.zeros((140, 16), np.float32)

@@ -49,7 +49,11 @@ def test_self_retrieval_and_distance_matrix(gpu, golden_dir):
     np.testing.assert_allclose(get_distance_matrix(X, Y, 'cosine'), cosine_distances(X, Y), atol=3e-6)
 
 
-@pytest.mark.parametrize("Nq,Ng,D,k", [(1, 50, 8, 50), (129, 1000, 128, 1), (1000, 20000, 512, 20), (33, 257, 40, 7)])
+# every partial kernel of csrc/topk.hip: query operand in registers with 4 / 8 / 16 k-tiles (D <= 128 / 256 / 512), the
+# 2-stage ring for D > 512, the short pending columns of a large k, several gallery slices with a ragged last one
+@pytest.mark.parametrize("Nq,Ng,D,k", [(1, 50, 8, 50), (129, 1000, 128, 1), (1000, 20000, 512, 20), (33, 257, 40, 7),
+                                       (200, 3001, 256, 50), (300, 40000, 200, 50), (64, 2000, 640, 10),
+                                       (100, 5000, 512, 88), (130, 700, 1024, 3)])
 def test_topk_shapes_vs_oracle(gpu, Nq, Ng, D, k):
     from oracle import retrieval as orr
     from video_similarity_search_amd.evaluate import cosine_topk

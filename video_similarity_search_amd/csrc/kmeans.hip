@@ -272,6 +272,8 @@ __global__ __launch_bounds__(256) void km_assign_dma(
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // the lane's centroid index rises with (ct, g), so a strict '<' alone keeps the first minimum; cn - 2 acc as ONE fma is the
+  // same float as the rounded difference (2 acc is exact)
   float best = INFINITY;
   int bidx = 0x7fffffff;
 #pragma unroll
@@ -279,10 +281,8 @@ __global__ __launch_bounds__(256) void km_assign_dma(
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
       const int c = cblock + (wc * TC + ct) * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-      if (c < K) {
-        const float s = cnorm[c] - 2.0f * acc[ct][g];
-        if (s < best || (s == best && c < bidx)) { best = s; bidx = c; }
-      }
+      const float s = c < K ? __builtin_fmaf(-2.0f, acc[ct][g], cnorm[c]) : INFINITY;
+      if (s < best) { best = s; bidx = c; }
     }
   const float ob = __shfl_xor(best, 32);
   const int oi = __shfl_xor(bidx, 32);
@@ -293,6 +293,188 @@ __global__ __launch_bounds__(256) void km_assign_dma(
     pscore[grp * N + p] = best;
     pidx[grp * N + p] = bidx;
   }
+}
+
+// D <= 512, K >= 128: the CENTROID operand lives in registers (the retrieval kernel's layout with the roles of the operands
+// swapped, csrc/topk.hip topk_partial_qreg).  A workgroup owns 128 centroids — wave w the 32 of them that form its MFMA A
+// operand, NK * 16 registers per lane, loaded once — and streams a contiguous slice of the points through a 4-stage LDS ring:
+// the grid is ONE residency round (centroid blocks x point slices <= the CUs), so no launch, prologue or epilogue sits between
+// the 16 k-tiles of a 128 x 128 tile as in km_assign_dma (6256 workgroups of 16 k-tiles each at 100k x 512 x 500), the DMA
+// of step s + 3 is issued at step s and waited for at step s + 2, and the last quarter of a step fetches the first fragments
+// of the next.  Same k order inside every accumulator, same score expression, same tie rule: bit-identical labels.
+// Partial lists: one per 32-centroid group (cb * 4 + wave), as km_combine expects.
+#ifdef KM_STAMPS
+__device__ unsigned long long km_cnt[8];
+extern "C" int slic_debug_km_counters(unsigned long long* out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(km_cnt), sizeof(km_cnt));
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(km_cnt), z, sizeof(z)); }
+  return 0;
+}
+static __device__ inline unsigned long long km_now() {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  return t;
+}
+#define KMS(...) __VA_ARGS__
+#else
+#define KMS(...)
+#endif
+template <int NK, int ST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void km_assign_creg(
+    const float* __restrict__ Xp, int64_t N, int D, int ldx, const float* __restrict__ Cp, int K,
+    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx) {
+  extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  static_assert(NK % ST == 0 && ST == 4, "a point tile is a whole number of ring turns; the DMA's LDS base (M0) reaches 64 KB: 4 stages of 16 KB");
+  constexpr int BP = 128;
+  constexpr int STAGE_FLOATS = BP * KM_BK;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  // this workgroup's point tiles: an even split of the ceil(N / 128) tiles over the gridDim.x slices
+  const int64_t tiles = (N + BP - 1) / BP;
+  const int64_t t0 = tiles * blockIdx.x / gridDim.x, t1 = tiles * (blockIdx.x + 1) / gridDim.x;
+  const int ntile = (int)(t1 - t0);
+#ifdef KM_DBG_HOT
+  const int64_t pbeg = 0;   // diagnostic: every slice streams the same rows (L2-resident)
+#else
+  const int64_t pbeg = t0 * BP;
+#endif
+  const int64_t prow = (N - pbeg) < (int64_t)ntile * BP ? (N - pbeg) : (int64_t)ntile * BP;     // rows of the slice
+  const int grp = blockIdx.y * 4 + wave;                       // this wave's 32-centroid group
+  const int cbase = grp * 32;
+  // lane (r, h) of MFMA step (kt, q, t) supplies C[cbase + r][32 kt + 8 q + 4 h + t] (operands are in the k8-permuted order)
+  f32x4 cr[NK][4];
+  {
+    const int crow = cbase + r;
+    const float* cp = Cp + (int64_t)(crow < K ? crow : K - 1) * ldc;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * kt + 8 * q + 4 * h;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        cr[kt][q] = (c < D && crow < K) ? *(const f32x4*)(cp + c) : z;
+      }
+  }
+  // accumulator element g of this lane is centroid cbase + (g & 3) + 8 (g >> 2) + 4 h
+  float cn[16];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    const int c = cbase + (g & 3) + 8 * (g >> 2) + 4 * h;
+    cn[g] = c < K ? cnorm[c] : INFINITY;
+  }
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Xp + pbeg * (int64_t)ldx), 0, prow > 0 ? (int)(((prow - 1) * (int64_t)ldx + D) * 4) : 0, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned xoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xoff[i] = ((unsigned)(srow + 32 * i) * (unsigned)ldx + cq * 4) * 4u;
+  const int klim = D - cq * 4;
+  // ring step (tile, kt): rows past the slice (the ragged last tile, the ring running past the last tile) lie past the buffer
+  // resource's range and come back as zeros by themselves; k-tiles past D are sent out of range explicitly
+  auto issue = [&](int tile, int kt, int stage) {
+    float* Xs = km_lds + stage * STAGE_FLOATS;
+    const bool kin = kt * KM_BK < klim;
+    const unsigned kb = (unsigned)kt * (KM_BK * 4u);
+    const unsigned tb = (unsigned)tile * (unsigned)(BP * ldx * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Xs + (8 * wave + 32 * i) * KM_BK),
+                                               16, (int)(kin ? tb + xoff[i] + kb : OOB), 0, 0, 0);
+  };
+  KMS(unsigned long long kc_[4] = {0, 0, 0, 0}; const unsigned long long kt00_ = km_now();)
+  f32x16 acc[4];                                               // 4 point sub-tiles of 32 x this wave's 32 centroids
+  f32x4 b[2][4];                                               // point fragments, double-buffered ACROSS k-tiles
+  float obest[4];                                              // the finished tile's results, stored one step later
+  int oidx[4];
+  int64_t op0 = -1;
+#pragma unroll
+  for (int u = 0; u < ST - 1; ++u) issue(u / NK, u % NK, u);   // steps 0 .. ST - 2
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ST - 2)) : "memory");             // step 0 has landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) b[0][pt] = *(const f32x4*)&km_lds[km_off(32 * pt + r, h)];
+  KMS(kc_[0] = km_now() - kt00_;)
+  for (int tile = 0; tile < ntile; ++tile) {
+    KMS(const unsigned long long ka_ = km_now();)
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[pt][g] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      // step s = (tile, kt) computes from stage kt % ST.  Outstanding loads here: the DMAs of steps s + 1 .. s + ST - 2 (4 each);
+      // stores of the previous tile's results may sit between them — they only make the wait stricter.
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ST - 3)) : "memory");         // step s + 1 has landed
+      __builtin_amdgcn_s_barrier();
+      {
+        const int kn = kt + ST - 1;                             // step s + ST - 1
+        issue(kn >= NK ? tile + 1 : tile, kn >= NK ? kn - NK : kn, kn % ST);
+      }
+      if (kt == 0 && op0 >= 0) {
+        // the previous tile's partial argmin: written HERE, a whole k-tile before the next vmcnt wait, not in front of it
+        if (h == 0 && cbase < K) {                              // a group entirely past K has no list
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt) {
+            const int64_t p = op0 + 32 * pt + r;
+            if (p < N) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
+          }
+        }
+      }
+      const float* Xs = km_lds + (kt % ST) * STAGE_FLOATS;
+      const float* Xn = km_lds + ((kt + 1) % ST) * STAGE_FLOATS;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cur = q & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+          b[nxt][pt] = q < 3 ? *(const f32x4*)&Xs[km_off(32 * pt + r, 2 * (q + 1) + h)]
+                             : *(const f32x4*)&Xn[km_off(32 * pt + r, h)];        // first fragments of the next step
+        // k order inside every accumulator: q ascending, t ascending, lane half 0 then 1 => k ascending (permuted operands)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int pt = 0; pt < 4; ++pt)
+            acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[kt][q][t], b[cur][pt][t], acc[pt], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    KMS(const unsigned long long kb_ = km_now(); kc_[1] += kb_ - ka_;)
+    // argmin over this wave's 32 centroids: ascending index inside the lane, then across the two lane halves; '<' / lower index
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      // the lane's centroid index rises with g, so a strict '<' alone keeps the first minimum; a centroid past K scores +inf
+      // (cn = +inf) and never wins; cn - 2 acc as ONE fma is the same float as the rounded difference (2 acc is exact)
+      float best = INFINITY;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float sc = __builtin_fmaf(-2.0f, acc[pt][g], cn[g]);
+        if (sc < best) { best = sc; bidx = cbase + (g & 3) + 8 * (g >> 2) + 4 * h; }
+      }
+      const float ob = __shfl_xor(best, 32);
+      const int oi = __shfl_xor(bidx, 32);
+      if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+      obest[pt] = best;
+      oidx[pt] = bidx;
+    }
+    op0 = pbeg + (int64_t)tile * BP;
+    KMS(kc_[2] += km_now() - kb_;)
+  }
+  if (op0 >= 0 && h == 0 && cbase < K) {
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const int64_t p = op0 + 32 * pt + r;
+      if (p < N) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
+  KMS(kc_[3] = km_now() - kt00_; if (lane == 0) for (int i_ = 0; i_ < 4; ++i_) atomicAdd(&km_cnt[i_], kc_[i_]);)
 }
 
 // out[i][8g + {0,1,2,3,4,5,6,7}] = in[i][8g + {0,2,4,6,1,3,5,7}]   (D % 8 == 0)
@@ -1250,13 +1432,50 @@ extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ld
   SLIC_REQUIRE(!labels_old || n_changed, "slic_kmeans_assign_perm: labels_old needs n_changed");
   // tile / ring: 128 points x 64 centroids, 2 stages (measured best: a 64 x 64 tile with 2 x 2 waves fills the grid more evenly
   // but loses the same few % inside the loop; 3 stages and 128 x 128 tiles were slower)
-  const int G = (int)slic_cdiv(K, 64);
+  int G = (int)slic_cdiv(K, 64);
   SlicCarver w(workspace);
   float* pscore = w.take<float>((size_t)slic_cdiv(K, 32) * N);
   int32_t* pidx = w.take<int32_t>((size_t)slic_cdiv(K, 32) * N);
   hipStream_t st = S(stream);
-  int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
-  if (rc) return rc;
+  // Centroids in registers (km_assign_creg) when a 128-centroid block per workgroup wastes little (K = 500 -> 512) and the
+  // blocks x slices grid can cover the device: one residency round of 1-workgroup-per-CU workgroups.
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    SLIC_HIP_CHECK(hipGetDevice(&dev));
+    SLIC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  const int ncb = (int)slic_cdiv(K, 128);
+  const int64_t tiles = slic_cdiv(N, 128);
+  int slices = ncb <= cus ? cus / ncb : 0;
+  if (slices > tiles) slices = (int)tiles;
+#ifdef KM_NO_CREG
+  const bool creg = false &&
+#else
+  const bool creg = D <= 512 &&
+#endif
+                     slices >= 1 && (int64_t)ncb * 128 * 7 <= (int64_t)K * 8 &&          // <= 1/8 padding
+                    tiles >= 4 * (int64_t)slices &&                                              // a few tiles per workgroup
+                    (slic_cdiv(tiles, slices) * 128 + 128) * (int64_t)ldx * 4 < (1ll << 31);        // slice inside one resource
+  if (creg) {
+    const size_t lds = (size_t)4 * 128 * KM_BK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_creg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_creg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_creg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    dim3 grid((unsigned)slices, (unsigned)ncb);
+    if (D > 256) km_assign_creg<16, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+    else if (D > 128) km_assign_creg<8, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+    else km_assign_creg<4, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+    SLIC_LAUNCH_CHECK();
+    G = (int)slic_cdiv(K, 32);                                // groups past K are never written and never read
+  } else {
+    int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+    if (rc) return rc;
+  }
   km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, st>>>(pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;

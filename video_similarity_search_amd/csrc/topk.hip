@@ -296,11 +296,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
   auto issue = [&](int tile, int kt, int stage) {
     float* Gs = lds + stage * STAGE_FLOATS;
     float* Qs = Gs + TK_BG * TK_BK;
-#if defined(TK_ABL) && (TK_ABL & 1)
-    const bool kin = false;
-#else
     const bool kin = kt * TK_BK < klim && tile < ntile;
-#endif
     const unsigned kb = (unsigned)kt * (TK_BK * 4u);
     const unsigned gb = (unsigned)tile * (unsigned)(TK_BG * D * 4);
 #pragma unroll
@@ -403,9 +399,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
       for (int sidx = 0; sidx < 2; ++sidx) {
         const int kt = s0 + sidx;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if !(defined(TK_ABL) && (TK_ABL & 4))
         __builtin_amdgcn_s_barrier();
-#endif
         const bool wrap = kt + 1 >= nkp;                       // the next ring step opens the next gallery tile
         issue(wrap ? tile + 1 : tile, wrap ? 0 : kt + 1, sidx ^ 1);
         // the best bound the other slices have published: asked for two k-tiles before the tile ends, so the round trip
@@ -446,12 +440,6 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
     // past Nq test against +inf
     const float gbb = __shfl(gb, r);
     float filt = fmaxf(__shfl(thr, r), gbb);
-#if defined(TK_ABL) && (TK_ABL & 2)
-    { float sm = 0.f;
-      for (int ct = 0; ct < 4; ++ct) for (int v = 0; v < 16; ++v) sm += acc[ct][v];
-      if (sm == 12345.678f) thr = sm;
-      filt = INFINITY; }
-#endif
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -510,7 +498,7 @@ __global__ __launch_bounds__(256) void topk_partial_dma(
 //  * the barrier of step s publishes stage s + 1, so the last quarter of step s already fetches the first fragments of step
 //    s + 1: after the next barrier the MFMAs start at once.
 // Same k order inside every accumulator as topk_partial_dma, same scan / drain / bound logic: bit-identical lists.
-template <int NK>
+template <int NK, int GS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void topk_partial_qreg(
     const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
     int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */,
@@ -518,7 +506,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   TKC_DECL
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(NK % 4 == 0, "a gallery tile is a whole number of ring turns");
-  constexpr int GS = 4;
   constexpr int STAGE_FLOATS = TK_BG * TK_BK;                  // gallery rows only
   const int kh = 1 + ((k + 2) / 4) * 4;
   unsigned long long* heaps = (unsigned long long*)(lds + 4 * STAGE_FLOATS);
@@ -903,7 +890,6 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   if ((int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31)) {
     static size_t lds_set2 = 0;
     if (lds > lds_set2) {
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       lds_set2 = lds;
@@ -911,25 +897,27 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
     int* gthr = w.take<int>((size_t)Nq);
     SLIC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)gthr, (int)0x807FFFFF, (size_t)Nq, st));   // the image of -inf
 #ifndef TK_NO_QREG
-    if (pcap >= 12 && D <= 512) {
+    if (D <= 512) {
       static size_t lds_set3 = 0;
       if (lds > lds_set3) {
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set3 = lds;
       }
-      if (D > 256) topk_partial_qreg<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
-      else if (D > 128) topk_partial_qreg<8><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
-      else topk_partial_qreg<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
+#define TK_LAUNCH_QREG(NK, GS) topk_partial_qreg<NK, GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr)
+      if (pcap >= 12) {                                       // pending columns long enough for groups of four scores
+        if (D > 256) TK_LAUNCH_QREG(16, 4); else if (D > 128) TK_LAUNCH_QREG(8, 4); else TK_LAUNCH_QREG(4, 4);
+      } else {
+        if (D > 256) TK_LAUNCH_QREG(16, 2); else if (D > 128) TK_LAUNCH_QREG(8, 2); else TK_LAUNCH_QREG(4, 2);
+      }
+#undef TK_LAUNCH_QREG
     } else
 #endif
-#ifdef TK_FORCE_GS
-    if (true) topk_partial_dma<TK_FORCE_GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
-    else
-#endif
     if (pcap >= 12) topk_partial_dma<4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
-    else if (pcap >= 400) topk_partial_dma<16><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
     else topk_partial_dma<2><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr);
   } else
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, (2 * pcap) & ~1, pval, pidx);

@@ -121,6 +121,7 @@ class ConvPlan:
                                            tab=torch.from_numpy(t).to(device), tap=tapt))
         self._wp = None
         self._wd = None
+        self._wp_key = self._wd_key = None
         self._row_tabs = {}
         self.prof = None      # bench.py: list collecting (start, end) HIP event pairs around conv_gemm launches
 
@@ -152,6 +153,7 @@ class ConvPlan:
         self.Kp = self.nchunks_fwd * 4
         self.dgrad_classes = []                              # the clip needs no gradient
         self._wp = self._wd = None
+        self._wp_key = self._wd_key = None
         self._row_tabs = {}
         self.prof = None
 
@@ -169,7 +171,19 @@ class ConvPlan:
         return y
 
     # ------------------------------------------------------------------ weights
+    # The packed operands are kept per plan and reused while `weight` is the tensor they were packed from: the encoder packs
+    # every layer's weights on a side stream when a pass starts (resnet._Engine.prepack — off the critical path), and the
+    # launches below then find them ready.  The key is dropped at every pass entry, so a pack never outlives a pass.
+    @staticmethod
+    def _wkey(weight):
+        return (weight.data_ptr(), weight._version)
+
+    def drop_packs(self):
+        self._wp_key = self._wd_key = None
+
     def pack_fwd(self, weight):
+        if self._wp_key is not None and self._wp_key == self._wkey(weight):
+            return self._wp
         if self._wp is None:     # zeroed once: the packer writes real elements only, the padding stays zero
             self._wp = torch.zeros(self.N, self.Kp, dtype=torch.float32, device=self.device)
         if self.wrun:
@@ -177,14 +191,18 @@ class ConvPlan:
                  ptr(self._wp), stream())
         else:
             call("slic_pack_weight_fwd", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kp, ptr(self._wp), stream())
+        self._wp_key = self._wkey(weight)
         return self._wp
 
     def pack_dgrad(self, weight):
         if self.wrun:
             raise _lib.SlicError("the W-run operand serves forward and weight gradient only (the clip needs no gradient)")
+        if self._wd_key is not None and self._wd_key == self._wkey(weight):
+            return self._wd
         if self._wd is None:
             self._wd = torch.zeros(self.Cs, self.Kd, dtype=torch.float32, device=self.device)
         call("slic_pack_weight_dgrad", ptr(weight), self.N, self.C, self.ntaps, self.Cs, self.Kd, ptr(self._wd), stream())
+        self._wd_key = self._wkey(weight)
         return self._wd
 
     # ------------------------------------------------------------------ launches
