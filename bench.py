@@ -145,7 +145,7 @@ def kmeans_secondary(rank, world, pg, run_cpu):
     flops = 2.0 * n_loc * K * D
     out["roofline"] = dict(bound="mfma", achieved=flops / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
                            unit="TFLOP/s", frac=flops / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, traffic=None,
-                           kernel="km_assign_dma<128,2,1,2> (+ km_combine)", ms_per_launch=ms,
+                           kernel="km_assign_creg<16,4> (centroids in registers, points through a 4-stage LDS ring) + km_combine", ms_per_launch=ms,
                            algorithmic_flops_per_launch=flops)
     if run_cpu:
         from oracle import kmeans as ok
@@ -205,7 +205,7 @@ def retrieval_secondary(run_cpu):
     out = dict(metric="retrieval queries/sec, 10k x 512 vs 100k x 512 cosine top-50", value=Nq / t, unit="queries/s",
                ms=t * 1e3, roofline=dict(bound="mfma", achieved=fl / t / 1e12, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                                          frac=fl / t / 1e12 / FP32_MFMA_PEAK_TFLOPS, traffic=None,
-                                         kernel="topk_partial_dma + topk_merge_kernel (whole call incl. row normalisation)",
+                                         kernel="topk_partial_qreg<16,4> + topk_merge_kernel (whole call incl. row normalisation)",
                                          algorithmic_flops_per_launch=fl))
     if run_cpu:
         # the reference's own arithmetic on the host (sklearn cosine_distances = normalise + GEMM; then top-k): NumPy
@@ -341,7 +341,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # dominant kernel: the gather-GEMM (conv_gemm_dma_kernel<128,64,2,2,2,1,true>) on the 64->64 3x3x3 layers (layer1: 4 forward +
+    # dominant kernel: the gather-GEMM (conv_gemm_dma_kernel<128,64,2,2,2,32>) on the 64->64 3x3x3 layers (layer1: 4 forward +
     # 4 data-gradient launches per step, identical M x N x K) — bracket every such launch of the timed steps with HIP events
     eng = net._engine(x)
     l1 = [p for (_, p1, p2, _) in eng.blocks[:2] for p in (p1, p2)]
@@ -397,7 +397,7 @@ def main():
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
                              traffic_source=traffic_src,
-                             kernel="conv_gemm_dma_kernel<128,64,2,2,2,1,true> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring, DMA issue interleaved with the MFMAs; fwd + dgrad of layer1)",
+                             kernel="conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring, DMA issue interleaved with the MFMAs; fwd + dgrad of layer1)",
                              ms_per_launch=ms_k, launches_timed=len(ev), algorithmic_flops_per_launch=flops_launch,
                              whole_step_frac=(world * B * args.steps / dt) * GFLOP_PER_CLIP_TRAIN / 1e3 /
                                              (FP32_MFMA_PEAK_TFLOPS * world)))
