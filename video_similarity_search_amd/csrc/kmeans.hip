@@ -1276,10 +1276,14 @@ __global__ __launch_bounds__(256) void kpp_dist_mfma(const float* __restrict__ X
 // then a fixed shuffle tree) — sel = first minimum, idx_out = cand[sel], csum[b] = inclusive scan over b of bpart[b][sel]
 // (per-thread runs, wave shuffle scans, one scan of the 16 wave totals).  Latency-bound: a handful of barriers in all.
 #define KPP_ST 1024
+// The draw of the NEXT step's candidates (kpp_search's arithmetic, wave t = candidate t) follows in the same launch when
+// u_next is given: it needs nothing but this launch's csum / sel / potential, and a separate 7 us launch per centre is a
+// tenth of a k-means++ run.  csum and cand are deliberately not __restrict__/const here: they are written and re-read.
 __global__ __launch_bounds__(KPP_ST) void kpp_select(const double* __restrict__ bpart, int64_t nblk, int T,
-                                                     const int32_t* __restrict__ cand, int32_t* __restrict__ sel,
-                                                     double* __restrict__ cur_pot, double* __restrict__ csum,
-                                                     int32_t* __restrict__ idx_out) {
+                                                     int32_t* cand, int32_t* __restrict__ sel,
+                                                     double* __restrict__ cur_pot, double* csum,
+                                                     int32_t* __restrict__ idx_out, const float* __restrict__ nd_cur, int64_t N,
+                                                     const double* __restrict__ u_next, int Tn) {
   __shared__ double pots[PP_TMAX];
   __shared__ double wtot[KPP_ST / 64];
   __shared__ int s_sel;
@@ -1317,6 +1321,33 @@ __global__ __launch_bounds__(KPP_ST) void kpp_select(const double* __restrict__ 
   for (int w = 0; w < wave; ++w) woff += wtot[w];                       // <= 15 adds, same order in every thread of the wave
   double a = woff + inc - run;                                          // exclusive offset of this thread's run
   for (int64_t c = c0; c < c1; ++c) { a += bpart[c * T + b]; csum[c] = a; }
+  if (!u_next) return;
+  __syncthreads();                                                       // csum is complete (and visible: one workgroup)
+  static_assert(KPP_CH == 64 && KPP_ST / 64 >= PP_TMAX, "one wave per candidate, one element per lane");
+  if (wave >= Tn) return;
+  // x = u * potential; searchsorted(cumsum(v), x, 'left') with the cumsum taken in KPP_CH-element chunks — kpp_search, verbatim
+  const float* v = nd_cur + (int64_t)b * N;
+  const double x = u_next[wave] * pots[b];
+  int64_t lo = 0, hi = nblk;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (csum[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  int64_t res = N;
+  if (lo < nblk) {
+    const double base = lo ? csum[lo - 1] : 0.0;
+    const int64_t e = lo * KPP_CH + lane;
+    const double part = e < N ? (double)v[e] : 0.0;
+    double runs = base, incl = 0.0;
+    for (int l = 0; l < 64; ++l) {                       // sequential inclusive scan in lane order
+      runs += __shfl(part, l);
+      if (l == lane) incl = runs;
+    }
+    const unsigned long long m = __ballot(incl >= x && e < N);
+    res = m ? lo * KPP_CH + (__ffsll((long long)m) - 1) : ((lo + 1) * KPP_CH < N ? (lo + 1) * KPP_CH : N);
+  }
+  if (res > N - 1) res = N - 1;
+  if (lane == 0) cand[wave] = (int32_t)res;
 }
 
 // one WAVE per query: x = u * (*cur_pot); searchsorted(cumsum(v), x, 'left') with the cumsum taken in KPP_CH-element
@@ -1701,19 +1732,18 @@ extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int 
   if (mfma) kpp_dist_mfma<<<dim3(nblk_m), dim3(256), lds_m, st>>>(Xp, xnorm, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart, nblk);
   else kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)D * 4, st>>>(X, N, D, ldx, cand, 1, nullptr, nullptr, nd, bpart);
   SLIC_LAUNCH_CHECK();
-  kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, 1, cand, sel, cur_pot, csum, idx_out);
+  // every select also draws the next step's T candidates (uniforms of step c at uniforms + (c - 1) T) from the distances it chose
+  kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, 1, cand, sel, cur_pot, csum, idx_out, nd, N, K > 1 ? uniforms : nullptr, T);
   SLIC_LAUNCH_CHECK();
   for (int c = 1; c < K; ++c) {
     const float* prev = nd + (size_t)((c - 1) & 1) * T * N;
     float* cur = nd + (size_t)(c & 1) * T * N;
-    kpp_search<<<dim3((unsigned)slic_cdiv(T, 4)), dim3(256), 0, st>>>(prev, sel, N, csum, nblk, uniforms + (size_t)(c - 1) * T,
-                                                                 cur_pot, T, cand);
-    SLIC_LAUNCH_CHECK();
     if (mfma) kpp_dist_mfma<<<dim3(nblk_m), dim3(256), lds_m, st>>>(Xp, xnorm, N, D, ldx, cand, T, prev, sel, cur, bpart, nblk);
     else if (T <= 8) kpp_dist_rows<8><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
     else kpp_dist_rows<16><<<dim3((unsigned)nblk), dim3(256), (size_t)T * D * 4, st>>>(X, N, D, ldx, cand, T, prev, sel, cur, bpart);
     SLIC_LAUNCH_CHECK();
-    kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c);
+    kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c, cur, N,
+                                                 c + 1 < K ? uniforms + (size_t)c * T : nullptr, T);
     SLIC_LAUNCH_CHECK();
   }
   return SLIC_OK;
