@@ -8,8 +8,8 @@ GRID = 12544 * 256                      # layer1 shape at B = 32: M = 1 605 632 
 
 
 def find(sub, pat):
-    f = sorted(glob.glob(os.path.join(scratch, sub, "**", pat), recursive=True))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(scratch, sub, "**", pat), recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None      # the newest: gpurun merges a new collection INTO the local scratch directory
 
 
 def counter_mean(sub, name):
