@@ -183,143 +183,6 @@ __global__ __launch_bounds__(64 * BN_MQ) void sum_merge_level(const Tin* __restr
   }
 }
 
-// The whole merge as ONE launch (BN_MG < R <= BN_MG * BN_MG * BN_MQ slab rows): every workgroup merges its group of BN_MG rows
-// (level 1, as bn_merge_level / sum_merge_level) and takes a ticket; the workgroup that draws the last ticket of its channel
-// block merges the level-1 rows — in row order, whoever it is, so the result does not depend on the arrival order — and
-// finalises.  Three short launches per BatchNorm and direction (two kernel boundaries of ~10 us on the critical path) become
-// one.  The level-1 rows are read back with agent-scope loads; the ticket counter is left at zero for the next launch.
-struct BnFinArgs {
-  float eps, momentum;
-  const float *gamma, *beta;
-  float *mean, *invstd, *scale, *shift, *running_mean, *running_var;
-};
-struct SumFinArgs {
-  float *dgamma, *dbeta;
-  double *ka, *kb;
-};
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool CHAN>
-__global__ __launch_bounds__(64 * BN_MQ) void merge_fused(const float* __restrict__ in, int R, int64_t rows_in, int C, int64_t M,
-                                                          double* lvl1, unsigned* tickets, BnFinArgs bf, SumFinArgs sf) {
-  __shared__ double sh[BN_MQ][4][64];
-  __shared__ unsigned s_ticket;
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  const int q = threadIdx.y;
-  const int grp = blockIdx.y, G = gridDim.y;
-  {
-    const int g0 = grp * BN_MG;
-    const int g1 = g0 + BN_MG < R ? g0 + BN_MG : R;
-    const int r0 = g0 + q * (BN_MG / BN_MQ);
-    const int r1 = r0 + BN_MG / BN_MQ < g1 ? r0 + BN_MG / BN_MQ : g1;
-    double n = 0.0, mean = 0.0, m2 = 0.0, sum = 0.0;       // CHAN: Chan's update; else sum = plane 0, m2 = plane 1
-    if (c < C) {
-      for (int r = r0; r < r1; ++r) {
-        const double p0 = (double)in[((int64_t)r * 2 + 0) * C + c], p1 = (double)in[((int64_t)r * 2 + 1) * C + c];
-        if (CHAN) {
-          const int64_t left = M - (int64_t)r * rows_in;
-          const double nb = (double)(left < rows_in ? left : rows_in);
-          const double d = p0 / nb - mean;
-          const double nn = n + nb;
-          m2 += p1 + d * d * n * nb / nn;
-          mean += d * nb / nn;
-          n = nn;
-        } else m2 += p1;
-        sum += p0;
-      }
-    }
-    sh[q][0][threadIdx.x] = n; sh[q][1][threadIdx.x] = mean; sh[q][2][threadIdx.x] = m2; sh[q][3][threadIdx.x] = sum;
-    __syncthreads();
-    if (q == 0 && c < C) {
-#pragma unroll
-      for (int u = 1; u < BN_MQ; ++u) {
-        const double nb = sh[u][0][threadIdx.x];
-        if (CHAN) {
-          if (nb > 0.0) {
-            const double d = sh[u][1][threadIdx.x] - mean;
-            const double nn = n + nb;
-            m2 += sh[u][2][threadIdx.x] + d * d * n * nb / nn;
-            mean += d * nb / nn;
-            n = nn;
-          }
-        } else m2 += sh[u][2][threadIdx.x];
-        sum += sh[u][3][threadIdx.x];
-      }
-      lvl1[((int64_t)grp * 2 + 0) * C + c] = sum;
-      lvl1[((int64_t)grp * 2 + 1) * C + c] = m2;
-    }
-  }
-  __threadfence();                                         // this group's row is out before the ticket is
-  __syncthreads();
-  if (threadIdx.x == 0 && q == 0) s_ticket = atomicAdd(&tickets[blockIdx.x], 1u);
-  __syncthreads();
-  if (s_ticket != (unsigned)(G - 1)) return;
-  __threadfence();
-  // ---- last workgroup of this channel block: the G level-1 rows (each covers rows_in * BN_MG slab rows' worth of samples)
-  const int64_t rows2 = rows_in * BN_MG;
-  const int per = (G + BN_MQ - 1) / BN_MQ;
-  const int r0 = q * per;
-  const int r1 = r0 + per < G ? r0 + per : G;
-  double n = 0.0, mean = 0.0, m2 = 0.0, sum = 0.0;
-  if (c < C) {
-    for (int r = r0; r < r1; ++r) {
-      const double p0 = ld_agent(&lvl1[((int64_t)r * 2 + 0) * C + c]), p1 = ld_agent(&lvl1[((int64_t)r * 2 + 1) * C + c]);
-      if (CHAN) {
-        const int64_t left = M - (int64_t)r * rows2;
-        const double nb = (double)(left < rows2 ? left : rows2);
-        const double d = p0 / nb - mean;
-        const double nn = n + nb;
-        m2 += p1 + d * d * n * nb / nn;
-        mean += d * nb / nn;
-        n = nn;
-      } else m2 += p1;
-      sum += p0;
-    }
-  }
-  __syncthreads();                                         // sh is reused
-  sh[q][0][threadIdx.x] = n; sh[q][1][threadIdx.x] = mean; sh[q][2][threadIdx.x] = m2; sh[q][3][threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0 && q == 0) tickets[blockIdx.x] = 0; // ready for the next launch on this stream
-  if (q != 0 || c >= C) return;
-#pragma unroll
-  for (int u = 1; u < BN_MQ; ++u) {
-    const double nb = sh[u][0][threadIdx.x];
-    if (CHAN) {
-      if (nb > 0.0) {
-        const double d = sh[u][1][threadIdx.x] - mean;
-        const double nn = n + nb;
-        m2 += sh[u][2][threadIdx.x] + d * d * n * nb / nn;
-        mean += d * nb / nn;
-        n = nn;
-      }
-    } else m2 += sh[u][2][threadIdx.x];
-    sum += sh[u][3][threadIdx.x];
-  }
-  if (CHAN) {                                               // as bn_merge_final
-    const double mu = sum / (double)M;
-    double var = m2 / (double)M;
-    if (var < 0.0) var = 0.0;
-    const float is = (float)(1.0 / sqrt(var + (double)bf.eps));
-    const float g = bf.gamma ? bf.gamma[c] : 1.f, b = bf.beta ? bf.beta[c] : 0.f;
-    bf.mean[c] = (float)mu;
-    bf.invstd[c] = is;
-    const float sc = g * is;
-    bf.scale[c] = sc;
-    bf.shift[c] = b - (float)mu * sc;
-    if (bf.running_mean) {
-      const double unb = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
-      bf.running_mean[c] = (1.f - bf.momentum) * bf.running_mean[c] + bf.momentum * (float)mu;
-      bf.running_var[c] = (1.f - bf.momentum) * bf.running_var[c] + bf.momentum * (float)unb;
-    }
-  } else {                                                  // as sum_merge_final
-    if (sf.dbeta) sf.dbeta[c] = (float)sum;
-    if (sf.dgamma) sf.dgamma[c] = (float)m2;
-    sf.ka[c] = sum / (double)M;
-    sf.kb[c] = m2 / (double)M;
-  }
-}
-
 // eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -484,23 +347,6 @@ static inline unsigned ew_grid(int64_t tot) {
   return (unsigned)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
 }
 
-// Ticket counters of merge_fused: 64 per stream (one per 64-channel block), library-owned — they must be zero when a launch
-// starts and the kernel leaves them zero, which a caller-provided scratch buffer could not promise.  Allocated on first use.
-#include <mutex>
-#include <unordered_map>
-static unsigned* bn_tickets(hipStream_t st) {
-  static std::mutex mu;
-  static std::unordered_map<hipStream_t, unsigned*> tab;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = tab.find(st);
-  if (it != tab.end()) return it->second;
-  unsigned* p = nullptr;
-  if (hipMalloc((void**)&p, 64 * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
-  tab[st] = p;
-  return p;
-}
-static inline bool merge_fusable(int R, int C) { return R > BN_MG && R <= BN_MG * BN_MG * BN_MQ && C <= 64 * 64; }
-
 // scratch for the merge levels: level l holds ceil(R / MG^l) rows of 2*C doubles (two ping-pong buffers)
 static size_t merge_ws_bytes(int R, int C) {
   const size_t rows1 = (size_t)slic_cdiv(R, BN_MG);
@@ -554,21 +400,12 @@ extern "C" int slic_bn_finalize(const float* partial, int R, int rows, int C, in
                (int64_t)R * rows >= M && (int64_t)(R - 1) * rows < M, "slic_bn_finalize: bad args (R*rows must cover M)");
   SLIC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "slic_bn_finalize: running stats come in pairs");
   hipStream_t st = S_(stream);
-  const dim3 grid((unsigned)slic_cdiv(C, 64)), blk(64, BN_MQ);
-  if (merge_fusable(R, C)) {
-    unsigned* tk = bn_tickets(st);
-    SLIC_REQUIRE(tk, "slic_bn_finalize: could not allocate the ticket counters");
-    BnFinArgs bf = {eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean, running_var};
-    SumFinArgs sf = {nullptr, nullptr, nullptr, nullptr};
-    merge_fused<true><<<dim3(grid.x, (unsigned)slic_cdiv(R, BN_MG)), blk, 0, st>>>(partial, R, rows, C, M, (double*)workspace, tk, bf, sf);
-    SLIC_LAUNCH_CHECK();
-    return SLIC_OK;
-  }
   const double* dsrc = nullptr;
   int Rl = 0;
   int64_t rows_l = 0;
   int rc = run_merge<true>(partial, R, rows, C, M, workspace, st, &dsrc, &Rl, &rows_l);
   if (rc) return rc;
+  const dim3 grid((unsigned)slic_cdiv(C, 64)), blk(64, BN_MQ);
   if (dsrc) bn_merge_final<double><<<grid, blk, 0, st>>>(dsrc, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
                                                         running_mean, running_var);
   else bn_merge_final<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
@@ -599,16 +436,6 @@ extern "C" int slic_bn_bwd_rows_per_partial(void) { return BNB_RB; }
 // merge levels + the fused (last level, finalize) launch of the backward sums
 static int bwd_merge_finalize(const float* partial, int R, int64_t rows, int C, int64_t M, void* mws, hipStream_t st,
                               float* dgamma, float* dbeta, double* ka, double* kb) {
-  if (merge_fusable(R, C)) {
-    unsigned* tk = bn_tickets(st);
-    SLIC_REQUIRE(tk, "slic_bn_bwd: could not allocate the ticket counters");
-    BnFinArgs bf = {0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    SumFinArgs sf = {dgamma, dbeta, ka, kb};
-    merge_fused<false><<<dim3((unsigned)slic_cdiv(C, 64), (unsigned)slic_cdiv(R, BN_MG)), dim3(64, BN_MQ), 0, st>>>(
-        partial, R, rows, C, M, (double*)mws, tk, bf, sf);
-    SLIC_LAUNCH_CHECK();
-    return SLIC_OK;
-  }
   const double* dsrc = nullptr;
   int Rl = 0;
   int64_t rows_l = 0;
