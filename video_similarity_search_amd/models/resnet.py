@@ -60,6 +60,12 @@ class _Bn:
     """per-call view of one BatchNorm layer: parameters + the statistics this pass produced"""
 
     def __init__(self, mod):
+        if isinstance(mod, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size(mod.process_group) > 1:
+            # online_train.py:466-468 converts to SyncBatchNorm only under cfg.SYNC_BATCH_NORM (default False, no shipped
+            # config sets it).  The engine takes rank-local statistics — refuse rather than train with different semantics.
+            raise NotImplementedError("SyncBatchNorm across ranks is not built (cfg.SYNC_BATCH_NORM is off in every shipped "
+                                      "config): the HIP BatchNorm uses rank-local batch statistics")
         self.mod = mod
         self.C = mod.num_features
         self.mean = self.invstd = self.scale = self.shift = None
