@@ -256,6 +256,27 @@ int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* 
  * the W-run stem operand */
 int slic_ncdhw_to_ndhwc_wpad(const float* x, int B, int C, int64_t R, int W, int pad_left, int Wp, float* y, void* stream);
 
+/* SyncBatchNorm (online_train.py:466-468 -> torch.nn.SyncBatchNorm.convert_sync_batchnorm): the rank-local halves of
+ * slic_bn_finalize / slic_bn_bwd*, with the collective left to the caller (torch.distributed over RCCL).
+ *   forward : slic_bn_merge_stats -> stats[0..C) = sum, stats[C..2C) = M2 (doubles); the caller writes its sample count to
+ *             stats[2C], all-gathers the rows in rank order, and every rank runs slic_bn_finalize_sync on [W][2C+1]
+ *             (Chan's merge in rank order; normalisation with the biased variance, running stats with the unbiased one over
+ *             the global count).
+ *   backward: slic_bn_bwd_sums -> sums[0..C) = sum g, sums[C..2C) = sum g*xhat (doubles, rank-local) + rank-local dgamma/dbeta,
+ *             from a dgrad epilogue's slab (partial, R_partial) or, partial == NULL, from dy / out (ReLU mask) / z with the masked
+ *             gradient written to g_out; the caller all-reduces `sums`, divides by the global count (ka, kb) and calls
+ *             slic_bn_bwd_apply. */
+int slic_bn_merge_stats(const float* partial, int R, int rows, int C, int64_t M, double* stats, void* workspace, void* stream);
+int slic_bn_finalize_sync(const double* stats_all, int W, int C, float eps, float momentum, const float* gamma,
+                          const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                          float* running_mean, float* running_var, void* stream);
+size_t slic_bn_bwd_sums_workspace_bytes(int64_t M, int C, int R_partial);
+int slic_bn_bwd_sums(const float* partial, int R_partial, const float* dy, const float* out, const float* z,
+                     const float* mean, const float* invstd, int64_t M, int C, float* g_out, double* sums,
+                     float* dgamma, float* dbeta, void* workspace, void* stream);
+int slic_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                      const double* ka, const double* kb, int64_t M, int C, float* dz, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * BatchNorm3d/1d + ReLU + residual + global average pool (models/resnet.py:34-57,132-133,173,183,
  * 294-299; torch defaults eps = 1e-5, momentum = 0.1).  Activations [M, C] row-major, C % 4 == 0.

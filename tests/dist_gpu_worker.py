@@ -205,6 +205,44 @@ def case_step39(rank, world, out):
              replicas_equal=all(torch.equal(allw[0], w) for w in allw), nbt=int(m.bn1.num_batches_tracked))
 
 
+def case_syncbn(rank, world, out):
+    """cfg.SYNC_BATCH_NORM (online_train.py:466-468): convert_sync_batchnorm(model) trained on W ranks with B / W clips each ==
+    the plain-BatchNorm model on all B clips in one process: same embeddings for this rank's clips, parameter gradients
+    summed over the ranks == the full-batch gradients, same running statistics.  W = 1 takes the same collective path."""
+    import copy
+    B = 4
+    m, sd0 = tiny_state_dict()
+    m = m.cuda().train()
+    rng = np.random.default_rng(77)                               # the SAME full batch on every rank
+    xfull = torch.from_numpy(rng.standard_normal((B, 3, 8, 32, 32)).astype(np.float32)).cuda()
+    wsum = torch.from_numpy(rng.standard_normal((B, 32)).astype(np.float32)).cuda()      # a fixed linear functional as the loss
+    # reference: plain BatchNorm over the whole batch
+    m.zero_grad(set_to_none=True)
+    emb_full = m(xfull)
+    (emb_full * wsum).sum().backward()
+    gfull = {k: p.grad.clone() for k, p in m.named_parameters()}
+    stats_full = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    # SyncBatchNorm on this rank's slice
+    ms = copy.deepcopy(m)
+    ms.load_state_dict(sd0)
+    ms = torch.nn.SyncBatchNorm.convert_sync_batchnorm(ms).cuda().train()
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    ms.zero_grad(set_to_none=True)
+    emb = ms(xfull[lo:hi])
+    (emb * wsum[lo:hi]).sum().backward()
+    res = dict(emb_err=float((emb - emb_full[lo:hi]).abs().max() / emb_full.abs().max()))
+    worst_g, worst_s = 0.0, 0.0
+    for k, p in ms.named_parameters():
+        g = p.grad.clone()
+        dist.all_reduce(g)                                        # sum over ranks of the rank-local gradients
+        worst_g = max(worst_g, float((g - gfull[k]).abs().max() / gfull[k].abs().max().clamp_min(1e-12)))
+    for k, v in ms.state_dict().items():
+        if "running" in k:
+            worst_s = max(worst_s, float((v - stats_full[k]).abs().max() / stats_full[k].abs().max().clamp_min(1e-12)))
+    res.update(worst_grad_rel=worst_g, worst_running_rel=worst_s, n_sync=sum(isinstance(x, torch.nn.SyncBatchNorm) for x in ms.modules()))
+    np.savez(out, **res)
+
+
 def case_launch(rank, world, out):
     raise SystemExit("case_launch is driven by the test itself (misc.distributed_helper.launch_processes)")
 

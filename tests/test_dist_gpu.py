@@ -60,6 +60,19 @@ def test_ddp_step_equals_plain_step(gpu, tmp_path, world):
 
 
 @pytest.mark.parametrize("world", _worlds())
+def test_sync_batchnorm_equals_full_batch(gpu, tmp_path, world):
+    """cfg.SYNC_BATCH_NORM (online_train.py:466-468): SyncBatchNorm over W ranks with B / W clips each == plain BatchNorm over
+    the B clips in one process — embeddings, parameter gradients summed over the ranks, running statistics (fp32 tolerance:
+    the statistics are merged in a different association)"""
+    res = _run("syncbn", world, tmp_path)
+    for r in res:
+        assert int(r["n_sync"]) == 21
+        assert float(r["emb_err"]) < 1e-5, float(r["emb_err"])
+        assert float(r["worst_grad_rel"]) < 5e-4, float(r["worst_grad_rel"])
+        assert float(r["worst_running_rel"]) < 1e-5, float(r["worst_running_rel"])
+
+
+@pytest.mark.parametrize("world", _worlds())
 def test_sharded_hip_kmeans_equals_oracle(gpu, golden_dir, tmp_path, world):
     """KMeans(process_group=WORLD) on the HIP kernels == the oracle with n_shards = W == sklearn's golden labels;
     first GPU coverage of slic_kmeans_combine_shards.  k-means++ in a sharded run: same rows on every rank, and the

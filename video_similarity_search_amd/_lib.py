@@ -62,6 +62,11 @@ SIGNATURES = {
     "slic_bn_finalize_workspace_bytes": (c_size_t, [I, I]),
     "slic_bn_finalize": (I, [P, I, I, I, L, F, F, P, P, P, P, P, P, P, P, P, P]),
     "slic_bn_eval_affine": (I, [P, P, P, P, F, I, P, P, P]),
+    "slic_bn_merge_stats": (I, [P, I, I, I, L, P, P, P]),
+    "slic_bn_finalize_sync": (I, [P, I, I, F, F, P, P, P, P, P, P, P, P, P]),
+    "slic_bn_bwd_sums_workspace_bytes": (c_size_t, [L, I, I]),
+    "slic_bn_bwd_sums": (I, [P, I, P, P, P, P, P, L, I, P, P, P, P, P, P]),
+    "slic_bn_bwd_apply": (I, [P, P, P, P, P, P, P, L, I, P, P]),
     "slic_bn_apply": (I, [P, P, P, P, I, L, I, P, P]),
     "slic_bn_bwd_workspace_bytes": (c_size_t, [L, I, I]),
     "slic_bn_bwd_rows_per_partial": (I, []),

@@ -183,6 +183,44 @@ __global__ __launch_bounds__(64 * BN_MQ) void sum_merge_level(const Tin* __restr
   }
 }
 
+// SyncBatchNorm (online_train.py:466-468, torch.nn.SyncBatchNorm): every rank's merged (sum, M2, count) row, gathered in rank
+// order, merged with Chan's update in that order (the same result on every rank) and finalised with the GLOBAL count —
+// normalisation with the biased variance, running statistics with the unbiased one over all ranks' samples.
+// stats: [W][2 C + 1] doubles = {sum[C], M2[C], n}.
+__global__ void bn_sync_final_kernel(const double* __restrict__ stats, int W, int C, float eps, float momentum,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean_o,
+                                     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                     float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int64_t ld = 2 * (int64_t)C + 1;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int w = 0; w < W; ++w) {
+    const double nb = stats[w * ld + 2 * C];
+    if (nb > 0.0) {
+      const double d = stats[w * ld + c] / nb - mean;
+      const double nn = n + nb;
+      m2 += stats[w * ld + C + c] + d * d * n * nb / nn;
+      mean += d * nb / nn;
+      n = nn;
+    }
+  }
+  double var = n > 0.0 ? m2 / n : 0.0;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_o[c] = (float)mean;
+  invstd[c] = is;
+  const float sc = g * is;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  if (running_mean) {
+    const double unb = n > 1.0 ? var * (n / (n - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
 // eval mode: scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
@@ -410,6 +448,78 @@ extern "C" int slic_bn_finalize(const float* partial, int R, int rows, int C, in
                                                         running_mean, running_var);
   else bn_merge_final<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
                                                    running_mean, running_var);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+// ---- SyncBatchNorm: the rank-local halves of slic_bn_finalize / slic_bn_bwd*, with the collective left to the caller ----
+static int bwd_merge_finalize(const float* partial, int R, int64_t rows, int C, int64_t M, void* mws, hipStream_t st,
+                              float* dgamma, float* dbeta, double* ka, double* kb);
+// merges a conv epilogue's slab down to ONE row: stats[0 .. C) = sum, stats[C .. 2C) = M2 (doubles); the caller appends its
+// sample count M as stats[2C] before the all-gather
+extern "C" int slic_bn_merge_stats(const float* partial, int R, int rows, int C, int64_t M, double* stats, void* workspace,
+                                   void* stream) {
+  SLIC_REQUIRE(partial && stats && workspace && R > 0 && C > 0 && M > 0 && rows > 0 && (int64_t)R * rows >= M &&
+               (int64_t)(R - 1) * rows < M, "slic_bn_merge_stats: bad args (R*rows must cover M)");
+  hipStream_t st = S_(stream);
+  const double* dsrc = nullptr;
+  int Rl = 0;
+  int64_t rows_l = 0;
+  int rc = run_merge<true>(partial, R, rows, C, M, workspace, st, &dsrc, &Rl, &rows_l);
+  if (rc) return rc;
+  const dim3 grid((unsigned)slic_cdiv(C, 64), 1), blk(64, BN_MQ);
+  if (dsrc) bn_merge_level<double><<<grid, blk, 0, st>>>(dsrc, Rl, rows_l, C, M, stats);
+  else bn_merge_level<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, stats);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+// stats_all: [W][2 C + 1] doubles, the W ranks' slic_bn_merge_stats rows in rank order (all-gathered by the caller)
+extern "C" int slic_bn_finalize_sync(const double* stats_all, int W, int C, float eps, float momentum, const float* gamma,
+                                     const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                                     float* running_mean, float* running_var, void* stream) {
+  SLIC_REQUIRE(stats_all && mean && invstd && scale && shift && W > 0 && C > 0, "slic_bn_finalize_sync: bad args");
+  SLIC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "slic_bn_finalize_sync: running stats come in pairs");
+  bn_sync_final_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, S_(stream)>>>(stats_all, W, C, eps, momentum, gamma, beta, mean,
+                                                                                invstd, scale, shift, running_mean, running_var);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+// backward, phase 1: the rank-local sums  sums[0 .. C) = sum g,  sums[C .. 2C) = sum g * xhat  (doubles) and the parameter
+// gradients (dgamma, dbeta are rank-local, as torch's SyncBatchNorm leaves them to DistributedDataParallel).  partial = a dgrad
+// epilogue's slab of R rows, or NULL: then pass 1 (ReLU mask if `out`, masked gradient to g_out if given) runs here first.
+extern "C" size_t slic_bn_bwd_sums_workspace_bytes(int64_t M, int C, int R_partial) {
+  const int R = R_partial > 0 ? R_partial : (int)slic_cdiv(M, BNB_RB);
+  return slic_align_up((size_t)R * 2 * C * 4, 256) + slic_align_up(merge_ws_bytes(R, C), 256);
+}
+extern "C" int slic_bn_bwd_sums(const float* partial, int R_partial, const float* dy, const float* out, const float* z,
+                                const float* mean, const float* invstd, int64_t M, int C, float* g_out, double* sums,
+                                float* dgamma, float* dbeta, void* workspace, void* stream) {
+  SLIC_REQUIRE(sums && workspace && M > 0 && C > 0 && C % 4 == 0, "slic_bn_bwd_sums: bad args (C %% 4 == 0)");
+  SLIC_REQUIRE(partial ? R_partial > 0 : (dy && z && mean && invstd && (!out || g_out)),
+               "slic_bn_bwd_sums: either a slab, or dy/z/mean/invstd (and g_out when a ReLU mask is applied)");
+  hipStream_t st = S_(stream);
+  SlicCarver w(workspace);
+  int R = R_partial;
+  if (!partial) {
+    R = (int)slic_cdiv(M, BNB_RB);
+    float* pl = w.take<float>((size_t)R * 2 * C);
+    bn_bwd_reduce_kernel<<<dim3(R), dim3(256), 0, st>>>(dy, out, z, mean, invstd, M, C / 4, g_out, pl);
+    SLIC_LAUNCH_CHECK();
+    partial = pl;
+  } else (void)w.take<float>((size_t)R * 2 * C);
+  void* mws = w.take<char>(merge_ws_bytes(R, C));
+  // sum_merge_final also writes ka = s1 / M, kb = s2 / M: pointed at `sums` with M = 1 they ARE the sums
+  int rc = bwd_merge_finalize(partial, R, 1, C, 1, mws, st, dgamma, dbeta, sums, sums + C);
+  return rc;
+}
+
+// backward, phase 2: dz = gamma * invstd * (g - ka - xhat * kb) with ka = global sum g / global count, kb likewise
+extern "C" int slic_bn_bwd_apply(const float* g, const float* z, const float* mean, const float* invstd, const float* gamma,
+                                 const double* ka, const double* kb, int64_t M, int C, float* dz, void* stream) {
+  SLIC_REQUIRE(g && z && mean && invstd && gamma && ka && kb && dz && M > 0 && C > 0 && C % 4 == 0, "slic_bn_bwd_apply: bad args");
+  bn_bwd_apply_kernel<<<dim3(ew_grid(M * (C / 4))), dim3(256), 0, S_(stream)>>>(g, z, mean, invstd, gamma, ka, kb, M, C / 4, dz);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -113,13 +113,20 @@ class R3DNet(nn.Module):
         self._view = None
         self._engines = {}
 
+    def __getstate__(self):
+        # copy.deepcopy(model) / torch.save(model): the module views and execution plans are rebuilt on demand
+        state = self.__dict__.copy()
+        state["_view"], state["_engines"] = None, {}
+        return state
+
     def forward(self, x):
         if not x.is_cuda:
             raise _lib.SlicError("R3DNet.forward needs a gfx950 device tensor: the encoder has no CPU/PyTorch fallback")
         _lib.load()
         x = x.to(torch.float32)
-        if self._view is None:
+        if self._view is None or self._view.bn1 is not self.bn1:     # first call, or the modules were swapped (convert_sync_batchnorm)
             self._view = _NetView(self)
+            self._engines = {}
         key = (tuple(x.shape), str(x.device))
         eng = self._engines.get(key)
         if eng is None:

@@ -60,15 +60,19 @@ class _Bn:
     """per-call view of one BatchNorm layer: parameters + the statistics this pass produced"""
 
     def __init__(self, mod):
-        if isinstance(mod, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size(mod.process_group) > 1:
-            # online_train.py:466-468 converts to SyncBatchNorm only under cfg.SYNC_BATCH_NORM (default False, no shipped
-            # config sets it).  The engine takes rank-local statistics — refuse rather than train with different semantics.
-            raise NotImplementedError("SyncBatchNorm across ranks is not built (cfg.SYNC_BATCH_NORM is off in every shipped "
-                                      "config): the HIP BatchNorm uses rank-local batch statistics")
         self.mod = mod
         self.C = mod.num_features
         self.mean = self.invstd = self.scale = self.shift = None
+        # online_train.py:466-468 (cfg.SYNC_BATCH_NORM): torch.nn.SyncBatchNorm.convert_sync_batchnorm swaps the modules; in
+        # training the statistics are then taken over all ranks of the module's process group (one all-gather of [2C + 1]
+        # doubles forward, one all-reduce of [2C] doubles backward, per layer — SURVEY.md §8e).  Without an initialised
+        # process group a SyncBatchNorm module is plain BatchNorm, as in torch.
+        self.group = None
+        self.sync = False
+        if isinstance(mod, nn.SyncBatchNorm) and torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.sync = True
+            self.group = mod.process_group if mod.process_group is not None else torch.distributed.group.WORLD
+        self.n_total = None        # sync: 0-dim double device tensor, the global sample count of this pass
 
 
 COUNTS = {"bn_bwd": 0, "bn_bwd_fused": 0}     # launches by flavour (diagnostics / tests)
@@ -167,6 +171,19 @@ class _Engine:
         bn.mean, bn.invstd, bn.scale, bn.shift = self._vec(bn.C), self._vec(bn.C), self._vec(bn.C), self._vec(bn.C)
         part, rows = part
         ws = _lib.workspace(_lib.load().slic_bn_finalize_workspace_bytes(part.shape[0], bn.C), part.device, "bn_fin")
+        if bn.sync:
+            C = bn.C
+            W = torch.distributed.get_world_size(bn.group)
+            stats = torch.empty(2 * C + 1, dtype=torch.float64, device=part.device)
+            call("slic_bn_merge_stats", ptr(part), part.shape[0], rows, C, M, ptr(stats), ptr(ws), stream())
+            stats[2 * C] = float(M)
+            allst = torch.empty(W, 2 * C + 1, dtype=torch.float64, device=part.device)
+            torch.distributed.all_gather_into_tensor(allst, stats, group=bn.group)
+            bn.n_total = allst[:, 2 * C].sum()
+            call("slic_bn_finalize_sync", ptr(allst), W, C, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias), ptr(bn.mean),
+                 ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var), stream())
+            self._nbt.append(m.num_batches_tracked)
+            return
         call("slic_bn_finalize", ptr(part), part.shape[0], rows, bn.C, M, BN_EPS, BN_MOMENTUM, ptr(m.weight), ptr(m.bias),
              ptr(bn.mean), ptr(bn.invstd), ptr(bn.scale), ptr(bn.shift), ptr(m.running_mean), ptr(m.running_var),
              ptr(ws), stream())
@@ -195,11 +212,34 @@ class _Engine:
         g = torch.empty_like(z) if want_g else None
         dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        if bn.sync:
+            gm = g if (g is not None or out is None) else torch.empty_like(z)     # the masked gradient must exist for phase 2
+            _Engine._bn_bwd_sync(None, dy, out, z, bn, gm, dz, dgamma, dbeta)
+            return dz, g, dgamma, dbeta
         need_buf = int(out is not None and not want_g)
         ws = _lib.workspace(lib.slic_bn_bwd_workspace_bytes(M, bn.C, need_buf), z.device, "bn_bwd")
         call("slic_bn_bwd", ptr(dy), ptr(out), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), M, bn.C,
              ptr(g), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
         return dz, g, dgamma, dbeta
+
+    @staticmethod
+    def _bn_bwd_sync(part, dy, out, z, bn, g, dz, dgamma, dbeta):
+        """SyncBatchNorm backward: rank-local sums (from a dgrad epilogue's slab `part`, or from dy / out / z with the masked
+        gradient written to g) -> all-reduce over the group -> / global count -> dz.  dgamma, dbeta stay rank-local
+        (DistributedDataParallel averages parameter gradients, as with torch's SyncBatchNorm)."""
+        lib = _lib.load()
+        C = bn.C
+        M = z.numel() // C
+        R = part.shape[0] if part is not None else 0
+        sums = torch.empty(2 * C, dtype=torch.float64, device=z.device)
+        ws = _lib.workspace(lib.slic_bn_bwd_sums_workspace_bytes(M, C, R), z.device, "bn_bwd_sums")
+        gin = g if part is not None else (g if out is not None else dy)      # what phase 2 reads as the gradient
+        call("slic_bn_bwd_sums", ptr(part), R, ptr(dy), ptr(out), ptr(z), ptr(bn.mean), ptr(bn.invstd), M, C,
+             ptr(g) if (part is None and out is not None) else None, ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
+        torch.distributed.all_reduce(sums, group=bn.group)
+        k = sums / bn.n_total
+        call("slic_bn_bwd_apply", ptr(gin), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), ptr(k[:C]), ptr(k[C:]),
+             M, C, ptr(dz), stream())
 
     @staticmethod
     def _bn_bwd_fused(part, g, z, bn):
@@ -212,6 +252,9 @@ class _Engine:
         dz = torch.empty_like(z)
         dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        if bn.sync:
+            _Engine._bn_bwd_sync(part, None, None, z, bn, g, dz, dgamma, dbeta)
+            return dz, dgamma, dbeta
         ws = _lib.workspace(lib.slic_bn_bwd_fused_workspace_bytes(R, bn.C), z.device, "bn_bwd_fused")
         call("slic_bn_bwd_fused", ptr(part), R, ptr(g), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), M, bn.C,
              ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
@@ -586,6 +629,12 @@ class ResNet(nn.Module):
         for _ in range(1, blocks):
             layers.append(block(self.in_planes, planes))
         return nn.Sequential(*layers)
+
+    def __getstate__(self):
+        # copy.deepcopy(model) / torch.save(model): the execution plans (device tables, streams, events) are rebuilt on demand
+        state = self.__dict__.copy()
+        state["_engines"] = {}
+        return state
 
     def _engine(self, x):
         key = (tuple(x.shape), str(x.device))
