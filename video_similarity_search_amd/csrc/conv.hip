@@ -861,6 +861,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
 #pragma unroll
           for (int d = q * PER; d < (q + 1) * PER && d < NP; ++d) issue_piece(tn, stn, d);
           if (q == 7) step();
+          // keep the operand fetch of group q + 1 in FRONT of group q's MFMAs (left alone, the scheduler sinks the ds_reads
+          // next to their first use: no prefetch distance at all)
+          if (q < 7) __builtin_amdgcn_sched_group_barrier(0x100, G + 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * G, 0);
         } else {
           if (q < 7) __builtin_amdgcn_sched_group_barrier(0x100, G + 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x008, 2 * G, 0);
