@@ -285,8 +285,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)          # >= 20 timed steps ...
+    ap.add_argument("--warmup", type=int, default=5)         # ... after >= 5 warm-up steps
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step (16 anchors || 16 positives)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
