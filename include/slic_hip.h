@@ -230,11 +230,14 @@ int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);
 /* n (<= 8) independent GEMMs with the same N in ONE launch (blockIdx.z picks the GEMM): the parity classes of a stride-2
  * data gradient, whose K loops are too short (1-8 taps) to fill the chip one launch at a time.  Variants 20 and 22. */
 int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant, void* stream);
-/* The same GEMM with the K loop cut into `splits` ranges run by separate workgroups (small-M layers whose 64 x 64 tiles
- * do not fill the chip): raw accumulators go to workspace[splits][M][N], a second launch sums them in split order and
- * runs the epilogue.  Deterministic; variants 11 and 20 only; splits <= 1 forwards to slic_conv_gemm. */
-size_t slic_conv_gemm_splitk_workspace_bytes(const SlicConvArgs* args, int splits);
-int slic_conv_gemm_splitk(const SlicConvArgs* args, int variant, int splits, void* workspace, void* stream);
+/* Tail-split launch of the same GEMM (variants 20 and 22): row blocks [0, nfull_rb) run whole; the remaining ones — what
+ * would be a last, partly filled round of the chip's residency slots — are cut `splits` ways along K into the same grid and
+ * finished (pieces added in split order, then the ordinary epilogue) by a second pass over those rows only.  nfull_rb = 0 is plain
+ * split-K (raw accumulators to workspace[splits][M][N]); splits <= 1 forwards to slic_conv_gemm.  Deterministic.  Stands in for cuDNN's algorithm choice on
+ * the few-tile layers of models/resnet.py:126-131 (layer3 / layer4 at small M). */
+size_t slic_conv_gemm_tailsplit_workspace_bytes(const SlicConvArgs* args, int variant, int nfull_rb, int splits);
+int slic_conv_gemm_tailsplit(const SlicConvArgs* args, int variant, int nfull_rb, int splits, void* workspace, void* stream);
+
 /* dW[N][C][ntaps] (reference layout) = sum_m gather(src)[m, tap*Cs + c] * dy[m, n]; `splits` slices of
  * m reduced in fixed order.  args->wgt/dst unused. */
 size_t slic_conv_wgrad_workspace_bytes(const SlicConvArgs* args, int splits);
@@ -330,6 +333,10 @@ int slic_ntxent_bwd(const void* workspace, int n, int D, float temperature, cons
 /* rowwise distance of two [n, D] matrices: 1 - cos (per-norm clamp 1e-8) or ||x - y + 1e-6||_2
  * (models/triplet_net.py:29-33: F.cosine_similarity / F.pairwise_distance) */
 int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclidean, float* out, void* stream);
+/* its backward: dX, dY [n, D] from g [n] = dL/d dist (the reference's distances are ordinary autograd nodes,
+ * models/triplet_net.py:28-32) */
+int slic_pair_distance_bwd(const float* X, const float* Y, const float* g, int n, int D, int euclidean, float* dX, float* dY,
+                           void* stream);
 /* LLC margin term of triplet_train_epoch (online_train.py:317-332): loss = mean_i max(0, (1 - cos(x_i, y_i)) -
  * (1 - cos(x_i, z_i)) + margin)  (MarginRankingLoss with target -1 on the two cosine distances).
  * state: [n, 8] floats kept for bwd; rowloss: [n] scratch.  bwd: gradients to all three inputs. */

@@ -42,4 +42,21 @@ X3 = (np.ones((3, 8)) + 0.05 * np.random.default_rng(33).standard_normal((3, 8))
 c3, nc3, _ = FINCH(X3, distance='cosine', verbose=False)
 out.update(one_X=X3, one_c=c3.astype(np.int32), one_num_clust=np.array(nc3))
 print("one", nc3, c3.shape)
+
+# datasets on which the early-exit cut DROPS links, and on which the reference's adjacency weight matters (a mutual
+# first-neighbour pair stands at 2 d in the bound and in the cut, clustering/finch.py:38-40,44-45,144): with the plain
+# distance in its place the partitions differ.  Several seeds, small.
+for t, seed in enumerate((4, 7, 32)):
+    r = np.random.default_rng(seed)
+    Nc, Dc, Cc = 600, 16, 30
+    cc = r.standard_normal((Cc, Dc))
+    zc = r.integers(0, Cc, Nc)
+    Xc = (cc[zc] + 0.5 * r.standard_normal((Nc, Dc))).astype(np.float32)
+    ce, nce, _ = FINCH(Xc, distance='cosine', verbose=False)
+    cn_, ncn_, _ = FINCH(Xc, distance='cosine', ensure_early_exit=False, verbose=False)
+    assert list(nce) != list(ncn_), "the cut must drop a link on this dataset"
+    _, _, rq = FINCH(Xc, req_clust=10, distance='cosine', verbose=False)
+    out.update({f"cut{t}_X": Xc, f"cut{t}_c": ce.astype(np.int32), f"cut{t}_num_clust": np.array(nce),
+                f"cut{t}_noexit_num_clust": np.array(ncn_), f"cut{t}_req_c": rq.astype(np.int32)})
+    print("cut", seed, nce, "no early exit", ncn_)
 np.savez_compressed(os.path.join(HERE, "finch.npz"), **out)

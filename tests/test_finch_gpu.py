@@ -59,6 +59,50 @@ def test_finch_single_cluster_at_level_zero(gpu, golden_dir):
     assert list(nc1) == [1] and c1.shape == (1, 1)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [0, 1, 2])
+def test_finch_weighted_early_exit_cut_matches_reference(gpu, golden_dir, t):
+    """datasets on which the early-exit cut drops links AND the reference's adjacency weight (a mutual first-neighbour pair
+    counts at 2 d, clustering/finch.py:38-40,44-45,144) decides the partition (the un-weighted cut gives
+    other partitions here)"""
+    from video_similarity_search_amd.clustering.finch import FINCH
+    g = dict(np.load(os.path.join(golden_dir, "finch.npz")))
+    X = g[f"cut{t}_X"]
+    c, nc, _ = FINCH(X, distance='cosine', verbose=False)
+    assert list(nc) == list(g[f"cut{t}_num_clust"]) and np.array_equal(c, g[f"cut{t}_c"])
+    assert list(nc) != list(g[f"cut{t}_noexit_num_clust"])                         # the cut did drop links
+    _, ncn, _ = FINCH(X, distance='cosine', ensure_early_exit=False, verbose=False)
+    assert list(ncn) == list(g[f"cut{t}_noexit_num_clust"])
+    _, _, req = FINCH(X, req_clust=10, distance='cosine', verbose=False)
+    assert _same_partition(req, g[f"cut{t}_req_c"])
+
+
+@pytest.mark.parametrize("name", ["cut0", "cut1", "cut2", "deep", "one"])
+def test_finch_host_logic_vs_reference_golden_numpy_kernels(golden_dir, name):
+    """the host side of clustering/finch.py (link list, weighted cut, hierarchy, stop rules) on a NumPy kernel provider
+    passed as an argument: runs without a GPU, against the goldens of the imported reference"""
+    from video_similarity_search_amd.clustering.finch import FINCH
+    from finch_cpu_kernels import NumpyFinchKernels
+    g = dict(np.load(os.path.join(golden_dir, "finch.npz")))
+    c, nc, _ = FINCH(g[f"{name}_X"], distance='cosine', verbose=False, kernels=NumpyFinchKernels())
+    assert list(nc) == list(g[f"{name}_num_clust"]) and np.array_equal(c, g[f"{name}_c"])
+    if name.startswith("cut") or name == "deep":
+        _, ncn, _ = FINCH(g[f"{name}_X"], distance='cosine', ensure_early_exit=False, verbose=False, kernels=NumpyFinchKernels())
+        assert list(ncn) == list(g[f"{name}_noexit_num_clust"])
+        rq = int(g["deep_req_clust"]) if name == "deep" else 10
+        _, _, req = FINCH(g[f"{name}_X"], req_clust=rq, distance='cosine', verbose=False, kernels=NumpyFinchKernels())
+        assert _same_partition(req, g[f"{name}_req_c"])
+
+
+def test_finch_without_gpu_fails_loudly():
+    from video_similarity_search_amd.clustering.finch import FINCH
+    from video_similarity_search_amd._lib import SlicError
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(SlicError):
+        FINCH(np.zeros((4, 8), np.float32), verbose=False)
+
+
 def test_link_pairs_definition():
     """the link set is exactly {i ~ j : j = k(i) or i = k(j) or k(i) = k(j)} (host-only helper)"""
     from video_similarity_search_amd.clustering.finch import link_pairs, components

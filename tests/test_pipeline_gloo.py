@@ -49,13 +49,9 @@ def _encoder():
 
 
 def _cfg(out_dir, world, sharded, drop_last=False):
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from kmeans_cpu_kernels import OracleKernels
     ns = types.SimpleNamespace
     return ns(NUM_GPUS=world, OUTPUT_PATH=out_dir, DATASET=ns(POSITIVE_SAMPLING_P=0.2),
-              ITERCLUSTER=ns(METHOD='kmeans', K=K, L2_NORMALIZE=True, FINCH_PARTITION=0, ADAPTIVEP=True, SHARDED=sharded,
-                             KMEANS_KERNELS=OracleKernels()))
+              ITERCLUSTER=ns(METHOD='kmeans', K=K, L2_NORMALIZE=True, FINCH_PARTITION=0, ADAPTIVEP=True, SHARDED=sharded))
 
 
 def _worker(rank, world, port, out_dir):
@@ -65,6 +61,7 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     try:
         from video_similarity_search_amd.online_train import iterative_cluster_step, broadcast_cluster_labels
+        from kmeans_cpu_kernels import OracleKernels
         ds = _EvalSet()
         enc = _encoder()
         res = {}
@@ -77,7 +74,7 @@ def _worker(rank, world, port, out_dir):
             cfg = _cfg(d, world, sharded)
             np.random.seed(1)
             labels, nmi = iterative_cluster_step(None, cfg, enc, loader, epoch=2, cuda=False, device="cpu",
-                                                 is_master_proc=(rank == 0))
+                                                 is_master_proc=(rank == 0), kmeans_kernels=OracleKernels())
             res[tag] = labels
             res[tag + "_nmi"] = -1.0 if nmi is None else nmi
             res[tag + "_p"] = cfg.DATASET.POSITIVE_SAMPLING_P

@@ -48,8 +48,8 @@ SIGNATURES = {
     "slic_conv_tile_m": (I, [P, I]),
     "slic_conv_gemm": (I, [P, I, P]),
     "slic_conv_gemm_multi": (I, [P, I, I, P]),
-    "slic_conv_gemm_splitk_workspace_bytes": (c_size_t, [P, I]),
-    "slic_conv_gemm_splitk": (I, [P, I, I, P, P]),
+    "slic_conv_gemm_tailsplit_workspace_bytes": (c_size_t, [P, I, I, I]),
+    "slic_conv_gemm_tailsplit": (I, [P, I, I, I, P, P]),
     "slic_conv_wgrad_workspace_bytes": (c_size_t, [P, I]),
     "slic_conv_row_table": (I, [P, P, P]),
     "slic_conv_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
@@ -81,6 +81,7 @@ SIGNATURES = {
     "slic_ntxent_fwd": (I, [P, I, I, I, F, P, P, P]),
     "slic_ntxent_bwd": (I, [P, I, I, F, P, P, I, P]),
     "slic_pair_distance": (I, [P, P, I, I, I, P, P]),
+    "slic_pair_distance_bwd": (I, [P, P, P, I, I, I, P, P, P]),
     "slic_margin_cos_fwd": (I, [P, P, P, I, I, F, P, P, P, P]),
     "slic_margin_cos_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P]),
     "slic_triplet_select": (I, [P, P, I, P, P, I, F, I, P, P, P]),

@@ -14,7 +14,8 @@ written against the paper's definition and the golden outputs:
   level 0   every point i has a first neighbour k(i) (nearest other point, cosine).  Points i, j are linked when
             j = k(i), i = k(j) or k(i) = k(j); the partition is the connected components of the link graph.
   level l   the clusters of level l-1 are replaced by the means of their ORIGINAL rows and linked the same way; with
-            `ensure_early_exit` a link whose cosine distance exceeds the largest link distance of level 0 is dropped.
+            `ensure_early_exit` a link whose weighted cosine distance (x 2 for a mutual first-neighbour pair, the
+            reference's adjacency weight) exceeds the largest weighted link distance of level 0 is dropped.
   stop      when one cluster is left or the number of clusters stops decreasing.
   req_clust from the finest partition with at least req_clust clusters, merge the single closest linked pair per step.
 
@@ -40,20 +41,67 @@ from ..evaluate import cosine_topk
 from .kmeans_hip import HipKernels
 
 
-def _resident(mat):
-    """fp32 device copy of the rows (no copy when they already are one)"""
-    if torch.is_tensor(mat):
-        return mat.detach().to(device="cuda", dtype=torch.float32).contiguous()
-    return torch.as_tensor(np.ascontiguousarray(mat, dtype=np.float32)).cuda()
+class HipFinchKernels:
+    """the device side of FINCH: resident rows, first neighbours (top-k kernel, k = 1, diagonal masked), link distances on
+    gathered rows, per-cluster means (k-means M-step kernel).  `FINCH(..., kernels=)` takes another provider with the same
+    four methods (tests of the host logic on a GPU-less machine pass a NumPy one as an ARGUMENT; the product has no other)."""
+
+    def __init__(self):
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.SlicError("FINCH needs a gfx950 device for its first-neighbour search (no CPU fallback)")
+        self.kern = HipKernels()
+
+    def resident(self, mat):
+        """fp32 device copy of the rows (no copy when they already are one)"""
+        if torch.is_tensor(mat):
+            return mat.detach().to(device="cuda", dtype=torch.float32).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(mat, dtype=np.float32)).cuda()
+
+    def first_neighbours(self, rows):
+        """index of the nearest OTHER row (cosine) for every row of a device matrix; a single row is its own neighbour"""
+        n = rows.shape[0]
+        if n == 1:
+            return np.zeros(1, np.int64)
+        idx, _ = cosine_topk(rows, None, k=1)
+        return idx.view(-1).cpu().numpy().astype(np.int64)
+
+    def pair_cosine_distance(self, rows, a, b, chunk=1 << 20):
+        """1 - cos(rows[a[i]], rows[b[i]]) for host index arrays; the rows are gathered on the device in chunks"""
+        out = np.empty(len(a), np.float32)
+        D = rows.shape[1]
+        for s in range(0, len(a), chunk):
+            ia = torch.from_numpy(np.ascontiguousarray(a[s:s + chunk])).cuda()
+            ib = torch.from_numpy(np.ascontiguousarray(b[s:s + chunk])).cuda()
+            x, y = rows.index_select(0, ia), rows.index_select(0, ib)
+            d = torch.empty(len(ia), dtype=torch.float32, device=rows.device)
+            call("slic_pair_distance", ptr(x), ptr(y), len(ia), D, 0, ptr(d), stream())
+            out[s:s + chunk] = d.cpu().numpy()
+        return out
+
+    def cluster_means(self, rows, assign, K):
+        """per-cluster means of the rows on the device (sums in ascending row order: deterministic)"""
+        N, D = rows.shape
+        Dp = (D + 3) // 4 * 4                               # the M-step kernel wants 16-byte rows
+        if Dp != D:
+            key = (rows.data_ptr(), N, D)
+            if getattr(self, "_pad_key", None) != key:
+                padded = torch.zeros(N, Dp, dtype=torch.float32, device=rows.device)
+                padded[:, :D] = rows
+                self._pad_key, self._padded = key, padded
+            acc = self._padded
+        else:
+            acc = rows
+        sums = torch.empty(K * Dp, dtype=torch.float32, device=rows.device)
+        counts = torch.empty(K, dtype=torch.float32, device=rows.device)
+        lab = torch.from_numpy(assign.astype(np.int32)).to(rows.device)
+        self.kern.accumulate(acc, lab, K, sums, counts)
+        return (sums.view(K, Dp) / counts[:, None])[:, :D].contiguous()
 
 
 def first_neighbours(rows):
-    """index of the nearest OTHER row (cosine) for every row of a device matrix; a single row is its own neighbour"""
-    n = rows.shape[0]
-    if n == 1:
-        return np.zeros(1, np.int64)
-    idx, _ = cosine_topk(rows, None, k=1)
-    return idx.view(-1).cpu().numpy().astype(np.int64)
+    """module-level form of HipFinchKernels.first_neighbours (used by callers that only want the 1-NN map)"""
+    return HipFinchKernels().first_neighbours(rows)
 
 
 def link_pairs(nn):
@@ -81,20 +129,6 @@ def link_pairs(nn):
     return code // n, code % n
 
 
-def pair_cosine_distance(rows, a, b, chunk=1 << 20):
-    """1 - cos(rows[a[i]], rows[b[i]]) for host index arrays; the rows are gathered on the device in chunks"""
-    out = np.empty(len(a), np.float32)
-    D = rows.shape[1]
-    for s in range(0, len(a), chunk):
-        ia = torch.from_numpy(np.ascontiguousarray(a[s:s + chunk])).cuda()
-        ib = torch.from_numpy(np.ascontiguousarray(b[s:s + chunk])).cuda()
-        x, y = rows.index_select(0, ia), rows.index_select(0, ib)
-        d = torch.empty(len(ia), dtype=torch.float32, device=rows.device)
-        call("slic_pair_distance", ptr(x), ptr(y), len(ia), D, 0, ptr(d), stream())
-        out[s:s + chunk] = d.cpu().numpy()
-    return out
-
-
 def components(n, a, b):
     """labels 0..C-1 of the connected components of an undirected pair list, numbered by their smallest member"""
     g = sp.coo_matrix((np.ones(len(a), np.int8), (a, b)), shape=(n, n))
@@ -106,42 +140,32 @@ class _Hierarchy:
     """state of one FINCH run: the resident rows, the current assignment of every original row, the current
     representatives (device), and the partitions accepted so far"""
 
-    def __init__(self, data):
-        self.rows = _resident(data)                         # [N, D], stays in HBM
-        N, D = self.rows.shape
-        self.N, self.D = N, D
-        Dp = (D + 3) // 4 * 4                               # the M-step kernel wants 16-byte rows
-        if Dp != D:
-            padded = torch.zeros(N, Dp, dtype=torch.float32, device=self.rows.device)
-            padded[:, :D] = self.rows
-            self._acc_rows = padded
-        else:
-            self._acc_rows = self.rows
-        self.kern = HipKernels()
+    def __init__(self, data, kernels):
+        self.k = kernels
+        self.rows = kernels.resident(data)                  # [N, D], stays in HBM
+        self.N, self.D = self.rows.shape
         self.assign = None                                  # np.int64 [N]: cluster of every original row at the current level
         self.reps = self.rows                               # what the next level links: rows, then cluster means
         self.cut = None                                     # early-exit bound on link distances
         self.levels, self.sizes = [], []
 
     def means_of(self, assign, K):
-        """per-cluster means of the ORIGINAL rows on the device (sums in ascending row order: deterministic)"""
-        Dp = self._acc_rows.shape[1]
-        sums = torch.empty(K * Dp, dtype=torch.float32, device=self.rows.device)
-        counts = torch.empty(K, dtype=torch.float32, device=self.rows.device)
-        lab = torch.from_numpy(assign.astype(np.int32)).to(self.rows.device)
-        self.kern.accumulate(self._acc_rows, lab, K, sums, counts)
-        return (sums.view(K, Dp) / counts[:, None])[:, : self.D].contiguous()
+        return self.k.cluster_means(self.rows, assign, K)
 
     def link_level(self, nn=None, want_max=False):
         """link the current representatives; returns (labels of the representatives, count, largest kept link distance)"""
         reps = self.reps
         n = reps.shape[0]
         if nn is None:
-            nn = first_neighbours(reps)
-        a, b = link_pairs(np.asarray(nn, dtype=np.int64))
+            nn = self.k.first_neighbours(reps)
+        nn = np.asarray(nn, dtype=np.int64)
+        a, b = link_pairs(nn)
         dmax = None
         if (self.cut is not None or want_max) and len(a):
-            d = pair_cosine_distance(reps, a, b)
+            # The reference bounds and cuts on (distance x adjacency weight) (clustering/finch.py:44-45,144): its adjacency
+            # (A+I)(A+I)^T counts a MUTUAL first-neighbour pair twice, so such a link stands at 2 d in both the level-0
+            # bound and the later cuts; every other link (one-directional, or a shared first neighbour) at d.
+            d = self.k.pair_cosine_distance(reps, a, b) * np.where((nn[a] == b) & (nn[b] == a), np.float32(2), np.float32(1))
             if self.cut is not None:
                 keep = ~(d > self.cut)
                 a, b, d = a[keep], b[keep], d[keep]
@@ -157,25 +181,23 @@ class _Hierarchy:
     def merge_closest_pair(self):
         """one agglomeration step of the req_clust refinement: of all first-neighbour links keep the single closest"""
         n = self.reps.shape[0]
-        a, b = link_pairs(first_neighbours(self.reps))
-        d = pair_cosine_distance(self.reps, a, b)
+        a, b = link_pairs(self.k.first_neighbours(self.reps))
+        d = self.k.pair_cosine_distance(self.reps, a, b)
         j = int(np.lexsort((b, a, d))[0])                   # smallest distance; ties -> lowest pair
         labels, count = components(n, a[j:j + 1], b[j:j + 1])
         self.descend(labels, count)
         return count
 
 
-def FINCH(data, initial_rank=None, req_clust=None, distance='cosine', ensure_early_exit=True, verbose=True):
+def FINCH(data, initial_rank=None, req_clust=None, distance='cosine', ensure_early_exit=True, verbose=True, kernels=None):
     """Same call contract as the reference (clustering/finch.py:108): data [N, D] (ndarray or tensor; a device tensor is used
     in place), optional precomputed first neighbours `initial_rank` [N], optional `req_clust`.
     Returns (c, num_clust, req_c): c int [N, P] — column p = labels of partition p —, num_clust = clusters per
     partition, req_c = labels of the exactly-req_clust partition or None."""
-    _lib.load()
-    if not torch.cuda.is_available():
-        raise _lib.SlicError("FINCH needs a gfx950 device for its first-neighbour search (no CPU fallback)")
     if distance != 'cosine':
         raise NotImplementedError("FINCH on the GPU supports distance='cosine' (what SLIC passes, cluster_masks.py:81)")
-    h = _Hierarchy(data)
+    kernels = HipFinchKernels() if kernels is None else kernels      # raises SlicError without libslic_hip.so / a gfx950 device
+    h = _Hierarchy(data, kernels)
     # level 0: links between the points themselves; its largest link distance bounds the later levels' links
     labels, count, dmax = h.link_level(nn=initial_rank, want_max=ensure_early_exit and initial_rank is None)
     h.descend(labels, count)
@@ -208,7 +230,7 @@ def FINCH(data, initial_rank=None, req_clust=None, distance='cosine', ensure_ear
             finer = [p for p, v in enumerate(num_clust) if v >= req_clust]
             if not finer:
                 raise ValueError("req_clust = {} exceeds the finest partition ({} clusters)".format(req_clust, num_clust[0]))
-            r = _Hierarchy(h.rows)
+            r = _Hierarchy(h.rows, kernels)
             r.descend(h.levels[finer[-1]], num_clust[finer[-1]])
             count = num_clust[finer[-1]]
             while count > req_clust:

@@ -147,6 +147,42 @@ __global__ void pair_distance_kernel(const float* __restrict__ X, const float* _
   if (lane == 0) out[row] = euclid ? sqrtf(a) : 1.0f - a / (fmaxf(sqrtf(b), 1e-8f) * fmaxf(sqrtf(c), 1e-8f));
 }
 
+// backward of pair_distance_kernel: dX, dY from g = dL/d dist (one wave per row).
+//   cosine:    d = 1 - s / (nx ny), nx = max(|x|, 1e-8), ny likewise: dd/dx = -(y / (nx ny) - s x / (nx^3 ny)) where |x| > 1e-8
+//              (the clamp is flat below it: only the y / (nx ny) term is left), symmetrically for y
+//   euclidean: d = |x - y + 1e-6|: dd/dx = (x - y + 1e-6) / d = -dd/dy  (0 where d == 0, as torch's norm backward)
+__global__ void pair_distance_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ G, int n,
+                                         int D, int euclid, float* __restrict__ dX, float* __restrict__ dY) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = X + (int64_t)row * D;
+  const float* y = Y + (int64_t)row * D;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    if (euclid) { const float d = x[k] - y[k] + 1e-6f; a = fmaf(d, d, a); }
+    else { a = fmaf(x[k], y[k], a); b = fmaf(x[k], x[k], b); c = fmaf(y[k], y[k], c); }
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+  const float g = G[row];
+  float* dx = dX + (int64_t)row * D;
+  float* dy = dY + (int64_t)row * D;
+  if (euclid) {
+    const float d = sqrtf(a), inv = d > 0.f ? g / d : 0.f;
+    for (int k = lane; k < D; k += 64) { const float v = (x[k] - y[k] + 1e-6f) * inv; dx[k] = v; dy[k] = -v; }
+    return;
+  }
+  const float rx = sqrtf(b), ry = sqrtf(c);
+  const float nx = fmaxf(rx, 1e-8f), ny = fmaxf(ry, 1e-8f);
+  const float inv = 1.0f / (nx * ny);
+  const float cx = rx > 1e-8f ? a * inv / (nx * nx) : 0.f;      // s / (nx^3 ny)
+  const float cy = ry > 1e-8f ? a * inv / (ny * ny) : 0.f;
+  for (int k = lane; k < D; k += 64) {
+    dx[k] = -g * (y[k] * inv - cx * x[k]);
+    dy[k] = -g * (x[k] * inv - cy * y[k]);
+  }
+}
+
 // full distance matrix (loss/triplet_loss.py:429-437): one wave per (i, j)
 __global__ void pdist_kernel(const float* __restrict__ V, int n, int D, float eps, int euclid,
                              float* __restrict__ out) {
@@ -439,6 +475,14 @@ extern "C" int slic_pair_distance(const float* X, const float* Y, int n, int D, 
                                   void* stream) {
   SLIC_REQUIRE(X && Y && out && n > 0 && D > 0, "slic_pair_distance: bad args");
   pair_distance_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, n, D, euclidean, out);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_pair_distance_bwd(const float* X, const float* Y, const float* g, int n, int D, int euclidean, float* dX,
+                                      float* dY, void* stream) {
+  SLIC_REQUIRE(X && Y && g && dX && dY && n > 0 && D > 0, "slic_pair_distance_bwd: bad args");
+  pair_distance_bwd_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, g, n, D, euclidean, dX, dY);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

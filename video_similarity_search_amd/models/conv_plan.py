@@ -174,6 +174,9 @@ class ConvPlan:
     # The packed operands are kept per plan and reused while `weight` is the tensor they were packed from: the encoder packs
     # every layer's weights on a side stream when a pass starts (resnet._Engine.prepack — off the critical path), and the
     # launches below then find them ready.  The key is dropped at every pass entry, so a pack never outlives a pass.
+    # CONTRACT for direct users of a ConvPlan: the key is (data_ptr, _version) of the weight tensor, and writes made through
+    # `weight.data` bump a different version counter — call drop_packs() (or pass fresh=True) after ANY update of the weights,
+    # otherwise pack_fwd / pack_dgrad hand back the operand packed from the old values.
     @staticmethod
     def _wkey(weight):
         return (weight.data_ptr(), weight._version)
@@ -181,8 +184,8 @@ class ConvPlan:
     def drop_packs(self):
         self._wp_key = self._wd_key = None
 
-    def pack_fwd(self, weight):
-        if self._wp_key is not None and self._wp_key == self._wkey(weight):
+    def pack_fwd(self, weight, fresh=False):
+        if not fresh and self._wp_key is not None and self._wp_key == self._wkey(weight):
             return self._wp
         if self._wp is None:     # zeroed once: the packer writes real elements only, the padding stays zero
             self._wp = torch.zeros(self.N, self.Kp, dtype=torch.float32, device=self.device)
@@ -194,10 +197,10 @@ class ConvPlan:
         self._wp_key = self._wkey(weight)
         return self._wp
 
-    def pack_dgrad(self, weight):
+    def pack_dgrad(self, weight, fresh=False):
         if self.wrun:
             raise _lib.SlicError("the W-run operand serves forward and weight gradient only (the clip needs no gradient)")
-        if self._wd_key is not None and self._wd_key == self._wkey(weight):
+        if not fresh and self._wd_key is not None and self._wd_key == self._wkey(weight):
             return self._wd
         if self._wd is None:
             self._wd = torch.zeros(self.Cs, self.Kd, dtype=torch.float32, device=self.device)
@@ -259,34 +262,41 @@ class ConvPlan:
             return 22 if (a.M >= 100000 and a.N <= 64) else 20
         return variant
 
-    SPLIT_MIN_KTILES = 24      # k-tiles of 32 a split keeps at least
+    SPLIT_MIN_KTILES = 16      # k-tiles of 32 a split piece keeps at least
+    SLOTS = {20: 256 * 5, 22: 256 * 3}     # workgroups the chip holds at once (CUs x workgroups per CU the LDS ring allows)
 
     @classmethod
-    def _splits(cls, a, variant):
-        """split-K factor for the 64 x 64-tile variant: layer4 at B = 32 (392 tiles) and the like have too few tiles to keep
-        256 CUs x 5 workgroups busy, so cut K until ~SLIC_CONV_SPLIT_BLOCKS workgroups exist (0 = never split; tests switch
-        it), keeping at least SPLIT_MIN_KTILES k-tiles per workgroup.  Layer3's 1568 tiles gain from a 4-way split in isolation
-        (104 -> 117 TFLOP/s) but the whole step is 0.4 ms SLOWER with it (slab traffic + the finish pass's epilogue beside the
-        side-stream weight gradients; same-box A/B, scripts/ab_env.sh), so only launches with < target / 2 tiles are split."""
-        if variant != 20:
-            return 1
-        target = int(os.environ.get("SLIC_CONV_SPLIT_BLOCKS", "3000"))
-        if target <= 0:
-            return 1
-        tiles = ((a.M + 63) // 64) * ((a.N + 63) // 64)
-        nk = a.nchunks // 8
-        if tiles * 2 > target:
-            return 1
-        s = min((target + tiles - 1) // tiles, nk // cls.SPLIT_MIN_KTILES)
-        return s if s >= 4 else 1          # a 2-3 way split does not pay for the second launch
+    def _plan_split(cls, a, variant):
+        """(nfull_rb, splits) for slic_conv_gemm_tailsplit, or None for a plain launch.
+
+        A launch of T tiles on a chip that holds `slots` workgroups runs as T / slots rounds, and its last, partly filled
+        round costs a whole round's time at a fraction of the chip: layer3 at B = 32 has 1568 64 x 64 tiles for 1280 slots,
+        layer4 392.  So the tiles of the full rounds run whole, and the remainder — whole row blocks at the end of M — is cut
+        along K into as many pieces as fill the slots once more (each piece keeps >= SPLIT_MIN_KTILES k-tiles).  A remainder
+        that already fills most of a round is left alone.  SLIC_CONV_TAIL=0 switches the mechanism off (tests compare)."""
+        if variant not in (20, 22) or os.environ.get("SLIC_CONV_TAIL", "1") == "0":
+            return None
+        slots = int(os.environ.get("SLIC_CONV_TAIL_SLOTS", "0")) or cls.SLOTS[variant]
+        BM = 128 if variant == 22 else 64
+        nrb, ny = (a.M + BM - 1) // BM, (a.N + 63) // 64
+        tiles, nk = nrb * ny, a.nchunks // 8
+        full = (tiles // slots) * slots
+        nfull_rb = full // ny
+        tail_tiles = (nrb - nfull_rb) * ny
+        if tail_tiles == 0 or tail_tiles * 4 > slots * 3:
+            return None
+        s = min(slots // tail_tiles, nk // cls.SPLIT_MIN_KTILES)
+        return (nfull_rb, s) if s >= 2 else None
 
     def _launch(self, a, variant):
         variant = self._pick(a, variant)
-        splits = self._splits(a, variant)
-        if splits > 1:
+        plan = self._plan_split(a, variant)
+        if plan is not None:
             lib = _lib.load()
-            ws = _lib.workspace(lib.slic_conv_gemm_splitk_workspace_bytes(ctypes.byref(a), splits), self.device, "splitk")
-            go = lambda: call("slic_conv_gemm_splitk", ctypes.byref(a), variant, splits, ptr(ws), stream())
+            nfull_rb, splits = plan
+            ws = _lib.workspace(lib.slic_conv_gemm_tailsplit_workspace_bytes(ctypes.byref(a), variant, nfull_rb, splits),
+                                self.device, "splitk")
+            go = lambda: call("slic_conv_gemm_tailsplit", ctypes.byref(a), variant, nfull_rb, splits, ptr(ws), stream())
         else:
             go = lambda: call("slic_conv_gemm", ctypes.byref(a), variant, stream())
         if self.prof is None:
@@ -309,7 +319,9 @@ class ConvPlan:
         To, Ho, Wo = self.out_dims
         dx = out if out is not None else torch.empty((B, T, H, W, self.Cs), dtype=torch.float32, device=dz.device)
         launches = []
-        for dc in self.dgrad_classes:
+        # longest K loop first: the classes of a stride-2 layer have 1 ... 8 taps, one grid holds them all (blockIdx.z, dispatched
+        # in order), and a launch that ends with its longest workgroups ends on a nearly empty chip
+        for dc in sorted(self.dgrad_classes, key=lambda d: -d["nchunks"]):
             a = SlicConvArgs()
             a.src = dz.data_ptr()
             a.src_bytes = _lib.u32_bytes(dz, 'dgrad source')
@@ -347,7 +359,7 @@ class ConvPlan:
                 a.bwd_partial = part.data_ptr() + r0 * 2 * self.Cs * 4
                 r0 += r
         picks = [self._pick(a, variant) for a in launches]
-        if len(launches) > 1 and len(set(picks)) == 1 and picks[0] in (20, 22) and all(self._splits(a, picks[0]) == 1 for a in launches):
+        if len(launches) > 1 and len(set(picks)) == 1 and picks[0] in (20, 22):
             # the parity classes of a stride-2 layer as ONE launch: their K loops (1-8 taps) are too short to fill the chip
             # one class at a time
             arr = (SlicConvArgs * len(launches))(*launches)

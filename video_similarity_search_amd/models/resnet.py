@@ -213,7 +213,10 @@ class _Engine:
         dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
         if bn.sync:
-            gm = g if (g is not None or out is None) else torch.empty_like(z)     # the masked gradient must exist for phase 2
+            if out is None:      # no ReLU to undo: the gradient that reaches z's BatchNorm IS dy (slic_bn_bwd_sums writes no g then)
+                _Engine._bn_bwd_sync(None, dy, None, z, bn, None, dz, dgamma, dbeta)
+                return dz, (dy if want_g else None), dgamma, dbeta
+            gm = g if g is not None else torch.empty_like(z)                      # the masked gradient must exist for phase 2
             _Engine._bn_bwd_sync(None, dy, out, z, bn, gm, dz, dgamma, dbeta)
             return dz, g, dgamma, dbeta
         need_buf = int(out is not None and not want_g)

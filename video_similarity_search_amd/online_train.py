@@ -200,7 +200,8 @@ def _cluster_sharded(cfg):
             and cfg.ITERCLUSTER.METHOD in ('kmeans', 'spherical_kmeans') and bool(getattr(cfg.ITERCLUSTER, "SHARDED", True)))
 
 
-def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=True, device=None, is_master_proc=True):
+def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=True, device=None, is_master_proc=True,
+                           kmeans_kernels=None):
     """online_train.py:605-662: embeddings of the whole train set -> fit_cluster -> NMI/AMI logs -> vid_clusters.txt in
     the dataset's unshuffled order -> barrier.
 
@@ -211,7 +212,9 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
     its GPU (no per-batch all_gather + D2H, evaluate.py:189-193), fit_cluster runs row-sharded over the process group
     (one [K*D + K] all-gather per Lloyd iteration over RCCL), and the only other exchange is one int32 all-gather of
     (label, dataset index, true label).  FINCH — and SHARDED = False — keep the reference's shape: gather to every rank,
-    cluster on rank 0, and the dataset-ordered labels are broadcast (which is also the barrier of :662)."""
+    cluster on rank 0, and the dataset-ordered labels are broadcast (which is also the barrier of :662).
+    `kmeans_kernels`: another kernel provider for fit_cluster (the tests of the multi-process control flow pass a CPU one
+    as an argument; the product passes nothing and runs the HIP kernels)."""
     import numpy as np
     from .clustering.cluster_masks import fit_cluster
     from .evaluate import get_embeddings_and_labels
@@ -234,8 +237,7 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
         start_time = time.time()
         pg = torch.distributed.group.WORLD
         local = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
-                            getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0), process_group=pg,
-                            kernels=getattr(cfg.ITERCLUSTER, "KMEANS_KERNELS", None))
+                            getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0), process_group=pg, kernels=kmeans_kernels)
         trip = torch.from_numpy(np.stack([np.asarray(local, np.int32), np.asarray(idxs, np.int32),
                                           np.asarray(true_labels, np.int32)])).to(embeddings.device)
         cluster_labels, idxs, true_labels = (a.reshape(-1) for a in _all_gather_rows(trip, pg))
@@ -249,8 +251,7 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
         try:
             cluster_labels = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
                                          getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0),
-                                         **({"kernels": cfg.ITERCLUSTER.KMEANS_KERNELS}
-                                            if getattr(cfg.ITERCLUSTER, "KMEANS_KERNELS", None) is not None else {}))
+                                         **({"kernels": kmeans_kernels} if kmeans_kernels is not None else {}))
             print('Time to cluster: {:.2f}s'.format(time.time() - start_time))
             order = _dataset_order(n_data, idxs, cluster_labels)
         except Exception as e:              # the other ranks are about to enter a collective: tell them instead of hanging them
