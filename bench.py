@@ -87,8 +87,9 @@ def cpu_baseline_encoder(sd, seconds_budget=25.0):
 def kmeans_secondary(rank, world, pg, run_cpu):
     """k-means Lloyd throughput at BASELINE configs[2]: 100k x 512, K = 500, explicit init, tol = 0, fixed 20 iterations:
     embeddings/s = N * iters / wall (assign + update + status sync + collective).  With a process group the rows are sharded
-    over the ranks ([sums | counts] all-gathered over RCCL + rank-ordered add per iteration); without one (plain N = 1) the
-    whole matrix is on the one GPU and an iteration is one fused foreign call."""
+    over the ranks and an iteration is two foreign calls around ONE RCCL collective (fp64 all-reduce of the payload
+    [K*D sums | K counts | n_changed]); without one (plain N = 1) the whole matrix is on the one GPU and an iteration is one
+    fused foreign call."""
     from video_similarity_search_amd.clustering import KMeans
     N, D, K, iters = 100000, 512, 500, 20
     rng = np.random.default_rng(1)
@@ -115,7 +116,8 @@ def kmeans_secondary(rank, world, pg, run_cpu):
         tt = torch.tensor([dt, dt_fit], device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt, dt_fit = (float(v) for v in tt.tolist())
-    layout = ("rows sharded over the ranks of an RCCL group, centroid partials [K*D sums | K counts] all-gathered + added in rank order"
+    layout = ("rows sharded over the ranks of an RCCL group, ONE fp64 all-reduce of [K*D sums | K counts | n_changed] per iteration "
+              "between slic_kmeans_lloyd_local and slic_kmeans_lloyd_global"
               if pg is not None else "whole matrix on one GPU, no process group (one fused foreign call per iteration)")
     flops_iter = 2.0 * N * K * D
     out = dict(metric="k-means embeddings/sec 100kx512 K=500", value=N * iters / dt, unit="embeddings/s",

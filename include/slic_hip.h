@@ -130,6 +130,25 @@ int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N, int D, in
                            float* C_new, float* Cp_new, float* cnorm_new, float* shift, int spherical,
                            double* status, void* workspace, void* stream);
 
+/* The SHARDED Lloyd iteration (rows of X split over the ranks, centres replicated) as two calls around its ONE collective —
+ * the GPU form of what the reference does on rank 0 while the other ranks wait in a barrier (online_train.py:625-662), with the
+ * exchange SURVEY.md §8e row 2 specifies: one message [K*D sums | K counts | n_changed] per iteration.
+ *   slic_kmeans_lloyd_local : *n_changed = 0; slic_kmeans_assign_perm on this rank's rows; slic_kmeans_accumulate into `payload`
+ *       = [K*D sums | K counts | n_changed & 0xFFFFF | n_changed >> 20]  (K*D + K + 2 numbers; fp32, or — payload_f64 — the same
+ *       fp32 results widened to double: the operand of an fp64 all-reduce, whose sum of <= 2^29-apart fp32 values is exact and
+ *       therefore independent of RCCL's reduction order).
+ *   (caller) all-gather of the fp32 payloads [n_parts][stride], or all-reduce(sum) of the fp64 payload (n_parts = 1).
+ *   slic_kmeans_lloyd_global: sums / counts = the payloads added in part order (fp32), or the reduced fp64 payload rounded to
+ *       fp32; then slic_kmeans_finalize on them (status[2] = the summed n_changed).  sums / counts are also written out
+ *       (empty-cluster relocation reads them). */
+size_t slic_kmeans_lloyd_local_workspace_bytes(int64_t N, int K);
+int slic_kmeans_lloyd_local(const float* X, const float* Xp, int64_t N, int D, int ldx, const float* Cp_old,
+                            const float* cnorm_old, int K, int32_t* labels, const int32_t* labels_old, void* payload,
+                            int payload_f64, void* workspace, void* stream);
+int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, int n_parts, const float* C_old, int K, int D,
+                             float* sums, float* counts, float* C_new, float* Cp_new, float* cnorm_new, float* shift,
+                             int spherical, double* status, void* stream);
+
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
  * order) — X.mean(axis=0) and np.var(X, axis=0) of KMeans.fit / _tolerance
  * (_kmeans.py:1479-1481, 279-288). */

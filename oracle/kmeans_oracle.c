@@ -115,13 +115,20 @@ static void shard_range(int64_t N, int n_shards, int s, int64_t* lo, int64_t* hi
   *hi = *lo + per;        if (*hi > N) *hi = N;
 }
 
-/* M-step sums (fp32, ascending rows inside a shard, shards added in order) */
+/* M-step sums (fp32, ascending rows inside a shard).  n_shards > 0: shards added in order in fp32 (an all-gather + ordered
+ * add; == sklearn with n_threads = n_shards).  n_shards < 0: |n_shards| shards, their fp32 partials added in DOUBLE and the total
+ * rounded to fp32 once — the arithmetic of an fp64 all-reduce of the partials, whose result does not depend on the reduction
+ * order as long as the partials of one element lie within 2^29 of each other (the sum is then exact). */
 void slic_oracle_accumulate(const float* X, int64_t N, int D, const int32_t* labels, int K,
                             int n_shards, float* sums, float* counts) {
+  const int f64 = n_shards < 0;
+  if (f64) n_shards = -n_shards;
   memset(sums, 0, sizeof(float) * (size_t)K * D);
   memset(counts, 0, sizeof(float) * K);
   float* ps = (float*)malloc(sizeof(float) * (size_t)K * D);
   float* pc = (float*)malloc(sizeof(float) * K);
+  double* ds = f64 ? (double*)calloc((size_t)K * D, sizeof(double)) : 0;
+  double* dc = f64 ? (double*)calloc(K, sizeof(double)) : 0;
   for (int s = 0; s < n_shards; ++s) {
     int64_t lo, hi; shard_range(N, n_shards, s, &lo, &hi);
     memset(ps, 0, sizeof(float) * (size_t)K * D);
@@ -132,8 +139,18 @@ void slic_oracle_accumulate(const float* X, int64_t N, int D, const int32_t* lab
       pc[labels[i]] += 1.0f;
       for (int k = 0; k < D; ++k) d[k] += x[k];
     }
-    for (int j = 0; j < K; ++j) counts[j] += pc[j];
-    for (size_t e = 0; e < (size_t)K * D; ++e) sums[e] += ps[e];
+    if (f64) {
+      for (int j = 0; j < K; ++j) dc[j] += (double)pc[j];
+      for (size_t e = 0; e < (size_t)K * D; ++e) ds[e] += (double)ps[e];
+    } else {
+      for (int j = 0; j < K; ++j) counts[j] += pc[j];
+      for (size_t e = 0; e < (size_t)K * D; ++e) sums[e] += ps[e];
+    }
+  }
+  if (f64) {
+    for (int j = 0; j < K; ++j) counts[j] = (float)dc[j];
+    for (size_t e = 0; e < (size_t)K * D; ++e) sums[e] = (float)ds[e];
+    free(ds); free(dc);
   }
   free(ps); free(pc);
 }

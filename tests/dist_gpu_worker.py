@@ -76,17 +76,19 @@ def case_ddp(rank, world, out):
 
 
 def case_kmeans(rank, world, out):
-    """KMeans(process_group=WORLD) on the HIP kernels: rows sharded, [sums | counts] all-gathered over RCCL,
-    slic_kmeans_combine_shards, one n_changed all-reduce; explicit init (goldens) and the k-means++ branch"""
+    """KMeans(process_group=WORLD) on the HIP kernels: rows sharded, slic_kmeans_lloyd_local -> ONE collective over RCCL (fp64
+    all-reduce of [sums | counts | n_changed], or all-gather of the fp32 payloads) -> slic_kmeans_lloyd_global; explicit init
+    (goldens, both exchanges) and the k-means++ branch"""
     from video_similarity_search_amd.clustering.kmeans_hip import KMeans
     res = {}
-    for name in ("clustered_empty", "d128", "unstructured"):
+    for name, ex in [(n, e) for e in ("allreduce", "allgather") for n in ("clustered_empty", "d128", "unstructured")]:
         g = dict(np.load(os.path.join(HERE, "golden", f"kmeans_{name}.npz")))
         X, init = g["X"], g["init"]
         N = len(X)
         per = (N + world - 1) // world
         shard = torch.from_numpy(X[rank * per:(rank + 1) * per]).cuda()
-        km = KMeans(n_clusters=init.shape[0], init=init, n_init=1, process_group=dist.group.WORLD, trace=True).fit(shard)
+        km = KMeans(n_clusters=init.shape[0], init=init, n_init=1, process_group=dist.group.WORLD, trace=True, exchange=ex).fit(shard)
+        name = f"{ex}/{name}"
         lab = torch.from_numpy(km.labels_).cuda()
         sizes = [min(per, N - r * per) for r in range(world)]
         parts = [torch.empty(s, dtype=lab.dtype, device="cuda") for s in sizes]

@@ -63,6 +63,39 @@ class OracleKernels:
         sums.copy_(torch.from_numpy(s))
         counts.copy_(torch.from_numpy(c))
 
+    def lloyd_local(self, X, Xp, C_old, Cp_old, cnorm_old, labels, labels_old, payload):
+        """slic_kmeans_lloyd_local: E-step + ordered M-step -> [K*D sums | K counts | n_changed & 0xFFFFF | n_changed >> 20]"""
+        K, Dp = C_old.shape
+        lab = torch.from_numpy(ok.assign(_np(X), _np(C_old)))
+        nc = int((lab != labels_old).sum()) if labels_old is not None else 0
+        labels.copy_(lab)
+        s, c = ok.accumulate(_np(X), _np(labels), K, 1)
+        flat = payload.view(-1)
+        flat[:K * Dp] = torch.from_numpy(s.reshape(-1)).to(payload.dtype)
+        flat[K * Dp:K * Dp + K] = torch.from_numpy(c).to(payload.dtype)
+        flat[K * Dp + K] = float(nc & 0xFFFFF)
+        flat[K * Dp + K + 1] = float(nc >> 20)
+
+    def lloyd_global(self, parts, C_old, sums, counts, C_new, Cp_new, cnorm_new, shift, status, spherical=False):
+        """slic_kmeans_lloyd_global: fp32 payloads added in part order / the reduced fp64 payload rounded to fp32, then finalize"""
+        K, Dp = C_old.shape
+        ap = _np(parts)
+        if ap.dtype == np.float64:
+            tot = np.zeros(ap.shape[1], np.float64)
+            for r in range(ap.shape[0]):
+                tot = tot + ap[r]
+            comb = tot.astype(np.float32)
+            nc = int(round(tot[K * Dp + K] + 1048576.0 * tot[K * Dp + K + 1]))
+        else:
+            comb = np.zeros(ap.shape[1], np.float32)
+            for r in range(ap.shape[0]):                 # rank order, fp32 adds
+                comb = comb + ap[r]
+            nc = int(round(float(comb[K * Dp + K]) + 1048576.0 * float(comb[K * Dp + K + 1])))
+        sums.copy_(torch.from_numpy(comb[:K * Dp].copy()))
+        counts.copy_(torch.from_numpy(comb[K * Dp:K * Dp + K].copy()))
+        self.finalize(C_old, sums, counts, C_new, shift, torch.tensor([nc], dtype=torch.int32), status, cnorm_new,
+                      spherical=spherical)
+
     def l2norm_rows(self, X, out):
         x = _np(X).astype(np.float64)
         out.copy_(torch.from_numpy((x / np.sqrt((x * x).sum(1, keepdims=True))).astype(np.float32)))

@@ -74,18 +74,19 @@ def test_sync_batchnorm_equals_full_batch(gpu, tmp_path, world):
 
 @pytest.mark.parametrize("world", _worlds())
 def test_sharded_hip_kmeans_equals_oracle(gpu, golden_dir, tmp_path, world):
-    """KMeans(process_group=WORLD) on the HIP kernels == the oracle with n_shards = W == sklearn's golden labels;
-    first GPU coverage of slic_kmeans_combine_shards.  k-means++ in a sharded run: same rows on every rank, and the
+    """KMeans(process_group=WORLD) on the HIP kernels == the oracle with n_shards = -W (fp64 all-reduce exchange) / W (all-gather
+    + rank-ordered add) == sklearn's golden labels.  k-means++ in a sharded run: same rows on every rank, and the
     run from those rows equals the oracle's from the same rows."""
     from oracle import kmeans as ok
     res = _run("kmeans", world, tmp_path)
     r0 = res[0]
-    for name in ("clustered_empty", "d128", "unstructured"):
+    for name, ex in [(n, e) for e in ("allreduce", "allgather") for n in ("clustered_empty", "d128", "unstructured")]:
         g = dict(np.load(os.path.join(golden_dir, f"kmeans_{name}.npz")))
         X, init = g["X"], g["init"]
         mean = ok.col_mean(X)
         Xc = X - mean
-        ref = ok.lloyd(Xc, init - mean, tol_abs=ok.tolerance(Xc, 1e-4), n_shards=world, trace=True)
+        ref = ok.lloyd(Xc, init - mean, tol_abs=ok.tolerance(Xc, 1e-4), n_shards=-world if ex == "allreduce" else world, trace=True)
+        bare, name = name, f"{ex}/{name}"
         assert np.array_equal(r0[f"{name}/labels"], ref["labels"]), name
         assert np.array_equal(r0[f"{name}/labels"], g["labels"]), name
         assert int(r0[f"{name}/n_iter"]) == ref["n_iter"] == int(g["n_iter"])
@@ -98,7 +99,7 @@ def test_sharded_hip_kmeans_equals_oracle(gpu, golden_dir, tmp_path, world):
             tr = r[f"{name}/trace_local"]
             for it in range(ref["n_iter"]):
                 assert np.array_equal(tr[it], ref["trace"][it][rk * per:(rk + 1) * per]), (name, rk, it)
-        if name == "clustered_empty":
+        if bare == "clustered_empty":
             assert int(r0[f"{name}/nreloc"]) >= 1
     # k-means++ branch
     g = dict(np.load(os.path.join(golden_dir, "kmeans_d128.npz")))
@@ -109,7 +110,7 @@ def test_sharded_hip_kmeans_equals_oracle(gpu, golden_dir, tmp_path, world):
         assert np.array_equal(r["kpp/init_indices"], idx) and np.array_equal(r["kpp/centers"], r0["kpp/centers"])
     mean = ok.col_mean(X)
     Xc = X - mean
-    ref = ok.lloyd(Xc, Xc[idx], tol_abs=ok.tolerance(Xc, 1e-4), n_shards=world)
+    ref = ok.lloyd(Xc, Xc[idx], tol_abs=ok.tolerance(Xc, 1e-4), n_shards=-world)
     labels = np.concatenate([r["kpp/labels_local"] for r in res])
     assert np.array_equal(labels, ref["labels"]) and int(r0["kpp/n_iter"]) == ref["n_iter"]
     assert float(r0["kpp/inertia"]) == pytest.approx(ref["inertia"], rel=1e-9)

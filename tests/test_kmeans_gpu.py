@@ -276,3 +276,68 @@ def test_spherical_kmeans_matches_restatement(gpu):
     labels = fit_cluster(torch.from_numpy(X), method="spherical_kmeans", k=K)
     from sklearn.metrics import normalized_mutual_info_score as nmi
     assert labels.shape == (N,) and nmi(labels, ref_labels) > 0.9
+
+
+@pytest.mark.parametrize("f64", [False, True])
+def test_sharded_iteration_halves_vs_cpu_twin(gpu, f64):
+    """slic_kmeans_lloyd_local / slic_kmeans_lloyd_global (the sharded iteration around its ONE collective) on one GPU with W = 3
+    synthetic shards: the payload of each shard == the oracle's E-step + ordered M-step on that shard's rows, and the combine +
+    averaging (+ an empty cluster: the copy-the-biggest path) == the CPU twin (tests/kmeans_cpu_kernels.py) bit for bit"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kmeans_cpu_kernels import OracleKernels
+    from oracle import kmeans as ok
+    from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
+    hk, okk = HipKernels(), OracleKernels()
+    rng = np.random.default_rng(11)
+    N, D, K, W = 3 * 700, 40, 150, 3
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    C = X[rng.choice(N, K, replace=False)].copy()
+    C[7] = 50.0                                              # a centre no row is closest to: empty cluster
+    dt = torch.float64 if f64 else torch.float32
+    PL = K * D + K + 2
+    Cd = torch.from_numpy(C).cuda()
+    Cp = torch.empty_like(Cd)
+    cn = torch.empty(K, device="cuda")
+    hk.permute_k8(Cd, Cp)
+    hk.cnorm(Cd, cn)
+    parts_g, parts_c, labs = [], [], []
+    for s in range(W):
+        Xs = torch.from_numpy(X[s * 700:(s + 1) * 700]).cuda()
+        Xp = torch.empty_like(Xs)
+        hk.permute_k8(Xs, Xp)
+        lab = torch.empty(700, dtype=torch.int32, device="cuda")
+        old = torch.full((700,), -1, dtype=torch.int32, device="cuda")
+        pay = torch.empty(1, PL, dtype=dt, device="cuda")
+        hk.lloyd_local(Xs, Xp, Cd, Cp, cn, lab, old, pay)
+        payc = torch.empty(1, PL, dtype=dt)
+        labc = torch.empty(700, dtype=torch.int32)
+        okk.lloyd_local(Xs.cpu(), None, torch.from_numpy(C), None, None, labc, old.cpu(), payc)
+        assert torch.equal(lab.cpu(), labc)
+        assert torch.equal(pay.cpu(), payc), s
+        assert pay[0, K * D + K].item() == 700 and pay[0, K * D + K + 1].item() == 0      # every label changed from -1
+        parts_g.append(pay)
+        parts_c.append(payc)
+        labs.append(labc)
+    if f64:
+        pg, pc = sum(parts_g[1:], parts_g[0].clone()), sum(parts_c[1:], parts_c[0].clone())      # what the all-reduce hands back
+    else:
+        pg, pc = torch.cat(parts_g), torch.cat(parts_c)
+    out_g = [torch.empty(K * D, device="cuda"), torch.empty(K, device="cuda"), torch.empty(K, D, device="cuda"),
+             torch.empty(K, D, device="cuda"), torch.empty(K, device="cuda"), torch.empty(K, device="cuda"),
+             torch.empty(4, dtype=torch.float64, device="cuda")]
+    hk.lloyd_global(pg, Cd, *out_g)
+    out_c = [torch.empty(K * D), torch.empty(K), torch.empty(K, D), None, torch.empty(K), torch.empty(K),
+             torch.empty(4, dtype=torch.float64)]
+    okk.lloyd_global(pc, torch.from_numpy(C), *out_c)
+    torch.cuda.synchronize()
+    sums_ref, counts_ref = ok.accumulate(X, np.concatenate([l.numpy() for l in labs]), K, -W if f64 else W)
+    assert np.array_equal(out_g[0].cpu().numpy().reshape(K, D), sums_ref) and np.array_equal(out_g[1].cpu().numpy(), counts_ref)
+    assert counts_ref[7] == 0
+    for i in (0, 1, 2, 4, 5):
+        assert torch.equal(out_g[i].cpu(), out_c[i]), i
+    Cp_new = torch.empty(K, D, device="cuda")
+    hk.permute_k8(out_g[2], Cp_new)
+    assert torch.equal(Cp_new, out_g[3])
+    sg, sc = out_g[6].cpu().numpy(), out_c[6].numpy()
+    assert sg[0] == pytest.approx(sc[0], rel=1e-12) and sg[1] == sc[1] == 1.0 and sg[2] == sc[2] == N

@@ -1,6 +1,7 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the sharded k-means (KMeans(process_group=...)) — per-iteration
-all-gather of [sums | counts], rank-ordered combine, n_changed all-reduce, relocation candidate merge — driven with
-the oracle-backed kernel provider, and checked against the single-process oracle run with n_shards = 2.
+"""CPU, world_size 2 over gloo: the N>1 path of the sharded k-means (KMeans(process_group=...)) — ONE collective per
+iteration (fp64 all-reduce of [sums | counts | n_changed], or all-gather of the fp32 payloads + rank-ordered combine),
+relocation candidate merge — driven with the oracle-backed kernel provider, and checked against the single-process
+oracle run with n_shards = -2 (fp64 combine) / 2 (ordered fp32 combine).
 Also the reference-shaped collectives of misc/distributed_helper.py."""
 import os
 import socket
@@ -19,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, exchange):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,8 +34,15 @@ def _worker(rank, world, port, case, out_dir):
         N = len(X)
         per = (N + world - 1) // world
         shard = torch.from_numpy(X[rank * per:(rank + 1) * per])
+        calls = {"n": 0}
+        for fn in ("all_reduce", "all_gather_into_tensor", "all_gather", "broadcast"):
+            def counted(*a, _f=getattr(torch.distributed, fn), **kw):
+                calls["n"] += 1
+                return _f(*a, **kw)
+            setattr(torch.distributed, fn, counted)
         km = KMeans(n_clusters=init.shape[0], init=init, n_init=1, process_group=torch.distributed.group.WORLD,
-                    kernels=OracleKernels(), trace=True).fit(shard)
+                    kernels=OracleKernels(), trace=True, exchange=exchange).fit(shard)
+        n_coll = calls["n"]
         # reference-shaped helpers (misc/distributed_helper.py:41-64)
         t = torch.tensor([float(rank + 1)])
         du.all_reduce([t], avg=True)
@@ -46,22 +54,24 @@ def _worker(rank, world, port, case, out_dir):
         got = broadcast_cluster_labels(gl.numpy() if rank == 0 else None, N, "cpu", rank == 0)
         assert got.dtype == np.int32 and np.array_equal(got, gl.numpy())
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), labels=km.labels_, centers=km.cluster_centers_, n_iter=km.n_iter_,
-                 strict=km.strict_, inertia=km.inertia_, all_labels=gl.numpy(), nreloc=km.n_relocations_)
+                 strict=km.strict_, inertia=km.inertia_, all_labels=gl.numpy(), nreloc=km.n_relocations_, n_coll=n_coll)
     finally:
         torch.distributed.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["allreduce", "allgather"])
 @pytest.mark.parametrize("name", ["clustered_empty", "d128"])
-def test_sharded_kmeans_two_ranks_gloo(golden_dir, tmp_path, name):
+def test_sharded_kmeans_two_ranks_gloo(golden_dir, tmp_path, name, exchange, monkeypatch):
     from oracle import kmeans as ok
     case = os.path.join(golden_dir, f"kmeans_{name}.npz")
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    # count the collectives the Lloyd loop issues: the workers log every torch.distributed call they make
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), exchange), nprocs=world, join=True)
     g = dict(np.load(case))
     X, init = g["X"], g["init"]
     mean = ok.col_mean(X)
     Xc = X - mean
-    ref = ok.lloyd(Xc, init - mean, tol_abs=ok.tolerance(Xc, 1e-4), n_shards=world)
+    ref = ok.lloyd(Xc, init - mean, tol_abs=ok.tolerance(Xc, 1e-4), n_shards=-world if exchange == "allreduce" else world)
     r0, r1 = (dict(np.load(os.path.join(tmp_path, f"r{r}.npz"))) for r in range(world))
     labels = np.concatenate([r0["labels"], r1["labels"]])
     assert np.array_equal(labels, ref["labels"])                      # sharded run == oracle with n_shards = 2
@@ -74,6 +84,10 @@ def test_sharded_kmeans_two_ranks_gloo(golden_dir, tmp_path, name):
     assert abs(float(r0["inertia"]) - ref["inertia"]) <= 1e-9 * ref["inertia"]
     if name == "clustered_empty":
         assert int(r0["nreloc"]) >= 1
+    else:
+        # ONE collective per Lloyd iteration: n_iter + 1 launches (the loop runs one iteration ahead of
+        # the host) + the fit's fixed set-up / wrap-up exchanges (shard sizes, column means, tolerance, inertia)
+        assert int(r0["n_coll"]) <= int(r0["n_iter"]) + 1 + 6, (int(r0["n_coll"]), int(r0["n_iter"]))
 
 
 def test_single_process_driver_matches_oracle_cpu(golden_dir):

@@ -34,6 +34,9 @@ SIGNATURES = {
     "slic_kmeans_lloyd_step_workspace_bytes": (c_size_t, [L, I]),
     "slic_kmeans_lloyd_step": (I, [P, P, L, I, I, P, P, P, I, P, P, P, P, P, P, P, P, P, I, P, P, P]),
     "slic_kmeans_assign_perm": (I, [P, L, I, I, P, I, I, P, P, P, P, P, P, P]),
+    "slic_kmeans_lloyd_local_workspace_bytes": (c_size_t, [L, I]),
+    "slic_kmeans_lloyd_local": (I, [P, P, L, I, I, P, P, I, P, P, P, I, P, P]),
+    "slic_kmeans_lloyd_global": (I, [P, I, L, I, P, I, I, P, P, P, P, P, P, I, P, P]),
     "slic_col_stats_workspace_bytes": (c_size_t, [L, I]),
     "slic_col_stats": (I, [P, L, I, I, P, P, P, P]),
     "slic_sub_rowvec": (I, [P, L, I, I, P, P, I, P]),

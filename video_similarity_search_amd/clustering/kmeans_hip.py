@@ -12,9 +12,15 @@ Only control flow lives here; every reduction/contraction is a HIP kernel reache
 status word).
 
 Multi-GPU: pass `process_group`; X is then this rank's contiguous row shard
-(rank order == row order).  Per iteration the per-rank partial sums/counts are all-gathered
-(RCCL over xGMI) and added in rank order on every GPU, so all ranks hold bit-identical centres
-and the result equals the oracle run with n_shards = world size.
+(rank order == row order).  An iteration is two foreign calls around ONE collective over RCCL/xGMI
+(it replaces the rank-0 k-means + barrier of online_train.py:625-662):
+    slic_kmeans_lloyd_local  : E-step + ordered M-step on the rank's rows -> payload [K*D sums | K counts | n_changed]
+    exchange='allreduce' (default): ONE all-reduce(sum) of the payload, widened to fp64 — a sum of a few fp32 values in
+        fp64 is exact, so the result does not depend on RCCL's reduction order and every rank holds bit-identical
+        centres; equals the oracle run with n_shards = -world (fp64 combine);
+    exchange='allgather': ONE all-gather of the fp32 payloads, added in rank order on every GPU; equals the oracle
+        run with n_shards = world (== sklearn's per-thread buffers reduced in thread order);
+    slic_kmeans_lloyd_global : combine + averaging + shift + next norms + status word.
 """
 import os
 import time
@@ -86,6 +92,24 @@ class HipKernels:
              ptr(labels), ptr(labels_old), ptr(n_changed), ptr(sums), ptr(counts), ptr(C_new), ptr(Cp_new), ptr(cnorm_new),
              ptr(shift), int(spherical), ptr(status), ptr(ws), stream())
 
+    def lloyd_local(self, X, Xp, C_old, Cp_old, cnorm_old, labels, labels_old, payload):
+        """sharded iteration, part 1 (before the collective): E-step + ordered M-step -> payload (fp32 or fp64 tensor of
+        K*D + K + 2 numbers)"""
+        N, Dp = X.shape
+        K = Cp_old.shape[0]
+        assert X.stride(0) == Xp.stride(0) and Cp_old.is_contiguous() and payload.numel() == K * Dp + K + 2
+        ws = _lib.workspace(_lib.load().slic_kmeans_lloyd_local_workspace_bytes(N, K), X.device, "km_step")
+        call("slic_kmeans_lloyd_local", ptr(X), ptr(Xp), N, Dp, X.stride(0), ptr(Cp_old), ptr(cnorm_old), K, ptr(labels),
+             ptr(labels_old), ptr(payload), int(payload.dtype == torch.float64), ptr(ws), stream())
+
+    def lloyd_global(self, parts, C_old, sums, counts, C_new, Cp_new, cnorm_new, shift, status, spherical=False):
+        """sharded iteration, part 2 (after the collective): parts = [W, K*D + K + 2] gathered fp32 payloads or
+        [1, K*D + K + 2] reduced fp64 payload -> combined sums / counts, new centres, status word"""
+        K, Dp = C_old.shape
+        W, stride = parts.shape
+        call("slic_kmeans_lloyd_global", ptr(parts), int(parts.dtype == torch.float64), stride, W, ptr(C_old), K, Dp,
+             ptr(sums), ptr(counts), ptr(C_new), ptr(Cp_new), ptr(cnorm_new), ptr(shift), int(spherical), ptr(status), stream())
+
     def l2norm_rows(self, X, out):
         call("slic_l2norm_rows", ptr(X), X.shape[0], X.shape[1], X.stride(0), ptr(out), out.stride(0), stream())
 
@@ -152,7 +176,7 @@ class KMeans:
     copied to the current device)."""
 
     def __init__(self, n_clusters, n_init=10, max_iter=300, tol=1e-4, init="k-means++", random_state=None,
-                 process_group=None, fixed_iters=False, trace=False, kernels=None, spherical=False):
+                 process_group=None, fixed_iters=False, trace=False, kernels=None, spherical=False, exchange="allreduce"):
         self.n_clusters = int(n_clusters)
         self.n_init = int(n_init)
         self.max_iter = int(max_iter)
@@ -165,6 +189,8 @@ class KMeans:
         # spherical k-means (clustering/cluster_masks.py:73-77 -> spherecluster.SphericalKMeans): rows L2-normalised, no
         # mean-centring, centres renormalised after every averaging, tol compared unscaled
         self.spherical = bool(spherical)
+        assert exchange in ("allreduce", "allgather"), exchange
+        self.exchange = exchange               # the sharded run's one collective per iteration (module docstring)
         self.k = kernels if kernels is not None else HipKernels()
 
     # ------------------------------------------------------------------ helpers
@@ -305,7 +331,13 @@ class KMeans:
         side = self._side_stream(dev) if on_gpu else None
         if self._sharded:
             W = torch.distributed.get_world_size(self.process_group)
-            allpart = [torch.empty(W, K * Dp + K, dtype=torch.float32, device=dev) for _ in range(2)]
+            PL = K * Dp + K + 2                                          # [sums | counts | n_changed lo, hi]
+            if self.exchange == "allreduce":
+                payload = [torch.empty(1, PL, dtype=torch.float64, device=dev) for _ in range(2)]
+                parts = payload                                          # reduced in place
+            else:
+                payload = [torch.empty(1, PL, dtype=torch.float32, device=dev) for _ in range(2)]
+                parts = [torch.empty(W, PL, dtype=torch.float32, device=dev) for _ in range(2)]
             gsums = [torch.empty(K * Dp, dtype=torch.float32, device=dev) for _ in range(2)]
             gcounts = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(2)]
         else:
@@ -338,16 +370,23 @@ class KMeans:
                              Cout, Cp[(it + 1) % 3], cnorm[(it + 1) % 3], shift, status[sl], **sph)
                 read_back(sl)
                 return
+            if self._sharded:
+                # two foreign calls around the iteration's ONE collective
+                k.lloyd_local(Xc, Xp if perm else None, Cin, Cp[it % 3], cnorm[it % 3], lab, lab_old, payload[sl])
+                if self.exchange == "allreduce":
+                    torch.distributed.all_reduce(payload[sl], group=self.process_group)
+                else:
+                    torch.distributed.all_gather_into_tensor(parts[sl].view(-1), payload[sl].view(-1), group=self.process_group)
+                k.lloyd_global(parts[sl], Cin, gsums[sl], gcounts[sl], Cout, Cp[(it + 1) % 3], cnorm[(it + 1) % 3], shift,
+                               status[sl], **sph)
+                read_back(sl)
+                return
             n_changed[sl].zero_()
             if perm:
                 k.assign_perm(Xp, Cp[it % 3], cnorm[it % 3], lab, lab_old, n_changed[sl])
             else:
                 k.assign(Xc, Cin, cnorm[it % 3], lab, lab_old, n_changed[sl])
             k.accumulate(Xc, lab, K, part[sl][: K * Dp], part[sl][K * Dp:])
-            if self._sharded:
-                torch.distributed.all_gather_into_tensor(allpart[sl].view(-1), part[sl], group=self.process_group)
-                k.combine_shards(allpart[sl], K, Dp, gsums[sl], gcounts[sl])
-                torch.distributed.all_reduce(n_changed[sl], group=self.process_group)
             k.finalize(Cin, gsums[sl], gcounts[sl], Cout, shift, n_changed[sl], status[sl], cnorm[(it + 1) % 3],
                        *((Cp[(it + 1) % 3],) if perm else ()), **sph)
             read_back(sl)

@@ -639,10 +639,14 @@ __global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ la
   order[km_cl_off[l] + bc[(int64_t)blockIdx.x * K + l] + earlier + intra] = (int32_t)i;
 }
 
-// sums[j, 4*c4 .. 4*c4+3] = sequential fp32 sum over the cluster's rows in ascending order
+// sums[j, 4*c4 .. 4*c4+3] = sequential fp32 sum over the cluster's rows in ascending order.  TOut = double: the same fp32
+// sums, stored widened (the payload of the sharded run's fp64 all-reduce).  nch_out (optional, 2 slots): *n_changed split into
+// (low 20 bits, the rest) — two numbers whose sums over <= 16 ranks stay exact in fp32 as well.
+template <typename TOut>
 __global__ __launch_bounds__(128) void km_accumulate(
     const float* __restrict__ X, int D, int ldx, const int32_t* __restrict__ order,
-    const int32_t* __restrict__ cnt, float* __restrict__ sums, float* __restrict__ counts_f) {
+    const int32_t* __restrict__ cnt, TOut* __restrict__ sums, TOut* __restrict__ counts_f,
+    const int32_t* __restrict__ n_changed, TOut* __restrict__ nch_out) {
   __shared__ int red[128];
   const int j = blockIdx.x;
   const int c4 = blockIdx.y * 128 + threadIdx.x;
@@ -655,7 +659,12 @@ __global__ __launch_bounds__(128) void km_accumulate(
     __syncthreads();
   }
   const int n = cnt[j];
-  if (blockIdx.y == 0 && threadIdx.x == 0 && counts_f) counts_f[j] = (float)n;
+  if (blockIdx.y == 0 && threadIdx.x == 0 && counts_f) counts_f[j] = (TOut)n;
+  if (j == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nch_out) {
+    const int nc = *n_changed;
+    nch_out[0] = (TOut)(nc & 0xFFFFF);
+    nch_out[1] = (TOut)(nc >> 20);
+  }
   if (c4 * 4 >= D) return;
   const int32_t* ord = order + red[0];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -668,7 +677,15 @@ __global__ __launch_bounds__(128) void km_accumulate(
     for (int u = 0; u < 8; ++u) acc += v[u];
   }
   for (; m < n; ++m) acc += *(const f32x4*)(X + (int64_t)ord[m] * ldx + c4 * 4);
-  *(f32x4*)(sums + (int64_t)j * D + c4 * 4) = acc;
+  TOut* d = sums + (int64_t)j * D + c4 * 4;
+  if constexpr (sizeof(TOut) == 4) {
+    *(f32x4*)d = acc;
+  } else {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 lo = {(double)acc[0], (double)acc[1]}, hi = {(double)acc[2], (double)acc[3]};
+    *(f64x2*)d = lo;
+    *(f64x2*)(d + 2) = hi;
+  }
 }
 
 __global__ void km_combine_shards(const float* __restrict__ ps, const float* __restrict__ pc,
@@ -783,7 +800,27 @@ __global__ void km_apply_relocation(const float* __restrict__ xfar, int ldf,
 // computed by all threads; the two order-defining chains run on one lane each from LDS:
 //   cnorm_new[j] = k-ascending fmaf chain of c.c                     (same chain as km_cnorm)
 //   shift[j]     = sqrt( sum over groups g of (d0^2 + d1^2 + d2^2 + d3^2)_g, g ascending, then the D % 4 tail )
-__global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums, const float* __restrict__ counts,
+// PARTS (the sharded run, after its one collective): the sums / counts come as W payloads [K*D sums | K counts | ...] `stride`
+// elements apart — fp32 rank partials, added here in rank order (the all-gather exchange), or one fp64 row that an all-reduce
+// has summed already, rounded here to fp32 (W = 1).  The combined row and count are also written out (out_sums / out_counts:
+// the relocation of an empty cluster and km_status read them).
+template <typename TIn>
+__device__ __forceinline__ float km_comb(const TIn* __restrict__ p, int64_t stride, int W) {
+  if constexpr (sizeof(TIn) == 4) {
+    float a = 0.f;
+    for (int s = 0; s < W; ++s) a += p[(int64_t)s * stride];
+    return a;
+  } else {
+    double a = 0.0;
+    for (int s = 0; s < W; ++s) a += p[(int64_t)s * stride];
+    return (float)a;
+  }
+}
+
+template <typename TIn, bool PARTS>
+__global__ __launch_bounds__(128) void km_average(const TIn* __restrict__ sums, const TIn* __restrict__ counts,
+                                                  int64_t stride, int W, float* __restrict__ out_sums,
+                                                  float* __restrict__ out_counts,
                                                   const float* __restrict__ Co, int K, int D, float* __restrict__ Cn,
                                                   float* __restrict__ shift, float* __restrict__ cnorm_new,
                                                   float* __restrict__ Cn_perm, int spherical) {
@@ -793,7 +830,18 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
   __shared__ float mv[128];
   __shared__ int mi[128];
   const int j = blockIdx.x, t = threadIdx.x;
-  const float w = counts[j];
+  auto cnt_of = [&](int u) -> float {
+    if constexpr (PARTS) return km_comb<TIn>(counts + u, stride, W);
+    else return counts[u];
+  };
+  auto sum_of = [&](int u, int k) -> float {
+    if constexpr (PARTS) return km_comb<TIn>(sums + (int64_t)u * D + k, stride, W);
+    else return sums[(int64_t)u * D + k];
+  };
+  const float w = cnt_of(j);
+  if constexpr (PARTS) {
+    if (t == 0) out_counts[j] = w;
+  }
   int src = j;
   float alpha;
   if (w > 0.0f) {                                  // the common case needs no argmax
@@ -801,7 +849,7 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
   } else {
     // np.argmax(weight_in_clusters): first index of the maximum
     float bv = -1.f; int bi = 0;
-    for (int u = t; u < K; u += 128) { const float c = counts[u]; if (c > bv) { bv = c; bi = u; } }
+    for (int u = t; u < K; u += 128) { const float c = cnt_of(u); if (c > bv) { bv = c; bi = u; } }
     mv[t] = bv; mi[t] = bi;
     __syncthreads();
     for (int s2 = 64; s2 > 0; s2 >>= 1) {
@@ -811,9 +859,18 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
       __syncthreads();
     }
     src = mi[0];  // copy of the biggest cluster: averaged already iff it precedes j (sklearn's in-place loop order)
-    alpha = (src < j && counts[src] > 0.0f) ? (float)(1.0 / (double)counts[src]) : 1.0f;
+    const float ws = cnt_of(src);
+    alpha = (src < j && ws > 0.0f) ? (float)(1.0 / (double)ws) : 1.0f;
   }
-  for (int k = t; k < D; k += 128) row[k] = sums[(int64_t)src * D + k] * alpha;
+  for (int k = t; k < D; k += 128) {
+    if constexpr (PARTS) {
+      const float own = sum_of(j, k);
+      out_sums[(int64_t)j * D + k] = own;
+      row[k] = (src == j ? own : sum_of(src, k)) * alpha;
+    } else {
+      row[k] = sum_of(src, k) * alpha;
+    }
+  }
   __syncthreads();
   if (spherical) {
     // spherical k-means: the new centre is the mean direction, sklearn.preprocessing.normalize(centers) — a zero row stays
@@ -859,9 +916,12 @@ __global__ __launch_bounds__(128) void km_average(const float* __restrict__ sums
 }
 
 // status word: { sum_j shift_j^2, #empty clusters, n_changed, 0 }.  One workgroup; per-thread partials over a fixed
-// strided partition, then a fixed binary tree in LDS (deterministic).
+// strided partition, then a fixed binary tree in LDS (deterministic).  n_changed: a device int, or (the sharded run) the
+// (low 20 bits, rest) slot pairs of W payloads `stride` elements apart (fp32 or fp64), summed here.
+template <typename TIn>
 __global__ __launch_bounds__(256) void km_status(const float* __restrict__ shift, const float* __restrict__ counts, int K,
-                                                 const int32_t* n_changed, double* status) {
+                                                 const int32_t* n_changed, const TIn* __restrict__ nch_parts, int64_t stride,
+                                                 int W, double* status) {
   __shared__ double st[256];
   __shared__ int se[256];
   const int t = threadIdx.x;
@@ -880,7 +940,12 @@ __global__ __launch_bounds__(256) void km_status(const float* __restrict__ shift
   if (t == 0) {
     status[0] = st[0];
     status[1] = (double)se[0];
-    status[2] = n_changed ? (double)*n_changed : -1.0;
+    double nc = n_changed ? (double)*n_changed : -1.0;
+    if (nch_parts) {
+      nc = 0.0;
+      for (int s = 0; s < W; ++s) nc += (double)nch_parts[(int64_t)s * stride] + 1048576.0 * (double)nch_parts[(int64_t)s * stride + 1];
+    }
+    status[2] = nc;
     status[3] = 0.0;
   }
 }
@@ -1518,9 +1583,9 @@ extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
          slic_align_up((size_t)N * 4, 256);
 }
 
-extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
-                                      const int32_t* labels, int K, float* sums, float* counts,
-                                      void* workspace, void* stream) {
+template <typename TOut>
+static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const int32_t* labels, int K, TOut* sums,
+                              TOut* counts, const int32_t* n_changed, TOut* nch_out, void* workspace, void* stream) {
   SLIC_REQUIRE(X && labels && sums && counts && workspace, "slic_kmeans_accumulate: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldx >= D,
                "slic_kmeans_accumulate: need D %% 4 == 0 (N=%lld K=%d D=%d ldx=%d)", (long long)N, K, D, ldx);
@@ -1548,9 +1613,16 @@ extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
   }
   km_place<<<dim3(nblk), dim3(KM_SB), lds_place, st>>>(labels, N, K, bc, cnt, order, use_wcnt);
   SLIC_LAUNCH_CHECK();
-  km_accumulate<<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, cnt, sums, counts);
+  km_accumulate<TOut><<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, cnt, sums, counts,
+                                                                                     n_changed, nch_out);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_accumulate(const float* X, int64_t N, int D, int ldx,
+                                      const int32_t* labels, int K, float* sums, float* counts,
+                                      void* workspace, void* stream) {
+  return km_accumulate_impl<float>(X, N, D, ldx, labels, K, sums, counts, nullptr, nullptr, workspace, stream);
 }
 
 extern "C" int slic_kmeans_combine_shards(const float* ps, const float* pc, int64_t shard_stride,
@@ -1616,9 +1688,10 @@ extern "C" int slic_kmeans_finalize(const float* C_old, const float* sums, const
   SLIC_REQUIRE(!C_new_perm || D % 8 == 0, "slic_kmeans_finalize: C_new_perm needs D %% 8 == 0");
   hipStream_t st = S(stream);
   const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
-  km_average<<<dim3(K), dim3(128), lds, st>>>(sums, counts, C_old, K, D, C_new, shift, cnorm_new, C_new_perm, spherical);
+  km_average<float, false><<<dim3(K), dim3(128), lds, st>>>(sums, counts, 0, 1, nullptr, nullptr, C_old, K, D, C_new, shift,
+                                                            cnorm_new, C_new_perm, spherical);
   SLIC_LAUNCH_CHECK();
-  km_status<<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, status);
+  km_status<float><<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, n_changed, nullptr, 0, 0, status);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1644,6 +1717,64 @@ extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N
   rc = slic_kmeans_accumulate(X, N, D, ldx, labels, K, sums, counts, ws2, stream);
   if (rc) return rc;
   return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, spherical, n_changed, status, stream);
+}
+
+// The sharded iteration in two calls around its ONE collective:
+//   local : *n_changed = 0; E-step on this rank's rows; ordered M-step sums into the payload
+//           [K*D sums | K counts | n_changed low 20 bits | n_changed >> 20]  (fp32, or the same numbers widened to fp64)
+//   (host) all-gather of the fp32 payloads, or all-reduce(sum) of the fp64 payload, over RCCL
+//   global: combine + _average_centers + shift + next norms + permuted centres + the status word
+extern "C" size_t slic_kmeans_lloyd_local_workspace_bytes(int64_t N, int K) {
+  return slic_kmeans_lloyd_step_workspace_bytes(N, K) + 256;
+}
+
+extern "C" int slic_kmeans_lloyd_local(const float* X, const float* Xp, int64_t N, int D, int ldx, const float* Cp_old,
+                                       const float* cnorm_old, int K, int32_t* labels, const int32_t* labels_old,
+                                       void* payload, int payload_f64, void* workspace, void* stream) {
+  SLIC_REQUIRE(X && Xp && Cp_old && cnorm_old && labels && payload && workspace, "slic_kmeans_lloyd_local: null pointer");
+  char* ws = (char*)workspace;
+  const size_t a1 = slic_align_up(slic_kmeans_assign_workspace_bytes(N, K), 256);
+  void* ws2 = ws + a1;
+  int32_t* n_changed = (int32_t*)(ws + slic_kmeans_lloyd_step_workspace_bytes(N, K));
+  SLIC_HIP_CHECK(hipMemsetAsync(n_changed, 0, sizeof(int32_t), S(stream)));
+  int rc = slic_kmeans_assign_perm(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream);
+  if (rc) return rc;
+  const int64_t KD = (int64_t)K * D;
+  if (payload_f64) {
+    double* p = (double*)payload;
+    return km_accumulate_impl<double>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream);
+  }
+  float* p = (float*)payload;
+  return km_accumulate_impl<float>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream);
+}
+
+extern "C" int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, int n_parts, const float* C_old,
+                                        int K, int D, float* sums, float* counts, float* C_new, float* Cp_new,
+                                        float* cnorm_new, float* shift, int spherical, double* status, void* stream) {
+  SLIC_REQUIRE(parts && C_old && sums && counts && C_new && shift && status && K > 0 && D > 0 && n_parts > 0,
+               "slic_kmeans_lloyd_global: bad args");
+  const int64_t KD = (int64_t)K * D;
+  SLIC_REQUIRE(stride >= KD + K + 2 || n_parts == 1, "slic_kmeans_lloyd_global: payload stride %lld < K*D + K + 2", (long long)stride);
+  SLIC_REQUIRE(C_new != sums && C_new != C_old, "slic_kmeans_lloyd_global: C_new must not alias");
+  SLIC_REQUIRE(D <= 8192, "slic_kmeans_lloyd_global: D > 8192");
+  SLIC_REQUIRE(!Cp_new || D % 8 == 0, "slic_kmeans_lloyd_global: Cp_new needs D %% 8 == 0");
+  hipStream_t st = S(stream);
+  const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
+  if (parts_f64) {
+    const double* p = (const double*)parts;
+    km_average<double, true><<<dim3(K), dim3(128), lds, st>>>(p, p + KD, stride, n_parts, sums, counts, C_old, K, D, C_new, shift,
+                                                              cnorm_new, Cp_new, spherical);
+    SLIC_LAUNCH_CHECK();
+    km_status<double><<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, nullptr, p + KD + K, stride, n_parts, status);
+  } else {
+    const float* p = (const float*)parts;
+    km_average<float, true><<<dim3(K), dim3(128), lds, st>>>(p, p + KD, stride, n_parts, sums, counts, C_old, K, D, C_new, shift,
+                                                             cnorm_new, Cp_new, spherical);
+    SLIC_LAUNCH_CHECK();
+    km_status<float><<<dim3(1), dim3(256), 0, st>>>(shift, counts, K, nullptr, p + KD + K, stride, n_parts, status);
+  }
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
 }
 
 extern "C" size_t slic_col_stats_workspace_bytes(int64_t N, int D) {
