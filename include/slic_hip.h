@@ -272,6 +272,14 @@ int slic_pack_weight_fwd(const float* W, int N, int C, int ntaps, int Cs, int Kp
 int slic_pack_weight_fwd_runs(const float* W, int N, int C, int ntaps, int run_len, int run_px, int Kp, float* Wp, void* stream);
 /* Wd[c][tap*N + n] = W[n][c][tap] (Cs rows, Kd columns) — data-gradient operand */
 int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int Kd, float* Wd, void* stream);
+/* Operand of slic_conv_gemm variant 30 — Winograd F(4, 3) along W for the 3 x 3 x 3 / stride 1 / pad 1 layers (what cuDNN's
+ * algorithm search may pick behind nn.Conv3d, models/resnet.py:11-17, online_train.py:444): U_p = sum_kw G[p][kw] w[..][kw] for the
+ * six points p, laid out in the kernel's LDS stage order
+ *   U[(((tap9 * C_/8 + cc) * N_/64 + nb) * 12 + p * 2 + h) * 64 + nl][j],  tap9 = kt * 3 + kh, n = 64 nb + nl, c = 8 cc + 4 h + j.
+ * dgrad = 0: forward operand (N_ = N outputs, C_ = C reduction channels); dgrad = 1: data-gradient operand (N_ = C, C_ = N, taps
+ * flipped).  9 * C * N * 6 floats.  Needs N_ % 64 == 0 and C_ % 8 == 0.  Variant 30 itself: same SlicConvArgs as the other
+ * variants (stride-1 same-size geometry, Ws % 4 == 0, no bias), wgt / wgt_bytes = this operand; slab rows of 128 GEMM rows. */
+int slic_pack_weight_wino(const float* W, int N, int C, int dgrad, float* U, void* stream);
 /* [B, C, S] -> [B, S, Cp] with channels zero-padded to Cp (clip NCDHW -> NDHWC4, datasets/dataset_utils.py:104) */
 int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* y, void* stream);
 /* [B, C, R, W] -> [B, R, Wp, C] (R = T*H rows): column w lands at w + pad_left, the other columns are zero (Wp >= W + pad_left):

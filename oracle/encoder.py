@@ -90,12 +90,20 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None):
+def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None, relu_masks=None):
     """x: [B, C, T, H, W].  sd: dict of torch tensors (running stats are updated in place when training).
-    taps (optional dict) receives intermediate activations by name."""
+    taps (optional dict) receives intermediate activations by name.
+    relu_masks (optional dict name -> bool tensor, names 'stem', 'layer{L}.{b}.a1', 'layer{L}.{b}', 'head'): the branch every
+    ReLU takes is IMPOSED (y = x * mask) instead of decided by the sign of x — a ReLU input within rounding noise of zero goes
+    either way in any fp32 run, and a gradient comparison is only well posed between runs that took the same branches."""
+    def relu(v, name):
+        if relu_masks is not None and name in relu_masks:
+            return v * relu_masks[name].to(v.dtype)
+        return F.relu(v)
+
     kt = sd["conv1.weight"].shape[2]
     x = F.conv3d(x, sd["conv1.weight"], None, conv1_stride, (kt // 2, 3, 3))
-    x = F.relu(_bn(x, sd, "bn1", training))
+    x = relu(_bn(x, sd, "bn1", training), "stem")
     if taps is not None:
         taps["stem"] = x
     li = 1
@@ -106,7 +114,7 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
             stride = 2 if (li > 1 and b == 0) else 1
             res = x
             out = F.conv3d(x, sd[pre + ".conv1.weight"], None, stride, 1)
-            out = F.relu(_bn(out, sd, pre + ".bn1", training))
+            out = relu(_bn(out, sd, pre + ".bn1", training), pre + ".a1")
             if taps is not None:
                 taps[pre + ".a1"] = out
             out = F.conv3d(out, sd[pre + ".conv2.weight"], None, 1, 1)
@@ -116,7 +124,7 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
             if pre + ".downsample.0.weight" in sd:
                 res = F.conv3d(x, sd[pre + ".downsample.0.weight"], None, stride, 0)
                 res = _bn(res, sd, pre + ".downsample.1", training)
-            x = F.relu(out + res)
+            x = relu(out + res, pre)
             if taps is not None:
                 taps[pre] = x
             b += 1
@@ -127,7 +135,7 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
     if not projection_head or "fc1.weight" not in sd:
         return x
     h = F.linear(x, sd["fc1.weight"], sd["fc1.bias"])
-    h = F.relu(_bn(h, sd, "bn_proj", training))
+    h = relu(_bn(h, sd, "bn_proj", training), "head")
     return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
 
 

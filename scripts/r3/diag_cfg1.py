@@ -31,7 +31,10 @@ emb = m(x.cuda())
 loss = ntxent_loss(emb)
 loss.backward()
 head = ["fc1.weight", "fc1.bias", "bn_proj.weight", "bn_proj.bias", "fc2.weight", "fc2.bias"]
-g_gpu = {k: dict(m.named_parameters())[k].grad.cpu() for k in head}
+body = ["conv1.weight", "layer1.0.conv1.weight", "layer1.1.conv2.weight", "layer2.0.downsample.0.weight", "layer2.1.conv1.weight",
+        "layer3.1.bn2.weight", "layer3.1.conv2.weight", "layer4.0.conv1.weight", "layer4.1.conv1.weight", "layer4.1.conv2.weight",
+        "layer4.1.bn2.weight"]
+g_gpu = {k: dict(m.named_parameters())[k].grad.cpu() for k in head + body}
 emb_gpu = emb.detach().cpu()
 del m, emb, loss
 torch.cuda.empty_cache()
@@ -78,3 +81,14 @@ for k in head:
           f"gpu vs f64-head(gpu pooled) {(g_gpu[k].double() - g_from_gpu_pooled[k]).abs().max().item() / s:.3e}   "
           f"f64-head(gpu pooled) vs f64 {(g_from_gpu_pooled[k] - g_ref[k]).abs().max().item() / s:.3e}   "
           f"f64-head(cpu32 pooled) vs f64 {(g_from_cpu_pooled[k] - g_ref[k]).abs().max().item() / s:.3e}")
+
+# whole-model fp64 / fp32 gradients of the body tensors
+t64g = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
+l64 = oe.ntxent_loss(oe.encoder_forward(t64g, x.double(), training=True))
+g64 = dict(zip(body, torch.autograd.grad(l64, [t64g[k] for k in body])))
+t32g = oe.to_torch(sd, requires_grad=True)
+l32 = oe.ntxent_loss(oe.encoder_forward(t32g, x, training=True))
+g32 = dict(zip(body, torch.autograd.grad(l32, [t32g[k] for k in body])))
+for k in body:
+    sc_ = g64[k].abs().max().item()
+    print(f"{k:32s} gpu vs f64 {(g_gpu[k].double() - g64[k]).abs().max().item() / sc_:.3e}   cpu32 vs f64 {(g32[k].double() - g64[k]).abs().max().item() / sc_:.3e}")

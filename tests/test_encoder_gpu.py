@@ -21,6 +21,33 @@ def _ndhwc(x, Cs):
     return y.contiguous()
 
 
+def _gpu_relu_masks(m, xc):
+    """the branch every ReLU of the HIP encoder took on clip batch xc (train mode), as the oracle's relu_masks: the engine is
+    driven segment by segment with its saved activations kept (stem a0, per block a1 / out, head ah), mask = activation > 0"""
+    eng = m._engine(xc)
+    masks = {}
+
+    def ncdhw(t):
+        return (t > 0).permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+    with torch.no_grad():
+        eng.prepack(with_dgrad=False)
+        a = xc
+        for si in range(eng.N_SEG):
+            a, ctx = eng.seg_forward(si, a, True, True)
+            if si == 0:
+                masks["stem"] = ncdhw(ctx["a0"])
+            elif si <= 4:
+                for b, blk in enumerate(ctx["blocks"]):
+                    masks[f"layer{si}.{b}.a1"] = ncdhw(blk["a1"])
+                    masks[f"layer{si}.{b}"] = ncdhw(blk["out"])
+            elif "ah" in ctx:
+                masks["head"] = (ctx["ah"] > 0).view(xc.shape[0], -1).cpu()
+            del ctx
+    torch.cuda.synchronize()
+    return masks
+
+
 CONV_CASES = [
     # C, N, kernel, stride, pad, B, (T, H, W)
     (3, 8, (7, 7, 7), (1, 2, 2), (3, 3, 3), 2, (8, 20, 20)),      # RGB stem: W-run operand (and the 4-channel-padded one)
@@ -64,7 +91,7 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
             assert (dWr - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item()), f"W-run wgrad splits={splits}"
         with pytest.raises(Exception):
             wplan.pack_dgrad(wd_)
-    plan = ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False)
+    plan = ConvPlan(C, N, k, s, p, dims, "cuda", wrun=False, wino=False)
     xd = _ndhwc(x, plan.Cs).cuda()
     for variant in (0, 20, 22):
         z, part = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True, variant=variant)
@@ -85,6 +112,68 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
     assert (dW - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
     dW3 = plan.wgrad(xd, dyd, B, torch.empty_like(wd_), splits=3).cpu()
     assert (dW3 - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
+
+
+@pytest.mark.parametrize("C,N,B,dims", [(64, 64, 2, (4, 10, 12)), (128, 64, 1, (3, 6, 8)), (64, 128, 2, (2, 5, 4)),
+                                        (64, 64, 1, (16, 56, 56)), (128, 128, 3, (2, 28, 28))])
+def test_conv_winograd_f43(gpu, C, N, B, dims):
+    """slic_conv_gemm variant 30 — Winograd F(4, 3) along W (3 x 3 x 3 / stride 1 / pad 1, layer1 / layer2 of R3D-18) — forward and
+    data gradient vs fp64 F.conv3d at the gather-GEMM's own tolerance, the fused epilogues (BatchNorm partials per 128 rows;
+    affine + addend + ReLU; addend + mask + BatchNorm-backward sums), and agreement with the direct kernel (variant 20)"""
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(C + N + dims[2])
+    k, s, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    x = torch.from_numpy(rng.standard_normal((B, C) + dims).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((N, C) + k) / np.sqrt(C * 27)).astype(np.float32))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, None, s, p)
+    dy = torch.from_numpy(rng.standard_normal(tuple(y64.shape)).astype(np.float32))
+    gx64, = torch.autograd.grad(y64, [x64], dy.double())
+    wino = ConvPlan(C, N, k, s, p, dims, "cuda")
+    direct = ConvPlan(C, N, k, s, p, dims, "cuda", wino=False)
+    assert wino.wino and not direct.wino
+    wd_ = w.cuda().contiguous()
+    xd = _ndhwc(x, C).cuda()
+    dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    tol = 2e-6 * np.sqrt(C * 27) + 1e-6
+    z, (part, rows) = wino.forward(xd, wino.pack_fwd(wd_), B, want_stats=True)
+    assert rows == 128
+    got = z.cpu().permute(0, 4, 1, 2, 3)
+    assert (got - y64.float()).abs().max() <= tol * max(1.0, y64.abs().max().item())
+    zd, _ = direct.forward(xd, direct.pack_fwd(wd_), B, variant=20)
+    assert (z - zd).abs().max().item() <= 2e-5 * max(1.0, y64.abs().max().item())
+    flat = y64.detach().permute(0, 2, 3, 4, 1).reshape(-1, N)
+    assert part.shape[0] == (flat.shape[0] + 127) // 128
+    for rr in range(part.shape[0]):
+        blk = flat[rr * rows:(rr + 1) * rows]
+        assert torch.allclose(part[rr, 0].double().cpu(), blk.sum(0), atol=1e-4, rtol=1e-4)
+        assert torch.allclose(part[rr, 1].double().cpu(), ((blk - blk.mean(0)) ** 2).sum(0), atol=1e-4, rtol=1e-4)
+    # eval-mode epilogue: affine + addend + ReLU
+    sc, sh = [torch.from_numpy(rng.standard_normal(N).astype(np.float32)) for _ in range(2)]
+    res = torch.from_numpy(rng.standard_normal((B, N) + dims).astype(np.float32))
+    ref = F.relu(y64.detach() * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1) + res.double())
+    y, _ = wino.forward(xd, wino.pack_fwd(wd_), B, scale=sc.cuda(), shift=sh.cuda(), addend=_ndhwc(res, N).cuda(), relu=True)
+    assert (y.cpu().permute(0, 4, 1, 2, 3).double() - ref).abs().max() <= 4 * tol * max(1.0, ref.abs().max().item())
+    # data gradient, plain and with the fused mask + BatchNorm-backward sums
+    dx = wino.dgrad(dyd, wino.pack_dgrad(wd_), B)
+    assert (dx.cpu().permute(0, 4, 1, 2, 3) - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item())
+    shp = (B,) + dims + (C,)
+    mask, zz, add = [torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda() for _ in range(3)]
+    mean = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda()
+    invstd = torch.from_numpy((0.5 + rng.random(C)).astype(np.float32)).cuda()
+    refg = wino.dgrad(dyd, wino.pack_dgrad(wd_), B, addend=add)
+    assert torch.allclose(refg, dx + add, atol=1e-6, rtol=0)
+    refg = torch.where(mask > 0, refg, torch.zeros_like(refg))
+    g, bpart = wino.dgrad(dyd, wino.pack_dgrad(wd_), B, addend=add, mask=mask, bwd=(zz, mean, invstd))
+    assert torch.equal(g, refg)
+    s1 = refg.double().reshape(-1, C).sum(0)
+    s2 = (refg.double() * ((zz.double() - mean.double()) * invstd.double())).reshape(-1, C).sum(0)
+    assert torch.allclose(bpart[:, 0].double().sum(0), s1, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(bpart[:, 1].double().sum(0), s2, atol=2e-3, rtol=1e-4)
+    # a refreshed weight must be re-packed (the pack is keyed by the tensor's version)
+    wd_.mul_(2.0)
+    z2, _ = wino.forward(xd, wino.pack_fwd(wd_), B)
+    assert torch.allclose(z2, 2 * z, atol=1e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("variant,slots,want", [(20, 8, (4, 4)), (20, 64, (0, 6)), (22, 4, (2, 2)), (22, 64, (0, 10))])
@@ -323,12 +412,12 @@ def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
         ev = m(xt.cuda()).cpu()
         ev_ref = oe.encoder_forward(oe.to_torch(sd), xt, training=False)
     assert (ev - ev_ref).abs().max().item() <= 1e-4 * max(1.0, ev_ref.abs().max().item())
-    tsd = oe.to_torch(sd, requires_grad=True)
-    emb_ref = oe.encoder_forward(tsd, xt, training=True)
-    loss_ref = oe.ntxent_loss(emb_ref)
-    names = ["conv1.weight", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.bn2.weight",
-             "layer4.1.conv2.weight", "fc1.weight", "fc2.bias", "bn_proj.bias"]
-    gref = dict(zip(names, torch.autograd.grad(loss_ref, [tsd[k] for k in names])))
+    with torch.no_grad():
+        emb_ref = oe.encoder_forward(oe.to_torch(sd), xt, training=True)
+        loss_ref = oe.ntxent_loss(emb_ref)
+    names = ["conv1.weight", "layer1.0.conv1.weight", "layer1.1.conv2.weight", "layer2.0.downsample.0.weight", "layer2.1.conv1.weight",
+             "layer3.1.bn2.weight", "layer3.1.conv2.weight", "layer4.0.conv1.weight", "layer4.1.conv2.weight", "layer4.1.bn2.weight",
+             "fc1.weight", "fc2.weight", "fc2.bias", "bn_proj.bias"]
     m.train()
     emb = m(xt.cuda())
     loss = ntxent_loss(emb)
@@ -336,18 +425,19 @@ def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
     assert (emb.detach().cpu() - emb_ref.detach()).abs().max().item() <= 1e-4
     assert abs(loss.item() - loss_ref.item()) <= 1e-4
     pd = dict(m.named_parameters())
+    g_gpu = {k: pd[k].grad.cpu() for k in names}
+    # Gradients: against an fp64 run of the oracle that takes the SAME branch at every ReLU as the HIP forward did (relu_masks:
+    # a pre-activation within rounding noise of zero goes either way in any fp32 run — scripts/r3/diag_cfg1.py: one such flip at
+    # layer4.1's output moves layer4.1.conv2.weight's gradient by 6 % of its largest entry at B = 4 — and only runs on the same
+    # branches have the same derivative).  Max-norm, relative to the tensor's largest entry.
+    masks = _gpu_relu_masks(m, xt.cuda())
     t64g = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
-    l64 = oe.ntxent_loss(oe.encoder_forward(t64g, xt.double(), training=True))
+    l64 = oe.ntxent_loss(oe.encoder_forward(t64g, xt.double(), training=True, relu_masks=masks))
     g64 = dict(zip(names, torch.autograd.grad(l64, [t64g[k] for k in names])))
-    # Gradients are judged against an fp64 run of the oracle, in max-norm relative to the tensor's largest entry: 1e-3, or
-    # three times the fp32 CPU oracle's own distance from fp64 where that is larger (below the head the chain passes ~20 ReLUs
-    # whose masks flip for pre-activations within fp32 noise of zero — scripts/diag_grads.py)
     for k in names:
         ref = g64[k]
-        scale = ref.abs().max().item()
-        d_gpu = (pd[k].grad.cpu().double() - ref).abs().max().item() / scale
-        d_cpu = (gref[k].double() - ref).abs().max().item() / scale
-        assert d_gpu <= max(1e-3, 3 * d_cpu), (k, d_gpu, d_cpu)
+        d_gpu = (g_gpu[k].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert d_gpu <= 1e-3, (k, d_gpu)
 
 
 def test_tripletnet_surface(gpu):
@@ -475,7 +565,9 @@ def test_config1_bench_batch_b32_train_step_vs_oracle(gpu):
     names = ["conv1.weight", "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.bn2.weight",
              "layer4.1.conv2.weight", "fc1.weight", "fc2.bias", "bn_proj.bias"]
     g_gpu = {k: dict(m.named_parameters())[k].grad.cpu() for k in names}
-    del m, emb, loss
+    del emb, loss
+    masks = _gpu_relu_masks(m, x.cuda())
+    del m
     torch.cuda.empty_cache()
     tsd = oe.to_torch(sd, requires_grad=True)
     emb_ref = oe.encoder_forward(tsd, x, training=True)
@@ -484,18 +576,18 @@ def test_config1_bench_batch_b32_train_step_vs_oracle(gpu):
     assert (emb_gpu - emb_ref.detach()).abs().max().item() <= 1e-4
     assert abs(loss_gpu - loss_ref.item()) <= 1e-4
     del tsd, emb_ref, loss_ref
-    # fp64 reference for the gradients where the host has the memory for it (the autograd graph of the fp64 run holds ~30 GB at
-    # B = 32); otherwise the fp32 oracle is the reference and the gate is the full-size test's floor
+    # Gradients against an fp64 run of the oracle on the SAME ReLU branches as the HIP forward took (see the B = 4 test: a
+    # pre-activation within rounding noise of zero — the head's BatchNorm1d output nearest to zero is 3.5e-6 away with this seed —
+    # goes either way in any fp32 run), where the host has the memory (the fp64 autograd graph holds ~30 GB at B = 32); otherwise
+    # the fp32 oracle is the reference and the gate is loose.
     if psutil.virtual_memory().available > 90 * 2 ** 30:
         t64 = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
-        l64 = oe.ntxent_loss(oe.encoder_forward(t64, x.double(), training=True))
+        l64 = oe.ntxent_loss(oe.encoder_forward(t64, x.double(), training=True, relu_masks=masks))
         g64 = dict(zip(names, torch.autograd.grad(l64, [t64[k] for k in names])))
         for k in names:
             ref = g64[k]
-            scale = ref.abs().max().item()
-            d_gpu = (g_gpu[k].double() - ref).abs().max().item() / scale
-            d_cpu = (g32[k].double() - ref).abs().max().item() / scale
-            assert d_gpu <= max(1e-3, 3 * d_cpu), (k, d_gpu, d_cpu)
+            d_gpu = (g_gpu[k].double() - ref).abs().max().item() / ref.abs().max().item()
+            assert d_gpu <= 1e-3, (k, d_gpu)
     else:
         for k in names:
             ref = g32[k]

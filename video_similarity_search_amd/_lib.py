@@ -59,6 +59,7 @@ SIGNATURES = {
     "slic_pack_weight_fwd": (I, [P, I, I, I, I, I, P, P]),
     "slic_pack_weight_fwd_runs": (I, [P, I, I, I, I, I, I, P, P]),
     "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
+    "slic_pack_weight_wino": (I, [P, I, I, I, P, P]),
     "slic_ncdhw_to_ndhwc": (I, [P, I, I, L, I, P, P]),
     "slic_ncdhw_to_ndhwc_wpad": (I, [P, I, I, L, I, I, I, P, P]),
     # batch norm / pool

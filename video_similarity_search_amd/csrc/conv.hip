@@ -67,11 +67,12 @@ extern "C" int slic_debug_set_stamps(unsigned long long* buf) {
 // waves ascending; one slab row per workgroup.
 constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * 4 * BN + BN; }
 
-template <int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
-                                              int wm, int wn, int r, int h, int tid) {
+// Part 2 of the epilogue: everything after the accumulators have been written to the LDS image [BM][BN] (and a barrier passed).
+// Also called on its own by kernels that build the image themselves (the Winograd kernel: its image rows are the four outputs
+// of each W-tile).  m0 = first GEMM row of the image, a multiple of BM.
+template <int BM, int BN>
+__device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float* lds, int64_t m0, int n0, int tid) {
   const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial / bwd_partial)
-  constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int CPR = BN / 4;       // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;    // rows per pass of the 256 threads
   constexpr int NPASS = BM / RPP;
@@ -95,21 +96,6 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
   };
   const bool want_stats = p.stat_partial != nullptr;
   const bool want_bwd = p.bwd_partial != nullptr;
-  // ---- 1. registers -> LDS image (the k-loop's ring is dead: every caller has drained its DMAs and passed a barrier)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * WTN + j * 32 + r;
-    const int n = n0 + col;
-    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int row = wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
-        tile[row * BN + col] = acc[i][j][g] + bias;
-      }
-  }
-  __syncthreads();
   // ---- 2. row-major pass: thread = (row group rr, chunk cq)
   constexpr unsigned OOBE = 0xFFFFFF00u;
   const int64_t dst_rows = p.dst_strided ? (p.M / ((int64_t)p.Ga * p.Gb * p.Gc)) * p.Da * p.Db * p.Dc : p.M;
@@ -224,6 +210,29 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
       if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
+                                              int wm, int wn, int r, int h, int tid) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  float* tile = lds;                       // [BM][BN]: acc + bias
+  // ---- 1. registers -> LDS image (the k-loop's ring is dead: every caller has drained its DMAs and passed a barrier)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * WTN + j * 32 + r;
+    const int n = n0 + col;
+    const float bias = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int row = wm * WTM + i * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+        tile[row * BN + col] = acc[i][j][g] + bias;
+      }
+  }
+  __syncthreads();
+  conv_epilogue_rows<BM, BN>(p, lds, m0, n0, tid);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1322,6 +1331,222 @@ __global__ void ncdhw_to_ndhwc_wpad(const float* __restrict__ x, int B, int C, i
 // ------------------------------------ C ABI ------------------------------------------------
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 
+// ------------------------------------------------------------------------------------------
+// Winograd F(4, 3) along W for the 3 x 3 x 3, stride-1, pad-1 convolutions (layer1 / layer2: W = 56 / 28) — forward and,
+// with the flipped / transposed operand, data gradient.  Exact fp32 arithmetic (v_mfma_f32_32x32x2_f32), half the multiplies:
+// four outputs along W and the three kw taps cost six products per (kt, kh, c, n) instead of twelve.
+//   A GEMM row is a W-TILE (b, t, h, wt): outputs w = 4 wt .. 4 wt + 3.  For every (kt, kh) and channel c the six input pixels
+//   d[a] = x[t + kt - 1, h + kh - 1, 4 wt - 1 + a, c] are transformed in registers, V = B^T d (six points), each point p is its
+//   own GEMM  M_p[tile][n] += V_p[tile][(kt, kh, c)] * U_p[(kt, kh, c)][n]  with  U_p = sum_kw G[p][kw] w[n][c][kt][kh][kw]
+//   (packed once per step by pack_w_wino), six accumulators per wave tile, and the outputs are Y = A^T M in registers.
+//   Workgroup: 64 W-tiles x 64 n, 2 x 2 waves of 32 x 32 (6 x 16 accumulator registers); K loop = 9 (kt, kh) x C / 8 stages of
+//   8 channels; a stage is 12 KB of raw pixels [a 6][h 2][tile 64][4 ch] + 12 KB of U [p 6][h 2][n 64][4 ch], both by LDS-DMA in
+//   the order the lanes read them (lane (r, h) of the MFMA fetches channels 4 h .. 4 h + 3 of tile / column r with ONE
+//   ds_read_b128 per pixel / point and feeds element j to MFMA j: k = 0 / 1 of MFMA j are channels j / 4 + j); 3-stage ring,
+//   counted vmcnt, one barrier per stage, the next stage's six DMAs spread over the six points' MFMA groups.
+//   Epilogue: the 256 x 64 outputs leave through the shared LDS-image epilogue in two 128-row halves (conv_epilogue_rows: store /
+//   addend / mask / BatchNorm partials with slab rows of 128 GEMM rows, as variant 22).
+// ------------------------------------------------------------------------------------------
+constexpr int WINO_STAGE_FLOATS = 2 * 12 * 64 * 4;     // A image + U image
+
+template <int STAGES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_wino_kernel(const SlicConvArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int bx = blockIdx.x, gdx = gridDim.x;
+  const int mb = (bx & 7) * (gdx >> 3) + (bx >> 3);          // XCD-aware order (see conv_gemm_dma_body)
+  const int64_t Mt = p.M >> 2;                                // W-tiles
+  const int64_t tile0 = (int64_t)mb * 64;
+  if (tile0 >= Mt) return;
+  const int nb = blockIdx.y, n0 = nb * 64;
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
+  const int Wq = W >> 2;
+  const int CCH = C >> 3;                                     // 8-channel stages per (kt, kh)
+  const int NS = 9 * CCH;
+  const int NB = p.N >> 6;
+  // ---- DMA roles: thread = (tile lane, pixel-half j = wave + 4 i): a = j >> 1, channel half = j & 1
+  const int64_t mytile = tile0 + lane;
+  const bool tvalid = mytile < Mt;
+  unsigned q = (unsigned)(tvalid ? mytile : 0);
+  const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+  const int hh = (int)(q % (unsigned)H); q /= (unsigned)H;
+  const int tt = (int)(q % (unsigned)T); q /= (unsigned)T;    // q = batch
+  unsigned aoff[3];
+  bool avalid[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave + 4 * i, a = j >> 1, hc = j & 1;
+    const int w = 4 * wt - 1 + a;
+    avalid[i] = tvalid && (unsigned)w < (unsigned)W;
+    aoff[i] = (unsigned)((((((int64_t)q * T + tt) * H + hh) * W + w) * C + 4 * hc) * 4);
+  }
+  unsigned tmask = 0, hmask = 0;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    tmask |= ((unsigned)(tt + o - 1) < (unsigned)T ? 1u : 0u) << o;
+    hmask |= ((unsigned)(hh + o - 1) < (unsigned)H ? 1u : 0u) << o;
+  }
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  const bool cch_pow2 = (CCH & (CCH - 1)) == 0;
+  const int cch_shift = 31 - __builtin_clz(CCH);
+  const unsigned uoff0 = (unsigned)tid * 16u;                 // this lane's 16 bytes of a U stage block, piece 0
+  // one DMA piece d (0..5) of stage s into the ring slot at float offset `toff`: pieces 0-2 raw pixels, 3-5 U
+  auto issue_piece = [&](int s, int toff, int d) {
+    const bool live = s < NS;
+    const int sc = live ? s : 0;
+    const int tap9 = cch_pow2 ? (sc >> cch_shift) : (sc / CCH);
+    const int cc = sc - tap9 * CCH;
+    if (d < 3) {
+      const int kt = (tap9 * 11) >> 5, kh = tap9 - 3 * kt;
+      const int delta = (((kt - 1) * H + (kh - 1)) * W * C + cc * 8) * 4;
+      const bool ok = live && ((tmask >> kt) & 1u) && ((hmask >> kh) & 1u) && avalid[d];
+      const unsigned off = ok ? aoff[d] + (unsigned)delta : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
+                                               16, (int)off, 0, 0, 0);
+    } else {
+      const int i = d - 3;
+      const unsigned blk = (unsigned)((tap9 * CCH + cc) * NB + nb) * (unsigned)(12 * 64 * 4 * 4);
+      const unsigned off = live ? blk + (unsigned)(i * 256 * 16) + uoff0 : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
+                                               16, (int)off, 0, 0, 0);
+    }
+  };
+  f32x16 acc[6];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t)
+#pragma unroll
+    for (int d = 0; d < 6; ++d) issue_piece(t, t * WINO_STAGE_FLOATS, d);
+  __builtin_amdgcn_s_setprio(0);
+  const int aro = (h * 64 + wm * 32 + r) * 4;                 // + a * 512: pixel a of this lane's tile, its channel half
+  const int bro = 12 * 64 * 4 + (h * 64 + wn * 32 + r) * 4;   // + p * 512: point p of this lane's column, its channel half
+  for (int s0 = 0; s0 < NS; s0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {
+      const int sg = s0 + sidx;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 6) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const float* St = lds + sidx * WINO_STAGE_FLOATS;
+      const int sn = sg + STAGES - 1, toffn = ((sidx + STAGES - 1) % STAGES) * WINO_STAGE_FLOATS;
+      f32x4 d0 = *(const f32x4*)&St[aro], d1 = *(const f32x4*)&St[aro + 512], d2 = *(const f32x4*)&St[aro + 1024];
+      f32x4 d3 = *(const f32x4*)&St[aro + 1536], d4 = *(const f32x4*)&St[aro + 2048], d5 = *(const f32x4*)&St[aro + 2560];
+      f32x4 b = *(const f32x4*)&St[bro];
+      // V = B^T d,  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+      f32x4 V[6];
+      {
+        const f32x4 t1 = d4 - 4.f * d2, t2 = d3 - 4.f * d1;
+        const f32x4 t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+        V[0] = 4.f * d0 - 5.f * d2 + d4;
+        V[1] = t1 + t2;
+        V[2] = t1 - t2;
+        V[3] = t3 + t4;
+        V[4] = t3 - t4;
+        V[5] = 4.f * d1 - 5.f * d3 + d5;
+      }
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) {
+        f32x4 bn = b;
+        if (pp < 5) bn = *(const f32x4*)&St[bro + (pp + 1) * 512];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][j], b[j], acc[pp], 0, 0, 0);
+        issue_piece(sn, toffn, pp);
+        b = bn;
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  // Y = A^T M,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]   (in place: acc[0..3] become the four outputs)
+  {
+    const f32x16 s12 = acc[1] + acc[2], d12 = acc[1] - acc[2], s34 = acc[3] + acc[4], d34 = acc[3] - acc[4];
+    acc[0] = acc[0] + s12 + s34;
+    acc[1] = d12 + 2.f * d34;
+    acc[2] = s12 + 4.f * s34;
+    acc[3] = d12 + 8.f * d34 + acc[5];
+  }
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    if (wm == hf) {
+      const int col = wn * 32 + r;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int trow = (g & 3) + 8 * (g >> 2) + 4 * h;
+          lds[(4 * trow + o) * 64 + col] = acc[o][g];
+        }
+    }
+    __syncthreads();
+    conv_epilogue_rows<128, 64>(p, lds, (tile0 + hf * 32) * 4, n0, tid);
+    __syncthreads();
+  }
+}
+
+// U[(((tap9 * C/8 + cc) * N/64 + nb) * 12 + p * 2 + h) * 64 + nl][j] = sum_kw G[p][kw] * w(n = 64 nb + nl, c = 8 cc + 4 h + j, kt, kh, kw)
+//   forward : w(n, c, kt, kh, kw) = W[n][c][kt][kh][kw]                    (N_ = out channels N, C_ = in channels C)
+//   dgrad   : w(n, c, kt, kh, kw) = W[c][n][2 - kt][2 - kh][2 - kw]        (N_ = C: channels of dx, C_ = N: channels of dy)
+// G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+__global__ void pack_w_wino(const float* __restrict__ Wt, int N, int C, int dgrad, float* __restrict__ U) {
+  const int N_ = dgrad ? C : N, C_ = dgrad ? N : C;
+  const int64_t tot = (int64_t)9 * C_ * N_;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= tot) return;
+  // e = ((((tap9 * CCH + cc) * NB + nb) * 2 + h) * 64 + nl) * 4 + j
+  int64_t q = e;
+  const int j = (int)(q & 3); q >>= 2;
+  const int nl = (int)(q & 63); q >>= 6;
+  const int h = (int)(q & 1); q >>= 1;
+  const int NB = N_ >> 6, CCH = C_ >> 3;
+  const int nb = (int)(q % NB); q /= NB;
+  const int cc = (int)(q % CCH); q /= CCH;
+  const int tap9 = (int)q;
+  const int kt = tap9 / 3, kh = tap9 % 3;
+  const int n = nb * 64 + nl, c = cc * 8 + 4 * h + j;
+  float w[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    if (dgrad) w[kw] = Wt[((int64_t)c * C + n) * 27 + (2 - kt) * 9 + (2 - kh) * 3 + (2 - kw)];
+    else w[kw] = Wt[((int64_t)n * C + c) * 27 + kt * 9 + kh * 3 + kw];
+  }
+  const float s02 = w[0] + w[2];
+  float u[6];
+  u[0] = 0.25f * w[0];
+  u[1] = (-1.f / 6.f) * (s02 + w[1]);
+  u[2] = (-1.f / 6.f) * (s02 - w[1]);
+  u[3] = (1.f / 24.f) * w[0] + (1.f / 12.f) * w[1] + (1.f / 6.f) * w[2];
+  u[4] = (1.f / 24.f) * w[0] - (1.f / 12.f) * w[1] + (1.f / 6.f) * w[2];
+  u[5] = w[2];
+  const int64_t blk = ((int64_t)(tap9 * CCH + cc) * NB + nb) * (12 * 64 * 4);
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) U[blk + ((pp * 2 + h) * 64 + nl) * 4 + j] = u[pp];
+}
+
+template <int STAGES>
+static int launch_wino(const SlicConvArgs& a, hipStream_t st) {
+  constexpr size_t ring = (size_t)STAGES * WINO_STAGE_FLOATS * sizeof(float), epi = (size_t)conv_epi_lds_floats(128, 64) * sizeof(float);
+  constexpr size_t lds = ring > epi ? ring : epi;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const unsigned gx = (unsigned)slic_cdiv(a.M / 4, 64);
+  dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64));
+  conv_wino_kernel<STAGES><<<grid, dim3(256), lds, st>>>(a);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 static int validate(const SlicConvArgs* a, const char* who) {
   SLIC_REQUIRE(a && a->src && a->tab, "%s: null pointer", who);
   if (a->k_run_len > 0)
@@ -1412,7 +1637,7 @@ static int launch_gemm_dma_tail(const SlicConvArgs& a, hipStream_t st, int nfull
 //   22  LDS-DMA ring, 128 x 64 tiles, 3 workgroups / CU  (N <= 64 and many rows: layer1)
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
   (void)a;
-  return variant == 22 ? 128 : 64;     // rows per workgroup (callers size stat_partial / bwd_partial with it)
+  return (variant == 22 || variant == 30) ? 128 : 64;     // rows per slab row (callers size stat_partial / bwd_partial with it)
 }
 
 extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) {
@@ -1423,8 +1648,18 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                "slic_conv_gemm: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
-  SLIC_REQUIRE(variant == 0 || variant == 20 || variant == 22, "slic_conv_gemm: variant must be 0, 20 or 22");
+  SLIC_REQUIRE(variant == 0 || variant == 20 || variant == 22 || variant == 30, "slic_conv_gemm: variant must be 0, 20, 22 or 30");
   hipStream_t st = S_(stream);
+  if (variant == 30) {
+    // Winograd F(4, 3) along W: wgt = the operand of slic_pack_weight_wino; 3 x 3 x 3, stride 1, pad 1 geometry only
+    SLIC_REQUIRE(a->Cs % 8 == 0 && a->N % 64 == 0 && a->Ws % 4 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
+                     a->Gb == a->Hs && a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len,
+                 "slic_conv_gemm: variant 30 needs a stride-1 same-size geometry, Cs %% 8 == 0, N %% 64 == 0, Ws %% 4 == 0, no bias");
+    SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
+    static const int stages = getenv("SLIC_WINO_STAGES") ? atoi(getenv("SLIC_WINO_STAGES")) : 3;
+    if (stages == 2) return launch_wino<2>(*a, st);
+    return launch_wino<3>(*a, st);
+  }
   if (variant != 0) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
                  "slic_conv_gemm: LDS-DMA variants need tap_tab, source channels %% 32 == 0 and <= 64 taps");
@@ -1582,6 +1817,16 @@ extern "C" int slic_pack_weight_fwd_runs(const float* W, int N, int C, int ntaps
                (int64_t)slic_cdiv(ntaps, run_px) * run_len <= Kp, "slic_pack_weight_fwd_runs: bad args");
   const int64_t tot = (int64_t)N * Kp;
   pack_w_fwd_runs<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(W, N, C, ntaps, run_len, run_px, Kp, Wp);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_pack_weight_wino(const float* W, int N, int C, int dgrad, float* U, void* stream) {
+  SLIC_REQUIRE(W && U && N > 0 && C > 0, "slic_pack_weight_wino: bad args");
+  const int N_ = dgrad ? C : N, C_ = dgrad ? N : C;
+  SLIC_REQUIRE(N_ % 64 == 0 && C_ % 8 == 0, "slic_pack_weight_wino: needs output channels %% 64 == 0 and reduction channels %% 8 == 0");
+  const int64_t tot = (int64_t)9 * C_ * N_;
+  pack_w_wino<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, S_(stream)>>>(W, N, C, dgrad, U);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -36,7 +36,7 @@ def _tap_mask(oa, ob, oc):
 class ConvPlan:
     """One conv layer at one input size.  kernel/stride/pad are (t, h, w) triples."""
 
-    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None):
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None):
         self.C, self.N = int(C), int(N)
         self.Cs = (self.C + 3) // 4 * 4
         self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
@@ -50,6 +50,15 @@ class ConvPlan:
         # kw taps of one (kt, kh) row are then ONE contiguous run of kw * C floats (21 -> padded to 24 with zero weights), in
         # bounds along W by construction; K = kt * kh * 24 = 1176 (12.5 % padding instead of 33 %).
         self.wrun = (self.C % 4 != 0 and self.kernel[2] * self.C <= 64) if wrun is None else bool(wrun)
+        # Winograd F(4, 3) along W (variant 30 of slic_conv_gemm): the 3 x 3 x 3 stride-1 pad-1 layers with 64-multiple channel
+        # counts on both sides (forward reduces over C, the data gradient over N) and W % 4 == 0 — layer1 and layer2 of R3D-18.
+        # Exact fp32, half the multiplies.  wino=None: on where eligible unless SLIC_WINO=0; explicit variants of forward() /
+        # dgrad() need a plan built with wino=False (the packed operand differs).
+        eligible = (self.kernel == (3, 3, 3) and self.stride == (1, 1, 1) and self.pad == (1, 1, 1) and self.C % 64 == 0 and
+                    self.N % 64 == 0 and self.in_dims[2] % 4 == 0 and not self.wrun)
+        self.wino = (eligible and os.environ.get("SLIC_WINO", "1") != "0") if wino is None else bool(wino)
+        assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N multiples of 64, W a multiple of 4"
+        self._wu = self._wud = None
         if self.wrun:
             self._init_wrun()
             return
@@ -185,6 +194,14 @@ class ConvPlan:
         self._wp_key = self._wd_key = None
 
     def pack_fwd(self, weight, fresh=False):
+        if self.wino:
+            if not fresh and self._wp_key is not None and self._wp_key == self._wkey(weight):
+                return self._wu
+            if self._wu is None:
+                self._wu = torch.empty(9 * self.C * self.N * 6, dtype=torch.float32, device=self.device)
+            call("slic_pack_weight_wino", ptr(weight), self.N, self.C, 0, ptr(self._wu), stream())
+            self._wp_key = self._wkey(weight)
+            return self._wu
         if not fresh and self._wp_key is not None and self._wp_key == self._wkey(weight):
             return self._wp
         if self._wp is None:     # zeroed once: the packer writes real elements only, the padding stays zero
@@ -200,6 +217,14 @@ class ConvPlan:
     def pack_dgrad(self, weight, fresh=False):
         if self.wrun:
             raise _lib.SlicError("the W-run operand serves forward and weight gradient only (the clip needs no gradient)")
+        if self.wino:
+            if not fresh and self._wd_key is not None and self._wd_key == self._wkey(weight):
+                return self._wud
+            if self._wud is None:
+                self._wud = torch.empty(9 * self.C * self.N * 6, dtype=torch.float32, device=self.device)
+            call("slic_pack_weight_wino", ptr(weight), self.N, self.C, 1, ptr(self._wud), stream())
+            self._wd_key = self._wkey(weight)
+            return self._wud
         if not fresh and self._wd_key is not None and self._wd_key == self._wkey(weight):
             return self._wd
         if self._wd is None:
@@ -233,6 +258,9 @@ class ConvPlan:
         """x: [B, T, H, W, Cs] -> z: [B, To, Ho, Wo, N]; returns (z, (stat_partial, rows_per_partial) or None)"""
         lib = _lib.load()
         a = self._fwd_args(x, B)
+        if self.wino:
+            assert variant in (0, 30) and bias is None, "a Winograd plan runs variant 30 only (build the plan with wino=False)"
+            variant = 30
         z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
         a.wgt = wp.data_ptr()
         a.wgt_bytes = _lib.u32_bytes(wp, 'packed weights')
@@ -256,6 +284,8 @@ class ConvPlan:
         """variant 0 = auto: the LDS-DMA kernel wherever a per-tap table exists (source channels % 32 == 0) — 128 x 64 tiles
         for the tall N <= 64 layers (layer1: 52 % of the FLOPs), 64 x 64 tiles (5 workgroups / CU) otherwise — else the
         register-staged kernel (W-run stem, tiny-channel layers).  Measured with scripts/bench_conv.py."""
+        if variant == 30:
+            return 30
         if not a.tap_tab:
             return 0
         if variant == 0:
@@ -315,6 +345,9 @@ class ConvPlan:
         bwd = (z, mean, invstd) of that layer's BatchNorm: also returns the per-workgroup partial sums
         (sum dx, sum dx * xhat) as a [R, 2, Cs] slab for slic_bn_bwd_fused -> returns (dx, partial)."""
         lib = _lib.load()
+        if self.wino:
+            assert variant in (0, 30), "a Winograd plan runs variant 30 only (build the plan with wino=False)"
+            variant = 30
         T, H, W = self.in_dims
         To, Ho, Wo = self.out_dims
         dx = out if out is not None else torch.empty((B, T, H, W, self.Cs), dtype=torch.float32, device=dz.device)
