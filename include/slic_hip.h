@@ -280,6 +280,15 @@ int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int 
  * flipped).  9 * C * N * 6 floats.  Needs N_ % 64 == 0 and C_ % 8 == 0.  Variant 30 itself: same SlicConvArgs as the other
  * variants (stride-1 same-size geometry, Ws % 4 == 0, no bias), wgt / wgt_bytes = this operand; slab rows of 128 GEMM rows. */
 int slic_pack_weight_wino(const float* W, int N, int C, int dgrad, float* U, void* stream);
+/* Weight gradient of the same layers by the transposed F(4, 3) algorithm, dW[kw] = sum over W-tiles of G^T[(B^T x) . (A dy)]
+ * (six multiplies per (kt, kh, c, n) and tile of four outputs instead of twelve); replaces slic_conv_wgrad where variant 30 runs the
+ * forward.  args: the forward geometry (src = x, 3 x 3 x 3 / stride 1 / pad 1, Cs %% 64 == 0, N %% 64 == 0, Ws %% 4 == 0); dy dense
+ * [M][N]; tile_tab: M / 4 records of 8 bytes written once per geometry by slic_conv_wino_tile_table; `splits` slices of the tiles,
+ * reduced in slice order (deterministic); dW in the reference layout [N][C][3][3][3].  workspace: splits x 9 x 6 x Cs x N floats. */
+size_t slic_conv_wgrad_wino_workspace_bytes(const SlicConvArgs* args, int splits);
+int slic_conv_wino_tile_table(const SlicConvArgs* args, uint32_t* tile_tab, void* stream);
+int slic_conv_wgrad_wino(const SlicConvArgs* args, const float* dy, int splits, const uint32_t* tile_tab, float* dW,
+                         void* workspace, void* stream);
 /* [B, C, S] -> [B, S, Cp] with channels zero-padded to Cp (clip NCDHW -> NDHWC4, datasets/dataset_utils.py:104) */
 int slic_ncdhw_to_ndhwc(const float* x, int B, int C, int64_t S, int Cp, float* y, void* stream);
 /* [B, C, R, W] -> [B, R, Wp, C] (R = T*H rows): column w lands at w + pad_left, the other columns are zero (Wp >= W + pad_left):

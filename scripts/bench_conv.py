@@ -55,4 +55,6 @@ for name, C, N, k, s, p, dims in SHAPES:
         line += f" | wino fwd {fl/t/1e9:6.1f}"
         t = timeit(lambda: wplan.dgrad(dz, wud, B))
         line += f" dg {fl/t/1e9:6.1f}"
+        t = timeit(lambda: wplan.wgrad(x, dz, B, dW))
+        line += f" wg {fl/t/1e9:6.1f}"
     print(line, flush=True)

@@ -128,7 +128,7 @@ def test_conv_winograd_f43(gpu, C, N, B, dims):
     x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
     y64 = F.conv3d(x64, w64, None, s, p)
     dy = torch.from_numpy(rng.standard_normal(tuple(y64.shape)).astype(np.float32))
-    gx64, = torch.autograd.grad(y64, [x64], dy.double())
+    gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy.double())
     wino = ConvPlan(C, N, k, s, p, dims, "cuda")
     direct = ConvPlan(C, N, k, s, p, dims, "cuda", wino=False)
     assert wino.wino and not direct.wino
@@ -170,6 +170,14 @@ def test_conv_winograd_f43(gpu, C, N, B, dims):
     s2 = (refg.double() * ((zz.double() - mean.double()) * invstd.double())).reshape(-1, C).sum(0)
     assert torch.allclose(bpart[:, 0].double().sum(0), s1, atol=2e-3, rtol=1e-4)
     assert torch.allclose(bpart[:, 1].double().sum(0), s2, atol=2e-3, rtol=1e-4)
+    # weight gradient by the transposed algorithm (slic_conv_wgrad_wino): default slicing, three slices, one slice; and the
+    # direct kernel's result beside it
+    for splits in (None, 3, 1):
+        dW = wino.wgrad(xd, dyd, B, torch.empty_like(wd_), splits=splits).cpu()
+        assert (dW - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item()), splits
+    dWd = direct.wgrad(xd, dyd, B, torch.empty_like(wd_)).cpu()
+    assert (dW - dWd).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
+    assert torch.equal(wino.wgrad(xd, dyd, B, torch.empty_like(wd_)), wino.wgrad(xd, dyd, B, torch.empty_like(wd_)))
     # a refreshed weight must be re-packed (the pack is keyed by the tensor's version)
     wd_.mul_(2.0)
     z2, _ = wino.forward(xd, wino.pack_fwd(wd_), B)

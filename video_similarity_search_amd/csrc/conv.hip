@@ -1393,26 +1393,34 @@ void conv_wino_kernel(const SlicConvArgs p) {
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
-  const bool cch_pow2 = (CCH & (CCH - 1)) == 0;
-  const int cch_shift = 31 - __builtin_clz(CCH);
+  const int cch_shift = 31 - __builtin_clz(CCH);             // CCH is a power of two (checked on the host)
   const unsigned uoff0 = (unsigned)tid * 16u;                 // this lane's 16 bytes of a U stage block, piece 0
-  // one DMA piece d (0..5) of stage s into the ring slot at float offset `toff`: pieces 0-2 raw pixels, 3-5 U
-  auto issue_piece = [&](int s, int toff, int d) {
-    const bool live = s < NS;
-    const int sc = live ? s : 0;
-    const int tap9 = cch_pow2 ? (sc >> cch_shift) : (sc / CCH);
-    const int cc = sc - tap9 * CCH;
+  unsigned avu[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) avu[i] = avalid[i] ? 1u : 0u;
+  // The six DMA pieces of stage s into the ring slot at float offset `toff`: pieces 0-2 raw pixels, 3-5 U.  Branch-free: a dead
+  // stage (s >= NS), a (kt, kh) row outside the clip or a pixel outside the row is an out-of-range offset (the DMA writes zeros).
+  struct StageRec { unsigned delta, ublk, live; int kt, kh; };
+  auto stage_rec = [&](int s) {
+    StageRec q;
+    q.live = s < NS ? 1u : 0u;
+    const int sc = s < NS ? s : 0;
+    const int tap9 = sc >> cch_shift, cc = sc & (CCH - 1);
+    q.kt = (tap9 * 11) >> 5;
+    q.kh = tap9 - 3 * q.kt;
+    q.delta = (unsigned)((((q.kt - 1) * H + (q.kh - 1)) * W * C + cc * 8) * 4);
+    q.ublk = (unsigned)((tap9 * CCH + cc) * NB + nb) * (unsigned)(12 * 64 * 4 * 4) + uoff0;
+    return q;
+  };
+  auto issue_piece = [&](const StageRec& q, int toff, int d) {
     if (d < 3) {
-      const int kt = (tap9 * 11) >> 5, kh = tap9 - 3 * kt;
-      const int delta = (((kt - 1) * H + (kh - 1)) * W * C + cc * 8) * 4;
-      const bool ok = live && ((tmask >> kt) & 1u) && ((hmask >> kh) & 1u) && avalid[d];
-      const unsigned off = ok ? aoff[d] + (unsigned)delta : OOB;
+      const unsigned ok = q.live & (tmask >> q.kt) & (hmask >> q.kh) & avu[d];
+      const unsigned off = ok ? aoff[d] + q.delta : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     } else {
       const int i = d - 3;
-      const unsigned blk = (unsigned)((tap9 * CCH + cc) * NB + nb) * (unsigned)(12 * 64 * 4 * 4);
-      const unsigned off = live ? blk + (unsigned)(i * 256 * 16) + uoff0 : OOB;
+      const unsigned off = q.live ? q.ublk + (unsigned)(i * 256 * 16) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     }
@@ -1423,45 +1431,71 @@ void conv_wino_kernel(const SlicConvArgs p) {
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
 #pragma unroll
-  for (int t = 0; t < STAGES - 1; ++t)
+  for (int t = 0; t < STAGES - 1; ++t) {
+    const StageRec q = stage_rec(t);
 #pragma unroll
-    for (int d = 0; d < 6; ++d) issue_piece(t, t * WINO_STAGE_FLOATS, d);
+    for (int d = 0; d < 6; ++d) issue_piece(q, t * WINO_STAGE_FLOATS, d);
+  }
   __builtin_amdgcn_s_setprio(0);
   const int aro = (h * 64 + wm * 32 + r) * 4;                 // + a * 512: pixel a of this lane's tile, its channel half
   const int bro = 12 * 64 * 4 + (h * 64 + wn * 32 + r) * 4;   // + p * 512: point p of this lane's column, its channel half
+  // Software pipeline across the stage barrier: the last two points of stage s - 1 (operands already in registers) are multiplied
+  // AFTER the barrier of stage s, under the latency of stage s's first LDS reads — the barrier then sits where no wave needs
+  // anything from LDS for the next 8 MFMAs, and a slot is free for the DMAs of stage s + STAGES - 1 as soon as the barrier is
+  // passed (every wave's LDS reads of stage s - 1 were issued before it).
+  f32x4 Vt0 = {0.f, 0.f, 0.f, 0.f}, Vt1 = Vt0, bt0 = Vt0, bt1 = Vt0;      // points 4, 5 of the previous stage
   for (int s0 = 0; s0 < NS; s0 += STAGES) {
 #pragma unroll
     for (int sidx = 0; sidx < STAGES; ++sidx) {
       const int sg = s0 + sidx;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * 6) : "memory");
+      // stage sg has landed; and this wave's LDS reads of stage sg - 1 are COMPLETE (lgkmcnt(0)), not merely issued, before the
+      // barrier lets another wave's DMAs overwrite that slot
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * 6) : "memory");
       __builtin_amdgcn_s_barrier();
       const float* St = lds + sidx * WINO_STAGE_FLOATS;
-      const int sn = sg + STAGES - 1, toffn = ((sidx + STAGES - 1) % STAGES) * WINO_STAGE_FLOATS;
-      f32x4 d0 = *(const f32x4*)&St[aro], d1 = *(const f32x4*)&St[aro + 512], d2 = *(const f32x4*)&St[aro + 1024];
-      f32x4 d3 = *(const f32x4*)&St[aro + 1536], d4 = *(const f32x4*)&St[aro + 2048], d5 = *(const f32x4*)&St[aro + 2560];
-      f32x4 b = *(const f32x4*)&St[bro];
+      const int toffn = ((sidx + STAGES - 1) % STAGES) * WINO_STAGE_FLOATS;
+      const StageRec qn = stage_rec(sg + STAGES - 1);
+      const f32x4 d0 = *(const f32x4*)&St[aro], d1 = *(const f32x4*)&St[aro + 512], d2 = *(const f32x4*)&St[aro + 1024];
+      const f32x4 d3 = *(const f32x4*)&St[aro + 1536], d4 = *(const f32x4*)&St[aro + 2048], d5 = *(const f32x4*)&St[aro + 2560];
+      f32x4 b0 = *(const f32x4*)&St[bro], b1 = *(const f32x4*)&St[bro + 512];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt0[j], bt0[j], acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt1[j], bt1[j], acc[5], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the eight ds_reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then the previous stage's tail MFMAs
       // V = B^T d,  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-      f32x4 V[6];
-      {
-        const f32x4 t1 = d4 - 4.f * d2, t2 = d3 - 4.f * d1;
-        const f32x4 t3 = d4 - d2, t4 = 2.f * (d3 - d1);
-        V[0] = 4.f * d0 - 5.f * d2 + d4;
-        V[1] = t1 + t2;
-        V[2] = t1 - t2;
-        V[3] = t3 + t4;
-        V[4] = t3 - t4;
-        V[5] = 4.f * d1 - 5.f * d3 + d5;
-      }
+      const f32x4 t1 = d4 - 4.f * d2, t2 = d3 - 4.f * d1;
+      const f32x4 t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+      const f32x4 V0 = 4.f * d0 - 5.f * d2 + d4, V1 = t1 + t2, V2 = t1 - t2, V3 = t3 + t4;
+      Vt0 = t3 - t4;
+      Vt1 = 4.f * d1 - 5.f * d3 + d5;
+      const f32x4 b2 = *(const f32x4*)&St[bro + 2 * 512], b3 = *(const f32x4*)&St[bro + 3 * 512];
 #pragma unroll
-      for (int pp = 0; pp < 6; ++pp) {
-        f32x4 bn = b;
-        if (pp < 5) bn = *(const f32x4*)&St[bro + (pp + 1) * 512];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][j], b[j], acc[pp], 0, 0, 0);
-        issue_piece(sn, toffn, pp);
-        b = bn;
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[j], b0[j], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[j], b1[j], acc[1], 0, 0, 0);
       }
+      issue_piece(qn, toffn, 0);
+      issue_piece(qn, toffn, 1);
+      issue_piece(qn, toffn, 2);
+      bt0 = *(const f32x4*)&St[bro + 4 * 512];
+      bt1 = *(const f32x4*)&St[bro + 5 * 512];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[j], b2[j], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[j], b3[j], acc[3], 0, 0, 0);
+      }
+      issue_piece(qn, toffn, 3);
+      issue_piece(qn, toffn, 4);
+      issue_piece(qn, toffn, 5);
     }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt0[j], bt0[j], acc[4], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt1[j], bt1[j], acc[5], 0, 0, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -1545,6 +1579,242 @@ static int launch_wino(const SlicConvArgs& a, hipStream_t st) {
   conv_wino_kernel<STAGES><<<grid, dim3(256), lds, st>>>(a);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the same layers by the TRANSPOSED F(4, 3) algorithm: with y = A^T [(G w) . (B^T x)] per W-tile,
+//   dL/dw[kw] = sum over tiles of  G^T [ (B^T x) . (A dy) ]
+// — the forward's input transform V = B^T x (six points from six pixels), the output transform run backwards Z = A dy (six points
+// from the tile's four output gradients), one 64 x 64 product-sum per point, (kt, kh) and tile, and G^T once at the very end: six
+// multiplies per (kt, kh, c, n) and tile instead of twelve.
+//   Workgroup = one (kt, kh), one 64 c x 64 n block, one slice of the tiles; 2 x 2 waves of 32 c x 32 n, six accumulators each
+//   (S_p[c][n], p = 0..5).  The MFMA's k dimension is the TILE: lane (r, h) reads its channel's six pixels of tile 2 ks + h and its
+//   column's four gradients with ds_read_b32 (the operands are channel-contiguous in LDS as in HBM; lanes r are consecutive
+//   channels: conflict-free, and odd tiles are stored with their channel halves swapped so that the two half-waves hit different
+//   banks), transforms them in registers and feeds one MFMA per point.  Stage = 8 tiles: 12 KB of pixels + 8 KB of gradients by
+//   LDS-DMA (per-tile records {byte offset of pixel 4 wt, validity bits} from slic_conv_wino_tile_table, loaded a stage ahead),
+//   3-stage ring, counted vmcnt, one barrier per stage, the last k-step of a stage multiplied after the next stage's barrier.
+//   Slabs [slice][tap9][p][c][n]; conv_wgrad_wino_reduce adds the slices in order, applies G^T and writes the reference layout.
+// ------------------------------------------------------------------------------------------
+constexpr int WW_TS = 8;                              // tiles per stage
+constexpr int WW_X_FLOATS = WW_TS * 6 * 64;
+constexpr int WW_Y_FLOATS = WW_TS * 4 * 64;
+constexpr int WW_STAGE_FLOATS = WW_X_FLOATS + WW_Y_FLOATS;
+
+// tile_tab[tile] = {byte offset of pixel (b, t, h, 4 wt) channel 0, bits 0-2: t - 1, t, t + 1 inside; 3-5: h - 1, h, h + 1 inside;
+//                   6: pixel 4 wt - 1 inside; 7: pixel 4 wt + 4 inside}
+__global__ void conv_wino_tile_table_kernel(const SlicConvArgs p, uint2* __restrict__ tab) {
+  const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= (p.M >> 2)) return;
+  const int Wq = p.Ws >> 2;
+  unsigned q = (unsigned)tile;
+  const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+  const int hh = (int)(q % (unsigned)p.Hs); q /= (unsigned)p.Hs;
+  const int tt = (int)(q % (unsigned)p.Ts); q /= (unsigned)p.Ts;
+  unsigned mk = 0;
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    mk |= ((unsigned)(tt + o - 1) < (unsigned)p.Ts ? 1u : 0u) << o;
+    mk |= ((unsigned)(hh + o - 1) < (unsigned)p.Hs ? 1u : 0u) << (3 + o);
+  }
+  mk |= (wt > 0 ? 1u : 0u) << 6;
+  mk |= (wt < Wq - 1 ? 1u : 0u) << 7;
+  tab[tile] = make_uint2((unsigned)((((((int64_t)q * p.Ts + tt) * p.Hs + hh) * p.Ws + 4 * wt) * p.Cs) * 4), mk);
+}
+
+template <int STAGES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, unsigned dy_bytes, const uint2* __restrict__ tile_tab,
+                            float* __restrict__ slab, int tiles_per_split, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int C = p.Cs, N = p.N, H = p.Hs, W = p.Ws;
+  const int CB = C >> 6, NBk = N >> 6;
+  const int per_slice = 9 * CB * NBk;
+  const int bx = blockIdx.x, gdx = gridDim.x;
+  const int v = (bx & 7) * (gdx >> 3) + (bx >> 3);            // XCD-aware: the workgroups of a slice (same tiles) share an L2
+  if (v >= per_slice * nsplit) return;
+  const int z = v / per_slice;
+  int rest = v - z * per_slice;
+  const int tap9 = rest / (CB * NBk); rest -= tap9 * (CB * NBk);
+  const int cb = rest / NBk, nb = rest - cb * NBk;
+  const int kt = tap9 / 3, kh = tap9 - 3 * kt;
+  const int64_t Mt = p.M >> 2;
+  const int64_t tbeg = (int64_t)z * tiles_per_split;
+  const int64_t tend = min(tbeg + tiles_per_split, Mt);
+  const int nst = tend > tbeg ? (int)((tend - tbeg + WW_TS - 1) / WW_TS) : 0;
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)dy, 0, (int)min((uint64_t)dy_bytes, (uint64_t)tend * 4u * (uint64_t)N * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)tile_tab, 0, (int)(tend * 8), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  // ---- DMA roles.  pixels: chunk q = i * 256 + tid of the stage image [tile 8][pixel 6][16 chunks]; gradients: [tile 8][out 4][16]
+  int xtl[3];
+  unsigned xneed[3], xconst[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = i * 256 + tid;
+    const int tl = q / 96, w96 = q - tl * 96;
+    const int a = w96 >> 4, j = w96 & 15;
+    const int c4 = j ^ ((tl & 1) << 3);                       // odd tiles: channel halves swapped (bank spread of the two half-waves)
+    xtl[i] = tl;
+    xneed[i] = (1u << kt) | (1u << (3 + kh)) | (a == 0 ? 1u << 6 : 0u) | (a == 5 ? 1u << 7 : 0u);
+    xconst[i] = (unsigned)(((((kt - 1) * H + (kh - 1)) * W + (a - 1)) * C + cb * 64 + 4 * c4) * 4);
+  }
+  unsigned yconst[2];
+  int ytl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = i * 256 + tid;
+    const int tl = q >> 6, w64 = q & 63;
+    const int o = w64 >> 4, j = w64 & 15;
+    const int n4 = j ^ ((tl & 1) << 3);
+    ytl[i] = tl;
+    yconst[i] = (unsigned)(((tl * 4 + o) * N + nb * 64 + 4 * n4) * 4);
+  }
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto load_recs = [&](int s, u32x2 (&dst)[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int64_t tile = tbeg + (int64_t)s * WW_TS + xtl[i];
+      dst[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_tab, (int)(tile * 8), 0, 0);      // past the slice: zeros (nothing valid)
+    }
+  };
+  auto issue_piece = [&](int s, int toff, int d, const u32x2 (&rec)[3]) {
+    if (d < 3) {
+      const unsigned off = ((rec[d].y & xneed[d]) == xneed[d]) ? rec[d].x + xconst[d] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
+                                               16, (int)off, 0, 0, 0);
+    } else {
+      const int i = d - 3;
+      const int64_t t0 = tbeg + (int64_t)s * WW_TS;
+      const unsigned off = (s < nst) ? (unsigned)(t0 * 4 * N * 4) + yconst[i] : OOB;     // rows past the slice end: resource bound
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(lds + toff + WW_X_FLOATS + (i * 256 + wave * 64) * 4),
+                                               16, (int)off, 0, 0, 0);
+    }
+  };
+  f32x16 acc[6];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
+  // prologue: stages 0 .. STAGES - 2 in flight, the records of stage STAGES - 1 loaded
+  u32x2 recn[3];
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t) {
+    u32x2 rc[3];
+    load_recs(t, rc);
+#pragma unroll
+    for (int d = 0; d < 5; ++d) issue_piece(t, t * WW_STAGE_FLOATS, d, rc);
+    asm volatile("" ::: "memory");
+  }
+  load_recs(STAGES - 1, recn);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_setprio(0);
+  const int xro = h * 6 * 64 + 32 * (wc ^ h) + r;            // + ks * 768 + a * 64
+  const int yro = WW_X_FLOATS + h * 4 * 64 + 32 * (wn ^ h) + r;   // + ks * 512 + o * 64
+  float Vt[6], Zt[6];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) { Vt[pp] = 0.f; Zt[pp] = 0.f; }
+  auto transform = [&](const float (&x)[6], const float (&y)[4], float (&V)[6], float (&Z)[6]) {
+    const float t1 = x[4] - 4.f * x[2], t2 = x[3] - 4.f * x[1], t3 = x[4] - x[2], t4 = 2.f * (x[3] - x[1]);
+    V[0] = 4.f * x[0] - 5.f * x[2] + x[4];
+    V[1] = t1 + t2; V[2] = t1 - t2; V[3] = t3 + t4; V[4] = t3 - t4;
+    V[5] = 4.f * x[1] - 5.f * x[3] + x[5];
+    const float e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.f * y[2], o4 = 2.f * y[1] + 8.f * y[3];
+    Z[0] = y[0]; Z[1] = e + o; Z[2] = e - o; Z[3] = e4 + o4; Z[4] = e4 - o4; Z[5] = y[3];
+  };
+  auto read_step = [&](const float* St, int ks, float (&x)[6], float (&y)[4]) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) x[a] = St[xro + ks * 768 + a * 64];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) y[o] = St[yro + ks * 512 + o * 64];
+  };
+  constexpr int PER = 8;                                       // VMEM ops per stage: five DMAs + three record loads
+  for (int s0 = 0; s0 < nst; s0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {
+      const int sg = s0 + sidx;
+      // stage sg has landed once only the younger ops are outstanding: the record loads issued behind its DMAs (3) and the
+      // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 + (STAGES - 2) * PER) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const float* St = lds + sidx * WW_STAGE_FLOATS;
+      const int sn = sg + STAGES - 1, toffn = ((sidx + STAGES - 1) % STAGES) * WW_STAGE_FLOATS;
+      float x0[6], y0[4], x1[6], y1[4], V[6], Z[6];
+      read_step(St, 0, x0, y0);
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[pp], Zt[pp], acc[pp], 0, 0, 0);
+      transform(x0, y0, V, Z);
+      read_step(St, 1, x1, y1);
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
+      issue_piece(sn, toffn, 0, recn);
+      issue_piece(sn, toffn, 1, recn);
+      transform(x1, y1, V, Z);
+      read_step(St, 2, x0, y0);
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
+      issue_piece(sn, toffn, 2, recn);
+      issue_piece(sn, toffn, 3, recn);
+      issue_piece(sn, toffn, 4, recn);
+      asm volatile("" ::: "memory");                         // the counted vmcnt relies on this order: five DMAs, then three records
+      load_recs(sn + 1, recn);
+      asm volatile("" ::: "memory");
+      transform(x0, y0, V, Z);
+      read_step(St, 3, x1, y1);
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
+      transform(x1, y1, Vt, Zt);
+    }
+  }
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[pp], Zt[pp], acc[pp], 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  // slab[z][tap9][p][c][n]
+  float* out = slab + ((int64_t)z * 9 + tap9) * 6 * (int64_t)C * N;
+  const int n = nb * 64 + 32 * wn + r;
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * h;
+      out[((int64_t)pp * C + c) * N + n] = acc[pp][g];
+    }
+}
+
+// dW[n][c][kt][kh][kw] = sum_p G[p][kw] * (sum over slices z, ascending, of slab[z][tap9][p][c][n])
+__global__ __launch_bounds__(256) void conv_wgrad_wino_reduce(const float* __restrict__ slab, int S, int C, int N, float* __restrict__ dW) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t CN = (int64_t)C * N;
+  if (e >= 9 * CN) return;
+  const int n = (int)(e % N);
+  const int c = (int)((e / N) % C);
+  const int tap9 = (int)(e / CN);
+  const int64_t zs = 9 * 6 * CN;
+  float sp[6];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) {
+    const float* q = slab + ((int64_t)tap9 * 6 + pp) * CN + (int64_t)c * N + n;
+    float a = 0.f;
+    int zi = 0;
+    for (; zi + 4 <= S; zi += 4) {
+      const float s0 = q[zi * zs], s1 = q[(zi + 1) * zs], s2 = q[(zi + 2) * zs], s3 = q[(zi + 3) * zs];
+      a += s0; a += s1; a += s2; a += s3;
+    }
+    for (; zi < S; ++zi) a += q[zi * zs];
+    sp[pp] = a;
+  }
+  // G^T rows: kw 0: [1/4 -1/6 -1/6 1/24 1/24 0], kw 1: [0 -1/6 1/6 1/12 -1/12 0], kw 2: [0 -1/6 -1/6 1/6 1/6 1]
+  const float s12 = sp[1] + sp[2], d12 = sp[2] - sp[1], s34 = sp[3] + sp[4], d34 = sp[3] - sp[4];
+  float* o = dW + ((int64_t)n * C + c) * 27 + tap9 * 3;
+  o[0] = 0.25f * sp[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+  o[1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+  o[2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + sp[5];
 }
 
 static int validate(const SlicConvArgs* a, const char* who) {
@@ -1655,6 +1925,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     SLIC_REQUIRE(a->Cs % 8 == 0 && a->N % 64 == 0 && a->Ws % 4 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
                      a->Gb == a->Hs && a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len,
                  "slic_conv_gemm: variant 30 needs a stride-1 same-size geometry, Cs %% 8 == 0, N %% 64 == 0, Ws %% 4 == 0, no bias");
+    SLIC_REQUIRE(((a->Cs / 8) & (a->Cs / 8 - 1)) == 0, "slic_conv_gemm: variant 30 needs Cs / 8 to be a power of two");
     SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
     static const int stages = getenv("SLIC_WINO_STAGES") ? atoi(getenv("SLIC_WINO_STAGES")) : 3;
     if (stages == 2) return launch_wino<2>(*a, st);
@@ -1783,6 +2054,62 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
     conv_wgrad_reduce<true><<<dim3((unsigned)slic_cdiv(tot / 4, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, RL, PPR, dW);
   else
     conv_wgrad_reduce<false><<<dim3((unsigned)slic_cdiv(tot / 4, 256)), dim3(256), 0, st>>>(slab, S, a->N, Kp, a->Cs, C, ntaps, RL, PPR, dW);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+static int wino_wgrad_plan(const SlicConvArgs* a, int splits, int* tps, int* S) {
+  const int64_t Mt = a->M / 4;
+  int64_t per = slic_cdiv(Mt, splits < 1 ? 1 : splits);
+  per = slic_cdiv(per, WW_TS) * WW_TS;
+  *tps = (int)per;
+  *S = (int)slic_cdiv(Mt, per);
+  return 0;
+}
+
+extern "C" size_t slic_conv_wgrad_wino_workspace_bytes(const SlicConvArgs* a, int splits) {
+  if (!a || a->M <= 0) return 0;
+  int tps, S;
+  wino_wgrad_plan(a, splits, &tps, &S);
+  return slic_align_up((size_t)S * 9 * 6 * a->Cs * a->N * sizeof(float), 256);
+}
+
+extern "C" int slic_conv_wino_tile_table(const SlicConvArgs* a, uint32_t* tile_tab, void* stream) {
+  SLIC_REQUIRE(a && tile_tab && a->M > 0 && a->Ws % 4 == 0 && a->Ga == a->Ts && a->Gb == a->Hs && a->Gc == a->Ws && a->Cs > 0,
+               "slic_conv_wino_tile_table: needs a stride-1 same-size geometry with Ws %% 4 == 0");
+  SLIC_REQUIRE(a->M * (int64_t)a->Cs * 4 < (int64_t)0xFFFFFF00u, "slic_conv_wino_tile_table: source larger than 4 GiB");
+  conv_wino_tile_table_kernel<<<dim3((unsigned)slic_cdiv(a->M / 4, 256)), dim3(256), 0, S_(stream)>>>(*a, (uint2*)tile_tab);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_conv_wgrad_wino(const SlicConvArgs* a, const float* dy, int splits, const uint32_t* tile_tab, float* dW,
+                                    void* workspace, void* stream) {
+  int rc = validate(a, "slic_conv_wgrad_wino");
+  if (rc) return rc;
+  SLIC_REQUIRE(dy && dW && workspace && tile_tab && splits >= 1, "slic_conv_wgrad_wino: bad args");
+  SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->Ws % 4 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
+                   a->Gb == a->Hs && a->Gc == a->Ws && !a->k_run_len,
+               "slic_conv_wgrad_wino: needs a 3x3x3 stride-1 same-size geometry, Cs %% 64 == 0, N %% 64 == 0, Ws %% 4 == 0");
+  const int64_t dyb = a->M * (int64_t)a->N * 4;
+  SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad_wino: dy larger than 4 GiB (split the batch)");
+  int tps, S;
+  wino_wgrad_plan(a, splits, &tps, &S);
+  hipStream_t st = S_(stream);
+  constexpr int STAGES = 3;
+  constexpr size_t lds = (size_t)STAGES * WW_STAGE_FLOATS * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_wino_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t total = (int64_t)9 * (a->Cs / 64) * (a->N / 64) * S;
+  SLIC_REQUIRE(total < (1ll << 30), "slic_conv_wgrad_wino: grid too large");
+  const unsigned gx = (unsigned)((total + 7) / 8 * 8);
+  conv_wgrad_wino_kernel<STAGES><<<dim3(gx), dim3(256), lds, st>>>(*a, dy, (unsigned)dyb, (const uint2*)tile_tab, (float*)workspace, tps, S);
+  SLIC_LAUNCH_CHECK();
+  const int64_t tot = (int64_t)9 * a->Cs * a->N;
+  conv_wgrad_wino_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>((const float*)workspace, S, a->Cs, a->N, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -59,6 +59,7 @@ class ConvPlan:
         self.wino = (eligible and os.environ.get("SLIC_WINO", "1") != "0") if wino is None else bool(wino)
         assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N multiples of 64, W a multiple of 4"
         self._wu = self._wud = None
+        self._wino_tabs = {}
         if self.wrun:
             self._init_wrun()
             return
@@ -423,6 +424,21 @@ class ConvPlan:
         """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
         lib = _lib.load()
         a = self._fwd_args(x, B)
+        if self.wino and os.environ.get("SLIC_WINO_WGRAD", "1") != "0":
+            # transposed F(4, 3): one workgroup per (kt, kh), 64 x 64 block and slice of the W-tiles; ~2 residency rounds of the
+            # 512 slots (2 workgroups / CU), at least 64 tiles per slice
+            blocks = 9 * (self.C // 64) * (self.N // 64)
+            mt = a.M // 4
+            if splits is None:
+                splits = max(1, min(int(os.environ.get("SLIC_WINO_WGRAD_WGS", "1024")) // blocks, mt // 64))
+            tab = self._wino_tabs.get(B)
+            if tab is None:
+                tab = torch.empty(mt, 2, dtype=torch.int32, device=self.device)
+                call("slic_conv_wino_tile_table", ctypes.byref(a), ptr(tab), stream())
+                self._wino_tabs[B] = tab
+            ws = _lib.workspace(lib.slic_conv_wgrad_wino_workspace_bytes(ctypes.byref(a), splits), x.device, "wgrad")
+            call("slic_conv_wgrad_wino", ctypes.byref(a), ptr(dz), splits, ptr(tab), ptr(dW), ptr(ws), stream())
+            return dW
         if splits is None:
             # measured (scripts/bench_conv.py, WGONLY=1 sweep): 128 x 64 output tiles, ~3000 workgroups, but at
             # least 1024 positions per slice so the slabs of the small-M layers stay small
