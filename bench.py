@@ -343,8 +343,11 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # dominant kernel: the gather-GEMM (conv_gemm_dma_kernel<128,64,2,2,2,32>) on the 64->64 3x3x3 layers (layer1: 4 forward +
-    # 4 data-gradient launches per step, identical M x N x K) — bracket every such launch of the timed steps with HIP events
+    # dominant kernel (largest share of a step's kernel time): conv_wino_kernel — Winograd F(4,3) along W — on the 64->64 3x3x3 layers
+    # (layer1: 4 forward + 4 data-gradient launches per step, identical M x N x K).  Every such launch of the timed steps is
+    # bracketed with HIP events on the launch stream.  ALGORITHMIC FLOPs of a launch = the direct convolution's 2 M N K;
+    # the kernel itself executes 6/12 of those multiplies on the matrix pipe, so `achieved` may exceed the fp32 MFMA peak — the
+    # fraction of the pipe's peak actually used is reported beside it (mfma_frac_executed).
     eng = net._engine(x)
     l1 = [p for (_, p1, p2, _) in eng.blocks[:2] for p in (p1, p2)]
     for p in l1:
@@ -371,6 +374,8 @@ def main():
     M = B * 16 * 56 * 56
     flops_launch = 2.0 * M * 64 * 1728
     ach = flops_launch / (ms_k * 1e-3) / 1e12
+    wino = bool(getattr(l1[0], "wino", False))
+    executed = flops_launch * 0.5 if wino else flops_launch          # F(4,3): 6 multiplies where the direct form has 12
 
     # HBM traffic of the dominant kernel comes from PMC counters, which need rocprofv3 around the process: the value below is
     # the one committed with the profile of the same command (profiles/), NOT measured in this run — `traffic` stays null
@@ -399,8 +404,12 @@ def main():
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
                              traffic_source=traffic_src,
-                             kernel="conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring, DMA issue interleaved with the MFMAs; fwd + dgrad of layer1)",
+                             kernel=("conv_wino_kernel<3> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
+                                     "over W-tiles, LDS-DMA 3-stage ring, transforms in registers; fwd + dgrad of layer1)" if wino else
+                                     "conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring; fwd + dgrad of layer1)"),
                              ms_per_launch=ms_k, launches_timed=len(ev), algorithmic_flops_per_launch=flops_launch,
+                             executed_mfma_flops_per_launch=executed,
+                             mfma_frac_executed=executed / (ms_k * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                              whole_step_frac=(world * B * args.steps / dt) * GFLOP_PER_CLIP_TRAIN / 1e3 /
                                              (FP32_MFMA_PEAK_TFLOPS * world)))
     if not args.no_secondary:

@@ -1348,6 +1348,9 @@ static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 //   addend / mask / BatchNorm partials with slab rows of 128 GEMM rows, as variant 22).
 // ------------------------------------------------------------------------------------------
 constexpr int WINO_STAGE_FLOATS = 2 * 12 * 64 * 4;     // A image + U image
+#ifndef SLIC_WINO_ABL
+#define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier
+#endif
 
 template <int STAGES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -1415,12 +1418,20 @@ void conv_wino_kernel(const SlicConvArgs p) {
   auto issue_piece = [&](const StageRec& q, int toff, int d) {
     if (d < 3) {
       const unsigned ok = q.live & (tmask >> q.kt) & (hmask >> q.kh) & avu[d];
+#if SLIC_WINO_ABL & 1
+      const unsigned off = OOB + 0 * (ok + aoff[d] + q.delta);     // diagnostic build: DMAs issued, no memory traffic
+#else
       const unsigned off = ok ? aoff[d] + q.delta : OOB;
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     } else {
       const int i = d - 3;
+#if SLIC_WINO_ABL & 1
+      const unsigned off = OOB + 0 * (q.live + q.ublk + i);
+#else
       const unsigned off = q.live ? q.ublk + (unsigned)(i * 256 * 16) : OOB;
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     }
@@ -1451,7 +1462,9 @@ void conv_wino_kernel(const SlicConvArgs p) {
       // stage sg has landed; and this wave's LDS reads of stage sg - 1 are COMPLETE (lgkmcnt(0)), not merely issued, before the
       // barrier lets another wave's DMAs overwrite that slot
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * 6) : "memory");
+#if !(SLIC_WINO_ABL & 2)
       __builtin_amdgcn_s_barrier();
+#endif
       const float* St = lds + sidx * WINO_STAGE_FLOATS;
       const int toffn = ((sidx + STAGES - 1) % STAGES) * WINO_STAGE_FLOATS;
       const StageRec qn = stage_rec(sg + STAGES - 1);
@@ -1685,13 +1698,21 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
   };
   auto issue_piece = [&](int s, int toff, int d, const u32x2 (&rec)[3]) {
     if (d < 3) {
+#if SLIC_WINO_ABL & 1
+      const unsigned off = OOB + 0 * (rec[d].y + rec[d].x);
+#else
       const unsigned off = ((rec[d].y & xneed[d]) == xneed[d]) ? rec[d].x + xconst[d] : OOB;
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     } else {
       const int i = d - 3;
       const int64_t t0 = tbeg + (int64_t)s * WW_TS;
+#if SLIC_WINO_ABL & 1
+      const unsigned off = OOB + 0 * (unsigned)(t0 + yconst[i]);
+#else
       const unsigned off = (s < nst) ? (unsigned)(t0 * 4 * N * 4) + yconst[i] : OOB;     // rows past the slice end: resource bound
+#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(lds + toff + WW_X_FLOATS + (i * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     }
@@ -1741,7 +1762,9 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
       // stage sg has landed once only the younger ops are outstanding: the record loads issued behind its DMAs (3) and the
       // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 + (STAGES - 2) * PER) : "memory");
+#if !(SLIC_WINO_ABL & 2)
       __builtin_amdgcn_s_barrier();
+#endif
       const float* St = lds + sidx * WW_STAGE_FLOATS;
       const int sn = sg + STAGES - 1, toffn = ((sidx + STAGES - 1) % STAGES) * WW_STAGE_FLOATS;
       float x0[6], y0[4], x1[6], y1[4], V[6], Z[6];
