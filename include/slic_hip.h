@@ -278,12 +278,14 @@ int slic_pack_weight_dgrad(const float* W, int N, int C, int ntaps, int Cs, int 
  *   U[(((tap9 * C_/8 + cc) * N_/64 + nb) * 12 + p * 2 + h) * 64 + nl][j],  tap9 = kt * 3 + kh, n = 64 nb + nl, c = 8 cc + 4 h + j.
  * dgrad = 0: forward operand (N_ = N outputs, C_ = C reduction channels); dgrad = 1: data-gradient operand (N_ = C, C_ = N, taps
  * flipped).  9 * C * N * 6 floats.  Needs N_ % 64 == 0 and C_ % 8 == 0.  Variant 30 itself: same SlicConvArgs as the other
- * variants (stride-1 same-size geometry, Ws % 4 == 0, no bias), wgt / wgt_bytes = this operand; slab rows of 128 GEMM rows. */
+ * variants (stride-1 same-size geometry, no bias), wgt / wgt_bytes = this operand; Ws % 4 == 0, or — the last tile of a row ragged —
+ * a padded width 4 ceil(Ws / 4) that divides 128; slab rows of slic_conv_tile_m(args, 30) GEMM rows (128, or 128 / Wp * Ws). */
 int slic_pack_weight_wino(const float* W, int N, int C, int dgrad, float* U, void* stream);
 /* Weight gradient of the same layers by the transposed F(4, 3) algorithm, dW[kw] = sum over W-tiles of G^T[(B^T x) . (A dy)]
  * (six multiplies per (kt, kh, c, n) and tile of four outputs instead of twelve); replaces slic_conv_wgrad where variant 30 runs the
- * forward.  args: the forward geometry (src = x, 3 x 3 x 3 / stride 1 / pad 1, Cs %% 64 == 0, N %% 64 == 0, Ws %% 4 == 0); dy dense
- * [M][N]; tile_tab: M / 4 records of 8 bytes written once per geometry by slic_conv_wino_tile_table; `splits` slices of the tiles,
+ * forward.  args: the forward geometry (src = x, 3 x 3 x 3 / stride 1 / pad 1, Cs % 64 == 0, N % 64 == 0, any Ws: the last tile of a
+ * row may be ragged); dy dense [M][N]; tile_tab: (M / Ws) * ceil(Ws / 4) records of 8 bytes written once per geometry by
+ * slic_conv_wino_tile_table; `splits` slices of the tiles,
  * reduced in slice order (deterministic); dW in the reference layout [N][C][3][3][3].  workspace: splits x 9 x 6 x Cs x N floats. */
 size_t slic_conv_wgrad_wino_workspace_bytes(const SlicConvArgs* args, int splits);
 int slic_conv_wino_tile_table(const SlicConvArgs* args, uint32_t* tile_tab, void* stream);

@@ -48,7 +48,7 @@ for name, C, N, k, s, p, dims in SHAPES:
             line += f" | dg v{v} {fl/t/1e9:6.1f}"
     t = timeit(lambda: plan.wgrad(x, dz, B, dW))
     line += f" | wg {fl/t/1e9:6.1f} TF"
-    if k == (3, 3, 3) and s == (1, 1, 1) and C % 64 == 0 and N % 64 == 0 and dims[2] % 4 == 0:
+    if k == (3, 3, 3) and s == (1, 1, 1) and C % 64 == 0 and N % 64 == 0:
         wplan = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True)      # Winograd F(4,3) along W: TFLOP/s of the direct conv's FLOPs
         wu, wud = wplan.pack_fwd(w), wplan.pack_dgrad(w)
         t = timeit(lambda: wplan.forward(x, wu, B, want_stats=True))

@@ -70,9 +70,27 @@ constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * 4 * BN 
 // Part 2 of the epilogue: everything after the accumulators have been written to the LDS image [BM][BN] (and a barrier passed).
 // Also called on its own by kernels that build the image themselves (the Winograd kernel: its image rows are the four outputs
 // of each W-tile).  m0 = first GEMM row of the image, a multiple of BM.
-template <int BM, int BN>
+// WPAD (the Winograd kernels on a width that is not a multiple of 4): the image rows live in a W-PADDED row space — image row
+// m' = (b, t, h) * Wp + w' with Wp = 4 ceil(W / 4) a power of two dividing BM; rows with w' >= W do not exist.  m0 is then the
+// padded index of the first row; the GEMM row of image row m' is (m' / Wp) * W + w', and a block holds BM / Wp * W real rows.
+template <int BM, int BN, bool WPAD = false>
 __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float* lds, int64_t m0, int n0, int tid) {
   const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial / bwd_partial)
+  [[maybe_unused]] const int wp_shift = WPAD ? 31 - __builtin_clz((p.Ws + 3) & ~3) : 0;
+  [[maybe_unused]] const int64_t bth_all = WPAD ? p.M / p.Ws : 0;
+  // image row -> (exists, GEMM row)
+  auto row_of = [&](int row, int64_t& m) -> bool {
+    if constexpr (WPAD) {
+      const int64_t mp = m0 + row;
+      const int64_t bth = mp >> wp_shift;
+      const int wq = (int)(mp - (bth << wp_shift));
+      m = bth * p.Ws + wq;
+      return wq < p.Ws && bth < bth_all;
+    } else {
+      m = m0 + row;
+      return m < p.M;
+    }
+  };
   constexpr int CPR = BN / 4;       // 16-byte chunks per tile row
   constexpr int RPP = 256 / CPR;    // rows per pass of the 256 threads
   constexpr int NPASS = BM / RPP;
@@ -118,8 +136,8 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int row = ps * RPP + rr;
-    const int64_t m = m0 + row;
-    const bool ok = nv && m < p.M;
+    int64_t m;
+    const bool ok = row_of(row, m) && nv;
     unsigned ro;
     if (p.dst_strided) {
       unsigned q = (unsigned)m;
@@ -174,8 +192,12 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
     // BatchNorm partials of v = acc + bias over this workgroup's valid rows, per channel:
     //   slab[blk][0][n] = sum v          slab[blk][1][n] = sum (v - mean_blk)^2   (second pass over the LDS image,
     // so the variance never comes from E[x^2] - mean^2); bn_finalize merges workgroups with Chan's formula in double.
-    const int64_t left = p.M - m0;
-    const float inv_rows = 1.0f / (float)(left < BM ? left : BM);
+    int64_t left = p.M - m0, full = BM;
+    if constexpr (WPAD) {
+      full = (BM >> wp_shift) * p.Ws;                 // real rows of a full block
+      left = p.M - mblk * full;
+    }
+    const float inv_rows = 1.0f / (float)(left < full ? left : full);
     if (want_bwd) __syncthreads();             // red1 is still being read by the block above
     fs = wave_rows_sum(fs);
     if (elane < CPR) *(f32x4*)&red1[ewave * BN + cq * 4] = fs;
@@ -194,7 +216,8 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + rr;
-      if (m0 + row < p.M) {
+      int64_t mm;
+      if (row_of(row, mm)) {
         const f32x4 d = *(const f32x4*)&tile[row * BN + cq * 4] - mu;
         q2 += d * d;
       }
@@ -1352,7 +1375,7 @@ constexpr int WINO_STAGE_FLOATS = 2 * 12 * 64 * 4;     // A image + U image
 #define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier
 #endif
 
-template <int STAGES>
+template <int STAGES, bool WPAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(const SlicConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1361,13 +1384,13 @@ void conv_wino_kernel(const SlicConvArgs p) {
   const int r = lane & 31, h = lane >> 5;
   const int bx = blockIdx.x, gdx = gridDim.x;
   const int mb = (bx & 7) * (gdx >> 3) + (bx >> 3);          // XCD-aware order (see conv_gemm_dma_body)
-  const int64_t Mt = p.M >> 2;                                // W-tiles
+  const int Wq = (p.Ws + 3) >> 2;                             // W-tiles per row (WPAD: the last one is ragged)
+  const int64_t Mt = WPAD ? (p.M / p.Ws) * Wq : (p.M >> 2);   // W-tiles
   const int64_t tile0 = (int64_t)mb * 64;
   if (tile0 >= Mt) return;
   const int nb = blockIdx.y, n0 = nb * 64;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
-  const int Wq = W >> 2;
   const int CCH = C >> 3;                                     // 8-channel stages per (kt, kh)
   const int NS = 9 * CCH;
   const int NB = p.N >> 6;
@@ -1534,7 +1557,7 @@ void conv_wino_kernel(const SlicConvArgs p) {
         }
     }
     __syncthreads();
-    conv_epilogue_rows<128, 64>(p, lds, (tile0 + hf * 32) * 4, n0, tid);
+    conv_epilogue_rows<128, 64, WPAD>(p, lds, (tile0 + hf * 32) * 4, n0, tid);
     __syncthreads();
   }
 }
@@ -1578,18 +1601,19 @@ __global__ void pack_w_wino(const float* __restrict__ Wt, int N, int C, int dgra
   for (int pp = 0; pp < 6; ++pp) U[blk + ((pp * 2 + h) * 64 + nl) * 4 + j] = u[pp];
 }
 
-template <int STAGES>
+template <int STAGES, bool WPAD>
 static int launch_wino(const SlicConvArgs& a, hipStream_t st) {
   constexpr size_t ring = (size_t)STAGES * WINO_STAGE_FLOATS * sizeof(float), epi = (size_t)conv_epi_lds_floats(128, 64) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino_kernel<STAGES, WPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const unsigned gx = (unsigned)slic_cdiv(a.M / 4, 64);
+  const int64_t tiles = (a.M / a.Ws) * ((a.Ws + 3) / 4);
+  const unsigned gx = (unsigned)slic_cdiv(tiles, 64);
   dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64));
-  conv_wino_kernel<STAGES><<<grid, dim3(256), lds, st>>>(a);
+  conv_wino_kernel<STAGES, WPAD><<<grid, dim3(256), lds, st>>>(a);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1614,12 +1638,13 @@ constexpr int WW_X_FLOATS = WW_TS * 6 * 64;
 constexpr int WW_Y_FLOATS = WW_TS * 4 * 64;
 constexpr int WW_STAGE_FLOATS = WW_X_FLOATS + WW_Y_FLOATS;
 
-// tile_tab[tile] = {byte offset of pixel (b, t, h, 4 wt) channel 0, bits 0-2: t - 1, t, t + 1 inside; 3-5: h - 1, h, h + 1 inside;
-//                   6: pixel 4 wt - 1 inside; 7: pixel 4 wt + 4 inside}
+// tile_tab[tile] = {pixel index of (b, t, h, 4 wt) (= its GEMM row), bits 0-2: t - 1, t, t + 1 inside; 3-5: h - 1, h, h + 1 inside;
+//                   6-11: pixel 4 wt - 1 + a inside the row (a = 0..5); 12-15: output 4 wt + o inside the row (o = 0..3)}
+// Tiles per row = ceil(W / 4): on a width that is not a multiple of 4 the last tile of a row is ragged.
 __global__ void conv_wino_tile_table_kernel(const SlicConvArgs p, uint2* __restrict__ tab) {
+  const int Wq = (p.Ws + 3) >> 2;
   const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tile >= (p.M >> 2)) return;
-  const int Wq = p.Ws >> 2;
+  if (tile >= (p.M / p.Ws) * Wq) return;
   unsigned q = (unsigned)tile;
   const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
   const int hh = (int)(q % (unsigned)p.Hs); q /= (unsigned)p.Hs;
@@ -1630,9 +1655,11 @@ __global__ void conv_wino_tile_table_kernel(const SlicConvArgs p, uint2* __restr
     mk |= ((unsigned)(tt + o - 1) < (unsigned)p.Ts ? 1u : 0u) << o;
     mk |= ((unsigned)(hh + o - 1) < (unsigned)p.Hs ? 1u : 0u) << (3 + o);
   }
-  mk |= (wt > 0 ? 1u : 0u) << 6;
-  mk |= (wt < Wq - 1 ? 1u : 0u) << 7;
-  tab[tile] = make_uint2((unsigned)((((((int64_t)q * p.Ts + tt) * p.Hs + hh) * p.Ws + 4 * wt) * p.Cs) * 4), mk);
+#pragma unroll
+  for (int a = 0; a < 6; ++a) mk |= ((unsigned)(4 * wt - 1 + a) < (unsigned)p.Ws ? 1u : 0u) << (6 + a);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) mk |= (4 * wt + o < p.Ws ? 1u : 0u) << (12 + o);
+  tab[tile] = make_uint2((unsigned)((((int64_t)q * p.Ts + tt) * p.Hs + hh) * p.Ws + 4 * wt), mk);
 }
 
 template <int STAGES>
@@ -1654,89 +1681,73 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
   const int tap9 = rest / (CB * NBk); rest -= tap9 * (CB * NBk);
   const int cb = rest / NBk, nb = rest - cb * NBk;
   const int kt = tap9 / 3, kh = tap9 - 3 * kt;
-  const int64_t Mt = p.M >> 2;
+  const int Wq = (W + 3) >> 2;
+  const int64_t Mt = (p.M / W) * Wq;
   const int64_t tbeg = (int64_t)z * tiles_per_split;
   const int64_t tend = min(tbeg + tiles_per_split, Mt);
   const int nst = tend > tbeg ? (int)((tend - tbeg + WW_TS - 1) / WW_TS) : 0;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)dy, 0, (int)min((uint64_t)dy_bytes, (uint64_t)tend * 4u * (uint64_t)N * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)tile_tab, 0, (int)(tend * 8), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFF00u;
-  // ---- DMA roles.  pixels: chunk q = i * 256 + tid of the stage image [tile 8][pixel 6][16 chunks]; gradients: [tile 8][out 4][16]
-  int xtl[3];
-  unsigned xneed[3], xconst[3];
+  // ---- DMA roles: a thread serves ONE tile of the stage (tl = tid / 32: lanes 0-31 of wave w tile 2 w, lanes 32-63 tile 2 w + 1)
+  // with five 16-byte chunks of its 160 (six pixels x 16, then four gradient rows x 16): chunk k = 32 i + (tid & 31).  The DMA
+  // writes lane-linear, so the stage image is [wave 4][piece 5][tile parity 2][32 chunks].
+  const int tl = tid >> 5, l32 = tid & 31, par = tl & 1;
+  unsigned need[5], cst[5], mul[5];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int q = i * 256 + tid;
-    const int tl = q / 96, w96 = q - tl * 96;
-    const int a = w96 >> 4, j = w96 & 15;
-    const int c4 = j ^ ((tl & 1) << 3);                       // odd tiles: channel halves swapped (bank spread of the two half-waves)
-    xtl[i] = tl;
-    xneed[i] = (1u << kt) | (1u << (3 + kh)) | (a == 0 ? 1u << 6 : 0u) | (a == 5 ? 1u << 7 : 0u);
-    xconst[i] = (unsigned)(((((kt - 1) * H + (kh - 1)) * W + (a - 1)) * C + cb * 64 + 4 * c4) * 4);
-  }
-  unsigned yconst[2];
-  int ytl[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = i * 256 + tid;
-    const int tl = q >> 6, w64 = q & 63;
-    const int o = w64 >> 4, j = w64 & 15;
-    const int n4 = j ^ ((tl & 1) << 3);
-    ytl[i] = tl;
-    yconst[i] = (unsigned)(((tl * 4 + o) * N + nb * 64 + 4 * n4) * 4);
+  for (int i = 0; i < 5; ++i) {
+    const int k = 32 * i + l32;
+    if (i < 3) {
+      const int a = k >> 4, j = k & 15;
+      const int c4 = j ^ (par << 3);                          // odd tiles: channel halves swapped (bank spread of the two half-waves)
+      need[i] = (1u << kt) | (1u << (3 + kh)) | (1u << (6 + a));
+      cst[i] = (unsigned)(((((kt - 1) * H + (kh - 1)) * W + (a - 1)) * C + cb * 64 + 4 * c4) * 4);
+      mul[i] = (unsigned)(C * 4);
+    } else {
+      const int kk = k - 96;
+      const int o = kk >> 4, j = kk & 15;
+      const int n4 = j ^ (par << 3);
+      need[i] = 1u << (12 + o);
+      cst[i] = (unsigned)((o * N + nb * 64 + 4 * n4) * 4);
+      mul[i] = (unsigned)(N * 4);
+    }
   }
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  auto load_recs = [&](int s, u32x2 (&dst)[3]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int64_t tile = tbeg + (int64_t)s * WW_TS + xtl[i];
-      dst[i] = __builtin_amdgcn_raw_buffer_load_b64(rs_tab, (int)(tile * 8), 0, 0);      // past the slice: zeros (nothing valid)
-    }
+  auto load_rec = [&](int s) -> u32x2 {
+    const int64_t tile = tbeg + (int64_t)s * WW_TS + tl;
+    return __builtin_amdgcn_raw_buffer_load_b64(rs_tab, (int)(tile * 8), 0, 0);          // past the slice: zeros (nothing valid)
   };
-  auto issue_piece = [&](int s, int toff, int d, const u32x2 (&rec)[3]) {
-    if (d < 3) {
+  auto issue_piece = [&](int toff, int d, const u32x2 rec) {
 #if SLIC_WINO_ABL & 1
-      const unsigned off = OOB + 0 * (rec[d].y + rec[d].x);
+    const unsigned off = OOB + 0 * (rec.y + rec.x);
 #else
-      const unsigned off = ((rec[d].y & xneed[d]) == xneed[d]) ? rec[d].x + xconst[d] : OOB;
+    const unsigned off = ((rec.y & need[d]) == need[d]) ? rec.x * mul[d] + cst[d] : OOB;
 #endif
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
-                                               16, (int)off, 0, 0, 0);
-    } else {
-      const int i = d - 3;
-      const int64_t t0 = tbeg + (int64_t)s * WW_TS;
-#if SLIC_WINO_ABL & 1
-      const unsigned off = OOB + 0 * (unsigned)(t0 + yconst[i]);
-#else
-      const unsigned off = (s < nst) ? (unsigned)(t0 * 4 * N * 4) + yconst[i] : OOB;     // rows past the slice end: resource bound
-#endif
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(lds + toff + WW_X_FLOATS + (i * 256 + wave * 64) * 4),
-                                               16, (int)off, 0, 0, 0);
-    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(d < 3 ? rs_src : rs_dy,
+                                             (__attribute__((address_space(3))) void*)(lds + toff + (wave * 5 + d) * 64 * 4), 16, (int)off, 0, 0, 0);
   };
   f32x16 acc[6];
 #pragma unroll
   for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
     for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
-  // prologue: stages 0 .. STAGES - 2 in flight, the records of stage STAGES - 1 loaded
-  u32x2 recn[3];
+  // prologue: stages 0 .. STAGES - 2 in flight, the record of stage STAGES - 1 loaded
+  u32x2 recn;
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t) {
-    u32x2 rc[3];
-    load_recs(t, rc);
+    const u32x2 rc = load_rec(t);
 #pragma unroll
-    for (int d = 0; d < 5; ++d) issue_piece(t, t * WW_STAGE_FLOATS, d, rc);
+    for (int d = 0; d < 5; ++d) issue_piece(t * WW_STAGE_FLOATS, d, rc);
     asm volatile("" ::: "memory");
   }
-  load_recs(STAGES - 1, recn);
+  recn = load_rec(STAGES - 1);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_setprio(0);
-  const int xro = h * 6 * 64 + 32 * (wc ^ h) + r;            // + ks * 768 + a * 64
-  const int yro = WW_X_FLOATS + h * 4 * 64 + 32 * (wn ^ h) + r;   // + ks * 512 + o * 64
+  // image offsets (floats): pixel a of tile 2 ks + h = piece a / 2 of wave ks, parity h, chunk 16 (a % 2) + channel / 4
+  const int xro = h * 128 + 32 * (wc ^ h) + r;               // + ks * 1280 + (a >> 1) * 256 + (a & 1) * 64
+  const int yro = 3 * 256 + h * 128 + 32 * (wn ^ h) + r;     // + ks * 1280 + (o >> 1) * 256 + (o & 1) * 64
   float Vt[6], Zt[6];
 #pragma unroll
   for (int pp = 0; pp < 6; ++pp) { Vt[pp] = 0.f; Zt[pp] = 0.f; }
@@ -1750,23 +1761,23 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
   };
   auto read_step = [&](const float* St, int ks, float (&x)[6], float (&y)[4]) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) x[a] = St[xro + ks * 768 + a * 64];
+    for (int a = 0; a < 6; ++a) x[a] = St[xro + ks * 1280 + (a >> 1) * 256 + (a & 1) * 64];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) y[o] = St[yro + ks * 512 + o * 64];
+    for (int o = 0; o < 4; ++o) y[o] = St[yro + ks * 1280 + (o >> 1) * 256 + (o & 1) * 64];
   };
-  constexpr int PER = 8;                                       // VMEM ops per stage: five DMAs + three record loads
+  constexpr int PER = 6;                                       // VMEM ops per stage: five DMAs + one record load
   for (int s0 = 0; s0 < nst; s0 += STAGES) {
 #pragma unroll
     for (int sidx = 0; sidx < STAGES; ++sidx) {
       const int sg = s0 + sidx;
-      // stage sg has landed once only the younger ops are outstanding: the record loads issued behind its DMAs (3) and the
+      // stage sg has landed once only the younger ops are outstanding: the record load issued behind its DMAs and the
       // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 + (STAGES - 2) * PER) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (STAGES - 2) * PER) : "memory");
 #if !(SLIC_WINO_ABL & 2)
       __builtin_amdgcn_s_barrier();
 #endif
       const float* St = lds + sidx * WW_STAGE_FLOATS;
-      const int sn = sg + STAGES - 1, toffn = ((sidx + STAGES - 1) % STAGES) * WW_STAGE_FLOATS;
+      const int toffn = ((sidx + STAGES - 1) % STAGES) * WW_STAGE_FLOATS;
       float x0[6], y0[4], x1[6], y1[4], V[6], Z[6];
       read_step(St, 0, x0, y0);
 #pragma unroll
@@ -1775,17 +1786,17 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
       read_step(St, 1, x1, y1);
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
-      issue_piece(sn, toffn, 0, recn);
-      issue_piece(sn, toffn, 1, recn);
+      issue_piece(toffn, 0, recn);
+      issue_piece(toffn, 1, recn);
       transform(x1, y1, V, Z);
       read_step(St, 2, x0, y0);
 #pragma unroll
       for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
-      issue_piece(sn, toffn, 2, recn);
-      issue_piece(sn, toffn, 3, recn);
-      issue_piece(sn, toffn, 4, recn);
-      asm volatile("" ::: "memory");                         // the counted vmcnt relies on this order: five DMAs, then three records
-      load_recs(sn + 1, recn);
+      issue_piece(toffn, 2, recn);
+      issue_piece(toffn, 3, recn);
+      issue_piece(toffn, 4, recn);
+      asm volatile("" ::: "memory");                         // the counted vmcnt relies on this order: five DMAs, then the record
+      recn = load_rec(sg + STAGES);
       asm volatile("" ::: "memory");
       transform(x0, y0, V, Z);
       read_step(St, 3, x1, y1);
@@ -1929,8 +1940,10 @@ static int launch_gemm_dma_tail(const SlicConvArgs& a, hipStream_t st, int nfull
 //   20  LDS-DMA ring, 64 x 64 tiles, 5 workgroups / CU   (source channels % 32 == 0)
 //   22  LDS-DMA ring, 128 x 64 tiles, 3 workgroups / CU  (N <= 64 and many rows: layer1)
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
-  (void)a;
-  return (variant == 22 || variant == 30) ? 128 : 64;     // rows per slab row (callers size stat_partial / bwd_partial with it)
+  // rows per slab row (callers size stat_partial / bwd_partial with it).  Variant 30 on a width that is not a multiple of 4: a
+  // block of 128 image rows holds 128 / Wp * W real rows (conv_epilogue_rows, WPAD)
+  if (variant == 30 && a && a->Ws % 4 != 0) return 128 / ((a->Ws + 3) / 4 * 4) * a->Ws;
+  return (variant == 22 || variant == 30) ? 128 : 64;
 }
 
 extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) {
@@ -1945,14 +1958,15 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   hipStream_t st = S_(stream);
   if (variant == 30) {
     // Winograd F(4, 3) along W: wgt = the operand of slic_pack_weight_wino; 3 x 3 x 3, stride 1, pad 1 geometry only
-    SLIC_REQUIRE(a->Cs % 8 == 0 && a->N % 64 == 0 && a->Ws % 4 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
+    SLIC_REQUIRE(a->Cs % 8 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
                      a->Gb == a->Hs && a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len,
-                 "slic_conv_gemm: variant 30 needs a stride-1 same-size geometry, Cs %% 8 == 0, N %% 64 == 0, Ws %% 4 == 0, no bias");
+                 "slic_conv_gemm: variant 30 needs a stride-1 same-size geometry, Cs %% 8 == 0, N %% 64 == 0, no bias");
+    const int Wp = (a->Ws + 3) / 4 * 4;
+    SLIC_REQUIRE(a->Ws % 4 == 0 || 128 % Wp == 0, "slic_conv_gemm: variant 30 needs Ws %% 4 == 0 or a padded width dividing 128 (Ws=%d)", a->Ws);
     SLIC_REQUIRE(((a->Cs / 8) & (a->Cs / 8 - 1)) == 0, "slic_conv_gemm: variant 30 needs Cs / 8 to be a power of two");
     SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
-    static const int stages = getenv("SLIC_WINO_STAGES") ? atoi(getenv("SLIC_WINO_STAGES")) : 3;
-    if (stages == 2) return launch_wino<2>(*a, st);
-    return launch_wino<3>(*a, st);
+    if (a->Ws % 4 != 0) return launch_wino<3, true>(*a, st);
+    return launch_wino<3, false>(*a, st);
   }
   if (variant != 0) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
@@ -2081,8 +2095,10 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   return SLIC_OK;
 }
 
+static int64_t wino_tiles(const SlicConvArgs* a) { return (a->M / a->Ws) * ((a->Ws + 3) / 4); }
+
 static int wino_wgrad_plan(const SlicConvArgs* a, int splits, int* tps, int* S) {
-  const int64_t Mt = a->M / 4;
+  const int64_t Mt = wino_tiles(a);
   int64_t per = slic_cdiv(Mt, splits < 1 ? 1 : splits);
   per = slic_cdiv(per, WW_TS) * WW_TS;
   *tps = (int)per;
@@ -2098,10 +2114,10 @@ extern "C" size_t slic_conv_wgrad_wino_workspace_bytes(const SlicConvArgs* a, in
 }
 
 extern "C" int slic_conv_wino_tile_table(const SlicConvArgs* a, uint32_t* tile_tab, void* stream) {
-  SLIC_REQUIRE(a && tile_tab && a->M > 0 && a->Ws % 4 == 0 && a->Ga == a->Ts && a->Gb == a->Hs && a->Gc == a->Ws && a->Cs > 0,
-               "slic_conv_wino_tile_table: needs a stride-1 same-size geometry with Ws %% 4 == 0");
+  SLIC_REQUIRE(a && tile_tab && a->M > 0 && a->Ws > 0 && a->Ga == a->Ts && a->Gb == a->Hs && a->Gc == a->Ws && a->Cs > 0,
+               "slic_conv_wino_tile_table: needs a stride-1 same-size geometry");
   SLIC_REQUIRE(a->M * (int64_t)a->Cs * 4 < (int64_t)0xFFFFFF00u, "slic_conv_wino_tile_table: source larger than 4 GiB");
-  conv_wino_tile_table_kernel<<<dim3((unsigned)slic_cdiv(a->M / 4, 256)), dim3(256), 0, S_(stream)>>>(*a, (uint2*)tile_tab);
+  conv_wino_tile_table_kernel<<<dim3((unsigned)slic_cdiv(wino_tiles(a), 256)), dim3(256), 0, S_(stream)>>>(*a, (uint2*)tile_tab);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -2111,9 +2127,9 @@ extern "C" int slic_conv_wgrad_wino(const SlicConvArgs* a, const float* dy, int 
   int rc = validate(a, "slic_conv_wgrad_wino");
   if (rc) return rc;
   SLIC_REQUIRE(dy && dW && workspace && tile_tab && splits >= 1, "slic_conv_wgrad_wino: bad args");
-  SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->Ws % 4 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
+  SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
                    a->Gb == a->Hs && a->Gc == a->Ws && !a->k_run_len,
-               "slic_conv_wgrad_wino: needs a 3x3x3 stride-1 same-size geometry, Cs %% 64 == 0, N %% 64 == 0, Ws %% 4 == 0");
+               "slic_conv_wgrad_wino: needs a 3x3x3 stride-1 same-size geometry, Cs %% 64 == 0, N %% 64 == 0");
   const int64_t dyb = a->M * (int64_t)a->N * 4;
   SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u, "slic_conv_wgrad_wino: dy larger than 4 GiB (split the batch)");
   int tps, S;

@@ -36,7 +36,9 @@ def _tap_mask(oa, ob, oc):
 class ConvPlan:
     """One conv layer at one input size.  kernel/stride/pad are (t, h, w) triples."""
 
-    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None):
+    WINO_MIN_WGS = 384     # forward / data gradient: fewer 64-tile x 64-n workgroups than this leave the chip too empty (layer4 at B = 32: 112)
+
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, batch=None):
         self.C, self.N = int(C), int(N)
         self.Cs = (self.C + 3) // 4 * 4
         self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
@@ -54,10 +56,22 @@ class ConvPlan:
         # counts on both sides (forward reduces over C, the data gradient over N) and W % 4 == 0 — layer1 and layer2 of R3D-18.
         # Exact fp32, half the multiplies.  wino=None: on where eligible unless SLIC_WINO=0; explicit variants of forward() /
         # dgrad() need a plan built with wino=False (the packed operand differs).
-        eligible = (self.kernel == (3, 3, 3) and self.stride == (1, 1, 1) and self.pad == (1, 1, 1) and self.C % 64 == 0 and
-                    self.N % 64 == 0 and self.in_dims[2] % 4 == 0 and not self.wrun)
-        self.wino = (eligible and os.environ.get("SLIC_WINO", "1") != "0") if wino is None else bool(wino)
-        assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N multiples of 64, W a multiple of 4"
+        base = (self.kernel == (3, 3, 3) and self.stride == (1, 1, 1) and self.pad == (1, 1, 1) and self.C % 64 == 0 and
+                self.N % 64 == 0 and not self.wrun)
+        Wd = self.in_dims[2]
+        Wp = (Wd + 3) // 4 * 4
+        # forward / data gradient: a width that is not a multiple of 4 runs with a ragged last tile per row (padded width must
+        # divide 128: 14 -> 16, 7 -> 8); and the launch must fill the chip: 64 W-tiles x 64 n per workgroup, no split of K
+        eligible = base and (Wd % 4 == 0 or 128 % Wp == 0)
+        on = os.environ.get("SLIC_WINO", "1") != "0"
+        fills = True
+        if batch is not None:        # the engine knows its batch: keep the direct kernel (with its K-split tail) for few-tile layers
+            tiles = batch * self.in_dims[0] * self.in_dims[1] * (Wp // 4)
+            fills = ((tiles + 63) // 64) * (self.N // 64) >= self.WINO_MIN_WGS
+        self.wino = (eligible and on and fills) if wino is None else bool(wino)
+        assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N multiples of 64, W % 4 == 0 or 4 ceil(W/4) | 128"
+        # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
+        self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
         self._wu = self._wud = None
         self._wino_tabs = {}
         if self.wrun:
@@ -424,11 +438,11 @@ class ConvPlan:
         """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
         lib = _lib.load()
         a = self._fwd_args(x, B)
-        if self.wino and os.environ.get("SLIC_WINO_WGRAD", "1") != "0":
+        if self.wino_wgrad:
             # transposed F(4, 3): one workgroup per (kt, kh), 64 x 64 block and slice of the W-tiles; ~2 residency rounds of the
             # 512 slots (2 workgroups / CU), at least 64 tiles per slice
             blocks = 9 * (self.C // 64) * (self.N // 64)
-            mt = a.M // 4
+            mt = (a.M // self.in_dims[2]) * ((self.in_dims[2] + 3) // 4)
             if splits is None:
                 splits = max(1, min(int(os.environ.get("SLIC_WINO_WGRAD_WGS", "1024")) // blocks, mt // 64))
             tab = self._wino_tabs.get(B)
