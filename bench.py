@@ -314,7 +314,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.distributed.init_process_group(backend="nccl")      # RCCL on ROCm
+        import datetime
+        # RCCL on ROCm.  A bounded timeout: should one rank fail inside a secondary row while its peers wait in a collective,
+        # the job aborts after five minutes instead of hanging (the headline line is printed before the secondary rows start)
+        torch.distributed.init_process_group(backend="nccl", timeout=datetime.timedelta(minutes=5))
         pg = torch.distributed.group.WORLD
 
     from video_similarity_search_amd import _lib
@@ -412,11 +415,24 @@ def main():
                              mfma_frac_executed=executed / (ms_k * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                              whole_step_frac=(world * B * args.steps / dt) * GFLOP_PER_CLIP_TRAIN / 1e3 /
                                              (FP32_MFMA_PEAK_TFLOPS * world)))
+    def all_ranks_ok(ok):
+        """every rank reports; False anywhere -> False everywhere (the rows after this point run collectives on all ranks)"""
+        if not use_dist:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        return bool(t.item())
+
+    if rank == 0 and use_dist and world > 1 and not args.no_secondary:
+        print(json.dumps(dict(res, note="headline only: printed before the secondary rows, which run collectives on all ranks")),
+              file=sys.stderr, flush=True)
     if not args.no_secondary:
+        sec_ok = True
         try:
             res["secondary"] = kmeans_secondary(rank, world, pg, run_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         except Exception as e:                                    # never lose the headline line
             res["secondary"] = dict(error=repr(e))
+            sec_ok = False
         run_cpu_rows = rank == 0 and world == 1 and not args.no_cpu_baseline
         if not args.quick and rank == 0:
             for key, fn in (("retrieval", lambda: retrieval_secondary(run_cpu_rows)), ("nce", nce_secondary)):
@@ -425,6 +441,10 @@ def main():
                 except Exception as e:
                     res["secondary"][key] = dict(error=repr(e))
         try:
+            # the rows below run DistributedDataParallel steps: every rank joins them, or none does
+            if not all_ranks_ok(sec_ok):
+                res["secondary"]["extra_error"] = "skipped: a secondary row failed on some rank"
+                raise _Skip()
             if args.quick:
                 raise _Skip()
             # embedding extraction (evaluate.py:146-205): eval-mode forward only, BN folded into the conv epilogue

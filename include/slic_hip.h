@@ -149,6 +149,20 @@ int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, i
                              float* sums, float* counts, float* C_new, float* Cp_new, float* cnorm_new, float* shift,
                              int spherical, double* status, void* stream);
 
+/* The collective of the sharded iteration behind the C ABI: an opaque RCCL communicator, created and destroyed explicitly (the
+ * library's only global state besides the last-error string), and an in-place sum all-reduce on the caller's stream — a thin wrapper
+ * over ncclAllReduce (RCCL over xGMI; bound at first use with dlopen, no link-time dependency).  One process per GPU: rank 0 calls
+ * slic_comm_unique_id and hands the SLIC_COMM_ID_BYTES bytes to the other ranks (any channel: torch.distributed, a file, MPI), then
+ * every rank calls slic_comm_create on its device.  Stands in for the NCCL group the reference sets up in
+ * misc/distributed_helper.py:8-26 where the path needs its one exchange (online_train.py:625-662 -> SURVEY.md §8e row 2). */
+#define SLIC_COMM_ID_BYTES 128
+typedef struct slic_comm slic_comm;
+int slic_comm_unique_id(void* id_out /* SLIC_COMM_ID_BYTES */);
+int slic_comm_create(const void* id, int world, int rank, slic_comm** out);
+int slic_allreduce_f32(slic_comm* comm, float* buf, int64_t n, void* stream);
+int slic_allreduce_f64(slic_comm* comm, double* buf, int64_t n, void* stream);
+int slic_comm_destroy(slic_comm* comm);
+
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
  * order) — X.mean(axis=0) and np.var(X, axis=0) of KMeans.fit / _tolerance
  * (_kmeans.py:1479-1481, 279-288). */

@@ -341,3 +341,27 @@ def test_sharded_iteration_halves_vs_cpu_twin(gpu, f64):
     assert torch.equal(Cp_new, out_g[3])
     sg, sc = out_g[6].cpu().numpy(), out_c[6].numpy()
     assert sg[0] == pytest.approx(sc[0], rel=1e-12) and sg[1] == sc[1] == 1.0 and sg[2] == sc[2] == N
+
+
+def test_slic_comm_one_rank_allreduce(gpu):
+    """slic_comm_unique_id / slic_comm_create / slic_allreduce_f32 / _f64 / slic_comm_destroy on a communicator of one rank (the
+    widest a one-GPU box allows): the sum over one rank is the buffer itself, on the caller's stream"""
+    import ctypes
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd._lib import call, ptr, stream
+    lib = _lib.load()
+    buf = (ctypes.c_ubyte * 128)()
+    _lib.check(lib.slic_comm_unique_id(buf), "slic_comm_unique_id")
+    assert any(buf)
+    comm = ctypes.c_void_p()
+    _lib.check(lib.slic_comm_create(bytes(buf), 1, 0, ctypes.byref(comm)), "slic_comm_create")
+    assert comm.value
+    a = torch.arange(1000, dtype=torch.float32, device="cuda") * 0.5
+    b = torch.arange(777, dtype=torch.float64, device="cuda") / 3
+    a0, b0 = a.clone(), b.clone()
+    call("slic_allreduce_f32", comm, ptr(a), a.numel(), stream())
+    call("slic_allreduce_f64", comm, ptr(b), b.numel(), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(a, a0) and torch.equal(b, b0)
+    assert lib.slic_allreduce_f32(comm, None, 4, None) != 0 and b"bad args" in lib.slic_last_error()
+    _lib.check(lib.slic_comm_destroy(comm), "slic_comm_destroy")

@@ -87,6 +87,21 @@ def _worker(rank, world, port, out_dir):
             res["bad_raised"] = True
         except Exception:
             res["bad_raised"] = False
+        # sharded route: one rank failing its device / shard check must raise on EVERY rank, not strand the other in a collective
+        class _Broken(OracleKernels):
+            def check(self):
+                if rank == 1:
+                    raise RuntimeError("no device on this rank")
+        sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=False)
+        loader = torch.utils.data.DataLoader(ds, batch_size=4, sampler=sampler)
+        d = os.path.join(out_dir, "broken")
+        os.makedirs(d, exist_ok=True)
+        try:
+            iterative_cluster_step(None, _cfg(d, world, True), enc, loader, epoch=2, cuda=False, device="cpu",
+                                   is_master_proc=(rank == 0), kmeans_kernels=_Broken())
+            res["shard_fail_raised"] = False
+        except RuntimeError as e:
+            res["shard_fail_raised"] = "failed on a rank" in str(e)
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
     finally:
         torch.distributed.destroy_process_group()
@@ -128,6 +143,7 @@ def test_extract_cluster_pipeline_two_ranks_gloo(tmp_path):
     lines = open(os.path.join(tmp_path, "rank0_drop", "vid_clusters.txt")).read().split()
     assert lines.count("None") == N_DATA - len(seen)
     assert bool(r0["bad_raised"]) and bool(r1["bad_raised"]) is False      # rank 1 gets the -2 marker, not an exception
+    assert bool(r0["shard_fail_raised"]) and bool(r1["shard_fail_raised"])
 
 
 def test_dataset_order_helper():

@@ -37,6 +37,11 @@ SIGNATURES = {
     "slic_kmeans_lloyd_local_workspace_bytes": (c_size_t, [L, I]),
     "slic_kmeans_lloyd_local": (I, [P, P, L, I, I, P, P, I, P, P, P, I, P, P]),
     "slic_kmeans_lloyd_global": (I, [P, I, L, I, P, I, I, P, P, P, P, P, P, I, P, P]),
+    "slic_comm_unique_id": (I, [P]),
+    "slic_comm_create": (I, [P, I, I, P]),
+    "slic_allreduce_f32": (I, [P, P, L, P]),
+    "slic_allreduce_f64": (I, [P, P, L, P]),
+    "slic_comm_destroy": (I, [P]),
     "slic_col_stats_workspace_bytes": (c_size_t, [L, I]),
     "slic_col_stats": (I, [P, L, I, I, P, P, P, P]),
     "slic_sub_rowvec": (I, [P, L, I, I, P, P, I, P]),

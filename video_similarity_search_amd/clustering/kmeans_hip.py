@@ -163,6 +163,31 @@ class HipKernels:
         call("slic_cumsum_search", ptr(v), v.numel(), ptr(vals), T, ptr(idx_out), ptr(ws), stream())
 
 
+_COMMS = {}        # process group -> slic_comm* (an RCCL communicator of the library's own, created once per group)
+
+
+def _slic_comm(pg, dev):
+    """the C-ABI communicator for the sharded iteration's all-reduce (include/slic_hip.h: slic_comm_create): rank 0 of the group
+    draws the unique id, torch.distributed carries it to the others, every rank joins on its device"""
+    import ctypes
+    key = id(pg)
+    if key in _COMMS:
+        return _COMMS[key]
+    lib = _lib.load()
+    W, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
+    idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf = (ctypes.c_ubyte * 128)()
+        _lib.check(lib.slic_comm_unique_id(buf), "slic_comm_unique_id")
+        idt.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+    torch.distributed.broadcast(idt, src=torch.distributed.get_global_rank(pg, 0), group=pg)
+    raw = bytes(idt.cpu().numpy().tobytes())
+    comm = ctypes.c_void_p()
+    _lib.check(lib.slic_comm_create(raw, W, rank, ctypes.byref(comm)), "slic_comm_create")
+    _COMMS[key] = comm
+    return comm
+
+
 def _dist_on(pg):
     # a process group of ONE rank still takes the sharded path (all-gather of one partial, ordered add): that is
     # how a single-GPU box exercises the RCCL code path
@@ -340,6 +365,12 @@ class KMeans:
                 parts = [torch.empty(W, PL, dtype=torch.float32, device=dev) for _ in range(2)]
             gsums = [torch.empty(K * Dp, dtype=torch.float32, device=dev) for _ in range(2)]
             gcounts = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(2)]
+            # the all-reduce goes through the library's own RCCL communicator (slic_allreduce_f64 on the compute stream) when
+            # the group runs on RCCL; under gloo (the CPU tests' kernel provider) through torch.distributed
+            comm = None
+            if (self.exchange == "allreduce" and on_gpu and torch.distributed.get_backend(self.process_group) == "nccl"
+                    and os.environ.get("SLIC_KMEANS_COMM", "slic") != "torch"):
+                comm = _slic_comm(self.process_group, dev)
         else:
             gsums = [p[: K * Dp] for p in part]
             gcounts = [p[K * Dp:] for p in part]
@@ -373,7 +404,9 @@ class KMeans:
             if self._sharded:
                 # two foreign calls around the iteration's ONE collective
                 k.lloyd_local(Xc, Xp if perm else None, Cin, Cp[it % 3], cnorm[it % 3], lab, lab_old, payload[sl])
-                if self.exchange == "allreduce":
+                if self.exchange == "allreduce" and comm is not None:
+                    call("slic_allreduce_f64", comm, ptr(payload[sl]), payload[sl].numel(), stream())
+                elif self.exchange == "allreduce":
                     torch.distributed.all_reduce(payload[sl], group=self.process_group)
                 else:
                     torch.distributed.all_gather_into_tensor(parts[sl].view(-1), payload[sl].view(-1), group=self.process_group)

@@ -236,8 +236,34 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
             print('embeddings shape (this rank)', tuple(embeddings.shape))
         start_time = time.time()
         pg = torch.distributed.group.WORLD
-        local = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
-                            getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0), process_group=pg, kernels=kmeans_kernels)
+        # A rank whose fit_cluster raises (bad K for its shard, out of memory) must not leave the others waiting in the label
+        # all-gather below: every rank reports, and all raise together.  (A failure in the MIDDLE of the Lloyd loop still strands
+        # the peers inside that iteration's collective until the process group's timeout — the argument checks run first, on
+        # every rank, for that reason.)
+        def all_or_raise(failure, what):
+            flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=embeddings.device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=pg)
+            if int(flag.item()):
+                raise RuntimeError(f"sharded fit_cluster: {what} failed on a rank (this rank: {failure!r})") from failure
+
+        failure = None
+        try:                                     # what can fail on ONE rank before the first collective of the fit
+            if kmeans_kernels is not None:
+                kmeans_kernels.check()
+            else:
+                from .clustering.kmeans_hip import HipKernels
+                HipKernels().check()
+            assert embeddings.dim() == 2 and embeddings.shape[0] > 0, "this rank holds no embeddings"
+        except Exception as e:
+            failure = e
+        all_or_raise(failure, "the device / shard check")
+        local, failure = None, None
+        try:
+            local = fit_cluster(embeddings, cfg.ITERCLUSTER.METHOD, cfg.ITERCLUSTER.K, cfg.ITERCLUSTER.L2_NORMALIZE,
+                                getattr(cfg.ITERCLUSTER, "FINCH_PARTITION", 0), process_group=pg, kernels=kmeans_kernels)
+        except Exception as e:
+            failure = e
+        all_or_raise(failure, "the clustering")
         trip = torch.from_numpy(np.stack([np.asarray(local, np.int32), np.asarray(idxs, np.int32),
                                           np.asarray(true_labels, np.int32)])).to(embeddings.device)
         cluster_labels, idxs, true_labels = (a.reshape(-1) for a in _all_gather_rows(trip, pg))
