@@ -239,16 +239,21 @@ def nce_secondary():
     ab = torch.randn(B, D, device="cuda", requires_grad=True)
     y = torch.randint(0, n_data, (B,), device="cuda")
 
-    def nce_step():
+    def nce_step_modules():
         o1, o2 = nce(l, ab, y)
         (crit(o1) + crit(o2)).backward()
 
+    def nce_step():                     # what contrastive_train_epoch runs: the same step as three launches
+        nce.softmax_loss(l, ab, y)[0].backward()
+
+    t_modules = _time_events(nce_step_modules, 20)
     t = _time_events(nce_step, 20)
     bytes_alg = 2 * B * (K + 1) * D * 4 + 2 * B * D * 4 * 2
-    return dict(metric="memory-bank NCE step (fwd + bwd + bank update), B=32 K=1024 D=128", ms=t * 1e3,
+    return dict(metric="memory-bank NCE step (fwd + bwd + bank update), B=32 K=1024 D=128", ms=t * 1e3, ms_module_by_module=t_modules * 1e3,
                 roofline=dict(bound="hbm", achieved=bytes_alg / t / 1e9, peak=8000.0, unit="GB/s", frac=bytes_alg / t / 1e9 / 8000.0,
                               traffic=None, algorithmic_bytes_per_step=bytes_alg,
-                              note="launch-bound: a handful of small kernels over 33.6 MB of gathered bank rows"))
+                              note="NCEAverage.softmax_loss: three launches (scores + cross-entropy, bank update + loss, backward) over 33.6 MB of "
+                                   "gathered bank rows; the module-by-module form (a dozen launches) is timed beside it"))
 
 
 def self_launch(n):
@@ -383,7 +388,7 @@ def main():
     # HBM traffic of the dominant kernel comes from PMC counters, which need rocprofv3 around the process: the value below is
     # the one committed with the profile of the same command (profiles/), NOT measured in this run — `traffic` stays null
     traffic_prof, traffic_src = None, None
-    for name in ("r02_pmc_conv_gemm_dma.json", "r01_pmc_conv_gemm_dma.json"):
+    for name in (("r03_pmc_conv_wino.json",) if wino else ("r02_pmc_conv_gemm_dma.json", "r01_pmc_conv_gemm_dma.json")):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:

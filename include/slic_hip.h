@@ -460,6 +460,20 @@ int slic_nce_bank_update(float* bank, const int64_t* y, const float* f, int B, i
 /* loss = mean_b (logsumexp(x[b, :]) - x[b, 0]); lse/rowloss: [B] scratch kept for the backward */
 int slic_softmax_ce0_fwd(const float* x, int B, int K1, float* lse, float* rowloss, float* loss, void* stream);
 int slic_softmax_ce0_bwd(const float* x, const float* lse, int B, int K1, const float* gscale, float* dx, void* stream);
+/* The contrastive step of online_train.py:175-190 — out_l, out_ab = contrast(feat_l, feat_ab, index); loss =
+ * NCESoftmaxLoss(out_l) + NCESoftmaxLoss(out_ab) — as three launches (the separate entry points above: a dozen):
+ *   slic_nce_fused_fwd   : scores[0] = <memory_l[idx], f_ab> / T (out_ab), scores[1] = <memory_ab[idx], f_l> / T (out_l), [2][B][K1];
+ *                          rows [2][B][K1][D] = the bank rows as scored (the update below changes the banks before the backward);
+ *                          lse / rowloss [2][B] = log-sum-exp of a score row and its cross-entropy against class 0
+ *   slic_nce_fused_update: both banks' momentum update (NCE_loss.py:73-86; on duplicate labels the last row wins, every row computed
+ *                          from the bank as it was) and loss = mean_b rowloss[0][b] + mean_b rowloss[1][b]
+ *   slic_nce_fused_bwd   : df[0] = d loss / d f_ab, df[1] = d loss / d f_l ([2][B][D]), scaled by *gscale (NULL = 1) */
+int slic_nce_fused_fwd(const float* bank_l, const float* bank_ab, const float* f_l, const float* f_ab, const int64_t* idx, int B,
+                       int K1, int D, float T, float* scores, float* rows, float* lse, float* rowloss, void* stream);
+int slic_nce_fused_update(float* bank_l, float* bank_ab, const int64_t* y, const float* f_l, const float* f_ab, int B, int D,
+                          float momentum, const float* rowloss, float* loss, void* stream);
+int slic_nce_fused_bwd(const float* rows, const float* scores, const float* lse, int B, int K1, int D, float T,
+                       const float* gscale, float* df, void* stream);
 
 #ifdef __cplusplus
 }

@@ -154,6 +154,83 @@ def test_nce_average_matches_reference_golden(gpu, golden_dir):
     assert o1.shape == (B, K + 1, 1) and torch.isfinite(o1).all()
 
 
+@pytest.mark.parametrize("dup", [False, True])
+def test_nce_fused_step_equals_separate_modules(gpu, golden_dir, dup):
+    """NCEAverage.softmax_loss (three launches) == NCESoftmaxLoss(out_l) + NCESoftmaxLoss(out_ab) of the module-by-module path:
+    loss, both feature gradients, both banks after the update — on the reference golden (and with a duplicated label: the last
+    row wins in both), and at the BASELINE shape B = 32, K = 1024"""
+    from video_similarity_search_amd.loss import NCEAverage, NCESoftmaxLoss
+    g = dict(np.load(os.path.join(golden_dir, "loss_ntxent.npz")))
+    B, D = g["nce_l"].shape
+    ndata, K = g["nce_memory_l"].shape[0], g["nce_idx"].shape[1] - 1
+    y = torch.from_numpy(g["nce_y"]).cuda()
+    idx = torch.from_numpy(g["nce_idx"]).cuda()
+    if dup:
+        y = y.clone()
+        idx = idx.clone()
+        y[-1] = y[0]
+        idx[-1, 0] = y[0]
+    res = []
+    for fused in (False, True):
+        nce = NCEAverage(D, ndata, K, 0.07, 0.5).cuda()
+        nce.memory_l.copy_(torch.from_numpy(g["nce_memory_l"]))
+        nce.memory_ab.copy_(torch.from_numpy(g["nce_memory_ab"]))
+        l = torch.from_numpy(g["nce_l"]).cuda().requires_grad_(True)
+        ab = torch.from_numpy(g["nce_ab"]).cuda().requires_grad_(True)
+        if fused:
+            tot, out_l, out_ab = nce.softmax_loss(l, ab, y, idx)
+            assert not out_l.requires_grad
+        else:
+            out_l, out_ab = nce(l, ab, y, idx)
+            tot = NCESoftmaxLoss()(out_l) + NCESoftmaxLoss()(out_ab)
+        (tot * 1.5).backward()
+        res.append((tot.item(), out_l.detach().clone(), out_ab.detach().clone(), l.grad.clone(), ab.grad.clone(),
+                    nce.memory_l.clone(), nce.memory_ab.clone()))
+    a, b = res
+    assert abs(a[0] - b[0]) < 1e-5
+    if not dup:
+        assert abs(b[0] - float(g["nce_loss"])) < 1e-4
+        np.testing.assert_allclose(b[3].cpu().numpy() / 1.5, g["nce_grad_l"], atol=1e-5, rtol=1e-3)
+        np.testing.assert_allclose(b[5].cpu().numpy(), g["nce_memory_l_after"], atol=1e-6)
+    for i in (1, 2):
+        assert torch.equal(a[i], b[i])
+    for i in (3, 4):
+        assert torch.allclose(a[i], b[i], atol=1e-6, rtol=1e-4), i
+    for i in (5, 6):
+        if dup:      # the module-by-module update races on a duplicated label (two waves, one row); compare the other rows
+            keep = torch.ones(ndata, dtype=torch.bool, device="cuda")
+            keep[y[0]] = False
+            assert torch.equal(a[i][keep], b[i][keep])
+            # the fused update: the LAST row with that label wins, computed from the bank as it was
+            which, feat = (g["nce_memory_l"], g["nce_l"]) if i == 5 else (g["nce_memory_ab"], g["nce_ab"])
+            v = which[int(y[0])] * 0.5 + feat[-1] * 0.5
+            np.testing.assert_allclose(b[i][y[0]].cpu().numpy(), v / np.linalg.norm(v), atol=1e-6)
+        else:
+            assert torch.equal(a[i], b[i]), i
+    # BASELINE shape
+    Bb, Kb, Db, n = 32, 1024, 128, 100000
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    nce = NCEAverage(Db, n, Kb).cuda()
+    l = torch.randn(Bb, Db, device="cuda", generator=gen, requires_grad=True)
+    ab = torch.randn(Bb, Db, device="cuda", generator=gen, requires_grad=True)
+    yb = torch.randperm(n, device="cuda", generator=gen)[:Bb]
+    ib = torch.randint(0, n, (Bb, Kb + 1), device="cuda", generator=gen)
+    ib[:, 0] = yb
+    m0 = nce.memory_l.clone(), nce.memory_ab.clone()
+    o_l, o_ab = nce(l, ab, yb, ib)
+    t0 = NCESoftmaxLoss()(o_l) + NCESoftmaxLoss()(o_ab)
+    t0.backward()
+    g0 = l.grad.clone(), ab.grad.clone()
+    m1 = nce.memory_l.clone(), nce.memory_ab.clone()
+    nce.memory_l.copy_(m0[0]); nce.memory_ab.copy_(m0[1])
+    l.grad = ab.grad = None
+    t1, _, _ = nce.softmax_loss(l, ab, yb, ib)
+    t1.backward()
+    assert abs(t0.item() - t1.item()) < 1e-4 * abs(t0.item())
+    assert torch.allclose(l.grad, g0[0], atol=1e-6, rtol=1e-3) and torch.allclose(ab.grad, g0[1], atol=1e-6, rtol=1e-3)
+    assert torch.equal(nce.memory_l, m1[0]) and torch.equal(nce.memory_ab, m1[1])
+
+
 def test_nce_full_size_properties(gpu):
     """BASELINE shape B=32, K=1024, D=128: scores vs a torch gather on the same device data (linearity / checksum)"""
     from video_similarity_search_amd._lib import call, ptr, stream

@@ -11,6 +11,7 @@
 //
 // Build: -ffp-contract=off (nothing fuses except explicit fmaf/MFMA).
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 #include <stdlib.h>
 
@@ -330,16 +331,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  // this workgroup's point tiles: an even split of the ceil(N / 128) tiles over the gridDim.x slices
-  const int64_t tiles = (N + BP - 1) / BP;
-  const int64_t t0 = tiles * blockIdx.x / gridDim.x, t1 = tiles * (blockIdx.x + 1) / gridDim.x;
-  const int ntile = (int)(t1 - t0);
+  // this workgroup's points: an even split of the ceil(N / 32) 32-point sub-tiles (one MFMA's worth of points) over the
+  // gridDim.x slices, walked as 128-point tiles; the LAST tile of a slice may hold fewer than four sub-tiles and then runs a k loop
+  // with that many accumulators (100k points over 64 slices: 12 tiles + one sub-tile instead of 13 tiles on the longest slice)
+  const int64_t subs = (N + 31) / 32;
+  const int64_t u0 = subs * blockIdx.x / gridDim.x, u1 = subs * (blockIdx.x + 1) / gridDim.x;
+  const int ntile = (int)((u1 - u0 + 3) / 4);
+  const int npt_last = (int)(u1 - u0) - 4 * (ntile - 1);        // 1 .. 4 sub-tiles in the last tile
 #ifdef KM_DBG_HOT
   const int64_t pbeg = 0;   // diagnostic: every slice streams the same rows (L2-resident)
 #else
-  const int64_t pbeg = t0 * BP;
+  const int64_t pbeg = u0 * 32;
 #endif
-  const int64_t prow = (N - pbeg) < (int64_t)ntile * BP ? (N - pbeg) : (int64_t)ntile * BP;     // rows of the slice
+  const int64_t prow = (N - pbeg) < (u1 - u0) * 32 ? (N - pbeg) : (u1 - u0) * 32;               // rows of the slice
+  const int64_t pend = pbeg + prow;
   const int grp = blockIdx.y * 4 + wave;                       // this wave's 32-centroid group
   const int cbase = grp * 32;
   // lane (r, h) of MFMA step (kt, q, t) supplies C[cbase + r][32 kt + 8 q + 4 h + t] (operands are in the k8-permuted order)
@@ -397,7 +402,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int pt = 0; pt < 4; ++pt) b[0][pt] = *(const f32x4*)&km_lds[km_off(32 * pt + r, h)];
   KMS(kc_[0] = km_now() - kt00_;)
-  for (int tile = 0; tile < ntile; ++tile) {
+  auto tile_body = [&](const int tile, auto npt_) {
+    constexpr int NPT = decltype(npt_)::value;                 // 32-point sub-tiles of this tile
     KMS(const unsigned long long ka_ = km_now();)
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt)
@@ -419,7 +425,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
           for (int pt = 0; pt < 4; ++pt) {
             const int64_t p = op0 + 32 * pt + r;
-            if (p < N) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
+            if (p < pend) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
           }
         }
       }
@@ -430,24 +436,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int q = 0; q < 4; ++q) {
         const int cur = q & 1, nxt = cur ^ 1;
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
+        for (int pt = 0; pt < 4; ++pt)                          // (all four: the step after a tile's last belongs to a full tile)
           b[nxt][pt] = q < 3 ? *(const f32x4*)&Xs[km_off(32 * pt + r, 2 * (q + 1) + h)]
                              : *(const f32x4*)&Xn[km_off(32 * pt + r, h)];        // first fragments of the next step
         // k order inside every accumulator: q ascending, t ascending, lane half 0 then 1 => k ascending (permuted operands)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int pt = 0; pt < 4; ++pt)
+          for (int pt = 0; pt < NPT; ++pt)
             acc[pt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[kt][q][t], b[cur][pt][t], acc[pt], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NPT, 0);
       }
       __builtin_amdgcn_s_setprio(0);
     }
     KMS(const unsigned long long kb_ = km_now(); kc_[1] += kb_ - ka_;)
     // argmin over this wave's 32 centroids: ascending index inside the lane, then across the two lane halves; '<' / lower index
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
+    for (int pt = 0; pt < NPT; ++pt) {
       // the lane's centroid index rises with g, so a strict '<' alone keeps the first minimum; a centroid past K scores +inf
       // (cn = +inf) and never wins; cn - 2 acc as ONE fma is the same float as the rounded difference (2 acc is exact)
       float best = INFINITY;
@@ -465,12 +471,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     op0 = pbeg + (int64_t)tile * BP;
     KMS(kc_[2] += km_now() - kb_;)
+  };
+  for (int tile = 0; tile < ntile - 1; ++tile) tile_body(tile, std::integral_constant<int, 4>{});
+  if (ntile > 0) {
+    if (npt_last == 4) tile_body(ntile - 1, std::integral_constant<int, 4>{});
+    else if (npt_last == 3) tile_body(ntile - 1, std::integral_constant<int, 3>{});
+    else if (npt_last == 2) tile_body(ntile - 1, std::integral_constant<int, 2>{});
+    else tile_body(ntile - 1, std::integral_constant<int, 1>{});
   }
   if (op0 >= 0 && h == 0 && cbase < K) {
 #pragma unroll
     for (int pt = 0; pt < 4; ++pt) {
       const int64_t p = op0 + 32 * pt + r;
-      if (p < N) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
+      if (p < pend) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
@@ -489,11 +502,19 @@ __global__ void km_permute_k8(const float* __restrict__ X, int64_t N, int D8, in
   *(f32x4*)(Xp + i * ldxp + 8 * g + 4) = od;
 }
 
-// labels = argmin over the G centroid groups (groups ascending, strict '<' => first index wins)
+// labels = argmin over the G centroid groups (groups ascending, strict '<' => first index wins).
+// HIST (workgroups of KM_SB = 1024 rows): also the per-block label histogram bc[block][K] the M-step's counting sort starts from
+// (km_block_hist's output: every entry written) — the labels are in registers here, the separate pass re-read them.
+template <bool HIST>
 __global__ void km_combine(const float* __restrict__ pscore, const int32_t* __restrict__ pidx,
                            int G, int64_t N, int K, int32_t* __restrict__ labels,
                            const int32_t* __restrict__ labels_old, int32_t* n_changed,
-                           float* __restrict__ best_score) {
+                           float* __restrict__ best_score, int32_t* __restrict__ bc) {
+  extern __shared__ int km_hist_c[];
+  if constexpr (HIST) {
+    for (int j = threadIdx.x; j < K; j += blockDim.x) km_hist_c[j] = 0;
+    __syncthreads();
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int changed = 0;
   if (i < N) {
@@ -516,10 +537,15 @@ __global__ void km_combine(const float* __restrict__ pscore, const int32_t* __re
     labels[i] = idx;
     if (best_score) best_score[i] = best;
     if (labels_old) changed = labels_old[i] != idx;
+    if constexpr (HIST) atomicAdd(&km_hist_c[idx], 1);      // integer counts: order-free
   }
   if (labels_old) {
     const unsigned long long m = __ballot(changed);
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(n_changed, (int)__popcll(m));
+  }
+  if constexpr (HIST) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < K; j += blockDim.x) bc[(int64_t)blockIdx.x * K + j] = km_hist_c[j];
   }
 }
 
@@ -1485,8 +1511,8 @@ extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, con
   if (nct == 2) km_assign_partial<2><<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
   else km_assign_partial<4><<<grid, dim3(256), 0, S(stream)>>>(X, N, D, ldx, C, K, ldc, cnorm, pscore, pidx);
   SLIC_LAUNCH_CHECK();
-  km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, S(stream)>>>(
-      pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
+  km_combine<false><<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, S(stream)>>>(
+      pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score, nullptr);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1515,10 +1541,11 @@ extern "C" int slic_kmeans_permute_k8(const float* X, int64_t N, int D, int ldx,
   return SLIC_OK;
 }
 
-extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K,
-                                       int ldc, const float* cnorm, int32_t* labels,
-                                       const int32_t* labels_old, int32_t* n_changed, float* best_score,
-                                       void* workspace, void* stream) {
+// bc (optional): also the M-step's per-1024-row-block label histogram [ceil(N / 1024)][K] (km_combine<true>)
+static int km_assign_perm_impl(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K,
+                               int ldc, const float* cnorm, int32_t* labels,
+                               const int32_t* labels_old, int32_t* n_changed, float* best_score,
+                               void* workspace, void* stream, int32_t* bc) {
   SLIC_REQUIRE(Xp && Cp && cnorm && labels && workspace, "slic_kmeans_assign_perm: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && D > 0, "slic_kmeans_assign_perm: N=%lld K=%d D=%d", (long long)N, K, D);
   SLIC_REQUIRE(D % 8 == 0 && ldx % 4 == 0 && ldc % 4 == 0 && ldx >= D && ldc >= D,
@@ -1572,9 +1599,26 @@ extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ld
     int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
     if (rc) return rc;
   }
-  km_combine<<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, st>>>(pscore, pidx, G, N, K, labels, labels_old, n_changed, best_score);
+  if (bc && (size_t)K * 4 <= 48 * 1024)
+    km_combine<true><<<dim3((unsigned)slic_cdiv(N, KM_SB)), dim3(KM_SB), (size_t)K * 4, st>>>(pscore, pidx, G, N, K, labels, labels_old,
+                                                                                           n_changed, best_score, bc);
+  else {
+    km_combine<false><<<dim3((unsigned)slic_cdiv(N, 256)), dim3(256), 0, st>>>(pscore, pidx, G, N, K, labels, labels_old, n_changed,
+                                                                              best_score, nullptr);
+    if (bc) {
+      SLIC_LAUNCH_CHECK();
+      km_block_hist<<<dim3((unsigned)slic_cdiv(N, KM_SB)), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc);
+    }
+  }
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+extern "C" int slic_kmeans_assign_perm(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K,
+                                       int ldc, const float* cnorm, int32_t* labels,
+                                       const int32_t* labels_old, int32_t* n_changed, float* best_score,
+                                       void* workspace, void* stream) {
+  return km_assign_perm_impl(Xp, N, D, ldx, Cp, K, ldc, cnorm, labels, labels_old, n_changed, best_score, workspace, stream, nullptr);
 }
 
 extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
@@ -1583,9 +1627,13 @@ extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
          slic_align_up((size_t)N * 4, 256);
 }
 
+// the per-block histogram slab the accumulate workspace starts with (km_assign_perm_impl can fill it in its combine pass)
+static int32_t* km_accumulate_hist_slab(void* workspace) { return (int32_t*)workspace; }
+
 template <typename TOut>
 static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const int32_t* labels, int K, TOut* sums,
-                              TOut* counts, const int32_t* n_changed, TOut* nch_out, void* workspace, void* stream) {
+                              TOut* counts, const int32_t* n_changed, TOut* nch_out, void* workspace, void* stream,
+                              bool have_hist = false) {
   SLIC_REQUIRE(X && labels && sums && counts && workspace, "slic_kmeans_accumulate: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldx >= D,
                "slic_kmeans_accumulate: need D %% 4 == 0 (N=%lld K=%d D=%d ldx=%d)", (long long)N, K, D, ldx);
@@ -1598,8 +1646,10 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
   int32_t* order = w.take<int32_t>((size_t)N);
   hipStream_t st = S(stream);
   SLIC_REQUIRE(K <= 16384, "slic_kmeans_accumulate: K > 16384");
-  km_block_hist<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc);
-  SLIC_LAUNCH_CHECK();
+  if (!have_hist) {
+    km_block_hist<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc);
+    SLIC_LAUNCH_CHECK();
+  }
   km_scan_blocks<<<dim3(K), dim3(64), 0, st>>>(bc, nblk, K, cnt);
   SLIC_LAUNCH_CHECK();
   const int use_wcnt = (size_t)K * 4 * (1 + KM_SB / 64) <= 96 * 1024;
@@ -1712,9 +1762,10 @@ extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N
   char* ws = (char*)workspace;
   void* ws2 = ws + slic_align_up(slic_kmeans_assign_workspace_bytes(N, K), 256);
   SLIC_HIP_CHECK(hipMemsetAsync(n_changed, 0, sizeof(int32_t), S(stream)));
-  int rc = slic_kmeans_assign_perm(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream);
+  int rc = km_assign_perm_impl(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream,
+                               km_accumulate_hist_slab(ws2));
   if (rc) return rc;
-  rc = slic_kmeans_accumulate(X, N, D, ldx, labels, K, sums, counts, ws2, stream);
+  rc = km_accumulate_impl<float>(X, N, D, ldx, labels, K, sums, counts, nullptr, nullptr, ws2, stream, true);
   if (rc) return rc;
   return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, spherical, n_changed, status, stream);
 }
@@ -1737,15 +1788,16 @@ extern "C" int slic_kmeans_lloyd_local(const float* X, const float* Xp, int64_t 
   void* ws2 = ws + a1;
   int32_t* n_changed = (int32_t*)(ws + slic_kmeans_lloyd_step_workspace_bytes(N, K));
   SLIC_HIP_CHECK(hipMemsetAsync(n_changed, 0, sizeof(int32_t), S(stream)));
-  int rc = slic_kmeans_assign_perm(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream);
+  int rc = km_assign_perm_impl(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream,
+                               km_accumulate_hist_slab(ws2));
   if (rc) return rc;
   const int64_t KD = (int64_t)K * D;
   if (payload_f64) {
     double* p = (double*)payload;
-    return km_accumulate_impl<double>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream);
+    return km_accumulate_impl<double>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true);
   }
   float* p = (float*)payload;
-  return km_accumulate_impl<float>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream);
+  return km_accumulate_impl<float>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true);
 }
 
 extern "C" int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, int n_parts, const float* C_old,

@@ -141,6 +141,57 @@ class NCEAverage(nn.Module):
                  float(momentum), stream())
         return out_l, out_ab
 
+    def softmax_loss(self, l, ab, y, idx=None):
+        """== NCESoftmaxLoss()(out_l) + NCESoftmaxLoss()(out_ab) for (out_l, out_ab) = self(l, ab, y, idx), banks updated the same
+        way — the contrastive step of online_train.py:175-190 as three launches instead of a dozen.  Returns (loss, out_l, out_ab)
+        with the outputs detached ([B, K+1, 1], for logging: the reference's loop only uses them through the loss)."""
+        if not self.use_softmax:
+            raise NotImplementedError("softmax_loss is the use_softmax=True step; NCECriterion goes through forward()")
+        if not l.is_cuda:
+            raise _lib.SlicError("NCEAverage needs device tensors (no CPU fallback)")
+        T = self.params[1].item()
+        momentum = self.params[4].item()
+        B = l.size(0)
+        if idx is None:
+            idx = self.multinomial.draw(B * (self.K + 1)).view(B, -1)
+            idx.select(1, 0).copy_(y.data)
+        loss, scores = _FusedContrastStep.apply(l, ab, self.memory_l, self.memory_ab, idx.contiguous(), y.contiguous(), T, momentum)
+        return loss, scores[1].unsqueeze(-1), scores[0].unsqueeze(-1)
+
+
+class _FusedContrastStep(torch.autograd.Function):
+    """contrast(l, ab, y) + NCESoftmaxLoss on both outputs as ONE autograd node over three launches (csrc/nce.hip:
+    nce_fused_fwd / nce_fused_update / nce_fused_bwd)"""
+
+    @staticmethod
+    def forward(ctx, l, ab, mem_l, mem_ab, idx, y, T, momentum):
+        l = l.contiguous().float()
+        ab = ab.contiguous().float()
+        B, D = l.shape
+        K1 = idx.shape[1]
+        dev = l.device
+        scores = torch.empty(2, B, K1, dtype=torch.float32, device=dev)
+        rows = torch.empty(2, B, K1, D, dtype=torch.float32, device=dev)
+        stat = torch.empty(2, 2, B, dtype=torch.float32, device=dev)        # [lse | rowloss][side][b]
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        call("slic_nce_fused_fwd", ptr(mem_l), ptr(mem_ab), ptr(l), ptr(ab), ptr(idx), B, K1, D, float(T), ptr(scores), ptr(rows),
+             ptr(stat[0]), ptr(stat[1]), stream())
+        call("slic_nce_fused_update", ptr(mem_l), ptr(mem_ab), ptr(y), ptr(l), ptr(ab), B, D, float(momentum), ptr(stat[1]),
+             ptr(loss), stream())
+        ctx.mark_non_differentiable(scores)
+        ctx.T, ctx.shape = float(T), (B, K1, D)
+        ctx.keep = (rows, scores, stat)
+        return loss, scores
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        B, K1, D = ctx.shape
+        rows, scores, stat = ctx.keep
+        df = torch.empty(2, B, D, dtype=torch.float32, device=g.device)
+        call("slic_nce_fused_bwd", ptr(rows), ptr(scores), ptr(stat[0]), B, K1, D, ctx.T, ptr(g.contiguous().float()), ptr(df), stream())
+        ctx.keep = None
+        return df[1], df[0], None, None, None, None, None, None
+
 
 class _SoftmaxCE0(torch.autograd.Function):
     @staticmethod

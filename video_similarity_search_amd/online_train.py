@@ -131,6 +131,9 @@ def contrastive_train_epoch(train_loader, model, criterion_1, criterion_2, contr
     contrast.train()
     start = time.time()
     pending = []
+    from .loss.NCE_loss import NCEAverage, NCESoftmaxLoss
+    fused_step = (isinstance(contrast, NCEAverage) and contrast.use_softmax and type(criterion_1) is NCESoftmaxLoss and
+                  type(criterion_2) is NCESoftmaxLoss)
     for batch_idx, (inputs, labels, index) in enumerate(train_loader):
         view1 = inputs[0]
         view2 = inputs[1] if modality == 'rgb' else diff(view1)
@@ -139,10 +142,14 @@ def contrastive_train_epoch(train_loader, model, criterion_1, criterion_2, contr
         index = index.to(device)
         feat_1 = model(view1)                # two separate forwards: BN statistics per view (online_train.py:175-176)
         feat_2 = model(view2)
-        out_1, out_2 = contrast(feat_1, feat_2, index)
-        view1_loss = criterion_1(out_1)
-        view2_loss = criterion_2(out_2)
-        loss = view1_loss + view2_loss
+        if fused_step:
+            # the same sum, banks updated the same way, as three launches (loss/NCE_loss.py: NCEAverage.softmax_loss)
+            loss, out_1, out_2 = contrast.softmax_loss(feat_1, feat_2, index)
+        else:
+            out_1, out_2 = contrast(feat_1, feat_2, index)
+            view1_loss = criterion_1(out_1)
+            view2_loss = criterion_2(out_2)
+            loss = view1_loss + view2_loss
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
