@@ -22,6 +22,7 @@
 // and split-K forms, conv_gemm_kernel (register-staged; stem), conv_wgrad_dma_kernel (+ row table).
 #include "common.h"
 #include "conv_common.h"
+#include <type_traits>
 #ifndef SLIC_WG_ILVQ
 #define SLIC_WG_ILVQ 7   // same for the weight gradient's eight MFMA groups per tile
 #endif
@@ -1370,6 +1371,54 @@ static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 //   Epilogue: the 256 x 64 outputs leave through the shared LDS-image epilogue in two 128-row halves (conv_epilogue_rows: store /
 //   addend / mask / BatchNorm partials with slab rows of 128 GEMM rows, as variant 22).
 // ------------------------------------------------------------------------------------------
+// Packed fp32 VALU ops as inline assembly: measured on this kernel family, wave time = MFMA cycles + VALU cycles (a diagnostic build
+// with no memory traffic and no barrier ran the forward kernel at 74 % of the matrix pipe with ~130 VALU instructions per stage,
+// the weight gradient at 66 % with ~46 per k-step — both what 64 cycles per MFMA plus 4 per VALU instruction predict), and left to
+// itself the compiler scalarises the transforms (it schedules element j of every point towards MFMA j).  Two floats per instruction:
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {        // a * b + c
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+static __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {       // c - a * b
+  f32x2 d;
+  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(b), "v"(c));
+  return d;
+}
+static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {                 // a - b
+  f32x2 d;
+  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// Two LDS words 256-byte units apart into ONE register pair (the compiler pairs neighbouring loads its own way and then moves
+// registers around to build the pairs the packed ops need).  The compiler does not track the result of an inline-assembly load:
+// the reader issues `s_waitcnt lgkmcnt(0)` itself before the first use.
+template <int O0, int O1>
+static __device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
+  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2st64_b32 offsets are 8 bits of 256-byte units");
+  f32x2 d;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(O0), "n"(O1));
+  return d;
+}
+// V = B^T d for two floats at a time,  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+// (c2 / c4 / c5: the constants 2, 4, 5 in both halves of a scalar register pair): 12 instructions for 12 outputs
+static __device__ __forceinline__ void wino_bt6(const f32x2 (&d)[6], f32x2 (&V)[6], f32x2 c2, f32x2 c4, f32x2 c5) {
+  const f32x2 t1 = pk_fnma(d[2], c4, d[4]), t2 = pk_fnma(d[1], c4, d[3]);
+  const f32x2 t3 = pk_sub(d[4], d[2]), u = pk_sub(d[3], d[1]);
+  V[0] = pk_fma(d[0], c4, pk_fnma(d[2], c5, d[4]));
+  V[1] = pk_add(t1, t2);
+  V[2] = pk_sub(t1, t2);
+  V[3] = pk_fma(u, c2, t3);
+  V[4] = pk_fnma(u, c2, t3);
+  V[5] = pk_fma(d[1], c4, pk_fnma(d[3], c5, d[5]));
+}
+
 constexpr int WINO_STAGE_FLOATS = 2 * 12 * 64 * 4;     // A image + U image
 #ifndef SLIC_WINO_ABL
 #define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier
@@ -1379,7 +1428,8 @@ template <int STAGES, bool WPAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(const SlicConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMAs' LDS bases (M0) then need no v_readfirstlane
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int bx = blockIdx.x, gdx = gridDim.x;
@@ -1418,45 +1468,59 @@ void conv_wino_kernel(const SlicConvArgs p) {
   }
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFF00u;
+  [[maybe_unused]] constexpr unsigned OOB = 0xFFFFFF00u;
   const int cch_shift = 31 - __builtin_clz(CCH);             // CCH is a power of two (checked on the host)
   const unsigned uoff0 = (unsigned)tid * 16u;                 // this lane's 16 bytes of a U stage block, piece 0
-  unsigned avu[3];
+  // Validity of pixel piece i at (kt, kh), as the bit tap9 = 3 kt + kh of an INVALID mask: v_bfe_i32 of one bit gives 0 / -1, and
+  // offset | -1 is out of range.  Bit 9 (the tap of a dead stage) is set.
+  unsigned inv9[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) avu[i] = avalid[i] ? 1u : 0u;
-  // The six DMA pieces of stage s into the ring slot at float offset `toff`: pieces 0-2 raw pixels, 3-5 U.  Branch-free: a dead
-  // stage (s >= NS), a (kt, kh) row outside the clip or a pixel outside the row is an out-of-range offset (the DMA writes zeros).
-  struct StageRec { unsigned delta, ublk, live; int kt, kh; };
+  for (int i = 0; i < 3; ++i) {
+    unsigned m = 1u << 9;
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+      const bool ok = avalid[i] && ((tmask >> (t9 / 3)) & 1u) && ((hmask >> (t9 % 3)) & 1u);
+      m |= (ok ? 0u : 1u) << t9;
+    }
+    inv9[i] = m;
+  }
+  unsigned uvoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) uvoff[i] = uoff0 + (unsigned)(i * 256 * 16);
+  // The six DMA pieces of stage s into the ring slot at float offset `toff`: pieces 0-2 raw pixels, 3-5 U.  Per stage everything
+  // but the validity test is scalar: pixels = (lane base + scalar delta) | (invalid ? -1 : 0) — three vector instructions per piece;
+  // U = a per-lane constant offset + the stage's block as the instruction's SCALAR offset — none.  A dead stage (s >= NS) reads
+  // tap 9: every pixel piece out of range (zeros), U block 0 (finite values times zeros).
+  struct StageRec { unsigned delta, ublk; int tap; };
   auto stage_rec = [&](int s) {
     StageRec q;
-    q.live = s < NS ? 1u : 0u;
-    const int sc = s < NS ? s : 0;
+    const bool live = s < NS;
+    const int sc = live ? s : 0;
     const int tap9 = sc >> cch_shift, cc = sc & (CCH - 1);
-    q.kt = (tap9 * 11) >> 5;
-    q.kh = tap9 - 3 * q.kt;
-    q.delta = (unsigned)((((q.kt - 1) * H + (q.kh - 1)) * W * C + cc * 8) * 4);
-    q.ublk = (unsigned)((tap9 * CCH + cc) * NB + nb) * (unsigned)(12 * 64 * 4 * 4) + uoff0;
+    const int kt = (tap9 * 11) >> 5, kh = tap9 - 3 * kt;
+    q.tap = live ? tap9 : 9;
+    q.delta = (unsigned)((((kt - 1) * H + (kh - 1)) * W * C + cc * 8) * 4);
+    q.ublk = (unsigned)((tap9 * CCH + cc) * NB + nb) * (unsigned)(12 * 64 * 4 * 4);
     return q;
   };
   auto issue_piece = [&](const StageRec& q, int toff, int d) {
     if (d < 3) {
-      const unsigned ok = q.live & (tmask >> q.kt) & (hmask >> q.kh) & avu[d];
 #if SLIC_WINO_ABL & 1
-      const unsigned off = OOB + 0 * (ok + aoff[d] + q.delta);     // diagnostic build: DMAs issued, no memory traffic
+      const unsigned off = OOB + 0 * (aoff[d] + q.delta);     // diagnostic build: DMAs issued, no memory traffic
 #else
-      const unsigned off = ok ? aoff[d] + q.delta : OOB;
+      const unsigned off = (aoff[d] + q.delta) | (unsigned)__builtin_amdgcn_sbfe(inv9[d], q.tap, 1);
 #endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     } else {
       const int i = d - 3;
 #if SLIC_WINO_ABL & 1
-      const unsigned off = OOB + 0 * (q.live + q.ublk + i);
-#else
-      const unsigned off = q.live ? q.ublk + (unsigned)(i * 256 * 16) : OOB;
-#endif
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
-                                               16, (int)off, 0, 0, 0);
+                                               16, (int)(OOB + 0 * q.ublk), 0, 0, 0);
+#else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
+                                               16, (int)uvoff[i], (int)q.ublk, 0, 0);
+#endif
     }
   };
   f32x16 acc[6];
@@ -1477,7 +1541,20 @@ void conv_wino_kernel(const SlicConvArgs p) {
   // AFTER the barrier of stage s, under the latency of stage s's first LDS reads — the barrier then sits where no wave needs
   // anything from LDS for the next 8 MFMAs, and a slot is free for the DMAs of stage s + STAGES - 1 as soon as the barrier is
   // passed (every wave's LDS reads of stage s - 1 were issued before it).
-  f32x4 Vt0 = {0.f, 0.f, 0.f, 0.f}, Vt1 = Vt0, bt0 = Vt0, bt1 = Vt0;      // points 4, 5 of the previous stage
+  f32x4 bt0 = {0.f, 0.f, 0.f, 0.f}, bt1 = bt0;               // U of points 4, 5 of the previous stage
+  const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
+  // V of the previous stage (channel pairs (0, 1) and (2, 3) of the lane's four): points 4, 5 are multiplied after the barrier
+  f32x2 Vl[6], Vh[6];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) { Vl[pp] = (f32x2){0.f, 0.f}; Vh[pp] = (f32x2){0.f, 0.f}; }
+  // four MFMAs each of points p0, p1: element j of the lane's four channels goes to MFMA j
+  auto mfma_pair = [&](const int p0, const int p1, const f32x4& u0, const f32x4& u1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(j < 2 ? Vl[p0][j] : Vh[p0][j - 2], u0[j], acc[p0], 0, 0, 0);
+      acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(j < 2 ? Vl[p1][j] : Vh[p1][j - 2], u1[j], acc[p1], 0, 0, 0);
+    }
+  };
   for (int s0 = 0; s0 < NS; s0 += STAGES) {
 #pragma unroll
     for (int sidx = 0; sidx < STAGES; ++sidx) {
@@ -1493,46 +1570,33 @@ void conv_wino_kernel(const SlicConvArgs p) {
       const StageRec qn = stage_rec(sg + STAGES - 1);
       const f32x4 d0 = *(const f32x4*)&St[aro], d1 = *(const f32x4*)&St[aro + 512], d2 = *(const f32x4*)&St[aro + 1024];
       const f32x4 d3 = *(const f32x4*)&St[aro + 1536], d4 = *(const f32x4*)&St[aro + 2048], d5 = *(const f32x4*)&St[aro + 2560];
-      f32x4 b0 = *(const f32x4*)&St[bro], b1 = *(const f32x4*)&St[bro + 512];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt0[j], bt0[j], acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt1[j], bt1[j], acc[5], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the eight ds_reads first ...
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then the previous stage's tail MFMAs
-      // V = B^T d,  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-      const f32x4 t1 = d4 - 4.f * d2, t2 = d3 - 4.f * d1;
-      const f32x4 t3 = d4 - d2, t4 = 2.f * (d3 - d1);
-      const f32x4 V0 = 4.f * d0 - 5.f * d2 + d4, V1 = t1 + t2, V2 = t1 - t2, V3 = t3 + t4;
-      Vt0 = t3 - t4;
-      Vt1 = 4.f * d1 - 5.f * d3 + d5;
+      const f32x4 b0 = *(const f32x4*)&St[bro], b1 = *(const f32x4*)&St[bro + 512];
+      mfma_pair(4, 5, bt0, bt1);                               // the previous stage's last two points, under the latency of these reads
+      // V = B^T d in packed pairs (wino_bt6).  The packed ops are inline assembly, which the compiler's hazard recogniser does not
+      // see as VALU: an MFMA reading a VGPR within two instructions of the VALU instruction that wrote it reads the OLD value (the
+      // compiler puts `s_nop 1` there for its own instructions).  So the transform is one block fenced off from the MFMAs that
+      // consume it, closed by the two wait states.
+      const f32x2 dl[6] = {{d0[0], d0[1]}, {d1[0], d1[1]}, {d2[0], d2[1]}, {d3[0], d3[1]}, {d4[0], d4[1]}, {d5[0], d5[1]}};
+      const f32x2 dh[6] = {{d0[2], d0[3]}, {d1[2], d1[3]}, {d2[2], d2[3]}, {d3[2], d3[3]}, {d4[2], d4[3]}, {d5[2], d5[3]}};
+      __builtin_amdgcn_sched_barrier(0);
+      wino_bt6(dl, Vl, c2, c4, c5);
+      wino_bt6(dh, Vh, c2, c4, c5);
+      asm volatile("s_nop 1" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       const f32x4 b2 = *(const f32x4*)&St[bro + 2 * 512], b3 = *(const f32x4*)&St[bro + 3 * 512];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V0[j], b0[j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(V1[j], b1[j], acc[1], 0, 0, 0);
-      }
+      mfma_pair(0, 1, b0, b1);
       issue_piece(qn, toffn, 0);
       issue_piece(qn, toffn, 1);
       issue_piece(qn, toffn, 2);
       bt0 = *(const f32x4*)&St[bro + 4 * 512];
       bt1 = *(const f32x4*)&St[bro + 5 * 512];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(V2[j], b2[j], acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(V3[j], b3[j], acc[3], 0, 0, 0);
-      }
+      mfma_pair(2, 3, b2, b3);
       issue_piece(qn, toffn, 3);
       issue_piece(qn, toffn, 4);
       issue_piece(qn, toffn, 5);
     }
   }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt0[j], bt0[j], acc[4], 0, 0, 0);
-    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt1[j], bt1[j], acc[5], 0, 0, 0);
-  }
+  mfma_pair(4, 5, bt0, bt1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
@@ -1667,7 +1731,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, unsigned dy_bytes, const uint2* __restrict__ tile_tab,
                             float* __restrict__ slab, int tiles_per_split, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMAs' LDS bases (M0) then need no v_readfirstlane
   const int wc = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
   const int C = p.Cs, N = p.N, H = p.Hs, W = p.Ws;
@@ -1723,7 +1788,7 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
 #if SLIC_WINO_ABL & 1
     const unsigned off = OOB + 0 * (rec.y + rec.x);
 #else
-    const unsigned off = ((rec.y & need[d]) == need[d]) ? rec.x * mul[d] + cst[d] : OOB;
+    const unsigned off = ((rec.y & need[d]) == need[d]) ? __umul24(rec.x, mul[d]) + cst[d] : OOB;    // pixel index < 2^24: one v_mad_u32_u24
 #endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(d < 3 ? rs_src : rs_dy,
                                              (__attribute__((address_space(3))) void*)(lds + toff + (wave * 5 + d) * 64 * 4), 16, (int)off, 0, 0, 0);
@@ -1745,68 +1810,95 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
   recn = load_rec(STAGES - 1);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_setprio(0);
-  // image offsets (floats): pixel a of tile 2 ks + h = piece a / 2 of wave ks, parity h, chunk 16 (a % 2) + channel / 4
-  const int xro = h * 128 + 32 * (wc ^ h) + r;               // + ks * 1280 + (a >> 1) * 256 + (a & 1) * 64
-  const int yro = 3 * 256 + h * 128 + 32 * (wn ^ h) + r;     // + ks * 1280 + (o >> 1) * 256 + (o & 1) * 64
-  float Vt[6], Zt[6];
-#pragma unroll
-  for (int pp = 0; pp < 6; ++pp) { Vt[pp] = 0.f; Zt[pp] = 0.f; }
-  auto transform = [&](const float (&x)[6], const float (&y)[4], float (&V)[6], float (&Z)[6]) {
-    const float t1 = x[4] - 4.f * x[2], t2 = x[3] - 4.f * x[1], t3 = x[4] - x[2], t4 = 2.f * (x[3] - x[1]);
-    V[0] = 4.f * x[0] - 5.f * x[2] + x[4];
-    V[1] = t1 + t2; V[2] = t1 - t2; V[3] = t3 + t4; V[4] = t3 - t4;
-    V[5] = 4.f * x[1] - 5.f * x[3] + x[5];
-    const float e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.f * y[2], o4 = 2.f * y[1] + 8.f * y[3];
-    Z[0] = y[0]; Z[1] = e + o; Z[2] = e - o; Z[3] = e4 + o4; Z[4] = e4 - o4; Z[5] = y[3];
+  // stage image (floats): pixel a of tile 2 ks + h = piece a / 2 of wave ks, parity h, chunk 16 (a % 2) + channel / 4:
+  //   h * 128 + 32 (wc ^ h) + r  +  ks * 1280 + (a >> 1) * 256 + (a & 1) * 64;   gradients: the same behind 3 * 256, with wn
+  // k-steps are transformed in PAIRS, two floats per VALU instruction (k-step 2 kp in .x, 2 kp + 1 in .y: the two values of a pair
+  // come out of LDS 5120 bytes apart, one ds_read2st64_b32): 21 packed instructions per pair instead of ~44 scalar ones — measured on
+  // this kernel family, wave time = MFMA cycles + VALU cycles (see the helpers above).
+  const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c8 = {8.f, 8.f};
+  const f32x2 zero2 = {0.f, 0.f};
+  // k-steps 2 kp (.x) and 2 kp + 1 (.y) of ring slot SL: every offset is an immediate (256-byte units: slot 80, k-step 20, piece 4,
+  // pixel parity 1, gradients 12), the two lane addresses are loop constants
+  const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  const unsigned xaddr = lbase + (unsigned)(h * 128 + 32 * (wc ^ h) + r) * 4u;
+  const unsigned yaddr = lbase + (unsigned)(h * 128 + 32 * (wn ^ h) + r) * 4u;
+  auto read_pair = [&](auto sl_, auto kp_, f32x2 (&x)[6], f32x2 (&y)[4]) {
+    constexpr int B0 = decltype(sl_)::value * 80 + decltype(kp_)::value * 40;
+    x[0] = lds_read2st64<B0 + 0, B0 + 20>(xaddr);
+    x[1] = lds_read2st64<B0 + 1, B0 + 21>(xaddr);
+    x[2] = lds_read2st64<B0 + 4, B0 + 24>(xaddr);
+    x[3] = lds_read2st64<B0 + 5, B0 + 25>(xaddr);
+    x[4] = lds_read2st64<B0 + 8, B0 + 28>(xaddr);
+    x[5] = lds_read2st64<B0 + 9, B0 + 29>(xaddr);
+    y[0] = lds_read2st64<B0 + 12, B0 + 32>(yaddr);
+    y[1] = lds_read2st64<B0 + 13, B0 + 33>(yaddr);
+    y[2] = lds_read2st64<B0 + 16, B0 + 36>(yaddr);
+    y[3] = lds_read2st64<B0 + 17, B0 + 37>(yaddr);
   };
-  auto read_step = [&](const float* St, int ks, float (&x)[6], float (&y)[4]) {
-#pragma unroll
-    for (int a = 0; a < 6; ++a) x[a] = St[xro + ks * 1280 + (a >> 1) * 256 + (a & 1) * 64];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) y[o] = St[yro + ks * 1280 + (o >> 1) * 256 + (o & 1) * 64];
+  // V = B^T x (wino_bt6) and the four inner points of Z = A y  (Z = [y0, y0+y1+y2+y3, y0-y1+y2-y3, y0+2y1+4y2+8y3, y0-2y1+4y2-8y3, y3];
+  // points 0 and 5 are y0 and y3 themselves); one fenced block closed by the two wait states an MFMA needs behind the
+  // (inline-assembly) VALU instruction that wrote its operand
+  auto transform_pair = [&](const f32x2 (&x)[6], const f32x2 (&y)[4], f32x2 (&V)[6], f32x2 (&Zi)[4]) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the pair's (inline-assembly) LDS reads
+    wino_bt6(x, V, c2, c4, c5);
+    const f32x2 e = pk_add(y[0], y[2]), o = pk_add(y[1], y[3]);
+    const f32x2 e4 = pk_fma(y[2], c4, y[0]), o4 = pk_fma(y[3], c8, pk_add(y[1], y[1]));
+    Zi[0] = pk_add(e, o);
+    Zi[1] = pk_sub(e, o);
+    Zi[2] = pk_add(e4, o4);
+    Zi[3] = pk_sub(e4, o4);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
+  // the six MFMAs of k-step `sel` (0 / 1) of a transformed pair
+  auto mfma6 = [&](const f32x2 (&V)[6], const f32x2 (&Zi)[4], const f32x2 (&y)[4], const int sel) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0][sel], y[0][sel], acc[0], 0, 0, 0);
+#pragma unroll
+    for (int pp = 1; pp < 5; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][sel], Zi[pp - 1][sel], acc[pp], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[5][sel], y[3][sel], acc[5], 0, 0, 0);
+  };
+  // the stage's second pair stays in registers across the barrier: its odd k-step is multiplied after the NEXT stage's barrier
+  f32x2 Vp[6], Zp[4], yp[4];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) Vp[pp] = zero2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { Zp[q] = zero2; yp[q] = zero2; }
   constexpr int PER = 6;                                       // VMEM ops per stage: five DMAs + one record load
-  for (int s0 = 0; s0 < nst; s0 += STAGES) {
-#pragma unroll
-    for (int sidx = 0; sidx < STAGES; ++sidx) {
-      const int sg = s0 + sidx;
-      // stage sg has landed once only the younger ops are outstanding: the record load issued behind its DMAs and the
-      // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (STAGES - 2) * PER) : "memory");
+  auto stage = [&](const int sg, auto sl_) {
+    constexpr int sidx = decltype(sl_)::value;
+    // stage sg has landed once only the younger ops are outstanding: the record load issued behind its DMAs and the
+    // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (STAGES - 2) * PER) : "memory");
 #if !(SLIC_WINO_ABL & 2)
-      __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
 #endif
-      const float* St = lds + sidx * WW_STAGE_FLOATS;
-      const int toffn = ((sidx + STAGES - 1) % STAGES) * WW_STAGE_FLOATS;
-      float x0[6], y0[4], x1[6], y1[4], V[6], Z[6];
-      read_step(St, 0, x0, y0);
-#pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[pp], Zt[pp], acc[pp], 0, 0, 0);
-      transform(x0, y0, V, Z);
-      read_step(St, 1, x1, y1);
-#pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
-      issue_piece(toffn, 0, recn);
-      issue_piece(toffn, 1, recn);
-      transform(x1, y1, V, Z);
-      read_step(St, 2, x0, y0);
-#pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
-      issue_piece(toffn, 2, recn);
-      issue_piece(toffn, 3, recn);
-      issue_piece(toffn, 4, recn);
-      asm volatile("" ::: "memory");                         // the counted vmcnt relies on this order: five DMAs, then the record
-      recn = load_rec(sg + STAGES);
-      asm volatile("" ::: "memory");
-      transform(x0, y0, V, Z);
-      read_step(St, 3, x1, y1);
-#pragma unroll
-      for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp], Z[pp], acc[pp], 0, 0, 0);
-      transform(x1, y1, Vt, Zt);
-    }
+    constexpr int toffn = ((sidx + STAGES - 1) % STAGES) * WW_STAGE_FLOATS;
+    f32x2 xa[6], ya[4], xb[6], V[6], Zi[4];
+    read_pair(sl_, std::integral_constant<int, 0>{}, xa, ya);
+    mfma6(Vp, Zp, yp, 1);                                      // the previous stage's last k-step, under the latency of these reads
+    transform_pair(xa, ya, V, Zi);
+    read_pair(sl_, std::integral_constant<int, 1>{}, xb, yp);
+    mfma6(V, Zi, ya, 0);
+    issue_piece(toffn, 0, recn);
+    issue_piece(toffn, 1, recn);
+    mfma6(V, Zi, ya, 1);
+    issue_piece(toffn, 2, recn);
+    issue_piece(toffn, 3, recn);
+    issue_piece(toffn, 4, recn);
+    asm volatile("" ::: "memory");                           // the counted vmcnt relies on this order: five DMAs, then the record
+    recn = load_rec(sg + STAGES);
+    asm volatile("" ::: "memory");
+    transform_pair(xb, yp, Vp, Zp);
+    mfma6(Vp, Zp, yp, 0);
+  };
+  static_assert(STAGES == 3, "the ring is unrolled by hand");
+  for (int s0 = 0; s0 < nst; s0 += STAGES) {
+    stage(s0, std::integral_constant<int, 0>{});
+    stage(s0 + 1, std::integral_constant<int, 1>{});
+    stage(s0 + 2, std::integral_constant<int, 2>{});
   }
-#pragma unroll
-  for (int pp = 0; pp < 6; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vt[pp], Zt[pp], acc[pp], 0, 0, 0);
+  mfma6(Vp, Zp, yp, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   // slab[z][tap9][p][c][n]
