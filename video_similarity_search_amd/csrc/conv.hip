@@ -949,203 +949,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Weight gradient, second form: the same 128 kidx x 64 n output tile, the same DMA ring and LDS image ([32 m][64] per
-// sub-tile, channel-contiguous as in HBM) — but the MFMA operands come out of LDS 16 bytes at a time.
-//   An MFMA's 32 output rows are free to stand for ANY 32 channels.  Lane (r, h) reads X[m + h][4 r' .. 4 r' + 3] with ONE
-//   ds_read_b128 (r' = r & 15 of sub-tile r >> 4) and feeds element t to MFMA t, whose row r therefore stands for channel
-//   64 (r >> 4) + 4 (r & 15) + t: four MFMAs (four accumulators) cover the tile's 128 kidx.  dY likewise: lane (r, h) reads
-//   dY[m + h][2 r, 2 r + 1] with one ds_read_b64 (NS = 1: two accumulators along n, columns 2 j + s) or one ds_read_b32
-//   (NS = 2: the wave owns 32 of the 64 columns).  The relabelling folds into the slab write-out.
-//   So that no operand is fetched by two waves, the waves split the REDUCTION rows of a tile instead of the output tile
-//   (NS = 1: four waves x 8 rows, each wave 128 x 64 outputs in 8 accumulators; NS = 2: two x 16 rows, 128 x 32 in 4) and
-//   add their accumulators through LDS at the end, in wave order (fixed order: bit-identical run to run).
-//   Per 32-row tile and wave: 4 x (b128 + b64) LDS reads for 32 MFMAs (NS = 1) against 24 ds_read2st64_b32 before.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int NS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void conv_wgrad_b128_kernel(const SlicConvArgs p, const float* __restrict__ dy, int ldy, unsigned dy_bytes,
-                            float* __restrict__ slab, int m_per_split, int nsplit) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int G = 2, STAGES = 2;
-  constexpr int SUB = 32 * 64;
-  constexpr int STAGE_FLOATS = (G + 1) * SUB;
-  constexpr int MW = 4 / NS;            // ways the 32 reduction rows of a tile are split over the waves
-  constexpr int RPW = 32 / MW;          // rows per wave per tile
-  constexpr int NSTEP = RPW / 2;        // MFMA steps (two rows each) per tile
-  constexpr int NB = 2 / NS;            // accumulators along n
-  static_assert(NS == 1 || NS == 2, "NS");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / NS, wn = wave % NS;
-  const int nx = (p.nchunks + 16 * G - 1) / (16 * G), ny = (p.N + 63) / 64;
-  const int L = blockIdx.x;
-  if (L >= nx * ny * nsplit) return;
-  const int bx = L % nx, by = (L / nx) % ny, bz = L / (nx * ny);
-  const int kc0 = bx * (16 * G);
-  const int n0 = by * 64;
-  const int mbeg = bz * m_per_split;
-  const int mend = min(mbeg + m_per_split, (int)p.M);
-  const int cq = tid & 15, srow = tid >> 4;
-  int ex[G];
-  unsigned tmk[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int q = kc0 + g * 16 + cq;
-    const int4 e = q < p.nchunks ? ((const int4*)p.tab)[q] : make_int4(0, -1, 0, 0);
-    ex[g] = e.x * 4;
-    tmk[g] = (unsigned)e.y;
-  }
-  const bool nvalid = (n0 + cq * 4) < p.N;
-  const unsigned ycol = (unsigned)(n0 + cq * 4) * 4u;
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)dy, 0, (int)min((unsigned)dy_bytes, (unsigned)mend * (unsigned)(ldy * 4)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_rt = __builtin_amdgcn_make_buffer_rsrc((void*)p.row_tab, 0, mend * 8, 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFF00u;
-  uint2 rec[2], recn[2];
-  auto load_rec = [&](int t, uint2 (&dst)[2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = mbeg + t * 32 + srow + 16 * i;
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_rt, m * 8, 0, 0);
-      dst[i] = make_uint2(v.x, v.y);
-    }
-  };
-  load_rec(0, rec);
-  auto issue_piece = [&](int t, int stage, int d) {
-    float* base = lds + stage * STAGE_FLOATS;
-    const int i = d / (G + 1), g = d % (G + 1);
-    if (g < G) {
-      const unsigned off = ((rec[i].y & tmk[g]) == tmk[g]) ? rec[i].x + (unsigned)ex[g] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(base + g * SUB + (4 * wave + 16 * i) * 64),
-                                               16, (int)off, 0, 0, 0);
-    } else {
-      const int m = mbeg + t * 32 + srow + 16 * i;
-      const unsigned yo = nvalid ? (unsigned)m * (unsigned)(ldy * 4) + ycol : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (__attribute__((address_space(3))) void*)(base + G * SUB + (4 * wave + 16 * i) * 64),
-                                               16, (int)yo, 0, 0, 0);
-    }
-  };
-  f32x16 acc[4][NB];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[t][j][v] = 0.f;
-  const int r = lane & 31, h = lane >> 5;
-  const int nmt = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
-  constexpr int NP = 2 * (G + 1);
-  load_rec(1, recn);
-#pragma unroll
-  for (int d = 0; d < NP; ++d) issue_piece(0, 0, d);
-  rec[0] = recn[0]; rec[1] = recn[1];
-  const int xo = (r >> 4) * SUB + (RPW * wm + h) * 64 + 4 * (r & 15);
-  const int yo_l = G * SUB + (RPW * wm + h) * 64 + (NS == 1 ? 2 * r : wn * 32 + r);
-  for (int s0 = 0; s0 < nmt; s0 += STAGES) {
-#pragma unroll
-    for (int sidx = 0; sidx < STAGES; ++sidx) {
-      const int sg = s0 + sidx;
-      const int tn = sg + 1, stn = sidx ^ 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      load_rec(tn + 1, recn);
-      const float* Xb = lds + sidx * STAGE_FLOATS + xo;
-      const float* Yb = lds + sidx * STAGE_FLOATS + yo_l;
-      f32x4 a[2];
-      float b[2][2];
-      a[0] = *(const f32x4*)Xb;
-      if constexpr (NS == 1) { const f32x2 v = *(const f32x2*)Yb; b[0][0] = v[0]; b[0][1] = v[1]; }
-      else b[0][0] = *Yb;
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int q = 0; q < NSTEP; ++q) {
-        const int cur = q & 1, nxt = cur ^ 1;
-        if (q < NSTEP - 1) {
-          a[nxt] = *(const f32x4*)(Xb + 2 * (q + 1) * 64);
-          if constexpr (NS == 1) { const f32x2 v = *(const f32x2*)(Yb + 2 * (q + 1) * 64); b[nxt][0] = v[0]; b[nxt][1] = v[1]; }
-          else b[nxt][0] = Yb[2 * (q + 1) * 64];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int j = 0; j < NB; ++j)
-            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][t], b[cur][j], acc[t][j], 0, 0, 0);
-        constexpr int PER = (NP + NSTEP - 2) / (NSTEP - 1);      // the pieces go out in the first NSTEP - 1 steps
-#pragma unroll
-        for (int d = q * PER; d < (q + 1) * PER && d < NP; ++d) issue_piece(tn, stn, d);
-        if (q == NSTEP - 1) { rec[0] = recn[0]; rec[1] = recn[1]; }
-        if (q < NSTEP - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB, 0);
-      }
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                     // the ring is dead: LDS becomes the exchange area of the wave sums
-  const int Kp = p.nchunks * 4;
-  float* out = slab + (int64_t)bz * p.N * Kp;          // slab[z][kidx][n]
-  constexpr int REG = NB * 16 * 64;                    // floats one wave parks per round
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    // round t: every wave parks its quarter t (channels = 4 r' + t); the round's owner adds the MW copies in wave order
-    float* mine = lds + wave * REG;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-#pragma unroll
-      for (int vq = 0; vq < 4; ++vq) {
-        f32x4 v4 = {acc[t][j][4 * vq], acc[t][j][4 * vq + 1], acc[t][j][4 * vq + 2], acc[t][j][4 * vq + 3]};
-        *(f32x4*)&mine[((j * 4 + vq) * 64 + lane) * 4] = v4;
-      }
-    __syncthreads();
-    const int owner = NS == 1 ? t : wn + 2 * (t & 1);          // NS = 2: the two column halves alternate between their waves
-    if (wave == owner) {
-#pragma unroll
-      for (int vq = 0; vq < 4; ++vq) {
-        f32x4 sum[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          sum[j] = *(const f32x4*)&lds[(wn * REG) + ((j * 4 + vq) * 64 + lane) * 4];     // wave wn = the first of this column half
-#pragma unroll
-          for (int w = 1; w < MW; ++w) sum[j] += *(const f32x4*)&lds[((wn + w * NS) * REG) + ((j * 4 + vq) * 64 + lane) * 4];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int v = 4 * vq + c;
-          const int i = (v & 3) + 8 * (v >> 2) + 4 * h;
-          const int kidx = kc0 * 4 + (i >> 4) * 64 + 4 * (i & 15) + t;
-          if (kidx < Kp) {
-            if constexpr (NS == 1) {
-              const int n = n0 + 2 * r;
-              if (n < p.N) *(float2*)&out[(int64_t)kidx * p.N + n] = make_float2(sum[0][c], sum[1][c]);
-            } else {
-              const int n = n0 + wn * 32 + r;
-              if (n < p.N) out[(int64_t)kidx * p.N + n] = sum[0][c];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-template <int NS>
-static int launch_wgrad_b128(const SlicConvArgs& a, const float* dy, int ldy, unsigned dyb, float* slab, int per, int S,
-                             hipStream_t st) {
-  const size_t lds = (size_t)2 * 3 * 32 * 64 * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_b128_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  const int64_t total = slic_cdiv(a.nchunks, 32) * slic_cdiv(a.N, 64) * S;
-  conv_wgrad_b128_kernel<NS><<<dim3((unsigned)total), dim3(256), lds, st>>>(a, dy, ldy, dyb, slab, per, S);
-  SLIC_LAUNCH_CHECK();
-  return SLIC_OK;
-}
-
 template <int G, int STAGES, bool ILV = false, bool RT = false>
 static int launch_wgrad_dma(const SlicConvArgs& a, const float* dy, int ldy, unsigned dyb, float* slab, int per, int S,
                             hipStream_t st) {
@@ -2171,10 +1974,7 @@ extern "C" int slic_conv_wgrad(const SlicConvArgs* a, const float* dy, int ldy, 
   SLIC_REQUIRE(a->M < (int64_t)0x7FFFFFFF, "slic_conv_wgrad: M must fit 31 bits");
   // LDS-DMA kernel, 128 x 64 output tile, 2-stage ring, interleaved issue; with args->row_tab the rows come from the table
   int rc2;
-  static const int which = getenv("SLIC_WGRAD_KERNEL") ? atoi(getenv("SLIC_WGRAD_KERNEL")) : 0;    // dev switch (A/B on the GPU box)
-  if (a->row_tab && which == 1) rc2 = launch_wgrad_b128<1>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-  else if (a->row_tab && which == 2) rc2 = launch_wgrad_b128<2>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
-  else if (a->row_tab) rc2 = launch_wgrad_dma<2, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
+  if (a->row_tab) rc2 = launch_wgrad_dma<2, 2, true, true>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
   else rc2 = launch_wgrad_dma<2, 2, true, false>(*a, dy, ldy, (unsigned)dyb, slab, (int)per, S, st);
   if (rc2) return rc2;
   SLIC_LAUNCH_CHECK();
