@@ -1229,7 +1229,7 @@ constexpr int WINO_STAGE_FLOATS = 2 * 12 * 64 * 4;     // A image + U image
 
 template <int STAGES, bool WPAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_wino_kernel(const SlicConvArgs p) {
+void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int st_per_split) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMAs' LDS bases (M0) then need no v_readfirstlane
@@ -1245,7 +1245,12 @@ void conv_wino_kernel(const SlicConvArgs p) {
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
   const int CCH = C >> 3;                                     // 8-channel stages per (kt, kh)
-  const int NS = 9 * CCH;
+  // split-K (few-tile launches: layer4): workgroup z of the grid's z dimension reduces stages [sbeg, NS) of the K loop, transforms
+  // its partial accumulators (A^T is linear) and writes the outputs to slab[z][GEMM row][n]; conv_splitk_finish adds the pieces in z
+  // order and runs the epilogue.  One piece (slab == NULL) covers everything.
+  const int NS_all = 9 * CCH;
+  const int sbeg = slab ? (int)blockIdx.z * st_per_split : 0;
+  const int NS = slab ? min(NS_all, sbeg + st_per_split) : NS_all;      // END of this workgroup's stage range
   const int NB = p.N >> 6;
   // ---- DMA roles: thread = (tile lane, pixel-half j = wave + 4 i): a = j >> 1, channel half = j & 1
   const int64_t mytile = tile0 + lane;
@@ -1333,7 +1338,7 @@ void conv_wino_kernel(const SlicConvArgs p) {
     for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
 #pragma unroll
   for (int t = 0; t < STAGES - 1; ++t) {
-    const StageRec q = stage_rec(t);
+    const StageRec q = stage_rec(sbeg + t);
 #pragma unroll
     for (int d = 0; d < 6; ++d) issue_piece(q, t * WINO_STAGE_FLOATS, d);
   }
@@ -1358,7 +1363,7 @@ void conv_wino_kernel(const SlicConvArgs p) {
       acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(j < 2 ? Vl[p1][j] : Vh[p1][j - 2], u1[j], acc[p1], 0, 0, 0);
     }
   };
-  for (int s0 = 0; s0 < NS; s0 += STAGES) {
+  for (int s0 = sbeg; s0 < NS; s0 += STAGES) {
 #pragma unroll
     for (int sidx = 0; sidx < STAGES; ++sidx) {
       const int sg = s0 + sidx;
@@ -1410,6 +1415,21 @@ void conv_wino_kernel(const SlicConvArgs p) {
     acc[1] = d12 + 2.f * d34;
     acc[2] = s12 + 4.f * s34;
     acc[3] = d12 + 8.f * d34 + acc[5];
+  }
+  if (slab) {
+    float* out = slab + (int64_t)blockIdx.z * p.M * p.N;
+    const int n = n0 + wn * 32 + r;
+    const int64_t bth_all = p.M / W;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int64_t tile = tile0 + wm * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+      const int64_t bth = tile / Wq;
+      const int wq4 = (int)(tile - bth * Wq) * 4;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (bth < bth_all && wq4 + o < W) out[(bth * W + wq4 + o) * p.N + n] = acc[o][g];
+    }
+    return;
   }
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
@@ -1469,7 +1489,7 @@ __global__ void pack_w_wino(const float* __restrict__ Wt, int N, int C, int dgra
 }
 
 template <int STAGES, bool WPAD>
-static int launch_wino(const SlicConvArgs& a, hipStream_t st) {
+static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
   constexpr size_t ring = (size_t)STAGES * WINO_STAGE_FLOATS * sizeof(float), epi = (size_t)conv_epi_lds_floats(128, 64) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
@@ -1479,8 +1499,21 @@ static int launch_wino(const SlicConvArgs& a, hipStream_t st) {
   }
   const int64_t tiles = (a.M / a.Ws) * ((a.Ws + 3) / 4);
   const unsigned gx = (unsigned)slic_cdiv(tiles, 64);
+  if (splits > 1) {
+    const int ns = 9 * (a.Cs / 8);
+    int per = (ns + splits - 1) / splits;
+    per = (per + STAGES - 1) / STAGES * STAGES;              // whole ring turns per piece
+    const int S = (ns + per - 1) / per;
+    dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64), (unsigned)S);
+    conv_wino_kernel<STAGES, WPAD><<<grid, dim3(256), lds, st>>>(a, slab, per);
+    SLIC_LAUNCH_CHECK();
+    conv_splitk_finish<128, 64, 2, 2><<<dim3((unsigned)slic_cdiv(a.M, 128), (unsigned)(a.N / 64)), dim3(256), 0, st>>>(
+        a, slab, S, 0, a.M * (int64_t)a.N);
+    SLIC_LAUNCH_CHECK();
+    return SLIC_OK;
+  }
   dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64));
-  conv_wino_kernel<STAGES, WPAD><<<grid, dim3(256), lds, st>>>(a);
+  conv_wino_kernel<STAGES, WPAD><<<grid, dim3(256), lds, st>>>(a, nullptr, 0);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1922,6 +1955,7 @@ extern "C" int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant
 
 extern "C" size_t slic_conv_gemm_tailsplit_workspace_bytes(const SlicConvArgs* a, int variant, int nfull_rb, int splits) {
   if (!a || splits < 1 || nfull_rb < 0) return 0;
+  if (variant == 30) return slic_align_up((size_t)splits * a->M * a->N * sizeof(float), 256);      // plain split-K: whole outputs per piece
   const int BM = variant == 22 ? 128 : 64;
   const int64_t tail_rb = slic_cdiv(a->M, BM) - nfull_rb;
   if (tail_rb <= 0) return 0;
@@ -1931,7 +1965,22 @@ extern "C" size_t slic_conv_gemm_tailsplit_workspace_bytes(const SlicConvArgs* a
 extern "C" int slic_conv_gemm_tailsplit(const SlicConvArgs* a, int variant, int nfull_rb, int splits, void* workspace, void* stream) {
   int rc = validate(a, "slic_conv_gemm_tailsplit");
   if (rc) return rc;
-  SLIC_REQUIRE(variant == 20 || variant == 22, "slic_conv_gemm_tailsplit: variants 20 and 22 only");
+  if (variant == 30) {
+    // Winograd with the K loop (the 9 x Cs / 8 stages) cut `splits` ways: the few-tile layers (layer4 at B = 32: 112 workgroups of
+    // 576 stages).  Pieces write transformed outputs to workspace[piece][M][N]; the finish pass adds them in piece order and runs
+    // the epilogue with slab rows of 128 GEMM rows (also on a ragged width).
+    if (splits <= 1) return slic_conv_gemm(a, variant, stream);
+    SLIC_REQUIRE(nfull_rb == 0 && workspace, "slic_conv_gemm_tailsplit: variant 30 is plain split-K (nfull_rb = 0)");
+    SLIC_REQUIRE(a->wgt && a->dst && a->Cs % 8 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
+                     a->Gb == a->Hs && a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len && ((a->Cs / 8) & (a->Cs / 8 - 1)) == 0,
+                 "slic_conv_gemm_tailsplit: variant 30 geometry (see slic_conv_gemm)");
+    SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm_tailsplit: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
+    SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
+                 "slic_conv_gemm_tailsplit: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
+    if (a->Ws % 4 != 0) return launch_wino<3, true>(*a, S_(stream), splits, (float*)workspace);
+    return launch_wino<3, false>(*a, S_(stream), splits, (float*)workspace);
+  }
+  SLIC_REQUIRE(variant == 20 || variant == 22, "slic_conv_gemm_tailsplit: variants 20, 22 (tail split) and 30 (split-K) only");
   const int BM = variant == 22 ? 128 : 64;
   const int64_t nrb = slic_cdiv(a->M, BM);
   if (splits <= 1 || nfull_rb >= nrb) return slic_conv_gemm(a, variant, stream);

@@ -36,7 +36,7 @@ def _tap_mask(oa, ob, oc):
 class ConvPlan:
     """One conv layer at one input size.  kernel/stride/pad are (t, h, w) triples."""
 
-    WINO_MIN_WGS = 384     # forward / data gradient: fewer 64-tile x 64-n workgroups than this leave the chip too empty (layer4 at B = 32: 112)
+    WINO_MIN_WGS = 384     # forward / data gradient: a launch of fewer 64-tile x 64-n workgroups than this (layer4 at B = 32: 112) cuts its K loop
 
     def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, batch=None):
         self.C, self.N = int(C), int(N)
@@ -64,11 +64,7 @@ class ConvPlan:
         # divide 128: 14 -> 16, 7 -> 8); and the launch must fill the chip: 64 W-tiles x 64 n per workgroup, no split of K
         eligible = base and (Wd % 4 == 0 or 128 % Wp == 0)
         on = os.environ.get("SLIC_WINO", "1") != "0"
-        fills = True
-        if batch is not None:        # the engine knows its batch: keep the direct kernel (with its K-split tail) for few-tile layers
-            tiles = batch * self.in_dims[0] * self.in_dims[1] * (Wp // 4)
-            fills = ((tiles + 63) // 64) * (self.N // 64) >= self.WINO_MIN_WGS
-        self.wino = (eligible and on and fills) if wino is None else bool(wino)
+        self.wino = (eligible and on) if wino is None else bool(wino)
         assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N multiples of 64, W % 4 == 0 or 4 ceil(W/4) | 128"
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
         self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
@@ -287,6 +283,8 @@ class ConvPlan:
         a.relu = int(relu)
         part = None
         tm = lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant))
+        if variant == 30 and self._plan_split(a, 30) is not None:
+            tm = 128                         # the split-K finish pass works on blocks of 128 real GEMM rows
         if want_stats:
             R = (a.M + tm - 1) // tm
             part = torch.empty(R, 2, self.N, dtype=torch.float32, device=x.device)
@@ -319,6 +317,18 @@ class ConvPlan:
         layer4 392.  So the tiles of the full rounds run whole, and the remainder — whole row blocks at the end of M — is cut
         along K into as many pieces as fill the slots once more (each piece keeps >= SPLIT_MIN_KTILES k-tiles).  A remainder
         that already fills most of a round is left alone.  SLIC_CONV_TAIL=0 switches the mechanism off (tests compare)."""
+        if variant == 30:
+            # Winograd: few-tile launches cut the K loop (9 x Cs / 8 stages) so that ~2 residency rounds of workgroups exist,
+            # each piece keeping >= 48 stages
+            if os.environ.get("SLIC_WINO_SPLIT", "1") == "0":
+                return None
+            Wd = a.Ws
+            wgs = ((a.M // Wd) * ((Wd + 3) // 4) + 63) // 64 * (a.N // 64)
+            ns = 9 * (a.Cs // 8)
+            if wgs >= cls.WINO_MIN_WGS:
+                return None
+            s = min((2 * 512 + wgs - 1) // wgs, ns // 48)
+            return (0, s) if s >= 2 else None
         if variant not in (20, 22) or os.environ.get("SLIC_CONV_TAIL", "1") == "0":
             return None
         slots = int(os.environ.get("SLIC_CONV_TAIL_SLOTS", "0")) or cls.SLOTS[variant]
@@ -398,8 +408,12 @@ class ConvPlan:
         if bwd is not None:
             z, mean, invstd = bwd
             assert z.shape == dx.shape and z.is_contiguous()
-            rows = [(a.M + lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant)) - 1)
-                    // lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant)) for a in launches]
+            def slab_rows(a):
+                tm = lib.slic_conv_tile_m(ctypes.byref(a), self._pick(a, variant))
+                if variant == 30 and self._plan_split(a, 30) is not None:
+                    tm = 128                 # the split-K finish pass works on blocks of 128 real GEMM rows
+                return (a.M + tm - 1) // tm
+            rows = [slab_rows(a) for a in launches]
             part = torch.empty(sum(rows), 2, self.Cs, dtype=torch.float32, device=dz.device)
             r0 = 0
             for a, r in zip(launches, rows):
