@@ -66,7 +66,7 @@ extern "C" int slic_debug_set_stamps(unsigned long long* buf) {
 // absent optional operand (resource of size 0) is an out-of-range access — loads return 0, stores are dropped.
 // Reductions have a fixed order: rows ascending inside a thread, an xor butterfly over the row groups of a wave, then the four
 // waves ascending; one slab row per workgroup.
-constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * 4 * BN + BN; }
+constexpr int conv_epi_lds_floats(int BM, int BN, int NW = 4) { return BM * BN + 2 * NW * BN + BN; }
 
 // Part 2 of the epilogue: everything after the accumulators have been written to the LDS image [BM][BN] (and a barrier passed).
 // Also called on its own by kernels that build the image themselves (the Winograd kernel: its image rows are the four outputs
@@ -74,7 +74,8 @@ constexpr int conv_epi_lds_floats(int BM, int BN) { return BM * BN + 2 * 4 * BN 
 // WPAD (the Winograd kernels on a width that is not a multiple of 4): the image rows live in a W-PADDED row space — image row
 // m' = (b, t, h) * Wp + w' with Wp = 4 ceil(W / 4) a power of two dividing BM; rows with w' >= W do not exist.  m0 is then the
 // padded index of the first row; the GEMM row of image row m' is (m' / Wp) * W + w', and a block holds BM / Wp * W real rows.
-template <int BM, int BN, bool WPAD = false>
+// NTHR = threads of the workgroup (256; the 512-thread Winograd workgroup passes 512: more rows per pass, eight wave partials)
+template <int BM, int BN, bool WPAD = false, int NTHR = 256>
 __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float* lds, int64_t m0, int n0, int tid) {
   const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial / bwd_partial)
   [[maybe_unused]] const int wp_shift = WPAD ? 31 - __builtin_clz((p.Ws + 3) & ~3) : 0;
@@ -93,13 +94,14 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
     }
   };
   constexpr int CPR = BN / 4;       // 16-byte chunks per tile row
-  constexpr int RPP = 256 / CPR;    // rows per pass of the 256 threads
+  constexpr int RPP = NTHR / CPR;   // rows per pass of the workgroup's threads
+  constexpr int NW = NTHR / 64;     // waves
   constexpr int NPASS = BM / RPP;
-  static_assert(256 % CPR == 0 && BM % RPP == 0, "tile shape");
+  static_assert(NTHR % CPR == 0 && BM % RPP == 0, "tile shape");
   float* tile = lds;                       // [BM][BN]: acc + bias
-  float* red1 = lds + BM * BN;             // [4 waves][BN]
-  float* red2 = red1 + 4 * BN;             // [4 waves][BN]
-  float* bmean = red2 + 4 * BN;            // [BN]
+  float* red1 = lds + BM * BN;             // [NW waves][BN]
+  float* red2 = red1 + NW * BN;            // [NW waves][BN]
+  float* bmean = red2 + NW * BN;           // [BN]
   const int ewave = tid >> 6, elane = tid & 63;
   // sum over the row groups a wave holds for one chunk column (lanes elane, elane ^ CPR, elane ^ 2 CPR, ...): every lane ends up
   // with the same value, added in the same order
@@ -181,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
     if (tid < BN) {
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
+      for (int w = 0; w < NW; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
       const int nn = n0 + tid;
       if (nn < p.N) {
         p.bwd_partial[(mblk * 2 + 0) * p.N + nn] = t1;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
     if (tid < BN) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) t += red1[w * BN + tid];
+      for (int w = 0; w < NW; ++w) t += red1[w * BN + tid];
       bmean[tid] = t * inv_rows;
       const int nn = n0 + tid;
       if (nn < p.N) p.stat_partial[(mblk * 2 + 0) * p.N + nn] = t;
@@ -229,7 +231,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float*
     if (tid < BN) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) t += red2[w * BN + tid];
+      for (int w = 0; w < NW; ++w) t += red2[w * BN + tid];
       const int nn = n0 + tid;
       if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
     }
@@ -1222,13 +1224,17 @@ static __device__ __forceinline__ void wino_bt6(const f32x2 (&d)[6], f32x2 (&V)[
   V[5] = pk_fma(d[1], c4, pk_fnma(d[3], c5, d[5]));
 }
 
-constexpr int WINO_STAGE_FLOATS = 2 * 12 * 64 * 4;     // A image + U image
 #ifndef SLIC_WINO_ABL
 #define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier
 #endif
 
-template <int STAGES, bool WPAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// TG = groups of 32 W-tiles per workgroup (two waves each, one per n half): 2 (256 threads, 2 workgroups / CU) or 4 (512 threads, ONE
+// workgroup / CU, the same two waves per SIMD: the 12 KB U stage — identical for every workgroup of a launch — is then fetched once
+// per 128 tiles instead of once per 64, and the ring holds the same bytes per CU)
+constexpr int wino_stage_floats(int TG) { return 12 * 32 * TG * 4 + (TG == 4 ? 1024 : 768) * 4; }
+
+template <int STAGES, bool WPAD, int TG>
+__global__ __launch_bounds__(128 * TG) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int st_per_split) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1239,7 +1245,13 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   const int mb = (bx & 7) * (gdx >> 3) + (bx >> 3);          // XCD-aware order (see conv_gemm_dma_body)
   const int Wq = (p.Ws + 3) >> 2;                             // W-tiles per row (WPAD: the last one is ragged)
   const int64_t Mt = WPAD ? (p.M / p.Ws) * Wq : (p.M >> 2);   // W-tiles
-  const int64_t tile0 = (int64_t)mb * 64;
+  constexpr int TW = 32 * TG;                                 // W-tiles per workgroup
+  constexpr int NT = 128 * TG;                                // threads
+  constexpr int A_FLOATS = 12 * TW * 4;
+  constexpr int STAGE_FLOATS = wino_stage_floats(TG);
+  constexpr int UP = TG == 4 ? 2 : 3;                         // U pieces per thread (TG = 4: 1024 chunk slots for 768 chunks)
+  constexpr int NPC = 3 + UP;                                 // DMA pieces per thread and stage
+  const int64_t tile0 = (int64_t)mb * TW;
   if (tile0 >= Mt) return;
   const int nb = blockIdx.y, n0 = nb * 64;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
@@ -1252,8 +1264,9 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   const int sbeg = slab ? (int)blockIdx.z * st_per_split : 0;
   const int NS = slab ? min(NS_all, sbeg + st_per_split) : NS_all;      // END of this workgroup's stage range
   const int NB = p.N >> 6;
-  // ---- DMA roles: thread = (tile lane, pixel-half j = wave + 4 i): a = j >> 1, channel half = j & 1
-  const int64_t mytile = tile0 + lane;
+  // ---- DMA roles: chunk q = i * NT + tid of the pixel image [j 12][tile TW][4 ch]: thread = (tile tid % TW, j = 4 i + tid / TW):
+  // a = j >> 1, channel half = j & 1
+  const int64_t mytile = tile0 + (tid % TW);
   const bool tvalid = mytile < Mt;
   unsigned q = (unsigned)(tvalid ? mytile : 0);
   const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
@@ -1263,7 +1276,7 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   bool avalid[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int j = wave + 4 * i, a = j >> 1, hc = j & 1;
+    const int j = 4 * i + tid / TW, a = j >> 1, hc = j & 1;
     const int w = 4 * wt - 1 + a;
     avalid[i] = tvalid && (unsigned)w < (unsigned)W;
     aoff[i] = (unsigned)((((((int64_t)q * T + tt) * H + hh) * W + w) * C + 4 * hc) * 4);
@@ -1292,9 +1305,9 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
     }
     inv9[i] = m;
   }
-  unsigned uvoff[3];
+  unsigned uvoff[UP];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) uvoff[i] = uoff0 + (unsigned)(i * 256 * 16);
+  for (int i = 0; i < UP; ++i) uvoff[i] = (i * NT + tid) < 768 ? uoff0 + (unsigned)(i * NT * 16) : 0xFFFFFF00u;    // past the block: zeros
   // The six DMA pieces of stage s into the ring slot at float offset `toff`: pieces 0-2 raw pixels, 3-5 U.  Per stage everything
   // but the validity test is scalar: pixels = (lane base + scalar delta) | (invalid ? -1 : 0) — three vector instructions per piece;
   // U = a per-lane constant offset + the stage's block as the instruction's SCALAR offset — none.  A dead stage (s >= NS) reads
@@ -1318,15 +1331,15 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
 #else
       const unsigned off = (aoff[d] + q.delta) | (unsigned)__builtin_amdgcn_sbfe(inv9[d], q.tap, 1);
 #endif
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 256 + wave * 64) * 4),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * NT + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
     } else {
       const int i = d - 3;
 #if SLIC_WINO_ABL & 1
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + A_FLOATS + (i * NT + wave * 64) * 4),
                                                16, (int)(OOB + 0 * q.ublk), 0, 0, 0);
 #else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + 12 * 64 * 4 + (i * 256 + wave * 64) * 4),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + A_FLOATS + (i * NT + wave * 64) * 4),
                                                16, (int)uvoff[i], (int)q.ublk, 0, 0);
 #endif
     }
@@ -1340,11 +1353,12 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   for (int t = 0; t < STAGES - 1; ++t) {
     const StageRec q = stage_rec(sbeg + t);
 #pragma unroll
-    for (int d = 0; d < 6; ++d) issue_piece(q, t * WINO_STAGE_FLOATS, d);
+    for (int d = 0; d < NPC; ++d) issue_piece(q, t * STAGE_FLOATS, d);
   }
   __builtin_amdgcn_s_setprio(0);
-  const int aro = (h * 64 + wm * 32 + r) * 4;                 // + a * 512: pixel a of this lane's tile, its channel half
-  const int bro = 12 * 64 * 4 + (h * 64 + wn * 32 + r) * 4;   // + p * 512: point p of this lane's column, its channel half
+  constexpr int AP = 2 * TW * 4;                              // floats between pixels a and a + 1 of the image
+  const int aro = (h * TW + wm * 32 + r) * 4;                 // + a * AP: pixel a of this lane's tile, its channel half
+  const int bro = A_FLOATS + (h * 64 + wn * 32 + r) * 4;      // + p * 512: point p of this lane's column, its channel half
   // Software pipeline across the stage barrier: the last two points of stage s - 1 (operands already in registers) are multiplied
   // AFTER the barrier of stage s, under the latency of stage s's first LDS reads — the barrier then sits where no wave needs
   // anything from LDS for the next 8 MFMAs, and a slot is free for the DMAs of stage s + STAGES - 1 as soon as the barrier is
@@ -1369,15 +1383,15 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
       const int sg = s0 + sidx;
       // stage sg has landed; and this wave's LDS reads of stage sg - 1 are COMPLETE (lgkmcnt(0)), not merely issued, before the
       // barrier lets another wave's DMAs overwrite that slot
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * 6) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((STAGES - 2) * NPC) : "memory");
 #if !(SLIC_WINO_ABL & 2)
       __builtin_amdgcn_s_barrier();
 #endif
-      const float* St = lds + sidx * WINO_STAGE_FLOATS;
-      const int toffn = ((sidx + STAGES - 1) % STAGES) * WINO_STAGE_FLOATS;
+      const float* St = lds + sidx * STAGE_FLOATS;
+      const int toffn = ((sidx + STAGES - 1) % STAGES) * STAGE_FLOATS;
       const StageRec qn = stage_rec(sg + STAGES - 1);
-      const f32x4 d0 = *(const f32x4*)&St[aro], d1 = *(const f32x4*)&St[aro + 512], d2 = *(const f32x4*)&St[aro + 1024];
-      const f32x4 d3 = *(const f32x4*)&St[aro + 1536], d4 = *(const f32x4*)&St[aro + 2048], d5 = *(const f32x4*)&St[aro + 2560];
+      const f32x4 d0 = *(const f32x4*)&St[aro], d1 = *(const f32x4*)&St[aro + AP], d2 = *(const f32x4*)&St[aro + 2 * AP];
+      const f32x4 d3 = *(const f32x4*)&St[aro + 3 * AP], d4 = *(const f32x4*)&St[aro + 4 * AP], d5 = *(const f32x4*)&St[aro + 5 * AP];
       const f32x4 b0 = *(const f32x4*)&St[bro], b1 = *(const f32x4*)&St[bro + 512];
       mfma_pair(4, 5, bt0, bt1);                               // the previous stage's last two points, under the latency of these reads
       // V = B^T d in packed pairs (wino_bt6).  The packed ops are inline assembly, which the compiler's hazard recogniser does not
@@ -1393,15 +1407,13 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
       __builtin_amdgcn_sched_barrier(0);
       const f32x4 b2 = *(const f32x4*)&St[bro + 2 * 512], b3 = *(const f32x4*)&St[bro + 3 * 512];
       mfma_pair(0, 1, b0, b1);
-      issue_piece(qn, toffn, 0);
-      issue_piece(qn, toffn, 1);
-      issue_piece(qn, toffn, 2);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) issue_piece(qn, toffn, d);
       bt0 = *(const f32x4*)&St[bro + 4 * 512];
       bt1 = *(const f32x4*)&St[bro + 5 * 512];
       mfma_pair(2, 3, b2, b3);
-      issue_piece(qn, toffn, 3);
-      issue_piece(qn, toffn, 4);
-      issue_piece(qn, toffn, 5);
+#pragma unroll
+      for (int d = 3; d < NPC; ++d) issue_piece(qn, toffn, d);
     }
   }
   mfma_pair(4, 5, bt0, bt1);
@@ -1432,7 +1444,9 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
     return;
   }
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf) {
+  for (int hf = 0; hf < TG; ++hf) {
+    // a 128-row block past the last W-tile does not exist: it has no slab row in stat_partial / bwd_partial (workgroup-uniform)
+    if (tile0 + hf * 32 >= Mt) break;
     if (wm == hf) {
       const int col = wn * 32 + r;
 #pragma unroll
@@ -1444,7 +1458,7 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
         }
     }
     __syncthreads();
-    conv_epilogue_rows<128, 64, WPAD>(p, lds, (tile0 + hf * 32) * 4, n0, tid);
+    conv_epilogue_rows<128, 64, WPAD, 128 * TG>(p, lds, (tile0 + hf * 32) * 4, n0, tid);
     __syncthreads();
   }
 }
@@ -1488,24 +1502,24 @@ __global__ void pack_w_wino(const float* __restrict__ Wt, int N, int C, int dgra
   for (int pp = 0; pp < 6; ++pp) U[blk + ((pp * 2 + h) * 64 + nl) * 4 + j] = u[pp];
 }
 
-template <int STAGES, bool WPAD>
+template <int STAGES, bool WPAD, int TG>
 static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
-  constexpr size_t ring = (size_t)STAGES * WINO_STAGE_FLOATS * sizeof(float), epi = (size_t)conv_epi_lds_floats(128, 64) * sizeof(float);
+  constexpr size_t ring = (size_t)STAGES * wino_stage_floats(TG) * sizeof(float), epi = (size_t)conv_epi_lds_floats(128, 64, 2 * TG) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino_kernel<STAGES, WPAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino_kernel<STAGES, WPAD, TG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int64_t tiles = (a.M / a.Ws) * ((a.Ws + 3) / 4);
-  const unsigned gx = (unsigned)slic_cdiv(tiles, 64);
+  const unsigned gx = (unsigned)slic_cdiv(tiles, 32 * TG);
   if (splits > 1) {
     const int ns = 9 * (a.Cs / 8);
     int per = (ns + splits - 1) / splits;
     per = (per + STAGES - 1) / STAGES * STAGES;              // whole ring turns per piece
     const int S = (ns + per - 1) / per;
     dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64), (unsigned)S);
-    conv_wino_kernel<STAGES, WPAD><<<grid, dim3(256), lds, st>>>(a, slab, per);
+    conv_wino_kernel<STAGES, WPAD, TG><<<grid, dim3(128 * TG), lds, st>>>(a, slab, per);
     SLIC_LAUNCH_CHECK();
     conv_splitk_finish<128, 64, 2, 2><<<dim3((unsigned)slic_cdiv(a.M, 128), (unsigned)(a.N / 64)), dim3(256), 0, st>>>(
         a, slab, S, 0, a.M * (int64_t)a.N);
@@ -1513,9 +1527,17 @@ static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, fl
     return SLIC_OK;
   }
   dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64));
-  conv_wino_kernel<STAGES, WPAD><<<grid, dim3(256), lds, st>>>(a, nullptr, 0);
+  conv_wino_kernel<STAGES, WPAD, TG><<<grid, dim3(128 * TG), lds, st>>>(a, nullptr, 0);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+// Workgroup shape: 256 threads (TG = 2).  The 512-thread form (TG = 4: one workgroup per CU, the U stage fetched once per 128
+// tiles — a quarter less L2 -> LDS traffic) measured no faster at the layer1 shape (218.7 against 220.2 effective TFLOP/s) and slower
+// at layer2's (188 against 213: the barrier then spans eight waves); it is not instantiated.
+static int launch_wino_pick(const SlicConvArgs& a, hipStream_t st, int splits, float* slab) {
+  if (a.Ws % 4 != 0) return launch_wino<3, true, 2>(a, st, splits, slab);
+  return launch_wino<3, false, 2>(a, st, splits, slab);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1893,8 +1915,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
     SLIC_REQUIRE(a->Ws % 4 == 0 || 128 % Wp == 0, "slic_conv_gemm: variant 30 needs Ws %% 4 == 0 or a padded width dividing 128 (Ws=%d)", a->Ws);
     SLIC_REQUIRE(((a->Cs / 8) & (a->Cs / 8 - 1)) == 0, "slic_conv_gemm: variant 30 needs Cs / 8 to be a power of two");
     SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
-    if (a->Ws % 4 != 0) return launch_wino<3, true>(*a, st);
-    return launch_wino<3, false>(*a, st);
+    return launch_wino_pick(*a, st, 1, nullptr);
   }
   if (variant != 0) {
     SLIC_REQUIRE(a->tap_tab && a->Cs % 32 == 0 && a->nchunks * 4 % a->Cs == 0 && a->nchunks * 4 / a->Cs <= 64,
@@ -1977,8 +1998,7 @@ extern "C" int slic_conv_gemm_tailsplit(const SlicConvArgs* a, int variant, int 
     SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm_tailsplit: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
     SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                  "slic_conv_gemm_tailsplit: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
-    if (a->Ws % 4 != 0) return launch_wino<3, true>(*a, S_(stream), splits, (float*)workspace);
-    return launch_wino<3, false>(*a, S_(stream), splits, (float*)workspace);
+    return launch_wino_pick(*a, S_(stream), splits, (float*)workspace);
   }
   SLIC_REQUIRE(variant == 20 || variant == 22, "slic_conv_gemm_tailsplit: variants 20, 22 (tail split) and 30 (split-K) only");
   const int BM = variant == 22 ? 128 : 64;
