@@ -10,7 +10,7 @@ from video_similarity_search_amd.models.conv_plan import ConvPlan
 from video_similarity_search_amd._lib import call, stream
 
 B = 32
-plan = ConvPlan(64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 56, 56), "cuda")
+plan = ConvPlan(64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 56, 56), "cuda", wino=False)
 x = torch.randn((B, 16, 56, 56, 64), device="cuda")
 w = torch.randn((64, 64, 3, 3, 3), device="cuda") * 0.05
 wp = plan.pack_fwd(w)

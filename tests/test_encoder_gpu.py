@@ -208,7 +208,7 @@ def test_conv_tailsplit_matches_single_pass(gpu, monkeypatch, variant, slots, wa
     from video_similarity_search_amd.models.conv_plan import ConvPlan
     rng = np.random.default_rng(5)
     C, N, B, dims = 256, 128, 3, (2, 7, 7)            # 27 taps x 8 k-tiles = 216 k-tiles, 5 x 2 tiles of 64 x 64 (3 x 2 of 128 x 64)
-    plan = ConvPlan(C, N, (3, 3, 3), (1, 1, 1), (1, 1, 1), dims, "cuda")
+    plan = ConvPlan(C, N, (3, 3, 3), (1, 1, 1), (1, 1, 1), dims, "cuda", wino=False)     # the direct kernels' launch forms
     x = torch.from_numpy(rng.standard_normal((B,) + dims + (C,)).astype(np.float32)).cuda()
     w = torch.from_numpy((rng.standard_normal((N, C, 3, 3, 3)) / np.sqrt(C * 27)).astype(np.float32)).cuda()
     res = torch.from_numpy(rng.standard_normal((B,) + dims + (N,)).astype(np.float32)).cuda()
