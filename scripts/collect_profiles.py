@@ -3,7 +3,7 @@ usage: collect_profiles.py <scratch dir> <out dir> <round tag>"""
 import csv, glob, json, os, sys
 
 scratch, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNEL = "conv_wino_kernel<3, false>"
+KERNEL = "conv_wino_kernel<3, false, 2>"
 GRID = 6272 * 256                       # layer1 shape at B = 32: 401 408 W-tiles / 64 per workgroup (one n block)
 
 
