@@ -1172,7 +1172,9 @@ static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 //   8 channels; a stage is 12 KB of raw pixels [a 6][h 2][tile 64][4 ch] + 12 KB of U [p 6][h 2][n 64][4 ch], both by LDS-DMA in
 //   the order the lanes read them (lane (r, h) of the MFMA fetches channels 4 h .. 4 h + 3 of tile / column r with ONE
 //   ds_read_b128 per pixel / point and feeds element j to MFMA j: k = 0 / 1 of MFMA j are channels j / 4 + j); 3-stage ring,
-//   counted vmcnt, one barrier per stage, the next stage's six DMAs spread over the six points' MFMA groups.
+//   counted vmcnt, one barrier per stage, the last two points of a stage multiplied after the NEXT stage's barrier; the transform is
+//   24 packed-fp32 instructions per stage (wino_bt6), the DMA addressing three vector instructions per pixel piece and none per U
+//   piece — a wave's VALU instructions do not hide under its own MFMAs on this part.
 //   Epilogue: the 256 x 64 outputs leave through the shared LDS-image epilogue in two 128-row halves (conv_epilogue_rows: store /
 //   addend / mask / BatchNorm partials with slab rows of 128 GEMM rows, as variant 22).
 // ------------------------------------------------------------------------------------------
@@ -1680,18 +1682,21 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
   const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
   const unsigned xaddr = lbase + (unsigned)(h * 128 + 32 * (wc ^ h) + r) * 4u;
   const unsigned yaddr = lbase + (unsigned)(h * 128 + 32 * (wn ^ h) + r) * 4u;
+  const unsigned xaddr2 = xaddr + 2u * WW_STAGE_FLOATS * 4u, yaddr2 = yaddr + 2u * WW_STAGE_FLOATS * 4u;      // slots 2, 3
   auto read_pair = [&](auto sl_, auto kp_, f32x2 (&x)[6], f32x2 (&y)[4]) {
-    constexpr int B0 = decltype(sl_)::value * 80 + decltype(kp_)::value * 40;
-    x[0] = lds_read2st64<B0 + 0, B0 + 20>(xaddr);
-    x[1] = lds_read2st64<B0 + 1, B0 + 21>(xaddr);
-    x[2] = lds_read2st64<B0 + 4, B0 + 24>(xaddr);
-    x[3] = lds_read2st64<B0 + 5, B0 + 25>(xaddr);
-    x[4] = lds_read2st64<B0 + 8, B0 + 28>(xaddr);
-    x[5] = lds_read2st64<B0 + 9, B0 + 29>(xaddr);
-    y[0] = lds_read2st64<B0 + 12, B0 + 32>(yaddr);
-    y[1] = lds_read2st64<B0 + 13, B0 + 33>(yaddr);
-    y[2] = lds_read2st64<B0 + 16, B0 + 36>(yaddr);
-    y[3] = lds_read2st64<B0 + 17, B0 + 37>(yaddr);
+    constexpr int SL = decltype(sl_)::value;
+    constexpr int B0 = (SL & 1) * 80 + decltype(kp_)::value * 40;      // the 8-bit offsets reach two slots from a base address
+    const unsigned xa = SL < 2 ? xaddr : xaddr2, ya = SL < 2 ? yaddr : yaddr2;
+    x[0] = lds_read2st64<B0 + 0, B0 + 20>(xa);
+    x[1] = lds_read2st64<B0 + 1, B0 + 21>(xa);
+    x[2] = lds_read2st64<B0 + 4, B0 + 24>(xa);
+    x[3] = lds_read2st64<B0 + 5, B0 + 25>(xa);
+    x[4] = lds_read2st64<B0 + 8, B0 + 28>(xa);
+    x[5] = lds_read2st64<B0 + 9, B0 + 29>(xa);
+    y[0] = lds_read2st64<B0 + 12, B0 + 32>(ya);
+    y[1] = lds_read2st64<B0 + 13, B0 + 33>(ya);
+    y[2] = lds_read2st64<B0 + 16, B0 + 36>(ya);
+    y[3] = lds_read2st64<B0 + 17, B0 + 37>(ya);
   };
   // V = B^T x (wino_bt6) and the four inner points of Z = A y  (Z = [y0, y0+y1+y2+y3, y0-y1+y2-y3, y0+2y1+4y2+8y3, y0-2y1+4y2-8y3, y3];
   // points 0 and 5 are y0 and y3 themselves); one fenced block closed by the two wait states an MFMA needs behind the
@@ -1750,11 +1755,12 @@ void conv_wgrad_wino_kernel(const SlicConvArgs p, const float* __restrict__ dy, 
     transform_pair(xb, yp, Vp, Zp);
     mfma6(Vp, Zp, yp, 0);
   };
-  static_assert(STAGES == 3, "the ring is unrolled by hand");
+  static_assert(STAGES == 3 || STAGES == 4, "the ring is unrolled by hand");
   for (int s0 = 0; s0 < nst; s0 += STAGES) {
     stage(s0, std::integral_constant<int, 0>{});
     stage(s0 + 1, std::integral_constant<int, 1>{});
     stage(s0 + 2, std::integral_constant<int, 2>{});
+    if constexpr (STAGES == 4) stage(s0 + 3, std::integral_constant<int, 3>{});
   }
   mfma6(Vp, Zp, yp, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2096,7 +2102,7 @@ extern "C" int slic_conv_wgrad_wino(const SlicConvArgs* a, const float* dy, int 
   int tps, S;
   wino_wgrad_plan(a, splits, &tps, &S);
   hipStream_t st = S_(stream);
-  constexpr int STAGES = 3;
+  constexpr int STAGES = 3;          // a 4-stage ring (80 KB, still two workgroups per CU) measured equal: the loss is not prefetch depth
   constexpr size_t lds = (size_t)STAGES * WW_STAGE_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
