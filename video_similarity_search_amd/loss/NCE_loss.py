@@ -105,9 +105,7 @@ class NCEAverage(nn.Module):
         self.register_buffer('memory_ab', torch.rand(outputSize, inputSize).mul_(2 * stdv).add_(-stdv))
 
     def forward(self, l, ab, y, idx=None):  # index = y = label
-        K = int(self.params[0].item())
-        T = self.params[1].item()
-        momentum = self.params[4].item()
+        K, T, momentum = self._host_params()
         batchSize = l.size(0)
         if not l.is_cuda:
             raise _lib.SlicError("NCEAverage needs device tensors (no CPU fallback)")
@@ -141,6 +139,16 @@ class NCEAverage(nn.Module):
                  float(momentum), stream())
         return out_l, out_ab
 
+    def _host_params(self):
+        """(K, T, momentum) as Python numbers without a device round trip per step: `params` is a registered buffer (the reference
+        reads it with .item() in every forward, NCE_loss.py:27-31); the host copy is refreshed when the buffer is written to"""
+        key = (self.params.data_ptr(), self.params._version)
+        if getattr(self, "_params_key", None) != key:
+            v = self.params.detach().cpu().tolist()
+            self._params_host = (int(v[0]), float(v[1]), float(v[4]))
+            self._params_key = key
+        return self._params_host
+
     def softmax_loss(self, l, ab, y, idx=None):
         """== NCESoftmaxLoss()(out_l) + NCESoftmaxLoss()(out_ab) for (out_l, out_ab) = self(l, ab, y, idx), banks updated the same
         way — the contrastive step of online_train.py:175-190 as three launches instead of a dozen.  Returns (loss, out_l, out_ab)
@@ -149,8 +157,7 @@ class NCEAverage(nn.Module):
             raise NotImplementedError("softmax_loss is the use_softmax=True step; NCECriterion goes through forward()")
         if not l.is_cuda:
             raise _lib.SlicError("NCEAverage needs device tensors (no CPU fallback)")
-        T = self.params[1].item()
-        momentum = self.params[4].item()
+        _, T, momentum = self._host_params()
         B = l.size(0)
         if idx is None:
             idx = self.multinomial.draw(B * (self.K + 1)).view(B, -1)

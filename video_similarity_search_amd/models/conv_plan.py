@@ -38,7 +38,7 @@ class ConvPlan:
 
     WINO_MIN_WGS = 384     # forward / data gradient: a launch of fewer 64-tile x 64-n workgroups than this (layer4 at B = 32: 112) cuts its K loop
 
-    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, batch=None):
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None):
         self.C, self.N = int(C), int(N)
         self.Cs = (self.C + 3) // 4 * 4
         self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
@@ -53,15 +53,15 @@ class ConvPlan:
         # bounds along W by construction; K = kt * kh * 24 = 1176 (12.5 % padding instead of 33 %).
         self.wrun = (self.C % 4 != 0 and self.kernel[2] * self.C <= 64) if wrun is None else bool(wrun)
         # Winograd F(4, 3) along W (variant 30 of slic_conv_gemm): the 3 x 3 x 3 stride-1 pad-1 layers with 64-multiple channel
-        # counts on both sides (forward reduces over C, the data gradient over N) and W % 4 == 0 — layer1 and layer2 of R3D-18.
-        # Exact fp32, half the multiplies.  wino=None: on where eligible unless SLIC_WINO=0; explicit variants of forward() /
-        # dgrad() need a plan built with wino=False (the packed operand differs).
+        # counts on both sides (forward reduces over C, the data gradient over N) — layers 1-4 of R3D-18.  Exact fp32, half the
+        # multiplies.  wino=None: on where eligible unless SLIC_WINO=0; explicit variants of forward() / dgrad() need a plan built
+        # with wino=False (the packed operand differs).
         base = (self.kernel == (3, 3, 3) and self.stride == (1, 1, 1) and self.pad == (1, 1, 1) and self.C % 64 == 0 and
                 self.N % 64 == 0 and not self.wrun)
         Wd = self.in_dims[2]
         Wp = (Wd + 3) // 4 * 4
         # forward / data gradient: a width that is not a multiple of 4 runs with a ragged last tile per row (padded width must
-        # divide 128: 14 -> 16, 7 -> 8); and the launch must fill the chip: 64 W-tiles x 64 n per workgroup, no split of K
+        # divide 128: 14 -> 16, 7 -> 8); a launch of few workgroups cuts its K loop across workgroups (_plan_split)
         eligible = base and (Wd % 4 == 0 or 128 % Wp == 0)
         on = os.environ.get("SLIC_WINO", "1") != "0"
         self.wino = (eligible and on) if wino is None else bool(wino)

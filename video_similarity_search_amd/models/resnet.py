@@ -102,9 +102,9 @@ class _Engine:
                 if not all(hasattr(blk, a) for a in ("conv1", "bn1", "conv2", "bn2", "downsample")) or hasattr(blk, "conv3"):
                     raise NotImplementedError("Bottleneck depths (50+) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
                 p1 = ConvPlan(blk.conv1.in_channels, blk.conv1.out_channels, blk.conv1.kernel_size, blk.conv1.stride,
-                              blk.conv1.padding, dims, device, batch=B)
+                              blk.conv1.padding, dims, device)
                 p2 = ConvPlan(blk.conv2.in_channels, blk.conv2.out_channels, blk.conv2.kernel_size, blk.conv2.stride,
-                              blk.conv2.padding, p1.out_dims, device, batch=B)
+                              blk.conv2.padding, p1.out_dims, device)
                 pd = None
                 if blk.downsample is not None:
                     if not (hasattr(blk.downsample, "__getitem__") and len(blk.downsample) == 2):
