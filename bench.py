@@ -412,7 +412,7 @@ def main():
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
                              traffic_source=traffic_src,
-                             kernel=("conv_wino_kernel<3> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
+                             kernel=("conv_wino_kernel<3,false,2> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
                                      "over W-tiles, LDS-DMA 3-stage ring, transforms in registers; fwd + dgrad of layer1)" if wino else
                                      "conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring; fwd + dgrad of layer1)"),
                              ms_per_launch=ms_k, launches_timed=len(ev), algorithmic_flops_per_launch=flops_launch,
