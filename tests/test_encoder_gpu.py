@@ -465,6 +465,71 @@ def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
         assert d_gpu <= 1e-3, (k, d_gpu)
 
 
+def test_eval_mode_backward_frozen_batchnorm_vs_oracle(gpu):
+    """backward through an EVAL-mode encoder (models/resnet.py:255-312 is an ordinary autograd graph in any mode: BatchNorm then
+    normalises with its running statistics, constants of the pass): embeddings, loss and every parameter gradient vs the oracle's
+    eval-mode graph on the same ReLU branches; running statistics and counters untouched; a following no_grad pass still folds
+    BatchNorm into the conv epilogues and gives the same embeddings"""
+    from oracle import encoder as oe
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    import contextlib
+    import io
+    rng = np.random.default_rng(21)
+    sd = oe.make_state_dict(rng, widen=0.125, hidden=64, out_dim=32)
+    for k in list(sd):                                            # non-trivial running statistics
+        if k.endswith("running_mean"):
+            sd[k] = (0.3 * rng.standard_normal(np.asarray(sd[k]).shape)).astype(np.float32)
+        elif k.endswith("running_var"):
+            sd[k] = (0.5 + rng.random(np.asarray(sd[k]).shape)).astype(np.float32)
+    x = torch.from_numpy(rng.standard_normal((4, 3, 8, 32, 32)).astype(np.float32))
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = generate_model(18, **dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32))
+    _load_into(m, sd)
+    m = m.cuda().eval()
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}
+    emb = m(x.cuda())
+    assert emb.requires_grad
+    loss = ntxent_loss(emb)
+    loss.backward()
+    for k, v in m.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k
+    with torch.no_grad():
+        assert torch.allclose(m(x.cuda()), emb.detach(), atol=1e-5, rtol=0)
+    # the oracle's eval-mode graph in fp64, on the branches the HIP forward took
+    m.eval()
+    masks = {}
+    eng = m._engine(x.cuda())
+    with torch.no_grad():
+        eng.prepack(with_dgrad=False)
+        a = x.cuda()
+        for si in range(eng.N_SEG):
+            a, ctx = eng.seg_forward(si, a, False, True)
+            if si == 0:
+                masks["stem"] = (ctx["a0"] > 0).permute(0, 4, 1, 2, 3).cpu()
+            elif si <= 4:
+                for b, blk in enumerate(ctx["blocks"]):
+                    masks[f"layer{si}.{b}.a1"] = (blk["a1"] > 0).permute(0, 4, 1, 2, 3).cpu()
+                    masks[f"layer{si}.{b}"] = (blk["out"] > 0).permute(0, 4, 1, 2, 3).cpu()
+            else:
+                masks["head"] = (ctx["ah"] > 0).view(4, -1).cpu()
+    t64 = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
+    names = [k for k, v in t64.items() if v.requires_grad]
+    e64 = oe.encoder_forward(t64, x.double(), training=False, relu_masks=masks)
+    l64 = oe.ntxent_loss(e64)
+    g64 = dict(zip(names, torch.autograd.grad(l64, [t64[k] for k in names])))
+    assert (emb.detach().cpu().double() - e64.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - l64.item()) <= 1e-4
+    pd = dict(m.named_parameters())
+    assert len(names) == len(pd) == 66
+    for k in names:
+        ref = g64[k]
+        scale = max(ref.abs().max().item(), 1e-12)
+        d = (pd[k].grad.cpu().double() - ref).abs().max().item() / scale
+        assert d <= 1e-3, (k, d)
+
+
 def test_tripletnet_surface(gpu):
     from video_similarity_search_amd.models import generate_model, Tripletnet
     m = generate_model(18, **dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32)).cuda().eval()

@@ -73,6 +73,10 @@ class _Bn:
             self.sync = True
             self.group = mod.process_group if mod.process_group is not None else torch.distributed.group.WORLD
         self.n_total = None        # sync: 0-dim double device tensor, the global sample count of this pass
+        # eval mode with gradients enabled (the reference's ResNet.forward is an ordinary autograd graph in any mode): the layer
+        # normalises with its RUNNING statistics, which are constants of the pass — backward is dz = gamma * invstd * g,
+        # dgamma = sum g * xhat, dbeta = sum g
+        self.frozen = False
 
 
 COUNTS = {"bn_bwd": 0, "bn_bwd_fused": 0}     # launches by flavour (diagnostics / tests)
@@ -195,6 +199,14 @@ class _Engine:
         call("slic_bn_eval_affine", ptr(m.weight), ptr(m.bias), ptr(m.running_mean), ptr(m.running_var), BN_EPS, bn.C,
              ptr(bn.scale), ptr(bn.shift), stream())
 
+    def _bn_frozen(self, bn):
+        """running statistics as the pass's (mean, invstd) + the eval affine; nothing is updated"""
+        m = bn.mod
+        self._bn_eval(bn)
+        bn.mean = m.running_mean.detach().float().contiguous()
+        bn.invstd = torch.rsqrt(m.running_var.detach().float() + BN_EPS)
+        bn.frozen = True
+
     @staticmethod
     def _apply(z, bn, res, relu):
         y = torch.empty_like(z)
@@ -212,7 +224,7 @@ class _Engine:
         g = torch.empty_like(z) if want_g else None
         dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
-        if bn.sync:
+        if bn.sync or bn.frozen:
             if out is None:      # no ReLU to undo: the gradient that reaches z's BatchNorm IS dy (slic_bn_bwd_sums writes no g then)
                 _Engine._bn_bwd_sync(None, dy, None, z, bn, None, dz, dgamma, dbeta)
                 return dz, (dy if want_g else None), dgamma, dbeta
@@ -239,8 +251,11 @@ class _Engine:
         gin = g if part is not None else (g if out is not None else dy)      # what phase 2 reads as the gradient
         call("slic_bn_bwd_sums", ptr(part), R, ptr(dy), ptr(out), ptr(z), ptr(bn.mean), ptr(bn.invstd), M, C,
              ptr(g) if (part is None and out is not None) else None, ptr(sums), ptr(dgamma), ptr(dbeta), ptr(ws), stream())
-        torch.distributed.all_reduce(sums, group=bn.group)
-        k = sums / bn.n_total
+        if bn.frozen:            # frozen statistics carry no gradient: no mean terms (and nothing to exchange)
+            k = torch.zeros(2 * C, dtype=torch.float64, device=z.device)
+        else:
+            torch.distributed.all_reduce(sums, group=bn.group)
+            k = sums / bn.n_total
         call("slic_bn_bwd_apply", ptr(gin), ptr(z), ptr(bn.mean), ptr(bn.invstd), ptr(bn.mod.weight), ptr(k[:C]), ptr(k[C:]),
              M, C, ptr(dz), stream())
 
@@ -255,7 +270,7 @@ class _Engine:
         dz = torch.empty_like(z)
         dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
         dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
-        if bn.sync:
+        if bn.sync or bn.frozen:
             _Engine._bn_bwd_sync(part, None, None, z, bn, g, dz, dgamma, dbeta)
             return dz, dgamma, dbeta
         ws = _lib.workspace(lib.slic_bn_bwd_fused_workspace_bytes(R, bn.C), z.device, "bn_bwd_fused")
@@ -280,10 +295,15 @@ class _Engine:
             mods = [net.fc1, net.bn_proj, net.fc2] if net.projection_head else []
         return [p for m in mods for p in m.parameters() if p.requires_grad]
 
-    def _conv_bn_act(self, plan, inp, weight, bnmod, res, relu, training, B):
-        """conv -> BN -> (+res) -> relu; returns (z or None, y, bn)"""
+    def _conv_bn_act(self, plan, inp, weight, bnmod, res, relu, training, B, keep=False):
+        """conv -> BN -> (+res) -> relu; returns (z or None, y, bn).  keep: an eval-mode pass whose backward will run — the
+        BatchNorm is applied unfolded on its running statistics, z is kept"""
         bn = _Bn(bnmod)
         wp = plan.pack_fwd(weight)
+        if not training and keep:
+            z, _ = plan.forward(inp, wp, B)
+            self._bn_frozen(bn)
+            return z, self._apply(z, bn, res, relu), bn
         if training:
             z, part = plan.forward(inp, wp, B, want_stats=True)
             self._bn_train(bn, part, z.numel() // bn.C)
@@ -309,7 +329,7 @@ class _Engine:
         dev = inp.device
         if si == 0:
             x4 = self.stem.make_source(inp)          # NCDHW clip -> the stem plan's operand layout (W-run for RGB)
-            z0, a, bn0 = self._conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True, training, B)
+            z0, a, bn0 = self._conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True, training, B, keep=save)
             return a, (dict(x4=x4, z0=z0, a0=a, bn0=bn0) if save else None)
         self._await_packs()
         if si <= 4:
@@ -317,12 +337,12 @@ class _Engine:
             saved = []
             for blk, p1, p2, pd in self.layer_blocks[si - 1]:
                 xin = a
-                z1, a1, b1 = self._conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True, training, B)
+                z1, a1, b1 = self._conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True, training, B, keep=save)
                 if pd is not None:
-                    zd, r, bd = self._conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False, training, B)
+                    zd, r, bd = self._conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False, training, B, keep=save)
                 else:
                     zd, r, bd = None, xin, None
-                z2, out, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True, training, B)
+                z2, out, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True, training, B, keep=save)
                 if save:
                     saved.append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, out=out, b2=b2, zd=zd, bd=bd))
                 a = out
@@ -342,6 +362,10 @@ class _Engine:
         if training:
             h1, part = self.fc1.forward(p5, w1, B, bias=net.fc1.bias, want_stats=True)
             self._bn_train(bnp, part, B)
+            ah = self._apply(h1, bnp, None, True)
+        elif save:             # eval mode with a backward to come: unfolded, on the running statistics
+            h1, _ = self.fc1.forward(p5, w1, B, bias=net.fc1.bias)
+            self._bn_frozen(bnp)
             ah = self._apply(h1, bnp, None, True)
         else:
             self._bn_eval(bnp)
@@ -655,33 +679,17 @@ class ResNet(nn.Module):
         return run_engine(self._engine(x), self, x)
 
 
-class _InferenceFn(torch.autograd.Function):
-    """an inference pass recorded in a live autograd graph: forward works, backward refuses loudly.  The reference can
-    back-propagate through an eval-mode encoder (BatchNorm frozen on its running statistics); the SLIC loop never does
-    (validation and extraction run under no_grad), so that backward is not built — but it must not fail obscurely or
-    silently train only the layers stacked on top of the encoder."""
-
-    @staticmethod
-    def forward(ctx, x, eng, training, *params):
-        return eng.forward(x, training=training, save=False)[0]
-
-    @staticmethod
-    def backward(ctx, dout):
-        raise NotImplementedError("backward through an eval-mode (or fully frozen) encoder is not implemented on the HIP path: "
-                                  "call .train() for a training step, or run inference under torch.no_grad()")
-
-
 def run_engine(eng, module, x):
-    """drive one encoder through its engine: autograd segments in train mode, a plain inference pass otherwise"""
+    """drive one encoder through its engine: autograd segments whenever a backward may follow — train mode (batch statistics)
+    or eval mode (BatchNorm frozen on its running statistics: the reference's ResNet.forward is an ordinary autograd graph in
+    any mode, models/resnet.py:255-312) — a plain inference pass with BatchNorm folded into the conv epilogues otherwise"""
     params = [p for p in module.parameters() if p.requires_grad]
-    if torch.is_grad_enabled() and module.training and params:
+    if torch.is_grad_enabled() and params:
         a = x
         eng.prepack(with_dgrad=True)
         for si in range(eng.N_SEG):
-            a = _SegmentFn.apply(a, eng, si, True, *eng.seg_params(si))
+            a = _SegmentFn.apply(a, eng, si, bool(module.training), *eng.seg_params(si))
         return a
-    if torch.is_grad_enabled() and (params or x.requires_grad):
-        return _InferenceFn.apply(x, eng, module.training, *params)      # usable forward, loud backward
     with torch.no_grad():
         return eng.forward(x, training=module.training, save=False)[0]
 
