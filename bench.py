@@ -252,8 +252,10 @@ def nce_secondary():
     return dict(metric="memory-bank NCE step (fwd + bwd + bank update), B=32 K=1024 D=128", ms=t * 1e3, ms_module_by_module=t_modules * 1e3,
                 roofline=dict(bound="hbm", achieved=bytes_alg / t / 1e9, peak=8000.0, unit="GB/s", frac=bytes_alg / t / 1e9 / 8000.0,
                               traffic=None, algorithmic_bytes_per_step=bytes_alg,
-                              note="NCEAverage.softmax_loss: three launches (scores + cross-entropy, bank update + loss, backward) over 33.6 MB of "
-                                   "gathered bank rows; the module-by-module form (a dozen launches) is timed beside it"))
+                              note="NCEAverage.softmax_loss: three launches (scores + cross-entropy pieces, bank update + loss, backward) over "
+                                   "33.6 MB of gathered bank rows — 16 + 11 + 10 us of kernel time (profiles/README.md); the wall time per step "
+                                   "timed here is the host's issue cost (Python autograd node + index draw); the module-by-module form "
+                                   "(a dozen launches) is timed beside it"))
 
 
 def self_launch(n):

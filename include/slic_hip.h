@@ -464,14 +464,17 @@ int slic_softmax_ce0_bwd(const float* x, const float* lse, int B, int K1, const 
  * NCESoftmaxLoss(out_l) + NCESoftmaxLoss(out_ab) — as three launches (the separate entry points above: a dozen):
  *   slic_nce_fused_fwd   : scores[0] = <memory_l[idx], f_ab> / T (out_ab), scores[1] = <memory_ab[idx], f_l> / T (out_l), [2][B][K1];
  *                          rows [2][B][K1][D] = the bank rows as scored (the update below changes the banks before the backward);
- *                          lse / rowloss [2][B] = log-sum-exp of a score row and its cross-entropy against class 0
+ *                          part [2][B][SLIC_NCE_PARTS][2] = (max, sum-exp) of each of the SLIC_NCE_PARTS pieces a score row is split into
  *   slic_nce_fused_update: both banks' momentum update (NCE_loss.py:73-86; on duplicate labels the last row wins, every row computed
- *                          from the bank as it was) and loss = mean_b rowloss[0][b] + mean_b rowloss[1][b]
+ *                          from the bank as it was); with part != NULL also lse / rowloss [2][B] = log-sum-exp of a score row and its
+ *                          cross-entropy against class 0, and loss = mean_b rowloss[0][b] + mean_b rowloss[1][b]
  *   slic_nce_fused_bwd   : df[0] = d loss / d f_ab, df[1] = d loss / d f_l ([2][B][D]), scaled by *gscale (NULL = 1) */
+#define SLIC_NCE_PARTS 16
 int slic_nce_fused_fwd(const float* bank_l, const float* bank_ab, const float* f_l, const float* f_ab, const int64_t* idx, int B,
-                       int K1, int D, float T, float* scores, float* rows, float* lse, float* rowloss, void* stream);
+                       int K1, int D, float T, float* scores, float* rows, float* part, void* stream);
 int slic_nce_fused_update(float* bank_l, float* bank_ab, const int64_t* y, const float* f_l, const float* f_ab, int B, int D,
-                          float momentum, const float* rowloss, float* loss, void* stream);
+                          float momentum, const float* part, const float* scores, int K1, float* lse, float* rowloss, float* loss,
+                          void* stream);
 int slic_nce_fused_bwd(const float* rows, const float* scores, const float* lse, int B, int K1, int D, float T,
                        const float* gscale, float* df, void* stream);
 

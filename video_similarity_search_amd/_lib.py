@@ -112,8 +112,8 @@ SIGNATURES = {
     "slic_nce_scores_fwd": (I, [P, P, P, I, I, I, F, P, P, P]),
     "slic_nce_scores_bwd": (I, [P, P, P, I, I, I, F, P, P]),
     "slic_nce_bank_update": (I, [P, P, P, I, I, F, P]),
-    "slic_nce_fused_fwd": (I, [P, P, P, P, P, I, I, I, F, P, P, P, P, P]),
-    "slic_nce_fused_update": (I, [P, P, P, P, P, I, I, F, P, P, P]),
+    "slic_nce_fused_fwd": (I, [P, P, P, P, P, I, I, I, F, P, P, P, P]),
+    "slic_nce_fused_update": (I, [P, P, P, P, P, I, I, F, P, P, I, P, P, P, P]),
     "slic_nce_fused_bwd": (I, [P, P, P, I, I, I, F, P, P, P]),
     "slic_softmax_ce0_fwd": (I, [P, I, I, P, P, P, P]),
     "slic_softmax_ce0_bwd": (I, [P, P, I, I, P, P, P]),

@@ -139,21 +139,24 @@ __global__ void mean_rows_serial(const float* __restrict__ v, int n, float* out)
 //   nce_fused_bwd   (b, side): dfeat[b] = gscale / (B T) sum_j (exp(s_j - lse_b) - [j = 0]) rows[b, j]   (j ascending per column)
 // side 0: feature ab scored against memory_l (-> out_ab), side 1: feature l against memory_ab (-> out_l)  (NCE_loss.py:41-48).
 // ---------------------------------------------------------------------------------------------------------------
+#define NCE_PARTS 16                 // a score row's K1 entries are split over this many workgroups (slic_hip.h: SLIC_NCE_PARTS)
 __global__ __launch_bounds__(256) void nce_fused_fwd(const float* __restrict__ bank0, const float* __restrict__ bank1,
                                                      const float* __restrict__ f0, const float* __restrict__ f1,
                                                      const int64_t* __restrict__ idx, int K1, int D, float invT,
                                                      float* __restrict__ scores /* [2][B][K1] */, float* __restrict__ rows /* [2][B][K1][D] */,
-                                                     float* __restrict__ lse /* [2][B] */, float* __restrict__ rowloss /* [2][B] */) {
+                                                     float* __restrict__ part /* [2][B][NCE_PARTS][2] */) {
   __shared__ float rm[8], rs[8];
-  const int b = blockIdx.x, side = blockIdx.y, B = gridDim.x;
+  const int b = blockIdx.x, side = blockIdx.y, c = blockIdx.z, B = gridDim.x;
   const float* bank = side ? bank1 : bank0;
   const float* fb = (side ? f1 : f0) + (int64_t)b * D;
   const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
   float* sc = scores + ((int64_t)side * B + b) * K1;
   float* rw = rows + ((int64_t)side * B + b) * K1 * (int64_t)D;
+  const int64_t* ix = idx + (int64_t)b * K1;
+  const int cl = (K1 + NCE_PARTS - 1) / NCE_PARTS, j1 = min(K1, (c + 1) * cl);
   float m = -INFINITY, sum = 0.f;
-  for (int j = sub; j < K1; j += 8) {
-    const float* row = bank + idx[(int64_t)b * K1 + j] * (int64_t)D;
+  for (int j = c * cl + sub; j < j1; j += 8) {
+    const float* row = bank + ix[j] * (int64_t)D;
     float a = 0.f;
     for (int k = l * 4; k < D; k += 128) {
       const f32x4 r = *(const f32x4*)(row + k);
@@ -170,20 +173,21 @@ __global__ __launch_bounds__(256) void nce_fused_fwd(const float* __restrict__ b
   }
   if (l == 0) { rm[sub] = m; rs[sub] = sum; }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) {                                      // the eight groups in a fixed order; an idle group has m = -inf, sum = 0
     float M = rm[0];
     for (int g = 1; g < 8; ++g) M = fmaxf(M, rm[g]);
     float S = 0.f;
-    for (int g = 0; g < 8; ++g) S += rs[g] * expf(rm[g] - M);  // a group that saw no row has m = -inf, sum = 0: contributes 0
-    const float L = M + logf(S);
-    lse[side * B + b] = L;
-    rowloss[side * B + b] = L - sc[0];                         // sc[0] was written by this thread (sub 0, lane 0, j = 0)
+    if (M > -INFINITY)
+      for (int g = 0; g < 8; ++g) S += rs[g] * expf(rm[g] - M);
+    float* pp = part + (((int64_t)side * B + b) * NCE_PARTS + c) * 2;
+    pp[0] = M; pp[1] = S;
   }
 }
 
 __global__ void nce_fused_update(float* __restrict__ bank_l, float* __restrict__ bank_ab, const int64_t* __restrict__ y,
                                  const float* __restrict__ fl, const float* __restrict__ fab, int B, int D, float momentum,
-                                 const float* __restrict__ rowloss, float* __restrict__ loss) {
+                                 const float* __restrict__ part, const float* __restrict__ scores, int K1,
+                                 float* __restrict__ lse, float* __restrict__ rowloss, float* __restrict__ loss) {
   const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // wave = (bank, b)
   const int lane = threadIdx.x & 63;
   if (w < 2 * B) {
@@ -203,49 +207,63 @@ __global__ void nce_fused_update(float* __restrict__ bank_l, float* __restrict__
     if (last)
       for (int k = lane; k < D; k += 64) row[k] = (row[k] * momentum + fb[k] * (1.f - momentum)) / nrm;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && loss) {
-    double a0 = 0.0, a1 = 0.0;
-    for (int i = 0; i < B; ++i) { a0 += (double)rowloss[i]; a1 += (double)rowloss[B + i]; }
-    *loss = (float)(a0 / (double)B) + (float)(a1 / (double)B);
+  if (blockIdx.x == 0 && part) {
+    // a score row's log-sum-exp from its NCE_PARTS pieces (ascending), its cross-entropy against class 0, then the two means
+    for (int r = threadIdx.x; r < 2 * B; r += blockDim.x) {
+      const float* pp = part + (int64_t)r * NCE_PARTS * 2;
+      float M = pp[0];
+      for (int c = 1; c < NCE_PARTS; ++c) M = fmaxf(M, pp[2 * c]);
+      float S = 0.f;
+      for (int c = 0; c < NCE_PARTS; ++c)
+        if (pp[2 * c] > -INFINITY) S += pp[2 * c + 1] * expf(pp[2 * c] - M);
+      const float L = M + logf(S);
+      lse[r] = L;
+      rowloss[r] = L - scores[(int64_t)r * K1];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int i = 0; i < B; ++i) { a0 += (double)rowloss[i]; a1 += (double)rowloss[B + i]; }
+      *loss = (float)(a0 / (double)B) + (float)(a1 / (double)B);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void nce_fused_bwd(const float* __restrict__ rows, const float* __restrict__ scores,
-                                                     const float* __restrict__ lse, int K1, int D, float invT,
-                                                     const float* __restrict__ gscale, float* __restrict__ df /* [2][B][D] */) {
-  __shared__ float red[8][512];
+// (b, side, 128-column slice): 32 groups of 32 lanes stride the K1 rows, four rows in flight per group; a group adds j-ascending and
+// the groups are summed in ascending order
+__global__ __launch_bounds__(1024) void nce_fused_bwd(const float* __restrict__ rows, const float* __restrict__ scores,
+                                                      const float* __restrict__ lse, int K1, int D, float invT,
+                                                      const float* __restrict__ gscale, float* __restrict__ df /* [2][B][D] */) {
+  __shared__ float red[32][128];
   const int b = blockIdx.x, side = blockIdx.y, B = gridDim.x;
   const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
   const float* sc = scores + ((int64_t)side * B + b) * K1;
   const float* rw = rows + ((int64_t)side * B + b) * K1 * (int64_t)D;
   const float L = lse[side * B + b];
   const float g = (gscale ? *gscale : 1.f) / (float)B;
-  for (int k0 = 0; k0 < D; k0 += 128) {
-    const int k = k0 + l * 4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (k < D) {
-      int j = sub;
-      for (; j + 24 < K1; j += 32) {                          // four rows in flight; the adds stay j-ascending
-        const float p0 = (expf(sc[j] - L) - (j == 0 ? 1.f : 0.f)) * g, p1 = expf(sc[j + 8] - L) * g;
-        const float p2 = expf(sc[j + 16] - L) * g, p3 = expf(sc[j + 24] - L) * g;
-        const f32x4 r0 = *(const f32x4*)(rw + (int64_t)j * D + k), r1 = *(const f32x4*)(rw + (int64_t)(j + 8) * D + k);
-        const f32x4 r2 = *(const f32x4*)(rw + (int64_t)(j + 16) * D + k), r3 = *(const f32x4*)(rw + (int64_t)(j + 24) * D + k);
-        a += r0 * p0; a += r1 * p1; a += r2 * p2; a += r3 * p3;
-      }
-      for (; j < K1; j += 8) {
-        const float pj = (expf(sc[j] - L) - (j == 0 ? 1.f : 0.f)) * g;
-        a += *(const f32x4*)(rw + (int64_t)j * D + k) * pj;
-      }
+  const int k0 = blockIdx.z * 128, k = k0 + l * 4;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (k < D) {
+    int j = sub;
+    for (; j + 96 < K1; j += 128) {
+      const float p0 = (expf(sc[j] - L) - (j == 0 ? 1.f : 0.f)) * g, p1 = expf(sc[j + 32] - L) * g;
+      const float p2 = expf(sc[j + 64] - L) * g, p3 = expf(sc[j + 96] - L) * g;
+      const f32x4 r0 = *(const f32x4*)(rw + (int64_t)j * D + k), r1 = *(const f32x4*)(rw + (int64_t)(j + 32) * D + k);
+      const f32x4 r2 = *(const f32x4*)(rw + (int64_t)(j + 64) * D + k), r3 = *(const f32x4*)(rw + (int64_t)(j + 96) * D + k);
+      a += r0 * p0; a += r1 * p1; a += r2 * p2; a += r3 * p3;
     }
-    *(f32x4*)&red[sub][l * 4] = a;
-    __syncthreads();
-    if (threadIdx.x < 128 && k0 + threadIdx.x < D) {
-      float t = 0.f;
+    for (; j < K1; j += 32) {
+      const float pj = (expf(sc[j] - L) - (j == 0 ? 1.f : 0.f)) * g;
+      a += *(const f32x4*)(rw + (int64_t)j * D + k) * pj;
+    }
+  }
+  *(f32x4*)&red[sub][l * 4] = a;
+  __syncthreads();
+  if (threadIdx.x < 128 && k0 + threadIdx.x < D) {
+    float t = 0.f;
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2) t += red[s2][threadIdx.x];
-      df[((int64_t)side * B + b) * D + k0 + threadIdx.x] = t * invT;
-    }
-    __syncthreads();
+    for (int s2 = 0; s2 < 32; ++s2) t += red[s2][threadIdx.x];
+    df[((int64_t)side * B + b) * D + k0 + threadIdx.x] = t * invT;
   }
 }
 
@@ -294,28 +312,32 @@ extern "C" int slic_softmax_ce0_bwd(const float* x, const float* lse, int B, int
 }
 
 extern "C" int slic_nce_fused_fwd(const float* bank_l, const float* bank_ab, const float* f_l, const float* f_ab,
-                                  const int64_t* idx, int B, int K1, int D, float T, float* scores, float* rows, float* lse,
-                                  float* rowloss, void* stream) {
-  SLIC_REQUIRE(bank_l && bank_ab && f_l && f_ab && idx && scores && rows && lse && rowloss && B > 0 && K1 > 0 && D > 0 &&
+                                  const int64_t* idx, int B, int K1, int D, float T, float* scores, float* rows, float* part,
+                                  void* stream) {
+  static_assert(NCE_PARTS == SLIC_NCE_PARTS, "slic_hip.h: SLIC_NCE_PARTS");
+  SLIC_REQUIRE(bank_l && bank_ab && f_l && f_ab && idx && scores && rows && part && B > 0 && K1 > 0 && D > 0 &&
                    D % 4 == 0 && T > 0.f, "slic_nce_fused_fwd: bad args (D %% 4 == 0)");
   // side 0 = out_ab: feature ab against memory_l; side 1 = out_l: feature l against memory_ab (NCE_loss.py:41-48)
-  nce_fused_fwd<<<dim3((unsigned)B, 2), dim3(256), 0, S_(stream)>>>(bank_l, bank_ab, f_ab, f_l, idx, K1, D, 1.0f / T, scores, rows,
-                                                                     lse, rowloss);
+  nce_fused_fwd<<<dim3((unsigned)B, 2, NCE_PARTS), dim3(256), 0, S_(stream)>>>(bank_l, bank_ab, f_ab, f_l, idx, K1, D, 1.0f / T, scores,
+                                                                                rows, part);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
 extern "C" int slic_nce_fused_update(float* bank_l, float* bank_ab, const int64_t* y, const float* f_l, const float* f_ab, int B,
-                                     int D, float momentum, const float* rowloss, float* loss, void* stream) {
-  SLIC_REQUIRE(bank_l && bank_ab && y && f_l && f_ab && B > 0 && D > 0 && (!loss || rowloss), "slic_nce_fused_update: bad args");
+                                     int D, float momentum, const float* part, const float* scores, int K1, float* lse,
+                                     float* rowloss, float* loss, void* stream) {
+  SLIC_REQUIRE(bank_l && bank_ab && y && f_l && f_ab && B > 0 && D > 0 && (!part || (scores && K1 > 0 && lse && rowloss)),
+               "slic_nce_fused_update: bad args");
   nce_fused_update<<<dim3((unsigned)slic_cdiv(2 * B, 4)), dim3(256), 0, S_(stream)>>>(bank_l, bank_ab, y, f_l, f_ab, B, D, momentum,
-                                                                                    rowloss, loss);
+                                                                                    part, scores, K1, lse, rowloss, loss);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
 extern "C" int slic_nce_fused_bwd(const float* rows, const float* scores, const float* lse, int B, int K1, int D, float T,
                                   const float* gscale, float* df, void* stream) {
   SLIC_REQUIRE(rows && scores && lse && df && B > 0 && K1 > 0 && D > 0 && D % 4 == 0 && T > 0.f, "slic_nce_fused_bwd: bad args");
-  nce_fused_bwd<<<dim3((unsigned)B, 2), dim3(256), 0, S_(stream)>>>(rows, scores, lse, K1, D, 1.0f / T, gscale, df);
+  nce_fused_bwd<<<dim3((unsigned)B, 2, (unsigned)slic_cdiv(D, 128)), dim3(1024), 0, S_(stream)>>>(rows, scores, lse, K1, D, 1.0f / T,
+                                                                                                gscale, df);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

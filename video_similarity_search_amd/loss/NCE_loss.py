@@ -166,6 +166,9 @@ class NCEAverage(nn.Module):
         return loss, scores[1].unsqueeze(-1), scores[0].unsqueeze(-1)
 
 
+_NCE_PARTS = 16          # slic_hip.h: SLIC_NCE_PARTS
+
+
 class _FusedContrastStep(torch.autograd.Function):
     """contrast(l, ab, y) + NCESoftmaxLoss on both outputs as ONE autograd node over three launches (csrc/nce.hip:
     nce_fused_fwd / nce_fused_update / nce_fused_bwd)"""
@@ -179,12 +182,14 @@ class _FusedContrastStep(torch.autograd.Function):
         dev = l.device
         scores = torch.empty(2, B, K1, dtype=torch.float32, device=dev)
         rows = torch.empty(2, B, K1, D, dtype=torch.float32, device=dev)
-        stat = torch.empty(2, 2, B, dtype=torch.float32, device=dev)        # [lse | rowloss][side][b]
-        loss = torch.empty((), dtype=torch.float32, device=dev)
+        # [lse | rowloss][side][b], then the SLIC_NCE_PARTS (max, sum-exp) pieces of every score row, then the loss
+        nstat = 4 * B
+        buf = torch.empty(nstat + 4 * B * _NCE_PARTS + 1, dtype=torch.float32, device=dev)
+        stat, part, loss = buf[:nstat].view(2, 2, B), buf[nstat:-1], buf[-1]
         call("slic_nce_fused_fwd", ptr(mem_l), ptr(mem_ab), ptr(l), ptr(ab), ptr(idx), B, K1, D, float(T), ptr(scores), ptr(rows),
-             ptr(stat[0]), ptr(stat[1]), stream())
-        call("slic_nce_fused_update", ptr(mem_l), ptr(mem_ab), ptr(y), ptr(l), ptr(ab), B, D, float(momentum), ptr(stat[1]),
-             ptr(loss), stream())
+             ptr(part), stream())
+        call("slic_nce_fused_update", ptr(mem_l), ptr(mem_ab), ptr(y), ptr(l), ptr(ab), B, D, float(momentum), ptr(part), ptr(scores),
+             K1, ptr(stat[0]), ptr(stat[1]), ptr(loss), stream())
         ctx.mark_non_differentiable(scores)
         ctx.T, ctx.shape = float(T), (B, K1, D)
         ctx.keep = (rows, scores, stat)
