@@ -182,8 +182,15 @@ __global__ __launch_bounds__(256) void km_assign_partial(
 template <int BP, int NCT, int WC, int STAGES>
 __global__ __launch_bounds__(256) void km_assign_dma(
     const float* __restrict__ Xp, int64_t N, int D, int ldx, const float* __restrict__ Cp, int K,
-    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx) {
+    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx,
+    int32_t* z0, int32_t* z1) {
   extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  // the iteration's two device counters (labels changed; M-step workgroups done) start at zero: nothing before this kernel in the
+  // iteration touches them, everything after it is ordered behind it on the stream
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (z0) *z0 = 0;
+    if (z1) *z1 = 0;
+  }
   constexpr int WP = 4 / WC;
   static_assert(BP == 32 * WP && NCT % WC == 0, "wave grid");
   constexpr int BC = NCT * 32;
@@ -323,8 +330,15 @@ static __device__ inline unsigned long long km_now() {
 template <int NK, int ST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void km_assign_creg(
     const float* __restrict__ Xp, int64_t N, int D, int ldx, const float* __restrict__ Cp, int K,
-    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx) {
+    int ldc, const float* __restrict__ cnorm, float* __restrict__ pscore, int32_t* __restrict__ pidx,
+    int32_t* z0, int32_t* z1) {
   extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  // the iteration's two device counters (labels changed; M-step workgroups done) start at zero: nothing before this kernel in the
+  // iteration touches them, everything after it is ordered behind it on the stream
+  if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {
+    if (z0) *z0 = 0;
+    if (z1) *z1 = 0;
+  }
   static_assert(NK % ST == 0 && ST == 4, "a point tile is a whole number of ring turns; the DMA's LDS base (M0) reaches 64 KB: 4 stages of 16 KB");
   constexpr int BP = 128;
   constexpr int STAGE_FLOATS = BP * KM_BK;
@@ -582,46 +596,50 @@ __global__ __launch_bounds__(KM_SB) void km_block_hist(const int32_t* __restrict
   for (int j = threadIdx.x; j < K; j += KM_SB) bc[(int64_t)blockIdx.x * K + j] = km_hist[j];
 }
 
-// per cluster: exclusive scan over blocks (in place) and total count.  One wave per cluster: 64 blocks per step,
-// shuffle scan inside the step, running carry between steps (integer adds: order-free)
-__global__ __launch_bounds__(64) void km_scan_blocks(int32_t* __restrict__ bc, int nblk, int K,
-                                                     int32_t* __restrict__ cnt) {
-  const int j = blockIdx.x, lane = threadIdx.x;
-  int carry = 0;
-  for (int b0 = 0; b0 < nblk; b0 += 64) {
-    const int b = b0 + lane;
-    const int v = b < nblk ? bc[(int64_t)b * K + j] : 0;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int u = __shfl_up(inc, d);
-      if (lane >= d) inc += u;
-    }
-    if (b < nblk) bc[(int64_t)b * K + j] = carry + inc - v;
-    carry += __shfl(inc, 63);
-  }
-  if (lane == 0) cnt[j] = carry;
-}
-
 // order[off[l] + (rows with label l in earlier blocks) + (rank inside the block)] = row: a stable counting sort.
-// off = exclusive scan of cnt over clusters, recomputed per workgroup in LDS (K is small) instead of a launch of its own.
+// Every workgroup first folds the per-block histograms bc[nblk][K] itself (a launch of its own for that scan cost more than the
+// nblk * K coalesced, L2-resident loads per workgroup): tot[l] = rows with label l, base[l] = those in earlier blocks; off =
+// exclusive scan of tot over clusters in LDS.  Block 0 also writes cnt = tot for the accumulate pass.
 // Rank inside the block = (same-label rows in earlier waves) + (same-label lanes below the row in its own wave).  In-wave:
 // the wave's distinct labels are peeled one ballot at a time (<= 64 rounds instead of an O(1024) scan per row); across
 // waves: per-wave label counts in LDS when they fit (use_wcnt: 16 x K ints), else a scan of the earlier waves' labels.
 __global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ labels, int64_t N, int K,
-                         const int32_t* __restrict__ bc, const int32_t* __restrict__ cnt,
+                         const int32_t* __restrict__ bc, int nblk, int32_t* __restrict__ cnt,
                          int32_t* __restrict__ order, int use_wcnt) {
-  extern __shared__ int km_cl_off[];          // [K] exclusive scan of cnt, then [16][K] per-wave label counts
+  extern __shared__ int km_cl_off[];          // [K] tot -> exclusive scan of tot, [K] base, then [16][K] per-wave label counts
   __shared__ int wtot[KM_SB / 64];
   __shared__ int lab[KM_SB];
-  int* wcnt = km_cl_off + K;
+  int* base = km_cl_off + K;
+  int* wcnt = km_cl_off + 2 * K;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int me = blockIdx.x;
+  for (int j = t; j < K; j += KM_SB) {
+    int before = 0, tot = 0;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = bc[(int64_t)(b + u) * K + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { tot += v[u]; before += (b + u < me) ? v[u] : 0; }
+    }
+    for (; b < nblk; ++b) {
+      const int v = bc[(int64_t)b * K + j];
+      tot += v; before += (b < me) ? v : 0;
+    }
+    km_cl_off[j] = tot;
+    base[j] = before;
+    if (me == 0) cnt[j] = tot;
+  }
+  if (use_wcnt)
+    for (int j = t; j < (KM_SB / 64) * K; j += KM_SB) wcnt[j] = 0;
+  __syncthreads();
   // ---- cluster offsets: thread t owns clusters [t * per, ...); wave shuffle scan of the run totals, then the 16 wave totals
   const int per = (K + KM_SB - 1) / KM_SB;
   int s = 0;
   for (int u = 0; u < per; ++u) {
     const int j = t * per + u;
-    if (j < K) s += cnt[j];
+    if (j < K) s += km_cl_off[j];
   }
   int inc = s;
   for (int d = 1; d < 64; d <<= 1) {
@@ -629,14 +647,12 @@ __global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ la
     if (lane >= d) inc += v;
   }
   if (lane == 63) wtot[wave] = inc;
-  if (use_wcnt)
-    for (int j = t; j < (KM_SB / 64) * K; j += KM_SB) wcnt[j] = 0;
   __syncthreads();
   int run = inc - s;
   for (int w = 0; w < wave; ++w) run += wtot[w];
   for (int u = 0; u < per; ++u) {
     const int j = t * per + u;
-    if (j < K) { km_cl_off[j] = run; run += cnt[j]; }
+    if (j < K) { const int c = km_cl_off[j]; km_cl_off[j] = run; run += c; }
   }
   // ---- ranks
   const int64_t i = (int64_t)blockIdx.x * KM_SB + t;
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(KM_SB) void km_place(const int32_t* __restrict__ la
     }
   }
   if (i >= N) return;
-  order[km_cl_off[l] + bc[(int64_t)blockIdx.x * K + l] + earlier + intra] = (int32_t)i;
+  order[km_cl_off[l] + base[l] + earlier + intra] = (int32_t)i;
 }
 
 // sums[j, 4*c4 .. 4*c4+3] = sequential fp32 sum over the cluster's rows in ascending order.  TOut = double: the same fp32
@@ -843,60 +859,33 @@ __device__ __forceinline__ float km_comb(const TIn* __restrict__ p, int64_t stri
   }
 }
 
-template <typename TIn, bool PARTS>
-__global__ __launch_bounds__(128) void km_average(const TIn* __restrict__ sums, const TIn* __restrict__ counts,
-                                                  int64_t stride, int W, float* __restrict__ out_sums,
-                                                  float* __restrict__ out_counts,
-                                                  const float* __restrict__ Co, int K, int D, float* __restrict__ Cn,
-                                                  float* __restrict__ shift, float* __restrict__ cnorm_new,
-                                                  float* __restrict__ Cn_perm, int spherical) {
-  extern __shared__ float km_avg_lds[];
-  float* row = km_avg_lds;                 // [D] the new centre
-  float* tg = km_avg_lds + D;              // [D / 4 + (D % 4)] group terms, then tail terms
-  __shared__ float mv[128];
-  __shared__ int mi[128];
-  const int j = blockIdx.x, t = threadIdx.x;
-  auto cnt_of = [&](int u) -> float {
-    if constexpr (PARTS) return km_comb<TIn>(counts + u, stride, W);
-    else return counts[u];
-  };
-  auto sum_of = [&](int u, int k) -> float {
-    if constexpr (PARTS) return km_comb<TIn>(sums + (int64_t)u * D + k, stride, W);
-    else return sums[(int64_t)u * D + k];
-  };
-  const float w = cnt_of(j);
-  if constexpr (PARTS) {
-    if (t == 0) out_counts[j] = w;
-  }
-  int src = j;
-  float alpha;
-  if (w > 0.0f) {                                  // the common case needs no argmax
-    alpha = (float)(1.0 / (double)w);
-  } else {
-    // np.argmax(weight_in_clusters): first index of the maximum
-    float bv = -1.f; int bi = 0;
-    for (int u = t; u < K; u += 128) { const float c = cnt_of(u); if (c > bv) { bv = c; bi = u; } }
-    mv[t] = bv; mi[t] = bi;
+// np.argmax(weight_in_clusters) for an empty cluster j (first index of the maximum): the biggest cluster's row is copied,
+// averaged already iff it precedes j (sklearn's in-place loop order).  Block-uniform; 128 threads.
+template <typename FC>
+__device__ __forceinline__ void km_pick_source(FC&& cnt_of, int j, int K, float* mv, int* mi, int& src, float& alpha) {
+  const int t = threadIdx.x;
+  float bv = -1.f; int bi = 0;
+  for (int u = t; u < K; u += 128) { const float c = cnt_of(u); if (c > bv) { bv = c; bi = u; } }
+  mv[t] = bv; mi[t] = bi;
+  __syncthreads();
+  for (int s2 = 64; s2 > 0; s2 >>= 1) {
+    if (t < s2) {
+      if (mv[t + s2] > mv[t] || (mv[t + s2] == mv[t] && mi[t + s2] < mi[t])) { mv[t] = mv[t + s2]; mi[t] = mi[t + s2]; }
+    }
     __syncthreads();
-    for (int s2 = 64; s2 > 0; s2 >>= 1) {
-      if (t < s2) {
-        if (mv[t + s2] > mv[t] || (mv[t + s2] == mv[t] && mi[t + s2] < mi[t])) { mv[t] = mv[t + s2]; mi[t] = mi[t + s2]; }
-      }
-      __syncthreads();
-    }
-    src = mi[0];  // copy of the biggest cluster: averaged already iff it precedes j (sklearn's in-place loop order)
-    const float ws = cnt_of(src);
-    alpha = (src < j && ws > 0.0f) ? (float)(1.0 / (double)ws) : 1.0f;
   }
-  for (int k = t; k < D; k += 128) {
-    if constexpr (PARTS) {
-      const float own = sum_of(j, k);
-      out_sums[(int64_t)j * D + k] = own;
-      row[k] = (src == j ? own : sum_of(src, k)) * alpha;
-    } else {
-      row[k] = sum_of(src, k) * alpha;
-    }
-  }
+  src = mi[0];
+  const float ws = cnt_of(src);
+  alpha = (src < j && ws > 0.0f) ? (float)(1.0 / (double)ws) : 1.0f;
+}
+
+// row[D] (LDS, written by the caller, not yet synchronised) = the new centre before the optional normalisation: write it out
+// (plain + k8-permuted), its squared norm (k-ascending fmaf chain) and the shift against the old centre (group terms, g ascending)
+template <bool AGENT_SHIFT = false>
+__device__ __forceinline__ void km_average_tail(int j, const float* __restrict__ Co, int D, float* __restrict__ Cn,
+                                                float* __restrict__ shift, float* __restrict__ cnorm_new,
+                                                float* __restrict__ Cn_perm, int spherical, float* row, float* tg, float* mv) {
+  const int t = threadIdx.x;
   __syncthreads();
   if (spherical) {
     // spherical k-means: the new centre is the mean direction, sklearn.preprocessing.normalize(centers) — a zero row stays
@@ -937,8 +926,52 @@ __global__ __launch_bounds__(128) void km_average(const TIn* __restrict__ sums, 
     float r = 0.f;
     const int nt = ng + (D - 4 * ng);
     for (int g = 0; g < nt; ++g) r += tg[g];
-    shift[j] = sqrtf(r);
+    // AGENT_SHIFT: a write-through store, visible device-wide once it has completed (km_accumulate_average's last workgroup
+    // reads every shift from another XCD without an L2 write-back fence)
+    if constexpr (AGENT_SHIFT) __hip_atomic_store(shift + j, sqrtf(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else shift[j] = sqrtf(r);
   }
+}
+
+template <typename TIn, bool PARTS>
+__global__ __launch_bounds__(128) void km_average(const TIn* __restrict__ sums, const TIn* __restrict__ counts,
+                                                  int64_t stride, int W, float* __restrict__ out_sums,
+                                                  float* __restrict__ out_counts,
+                                                  const float* __restrict__ Co, int K, int D, float* __restrict__ Cn,
+                                                  float* __restrict__ shift, float* __restrict__ cnorm_new,
+                                                  float* __restrict__ Cn_perm, int spherical) {
+  extern __shared__ float km_avg_lds[];
+  float* row = km_avg_lds;                 // [D] the new centre
+  float* tg = km_avg_lds + D;              // [D / 4 + (D % 4)] group terms, then tail terms
+  __shared__ float mv[128];
+  __shared__ int mi[128];
+  const int j = blockIdx.x, t = threadIdx.x;
+  auto cnt_of = [&](int u) -> float {
+    if constexpr (PARTS) return km_comb<TIn>(counts + u, stride, W);
+    else return counts[u];
+  };
+  auto sum_of = [&](int u, int k) -> float {
+    if constexpr (PARTS) return km_comb<TIn>(sums + (int64_t)u * D + k, stride, W);
+    else return sums[(int64_t)u * D + k];
+  };
+  const float w = cnt_of(j);
+  if constexpr (PARTS) {
+    if (t == 0) out_counts[j] = w;
+  }
+  int src = j;
+  float alpha;
+  if (w > 0.0f) alpha = (float)(1.0 / (double)w);                                  // the common case needs no argmax
+  else km_pick_source(cnt_of, j, K, mv, mi, src, alpha);
+  for (int k = t; k < D; k += 128) {
+    if constexpr (PARTS) {
+      const float own = sum_of(j, k);
+      out_sums[(int64_t)j * D + k] = own;
+      row[k] = (src == j ? own : sum_of(src, k)) * alpha;
+    } else {
+      row[k] = sum_of(src, k) * alpha;
+    }
+  }
+  km_average_tail(j, Co, D, Cn, shift, cnorm_new, Cn_perm, spherical, row, tg, mv);
 }
 
 // status word: { sum_j shift_j^2, #empty clusters, n_changed, 0 }.  One workgroup; per-thread partials over a fixed
@@ -972,6 +1005,131 @@ __global__ __launch_bounds__(256) void km_status(const float* __restrict__ shift
       for (int s = 0; s < W; ++s) nc += (double)nch_parts[(int64_t)s * stride] + 1048576.0 * (double)nch_parts[(int64_t)s * stride + 1];
     }
     status[2] = nc;
+    status[3] = 0.0;
+  }
+}
+
+// The single-GPU M-step after the counting sort as ONE launch when a 128-thread workgroup spans a whole row (D <= 512):
+// km_accumulate<float> (cluster j's ordered fp32 sums), km_average<float, false> on them (an empty cluster sums its source
+// cluster's rows itself, in the same order, instead of reading another workgroup's result), and — by the workgroup that
+// finishes last — km_status<float>'s word with the same partition and tree (thread t here stands for that kernel's threads t
+// and t + 128).  `done`: a device counter that is zero at launch (the E-step kernel resets it each iteration).
+__global__ __launch_bounds__(128) void km_accumulate_average(
+    const float* __restrict__ X, int D, int ldx, const int32_t* __restrict__ order, const int32_t* __restrict__ cnt,
+    float* __restrict__ sums, float* __restrict__ counts_f, const float* __restrict__ Co, int K, float* __restrict__ Cn,
+    float* shift, float* __restrict__ cnorm_new, float* __restrict__ Cn_perm, int spherical,
+    const int32_t* n_changed, int32_t* done, double* __restrict__ status) {
+  extern __shared__ float km_avg_lds[];
+  float* row = km_avg_lds;
+  float* tg = km_avg_lds + D;
+  __shared__ float mv[128];
+  __shared__ int mi[128];
+  __shared__ int red[128];
+  __shared__ double st[128];
+  __shared__ int is_last;
+  const int j = blockIdx.x, t = threadIdx.x;
+  auto offset_of = [&](int jj) -> int {                   // rows of clusters 0 .. jj-1 (block-uniform result)
+    int o = 0;
+    for (int u = t; u < jj; u += 128) o += cnt[u];
+    __syncthreads();
+    red[t] = o;
+    __syncthreads();
+    for (int d = 64; d > 0; d >>= 1) {
+      if (t < d) red[t] += red[t + d];
+      __syncthreads();
+    }
+    return red[0];
+  };
+#ifndef KM_ACC_DEPTH
+#define KM_ACC_DEPTH 16
+#endif
+  // rows in flight per batch; the NEXT batch's row ids (wave-uniform: scalar loads) are fetched while this batch's rows are in
+  // flight, byte offsets are 32-bit (the launcher checks N * ldx * 4 < 2^32); the adds stay in row order
+  const uint32_t rowbytes = (uint32_t)ldx * 4u;
+  auto ordered_sum = [&](const int32_t* ord, int n) -> f32x4 {
+    constexpr int DP = KM_ACC_DEPTH;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (t * 4 >= D) return acc;
+    const char* xc = (const char*)(X + t * 4);
+    int m = 0;
+    uint32_t nxt[DP];
+    if (DP <= n) {
+#pragma unroll
+      for (int u = 0; u < DP; ++u) nxt[u] = (uint32_t)ord[u];
+    }
+    for (; m + DP <= n; m += DP) {
+      f32x4 v[DP];
+#pragma unroll
+      for (int u = 0; u < DP; ++u) v[u] = *(const f32x4*)(xc + nxt[u] * rowbytes);
+#ifndef KM_ACC_NOPIPE
+      if (m + 2 * DP <= n) {
+#pragma unroll
+        for (int u = 0; u < DP; ++u) nxt[u] = (uint32_t)ord[m + DP + u];
+      }
+#endif
+#pragma unroll
+      for (int u = 0; u < DP; ++u) acc += v[u];
+#ifdef KM_ACC_NOPIPE
+      if (m + 2 * DP <= n) {
+#pragma unroll
+        for (int u = 0; u < DP; ++u) nxt[u] = (uint32_t)ord[m + DP + u];
+      }
+#endif
+    }
+    for (; m < n; ++m) acc += *(const f32x4*)(xc + (uint32_t)ord[m] * rowbytes);
+    return acc;
+  };
+  const int n = cnt[j];
+  f32x4 acc = ordered_sum(order + offset_of(j), n);
+  if (t == 0) counts_f[j] = (float)n;
+  if (t * 4 < D) *(f32x4*)(sums + (int64_t)j * D + t * 4) = acc;
+  int src = j;
+  float alpha;
+  if (n > 0) {
+    alpha = (float)(1.0 / (double)(float)n);
+  } else {
+    km_pick_source([&](int u) -> float { return (float)cnt[u]; }, j, K, mv, mi, src, alpha);
+    acc = ordered_sum(order + offset_of(src), cnt[src]);
+  }
+  if (t * 4 < D) {
+    const f32x4 r = {acc[0] * alpha, acc[1] * alpha, acc[2] * alpha, acc[3] * alpha};
+    *(f32x4*)(row + t * 4) = r;
+  }
+  km_average_tail<true>(j, Co, D, Cn, shift, cnorm_new, Cn_perm, spherical, row, tg, mv);
+  // ---- the status word, by the last workgroup to get here.  The only cross-workgroup data is shift[] (cnt and *n_changed come
+  // from earlier kernels): thread 64 stored shift[j] write-through, waits for that store to complete, then takes its ticket.
+  // (A __threadfence() here instead costs an L2 write-back per workgroup on this multi-XCD part: measured +30 us per launch.)
+#ifdef KM_ABL_NOSTATUS
+  return;
+#endif
+  if (t == 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == K - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double a_lo = 0.0, a_hi = 0.0;
+  int ne = 0;
+  for (int jj = t; jj < K; jj += 256) {
+    const double sj = (double)__hip_atomic_load(shift + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a_lo += sj * sj;
+    ne += cnt[jj] == 0;
+  }
+  for (int jj = t + 128; jj < K; jj += 256) {
+    const double sj = (double)__hip_atomic_load(shift + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a_hi += sj * sj;
+    ne += cnt[jj] == 0;
+  }
+  st[t] = a_lo + a_hi; mi[t] = ne;
+  __syncthreads();
+  for (int s2 = 64; s2 > 0; s2 >>= 1) {
+    if (t < s2) { st[t] += st[t + s2]; mi[t] += mi[t + s2]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    status[0] = st[0];
+    status[1] = (double)mi[0];
+    status[2] = n_changed ? (double)*n_changed : -1.0;
     status[3] = 0.0;
   }
 }
@@ -1519,7 +1677,8 @@ extern "C" int slic_kmeans_assign(const float* X, int64_t N, int D, int ldx, con
 
 template <int BP, int NCT, int WC, int STAGES>
 static int launch_assign_dma(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K, int ldc,
-                             const float* cnorm, float* pscore, int32_t* pidx, hipStream_t st) {
+                             const float* cnorm, float* pscore, int32_t* pidx, hipStream_t st, int32_t* z0 = nullptr,
+                             int32_t* z1 = nullptr) {
   const size_t lds = (size_t)STAGES * (BP + NCT * 32) * KM_BK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1527,7 +1686,7 @@ static int launch_assign_dma(const float* Xp, int64_t N, int D, int ldx, const f
     attr_set = true;
   }
   dim3 grid((unsigned)slic_cdiv(N, BP), (unsigned)slic_cdiv(K, NCT * 32));
-  km_assign_dma<BP, NCT, WC, STAGES><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+  km_assign_dma<BP, NCT, WC, STAGES><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, z0, z1);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1545,7 +1704,7 @@ extern "C" int slic_kmeans_permute_k8(const float* X, int64_t N, int D, int ldx,
 static int km_assign_perm_impl(const float* Xp, int64_t N, int D, int ldx, const float* Cp, int K,
                                int ldc, const float* cnorm, int32_t* labels,
                                const int32_t* labels_old, int32_t* n_changed, float* best_score,
-                               void* workspace, void* stream, int32_t* bc) {
+                               void* workspace, void* stream, int32_t* bc, int32_t* z0 = nullptr, int32_t* z1 = nullptr) {
   SLIC_REQUIRE(Xp && Cp && cnorm && labels && workspace, "slic_kmeans_assign_perm: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && D > 0, "slic_kmeans_assign_perm: N=%lld K=%d D=%d", (long long)N, K, D);
   SLIC_REQUIRE(D % 8 == 0 && ldx % 4 == 0 && ldc % 4 == 0 && ldx >= D && ldc >= D,
@@ -1590,13 +1749,13 @@ static int km_assign_perm_impl(const float* Xp, int64_t N, int D, int ldx, const
       attr_set = true;
     }
     dim3 grid((unsigned)slices, (unsigned)ncb);
-    if (D > 256) km_assign_creg<16, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
-    else if (D > 128) km_assign_creg<8, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
-    else km_assign_creg<4, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx);
+    if (D > 256) km_assign_creg<16, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, z0, z1);
+    else if (D > 128) km_assign_creg<8, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, z0, z1);
+    else km_assign_creg<4, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, z0, z1);
     SLIC_LAUNCH_CHECK();
     G = (int)slic_cdiv(K, 32);                                // groups past K are never written and never read
   } else {
-    int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st);
+    int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st, z0, z1);
     if (rc) return rc;
   }
   if (bc && (size_t)K * 4 <= 48 * 1024)
@@ -1630,10 +1789,20 @@ extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
 // the per-block histogram slab the accumulate workspace starts with (km_assign_perm_impl can fill it in its combine pass)
 static int32_t* km_accumulate_hist_slab(void* workspace) { return (int32_t*)workspace; }
 
+// what km_accumulate_average needs beyond the sums: the arguments of slic_kmeans_finalize
+struct KmFinish {
+  const float* C_old; float* C_new; float* shift; float* cnorm_new; float* C_new_perm; int spherical; double* status;
+  bool done;                                     // out: the fused launch ran (else the caller finalises separately)
+};
+// the M-step's "workgroups done" counter lives in the accumulate workspace's spare K-int slot
+static int32_t* km_accumulate_done_counter(void* workspace, int64_t N, int K) {
+  return (int32_t*)((char*)workspace + slic_align_up((size_t)slic_cdiv(N, KM_SB) * K * 4, 256) + slic_align_up((size_t)K * 4, 256));
+}
+
 template <typename TOut>
 static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const int32_t* labels, int K, TOut* sums,
                               TOut* counts, const int32_t* n_changed, TOut* nch_out, void* workspace, void* stream,
-                              bool have_hist = false) {
+                              bool have_hist = false, KmFinish* fin = nullptr) {
   SLIC_REQUIRE(X && labels && sums && counts && workspace, "slic_kmeans_accumulate: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldx >= D,
                "slic_kmeans_accumulate: need D %% 4 == 0 (N=%lld K=%d D=%d ldx=%d)", (long long)N, K, D, ldx);
@@ -1642,7 +1811,7 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
   SlicCarver w(workspace);
   int32_t* bc = w.take<int32_t>((size_t)nblk * K);
   int32_t* cnt = w.take<int32_t>(K);
-  (void)w.take<int32_t>(K);                  // (slot kept so the workspace size query stays valid)
+  int32_t* done = w.take<int32_t>(K);        // [0]: km_accumulate_average's counter (km_accumulate_done_counter)
   int32_t* order = w.take<int32_t>((size_t)N);
   hipStream_t st = S(stream);
   SLIC_REQUIRE(K <= 16384, "slic_kmeans_accumulate: K > 16384");
@@ -1650,10 +1819,8 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
     km_block_hist<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc);
     SLIC_LAUNCH_CHECK();
   }
-  km_scan_blocks<<<dim3(K), dim3(64), 0, st>>>(bc, nblk, K, cnt);
-  SLIC_LAUNCH_CHECK();
-  const int use_wcnt = (size_t)K * 4 * (1 + KM_SB / 64) <= 96 * 1024;
-  const size_t lds_place = (size_t)K * 4 * (use_wcnt ? 1 + KM_SB / 64 : 1);
+  const int use_wcnt = (size_t)K * 4 * (2 + KM_SB / 64) <= 96 * 1024;
+  const size_t lds_place = (size_t)K * 4 * (use_wcnt ? 2 + KM_SB / 64 : 2);
   if (lds_place > 48 * 1024) {
     static size_t lds_set = 0;
     if (lds_place > lds_set) {
@@ -1661,8 +1828,20 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
       lds_set = lds_place;
     }
   }
-  km_place<<<dim3(nblk), dim3(KM_SB), lds_place, st>>>(labels, N, K, bc, cnt, order, use_wcnt);
+  km_place<<<dim3(nblk), dim3(KM_SB), lds_place, st>>>(labels, N, K, bc, nblk, cnt, order, use_wcnt);
   SLIC_LAUNCH_CHECK();
+  if constexpr (sizeof(TOut) == 4) {
+    if (fin && D <= 512 && !nch_out && (uint64_t)N * (uint64_t)ldx * 4ull < (1ull << 32)) {
+      const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
+      km_accumulate_average<<<dim3(K), dim3(128), lds, st>>>(X, D, ldx, order, cnt, sums, counts, fin->C_old, K, fin->C_new, fin->shift,
+                                                           fin->cnorm_new, fin->C_new_perm, fin->spherical, n_changed, done,
+                                                           fin->status);
+      SLIC_LAUNCH_CHECK();
+      fin->done = true;
+      return SLIC_OK;
+    }
+  }
+  (void)done;
   km_accumulate<TOut><<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, cnt, sums, counts,
                                                                                      n_changed, nch_out);
   SLIC_LAUNCH_CHECK();
@@ -1759,14 +1938,16 @@ extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N
                                       float* shift, int spherical, double* status, void* workspace, void* stream) {
   SLIC_REQUIRE(X && Xp && C_old && Cp_old && cnorm_old && labels && n_changed && sums && counts && C_new && Cp_new &&
                cnorm_new && shift && status && workspace, "slic_kmeans_lloyd_step: null pointer");
+  SLIC_REQUIRE(C_new != sums && C_new != C_old && D <= 8192 && D % 8 == 0, "slic_kmeans_lloyd_step: C_new must not alias; D %% 8 == 0, D <= 8192");
   char* ws = (char*)workspace;
   void* ws2 = ws + slic_align_up(slic_kmeans_assign_workspace_bytes(N, K), 256);
-  SLIC_HIP_CHECK(hipMemsetAsync(n_changed, 0, sizeof(int32_t), S(stream)));
+  // the E-step kernel zeroes *n_changed and the M-step's done counter (no memset launch)
   int rc = km_assign_perm_impl(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream,
-                               km_accumulate_hist_slab(ws2));
+                               km_accumulate_hist_slab(ws2), n_changed, km_accumulate_done_counter(ws2, N, K));
   if (rc) return rc;
-  rc = km_accumulate_impl<float>(X, N, D, ldx, labels, K, sums, counts, nullptr, nullptr, ws2, stream, true);
-  if (rc) return rc;
+  KmFinish fin = {C_old, C_new, shift, cnorm_new, Cp_new, spherical, status, false};
+  rc = km_accumulate_impl<float>(X, N, D, ldx, labels, K, sums, counts, n_changed, nullptr, ws2, stream, true, &fin);
+  if (rc || fin.done) return rc;
   return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, spherical, n_changed, status, stream);
 }
 
@@ -1787,9 +1968,8 @@ extern "C" int slic_kmeans_lloyd_local(const float* X, const float* Xp, int64_t 
   const size_t a1 = slic_align_up(slic_kmeans_assign_workspace_bytes(N, K), 256);
   void* ws2 = ws + a1;
   int32_t* n_changed = (int32_t*)(ws + slic_kmeans_lloyd_step_workspace_bytes(N, K));
-  SLIC_HIP_CHECK(hipMemsetAsync(n_changed, 0, sizeof(int32_t), S(stream)));
   int rc = km_assign_perm_impl(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream,
-                               km_accumulate_hist_slab(ws2));
+                               km_accumulate_hist_slab(ws2), n_changed);
   if (rc) return rc;
   const int64_t KD = (int64_t)K * D;
   if (payload_f64) {
