@@ -1266,9 +1266,16 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   const int sbeg = slab ? (int)blockIdx.z * st_per_split : 0;
   const int NS = slab ? min(NS_all, sbeg + st_per_split) : NS_all;      // END of this workgroup's stage range
   const int NB = p.N >> 6;
-  // ---- DMA roles: chunk q = i * NT + tid of the pixel image [j 12][tile TW][4 ch]: thread = (tile tid % TW, j = 4 i + tid / TW):
-  // a = j >> 1, channel half = j & 1
-  const int64_t mytile = tile0 + (tid % TW);
+  // ---- DMA roles: chunk q = i * NT + tid of the pixel image [a 6][slot 2 TW][4 ch]: thread = (slot tid % (2 TW), a = 2 i + tid / (2 TW)).
+  // Slot 2 tile + (half ^ bit 3 of the tile): the two 16-byte halves of a pixel's 8 channels are fetched by NEIGHBOURING lanes (one
+  // 32-byte piece of a cache line instead of two lines' worth of lookups in two instructions), and the xor keeps the readers'
+  // ds_read_b128 conflict-free (lanes r and r + 8 of a 16-lane phase would otherwise share banks at the 32-byte tile stride)
+  const int myslot = tid % (2 * TW), mytl = myslot >> 1, myhc = (myslot & 1) ^ ((mytl >> 3) & 1);
+#if SLIC_WINO_ABL & 4
+  const int64_t mytile = (tile0 & 0x3C0) + mytl;     // diagnostic build: every workgroup reads one of 16 tile blocks (cache-resident input)
+#else
+  const int64_t mytile = tile0 + mytl;
+#endif
   const bool tvalid = mytile < Mt;
   unsigned q = (unsigned)(tvalid ? mytile : 0);
   const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
@@ -1278,7 +1285,7 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   bool avalid[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int j = 4 * i + tid / TW, a = j >> 1, hc = j & 1;
+    const int a = 2 * i + tid / (2 * TW), hc = myhc;
     const int w = 4 * wt - 1 + a;
     avalid[i] = tvalid && (unsigned)w < (unsigned)W;
     aoff[i] = (unsigned)((((((int64_t)q * T + tt) * H + hh) * W + w) * C + 4 * hc) * 4);
@@ -1359,7 +1366,7 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   }
   __builtin_amdgcn_s_setprio(0);
   constexpr int AP = 2 * TW * 4;                              // floats between pixels a and a + 1 of the image
-  const int aro = (h * TW + wm * 32 + r) * 4;                 // + a * AP: pixel a of this lane's tile, its channel half
+  const int aro = (2 * (wm * 32 + r) + (h ^ ((r >> 3) & 1))) * 4;   // + a * AP: pixel a of this lane's tile, its channel half
   const int bro = A_FLOATS + (h * 64 + wn * 32 + r) * 4;      // + p * 512: point p of this lane's column, its channel half
   // Software pipeline across the stage barrier: the last two points of stage s - 1 (operands already in registers) are multiplied
   // AFTER the barrier of stage s, under the latency of stage s's first LDS reads — the barrier then sits where no wave needs

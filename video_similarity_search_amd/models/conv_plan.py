@@ -318,16 +318,19 @@ class ConvPlan:
         along K into as many pieces as fill the slots once more (each piece keeps >= SPLIT_MIN_KTILES k-tiles).  A remainder
         that already fills most of a round is left alone.  SLIC_CONV_TAIL=0 switches the mechanism off (tests compare)."""
         if variant == 30:
-            # Winograd: few-tile launches cut the K loop (9 x Cs / 8 stages) so that ~2 residency rounds of workgroups exist,
-            # each piece keeping >= 48 stages
+            # Winograd: few-tile launches cut the K loop (9 x Cs / 8 stages) into as many even pieces as fill ONE residency round of
+            # the 512 slots (2 workgroups / CU), each piece keeping >= 48 stages.  Measured at layer4, B = 32 (112 workgroups, 576
+            # stages; scripts/r3/ab_split.sh): 4 pieces 167 / 171 TFLOP/s forward / data gradient, 8 pieces 157 / 161, 6 152 / 155,
+            # 10 (two rounds and a fifth) 143 / 146, 3 129 / 131
             if os.environ.get("SLIC_WINO_SPLIT", "1") == "0":
                 return None
             Wd = a.Ws
             wgs = ((a.M // Wd) * ((Wd + 3) // 4) + 63) // 64 * (a.N // 64)
             ns = 9 * (a.Cs // 8)
-            if wgs >= cls.WINO_MIN_WGS:
+            if wgs >= int(os.environ.get("SLIC_WINO_MIN_WGS", cls.WINO_MIN_WGS)):
                 return None
-            s = min((2 * 512 + wgs - 1) // wgs, ns // 48)
+            forced = os.environ.get("SLIC_WINO_SPLIT", "1")
+            s = int(forced) if forced not in ("0", "1") else min(512 // wgs, ns // 48)
             return (0, s) if s >= 2 else None
         if variant not in (20, 22) or os.environ.get("SLIC_CONV_TAIL", "1") == "0":
             return None
@@ -448,6 +451,29 @@ class ConvPlan:
             self._row_tabs[B] = t
         return t
 
+    @staticmethod
+    def _wino_wgrad_slices(blocks, mt):
+        """tile slices of the transposed-Winograd weight gradient: `blocks` = 9 (kt, kh) x 64 x 64 blocks, `mt` W-tiles.
+        Up to 512 blocks: ~2 residency rounds of the 512 slots (2 workgroups / CU), at least 64 tiles per slice.  More blocks than
+        slots (layer4: 576 = one round and an eighth): each slice costs a 6-point slab of 2 x the weight's size to write and re-read,
+        so only 1-3 slices are weighed — how full the rounds are x the main loop's share of a workgroup's time, less the slab traffic
+        (measured at layer4, B = 32: 1 slice 128 TFLOP/s, 2 143, 3 144, 4 131, 7 106; scripts/r3/ab_split.sh)."""
+        forced = os.environ.get("SLIC_WINO_WGRAD_WGS")
+        if forced is not None:
+            return max(1, min(int(forced) // blocks, mt // 64))
+        if blocks <= 512:
+            return max(1, min(1024 // blocks, mt // 64))
+        best, best_score = 1, -1.0
+        for s in (1, 2, 3):
+            if mt // s < 64:
+                break
+            wgs, stages = blocks * s, mt / s / 8.0
+            fill = wgs / (-(-wgs // 512) * 512.0)
+            score = fill * stages / (stages + 8.0) - 0.06 * s
+            if score > best_score:
+                best, best_score = s, score
+        return best
+
     def wgrad(self, x, dz, B, dW, splits=None):
         """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
         lib = _lib.load()
@@ -458,7 +484,7 @@ class ConvPlan:
             blocks = 9 * (self.C // 64) * (self.N // 64)
             mt = (a.M // self.in_dims[2]) * ((self.in_dims[2] + 3) // 4)
             if splits is None:
-                splits = max(1, min(int(os.environ.get("SLIC_WINO_WGRAD_WGS", "1024")) // blocks, mt // 64))
+                splits = self._wino_wgrad_slices(blocks, mt)
             tab = self._wino_tabs.get(B)
             if tab is None:
                 tab = torch.empty(mt, 2, dtype=torch.int32, device=self.device)
