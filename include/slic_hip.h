@@ -396,6 +396,18 @@ int slic_margin_cos_fwd(const float* X, const float* Y, const float* Z, int n, i
                         float* rowloss, float* loss, void* stream);
 int slic_margin_cos_bwd(const float* X, const float* Y, const float* Z, const float* state, int n, int D,
                         const float* gscale, float* dX, float* dY, float* dZ, void* stream);
+/* the same margin term on euclidean distances, F.pairwise_distance(x, y) = ||x - y + 1e-6||_2 (LOSS.DIST_METRIC 'euclidean':
+ * loss/triplet_loss.py:68-70, 212-214; online_train.py:289-291, 317-319, 345-347); state / rowloss as above */
+int slic_margin_euclid_fwd(const float* X, const float* Y, const float* Z, int n, int D, float margin, float* state,
+                           float* rowloss, float* loss, void* stream);
+int slic_margin_euclid_bwd(const float* X, const float* Y, const float* Z, const float* state, int n, int D,
+                           const float* gscale, float* dX, float* dY, float* dZ, void* stream);
+/* 'noise_contrastive' with dist_metric 'euclidean' (loss/triplet_loss.py:97-116): logits (1 - ||e_i - e_j||) / T, diagonal 0,
+ * target (n / 2 + i) mod n, mean cross-entropy.  dist, wm: [n, n] floats kept for the backward; rowloss: [n] scratch */
+int slic_ntxent_euclid_fwd(const float* E, int n, int D, float temperature, float* dist, float* wm, float* rowloss, float* loss,
+                           void* stream);
+int slic_ntxent_euclid_bwd(const float* E, const float* dist, const float* wm, int n, int D, const float* gscale, float* dE,
+                           void* stream);
 /* negative selection of NegativeTripletSelector.get_one_one_triplets (loss/triplet_loss.py:311-360) for P (anchor,
  * positive) pairs over the [n, n] distance matrix `dist`: mode 0 random_negative, 1 random_semi_hard, 2 fixed_semi_hard;
  * u[P] uniform in [0,1) stands in for Python's random.choice (unused for mode 2); fallback = hardest easy negative,

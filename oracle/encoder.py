@@ -190,6 +190,27 @@ def margin_cosine_loss(anchor, near, far, margin):
     return F.margin_ranking_loss(d_ap, d_an, torch.full_like(d_ap, -1.0), margin=margin)
 
 
+def ntxent_euclid_loss(emb, temperature=0.5):
+    """loss/triplet_loss.py:97-116 with dist_metric='euclidean': pdist (:429-437) = F.pairwise_distance(v_i, vectors, eps=0)"""
+    n = emb.shape[0]
+    rows = [F.pairwise_distance(emb[i], emb, eps=0) for i in range(n)]
+    sim = 1 - torch.stack(rows, 0)
+    sim = sim.masked_fill(torch.eye(n, dtype=torch.bool), 0)
+    sim = sim / temperature
+    tgt = (torch.arange(n) + n // 2) % n
+    return F.cross_entropy(sim, tgt)
+
+
+def margin_distance_loss(anchor, near, far, margin, dist_metric='cosine'):
+    """the margin terms of triplet_train_epoch (online_train.py:288-360): dist = F.pairwise_distance(a, b, 2) ('euclidean') or
+    1 - F.cosine_similarity, MarginRankingLoss(margin)(dist(anchor, near), dist(anchor, far), target = -1)"""
+    if dist_metric == 'euclidean':
+        d_ap, d_an = F.pairwise_distance(anchor, near, 2), F.pairwise_distance(anchor, far, 2)
+    else:
+        d_ap, d_an = 1 - F.cosine_similarity(anchor, near, dim=1), 1 - F.cosine_similarity(anchor, far, dim=1)
+    return F.margin_ranking_loss(d_ap, d_an, torch.full_like(d_ap, -1.0), margin=margin)
+
+
 def nce_average(l, ab, y, idx, memory_l, memory_ab, T=0.07, momentum=0.5):
     """NCEAverage.forward with use_softmax=True (loss/NCE_loss.py:26-88).  Banks are updated in place.
     Note the cross-wiring: out_ab uses memory_l, out_l uses memory_ab."""

@@ -93,5 +93,52 @@ for it in range(2):
                 f"nce0_grad_l{it}": l_f.grad.numpy().copy(), f"nce0_grad_ab{it}": ab_f.grad.numpy().copy()})
 out["nce0_params"] = nce.params.detach().numpy().copy()
 print("NCE without softmax: Z", nce.params[2:4].tolist(), "loss", float(tot))
+# ---- LOSS.DIST_METRIC = 'euclidean' (no shipped config selects it): the deterministic strategies of OnlineTripletLoss, three
+# MemTripletLoss calls, and the margin terms of triplet_train_epoch (online_train.py:288-360 — torch calls made inline there,
+# repeated here verbatim in meaning: F.pairwise_distance(.., 2) / 1 - F.cosine_similarity + MarginRankingLoss(margin)(ap, an, -1))
+import torch.nn.functional as F                          # noqa: E402
+for n_e, D_e in ((8, 128), (64, 512)):
+    Ee = (rng.standard_normal((n_e, D_e)) * 0.3).astype(np.float32)
+    et = torch.from_numpy(Ee).requires_grad_(True)
+    le, _ = OnlineTripletLoss(0.2, 'euclidean')(et, torch.arange(n_e // 2).repeat(2), sampling_strategy='noise_contrastive')
+    le.backward()
+    out.update({f"euc_nce_E_{n_e}": Ee, f"euc_nce_loss_{n_e}": le.detach().numpy(), f"euc_nce_grad_{n_e}": et.grad.numpy().copy()})
+    print("euclidean noise_contrastive", n_e, float(le))
+labs_e = np.repeat(np.arange(5), 4)[rng.permutation(20)].astype(np.int64)
+Ee = rng.standard_normal((20, 128)).astype(np.float32)
+et = torch.from_numpy(Ee).requires_grad_(True)
+le, ne = OnlineTripletLoss(0.5, 'euclidean')(et, torch.from_numpy(labs_e), sampling_strategy='fixed_semi_hard')
+le.backward()
+out.update(euc_fsh_E=Ee, euc_fsh_labels=labs_e, euc_fsh_margin=np.float32(0.5), euc_fsh_loss=le.detach().numpy(), euc_fsh_n=np.int64(ne),
+           euc_fsh_grad=et.grad.numpy().copy())
+print("euclidean fixed_semi_hard", float(le), ne)
+for strat in ("adapted_hard", "fixed_semi_hard"):
+    torch.manual_seed(11)
+    m = MemTripletLoss(0.2, 'euclidean')
+    out[f"euc_mem_{strat}_queue0"] = m.queue.clone().numpy()
+    for it in range(3):
+        e = torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal((8, 128)).astype(np.float32)), dim=1).numpy()
+        labs3 = (np.arange(4).repeat(2)[rng.permutation(8)] + (4 * it if it < 2 else 0)).astype(np.int64)
+        et = torch.from_numpy(e).requires_grad_(True)
+        l3, n3 = m(et, torch.from_numpy(labs3), sampling_strategy=strat)
+        l3.backward()
+        out[f"euc_mem_{strat}_E{it}"], out[f"euc_mem_{strat}_labels{it}"] = e, labs3
+        out[f"euc_mem_{strat}_loss{it}"], out[f"euc_mem_{strat}_n{it}"] = l3.detach().numpy(), np.int64(n3)
+        out[f"euc_mem_{strat}_grad{it}"] = et.grad.numpy().copy()
+    print("MemTripletLoss euclidean", strat, [float(out[f"euc_mem_{strat}_loss{i}"]) for i in range(3)])
+b3 = 6
+O = (rng.standard_normal((3 * b3, 128)) * 0.5).astype(np.float32)
+for metric in ("cosine", "euclidean"):
+    for name, margin, near, far in (("rsp", 0.1, 1, 2), ("llc", 0.3, 2, 1), ("intra", 0.04, 2, 1)):
+        ot = torch.from_numpy(O).requires_grad_(True)
+        parts = (ot[:b3], ot[b3:2 * b3], ot[2 * b3:])
+        if metric == "euclidean":
+            dist_ap, dist_an = F.pairwise_distance(parts[0], parts[near], 2), F.pairwise_distance(parts[0], parts[far], 2)
+        else:
+            dist_ap, dist_an = 1 - F.cosine_similarity(parts[0], parts[near], dim=1), 1 - F.cosine_similarity(parts[0], parts[far], dim=1)
+        lt = torch.nn.MarginRankingLoss(margin=margin)(dist_ap, dist_an, torch.FloatTensor(dist_ap.size()).fill_(-1))
+        lt.backward()
+        out[f"third_{metric}_{name}_loss"], out[f"third_{metric}_{name}_grad"] = lt.detach().numpy(), ot.grad.numpy().copy()
+out["third_O"] = O
 np.savez_compressed(os.path.join(HERE, "loss_variants.npz"), **out)
 print("loss_variants goldens:", len(out))

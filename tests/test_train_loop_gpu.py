@@ -80,6 +80,55 @@ def test_triplet_train_epoch_llc_vs_oracle(gpu, tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "tnet_checkpoints", "train_loss_and_acc.txt"))
 
 
+@pytest.mark.parametrize("third,metric", [("rsp", "euclidean"), ("intra", "cosine")])
+def test_triplet_train_epoch_third_clip_variants_vs_oracle(gpu, tmp_path, third, metric):
+    """RELATIVE_SPEED_PERCEPTION / INTRA_NEGATIVE steps (online_train.py:256-360) and LOSS.DIST_METRIC 'euclidean': two SGD steps on
+    the tiny model against the oracle's restatement of the same step"""
+    from oracle import encoder as oe
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    from video_similarity_search_amd.online_train import triplet_train_epoch
+    rng = np.random.default_rng(33)
+    sd = oe.make_state_dict(rng, widen=0.125, hidden=64, out_dim=32)
+    b, steps = 3, 2
+    batches = []
+    for _ in range(steps):
+        views = [torch.from_numpy(rng.standard_normal((b, 3, 8, 32, 32)).astype(np.float32)) for _ in range(3)]
+        batches.append((views, (torch.arange(b), torch.arange(b)), torch.arange(b)))
+    m = generate_model(18, **TINY)
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    m = m.cuda()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.5)
+    cfg = _cfg(tmp_path)
+    cfg.LOSS.LOCAL_LOCAL_CONTRAST = False
+    cfg.LOSS.RELATIVE_SPEED_PERCEPTION = third == "rsp"
+    cfg.LOSS.INTRA_NEGATIVE = third == "intra"
+    cfg.LOSS.DIST_METRIC = metric
+    avg = triplet_train_epoch(_Loader(batches, steps * b), m, OnlineTripletLoss(0.2, metric), opt, 0, cfg, True, "cuda")
+    t = oe.to_torch(sd, requires_grad=True)
+    params = {k: v for k, v in t.items() if v.requires_grad}
+    bufs, ref_losses = {}, []
+    for views, _, _ in batches:
+        out = oe.encoder_forward(t, torch.cat(views, 0), training=True)
+        anc, pos, extra = out[:b], out[b:2 * b], out[2 * b:]
+        nce = oe.ntxent_euclid_loss(out[:2 * b]) if metric == "euclidean" else oe.ntxent_loss(out[:2 * b])
+        if third == "rsp":
+            loss = nce + oe.margin_distance_loss(anc, pos, extra, 0.1, metric) * 1.0
+        else:
+            loss = nce + oe.margin_distance_loss(anc, extra, pos, 0.04, metric) * 0.4
+        grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+        oe.sgd_step(params, grads, bufs)
+        ref_losses.append(loss.item())
+    assert abs(avg - np.mean(ref_losses)) < 2e-4 * max(1.0, abs(np.mean(ref_losses)))
+    after = m.state_dict()
+    # the head's weights see the loss gradient and forward activations only: tight.  The early layers' updates also carry every
+    # ReLU branch behind them, and a pre-activation within rounding of zero may take the other branch on the device (the encoder
+    # tests impose the device's branches on the oracle for that reason; here the bound is loose instead): 2 % of the tensor's range
+    for k, rel in (("fc2.weight", 2e-3), ("layer4.1.bn2.running_mean", 2e-3), ("conv1.weight", 2e-2), ("layer2.0.downsample.0.weight", 2e-2)):
+        ref = t[k].detach().numpy()
+        np.testing.assert_allclose(after[k].cpu().numpy(), ref, atol=2e-5 + rel * np.abs(ref).max(), err_msg=k)
+
+
 def test_contrastive_epoch_and_cluster_step(gpu, tmp_path):
     from video_similarity_search_amd.models import generate_model
     from video_similarity_search_amd.loss import NCEAverage, NCESoftmaxLoss

@@ -96,6 +96,10 @@ SIGNATURES = {
     "slic_pair_distance_bwd": (I, [P, P, P, I, I, I, P, P, P]),
     "slic_margin_cos_fwd": (I, [P, P, P, I, I, F, P, P, P, P]),
     "slic_margin_cos_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P]),
+    "slic_margin_euclid_fwd": (I, [P, P, P, I, I, F, P, P, P, P]),
+    "slic_margin_euclid_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P]),
+    "slic_ntxent_euclid_fwd": (I, [P, I, I, F, P, P, P, P, P]),
+    "slic_ntxent_euclid_bwd": (I, [P, P, P, I, I, P, P, P]),
     "slic_triplet_select": (I, [P, P, I, P, P, I, F, I, P, P, P]),
     "slic_triplet_select_cross": (I, [P, P, I, P, P, P, I, F, I, P, P, P]),
     "slic_pdist": (I, [P, I, I, F, I, P, P]),

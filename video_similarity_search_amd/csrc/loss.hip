@@ -471,6 +471,145 @@ extern "C" int slic_margin_cos_bwd(const float* X, const float* Y, const float* 
 }
 
 
+// ---- the euclidean forms (LOSS.DIST_METRIC: 'euclidean'; loss/triplet_loss.py:68-70, 212-214, online_train.py:289-291, 317-319, 345-347)
+// margin term on F.pairwise_distance (eps 1e-6 inside the norm): v = |x - y + eps| - |x - z + eps| + margin, loss = mean max(0, v).
+// One wave per row; state = {d1, d2, -, -, -, active}.
+__global__ void margin_euclid_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ Z, int n,
+                                         int D, float margin, float* __restrict__ st /* [n][8] */, float* __restrict__ rowloss) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float *x = X + (int64_t)row * D, *y = Y + (int64_t)row * D, *z = Z + (int64_t)row * D;
+  float a = 0.f, b = 0.f;
+  for (int k = lane; k < D; k += 64) {
+    const float dy = x[k] - y[k] + 1e-6f, dz = x[k] - z[k] + 1e-6f;
+    a = fmaf(dy, dy, a); b = fmaf(dz, dz, b);
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if (lane == 0) {
+    const float d1 = sqrtf(a), d2 = sqrtf(b), v = d1 - d2 + margin;
+    float* s = st + (int64_t)row * 8;
+    s[0] = d1; s[1] = d2; s[5] = v > 0.f ? 1.f : 0.f;
+    rowloss[row] = fmaxf(v, 0.f);
+  }
+}
+__global__ void margin_euclid_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ Z,
+                                         const float* __restrict__ st, int n, int D, const float* __restrict__ gscale,
+                                         float* __restrict__ dX, float* __restrict__ dY, float* __restrict__ dZ) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* s = st + (int64_t)row * 8;
+  const float g = s[5] * (gscale ? *gscale : 1.f) / (float)n;
+  const float i1 = s[0] > 0.f ? g / s[0] : 0.f, i2 = s[1] > 0.f ? g / s[1] : 0.f;      // a zero norm has a zero gradient (torch)
+  const float *x = X + (int64_t)row * D, *y = Y + (int64_t)row * D, *z = Z + (int64_t)row * D;
+  for (int k = lane; k < D; k += 64) {
+    const float uy = (x[k] - y[k] + 1e-6f) * i1, uz = (x[k] - z[k] + 1e-6f) * i2;
+    dX[(int64_t)row * D + k] = uy - uz;
+    dY[(int64_t)row * D + k] = -uy;
+    dZ[(int64_t)row * D + k] = uz;
+  }
+}
+
+// NT-Xent on euclidean "similarities" (loss/triplet_loss.py:97-116 with dist_metric 'euclidean'): s_ij = (1 - |e_i - e_j|) / T,
+// the diagonal filled with 0 before the division, target (n / 2 + i) mod n, loss = mean_i (logsumexp_j s_ij - s_i,target).
+// One workgroup per row i.  Kept for the backward: dist [n][n] and wm [n][n] = d loss_i / d dist_ij = -(softmax_ij - [j = target]) / T
+// (0 on the diagonal: masked_fill_ cuts the gradient there).
+__global__ __launch_bounds__(256) void ntxent_euclid_fwd_kernel(const float* __restrict__ E, int n, int D, float invT,
+                                                                float* __restrict__ dist, float* __restrict__ wm,
+                                                                float* __restrict__ rowloss) {
+  extern __shared__ float sc[];                       // [n] the row's logits
+  __shared__ float red[4];
+  const int i = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* ei = E + (int64_t)i * D;
+  for (int j = wave; j < n; j += 4) {
+    const float* ej = E + (int64_t)j * D;
+    float a = 0.f;
+    for (int k = lane; k < D; k += 64) { const float d = ei[k] - ej[k]; a = fmaf(d, d, a); }
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) {
+      const float d = sqrtf(a);
+      dist[(int64_t)i * n + j] = d;
+      sc[j] = j == i ? 0.f : (1.f - d) * invT;
+    }
+  }
+  __syncthreads();
+  float m = -INFINITY;
+  for (int j = t; j < n; j += 256) m = fmaxf(m, sc[j]);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = t; j < n; j += 256) se += expf(sc[j] - m);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+  if (lane == 0) red[wave] = se;
+  __syncthreads();
+  se = red[0] + red[1] + red[2] + red[3];
+  const float lse = m + logf(se);
+  const int tgt = (n / 2 + i) % n;
+  if (t == 0) rowloss[i] = lse - sc[tgt];
+  for (int j = t; j < n; j += 256) {
+    const float pj = expf(sc[j] - lse) - (j == tgt ? 1.f : 0.f);
+    wm[(int64_t)i * n + j] = j == i ? 0.f : -pj * invT;
+  }
+}
+// dE_i = g / n * sum_j (wm_ij + wm_ji) (e_i - e_j) / dist_ij   (pairs at distance 0 contribute nothing, as torch's norm backward)
+__global__ __launch_bounds__(256) void ntxent_euclid_bwd_kernel(const float* __restrict__ E, const float* __restrict__ dist,
+                                                                const float* __restrict__ wm, int n, int D,
+                                                                const float* __restrict__ gscale, float* __restrict__ dE) {
+  extern __shared__ float cf[];                       // [n] coefficients of row i
+  const int i = blockIdx.x, t = threadIdx.x;
+  const float g = (gscale ? *gscale : 1.f) / (float)n;
+  for (int j = t; j < n; j += 256) {
+    const float d = dist[(int64_t)i * n + j];
+    cf[j] = d > 0.f ? g * (wm[(int64_t)i * n + j] + wm[(int64_t)j * n + i]) / d : 0.f;
+  }
+  __syncthreads();
+  const float* ei = E + (int64_t)i * D;
+  for (int k = t; k < D; k += 256) {
+    const float x = ei[k];
+    float a = 0.f;
+    for (int j = 0; j < n; ++j) a = fmaf(cf[j], x - E[(int64_t)j * D + k], a);
+    dE[(int64_t)i * D + k] = a;
+  }
+}
+
+extern "C" int slic_margin_euclid_fwd(const float* X, const float* Y, const float* Z, int n, int D, float margin,
+                                      float* state, float* rowloss, float* loss, void* stream) {
+  SLIC_REQUIRE(X && Y && Z && state && rowloss && loss && n > 0 && D > 0, "slic_margin_euclid_fwd: bad args");
+  margin_euclid_fwd_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, Z, n, D, margin, state, rowloss);
+  SLIC_LAUNCH_CHECK();
+  mean_serial<<<dim3(1), dim3(64), 0, S_(stream)>>>(rowloss, n, loss);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_margin_euclid_bwd(const float* X, const float* Y, const float* Z, const float* state, int n, int D,
+                                      const float* gscale, float* dX, float* dY, float* dZ, void* stream) {
+  SLIC_REQUIRE(X && Y && Z && state && dX && dY && dZ && n > 0 && D > 0, "slic_margin_euclid_bwd: bad args");
+  margin_euclid_bwd_kernel<<<dim3((unsigned)slic_cdiv(n, 4)), dim3(256), 0, S_(stream)>>>(X, Y, Z, state, n, D, gscale, dX, dY, dZ);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_ntxent_euclid_fwd(const float* E, int n, int D, float temperature, float* dist, float* wm, float* rowloss,
+                                      float* loss, void* stream) {
+  SLIC_REQUIRE(E && dist && wm && rowloss && loss && n >= 2 && n % 2 == 0 && n <= 8192 && D > 0 && temperature > 0.f,
+               "slic_ntxent_euclid_fwd: bad args (n even, 2 <= n <= 8192)");
+  ntxent_euclid_fwd_kernel<<<dim3((unsigned)n), dim3(256), (size_t)n * 4, S_(stream)>>>(E, n, D, 1.0f / temperature, dist, wm, rowloss);
+  SLIC_LAUNCH_CHECK();
+  mean_serial<<<dim3(1), dim3(64), 0, S_(stream)>>>(rowloss, n, loss);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_ntxent_euclid_bwd(const float* E, const float* dist, const float* wm, int n, int D, const float* gscale,
+                                      float* dE, void* stream) {
+  SLIC_REQUIRE(E && dist && wm && dE && n >= 2 && n <= 8192 && D > 0, "slic_ntxent_euclid_bwd: bad args");
+  ntxent_euclid_bwd_kernel<<<dim3((unsigned)n), dim3(256), (size_t)n * 4, S_(stream)>>>(E, dist, wm, n, D, gscale, dE);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" int slic_pair_distance(const float* X, const float* Y, int n, int D, int euclidean, float* out,
                                   void* stream) {
   SLIC_REQUIRE(X && Y && out && n > 0 && D > 0, "slic_pair_distance: bad args");

@@ -5,6 +5,9 @@ Drop-in for the reference's loss/triplet_loss.py on the SLIC training path:
 `sampling_strategy='noise_contrastive'` (NT-Xent over the 2B x 2B cosine matrix, T = 0.5, diagonal masked to
 0, target (B + i) mod 2B) is one fused HIP forward kernel + one backward kernel (csrc/loss.hip) instead of
 2B F.cosine_similarity launches + masked_fill + a Python target loop + F.cross_entropy.
+`dist_metric='euclidean'` (LOSS.DIST_METRIC; no shipped config selects it) runs the same strategies on F.pairwise_distance:
+the distance-matrix and selection kernels take the metric as a flag, the margin term and the noise-contrastive loss have
+euclidean kernels of their own (margin_euclid_*, ntxent_euclid_*).
 The margin-triplet strategies `random_negative`, `random_semi_hard` (the shipped default,
 config/custom_configs/*.yaml:13) and `fixed_semi_hard` (:205-227 with NegativeTripletSelector :230-360) run on the
 device too: one pdist kernel, one selection kernel (one wave per anchor/positive pair, csrc/loss.hip
@@ -61,19 +64,22 @@ def ntxent_loss(embeddings, temperature=NCE_TEMPERATURE):
     return _NTXent.apply(embeddings, temperature)
 
 
-class _MarginCos(torch.autograd.Function):
-    """mean(max(0, (1 - cos(x, y)) - (1 - cos(x, z)) + margin)) — relu(ap_dists - an_dists + margin).mean() on cosine
-    distances (loss/triplet_loss.py:216-227) and MarginRankingLoss(margin)(d_xy, d_xz, -1) (online_train.py:321-332)"""
+class _MarginDist(torch.autograd.Function):
+    """mean(max(0, d(x, y) - d(x, z) + margin)) — relu(ap_dists - an_dists + margin).mean() (loss/triplet_loss.py:212-227) and
+    MarginRankingLoss(margin)(d_xy, d_xz, -1) (online_train.py:289-360) — with d = 1 - cos (F.cosine_similarity) or
+    d = F.pairwise_distance (euclidean, eps 1e-6 inside the norm)"""
 
     @staticmethod
-    def forward(ctx, x, y, z, margin):
+    def forward(ctx, x, y, z, margin, euclid):
         x, y, z = (t.contiguous().float() for t in (x, y, z))
         n, D = x.shape
         state = torch.empty(n, 8, dtype=torch.float32, device=x.device)
         rowloss = torch.empty(n, dtype=torch.float32, device=x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
-        call("slic_margin_cos_fwd", ptr(x), ptr(y), ptr(z), n, D, float(margin), ptr(state), ptr(rowloss), ptr(loss), stream())
+        call("slic_margin_euclid_fwd" if euclid else "slic_margin_cos_fwd", ptr(x), ptr(y), ptr(z), n, D, float(margin), ptr(state),
+             ptr(rowloss), ptr(loss), stream())
         ctx.save_for_backward(x, y, z, state)
+        ctx.euclid = bool(euclid)
         return loss
 
     @staticmethod
@@ -81,16 +87,48 @@ class _MarginCos(torch.autograd.Function):
         x, y, z, state = ctx.saved_tensors
         n, D = x.shape
         dx, dy, dz = torch.empty_like(x), torch.empty_like(y), torch.empty_like(z)
-        call("slic_margin_cos_bwd", ptr(x), ptr(y), ptr(z), ptr(state), n, D, ptr(g.contiguous().float()), ptr(dx), ptr(dy),
-             ptr(dz), stream())
-        return dx, dy, dz, None
+        call("slic_margin_euclid_bwd" if ctx.euclid else "slic_margin_cos_bwd", ptr(x), ptr(y), ptr(z), ptr(state), n, D,
+             ptr(g.contiguous().float()), ptr(dx), ptr(dy), ptr(dz), stream())
+        return dx, dy, dz, None, None
+
+
+def margin_distance_loss(anchor, near, far, margin, dist_metric='cosine'):
+    """`near` should end up closer to `anchor` than `far` by `margin` in the metric's distance (mean hinge)"""
+    assert dist_metric in ('cosine', 'euclidean')
+    if not anchor.is_cuda:
+        raise _lib.SlicError("margin_distance_loss needs device tensors (no CPU fallback)")
+    return _MarginDist.apply(anchor, near, far, margin, dist_metric == 'euclidean')
 
 
 def margin_cosine_loss(anchor, near, far, margin):
-    """`near` should end up closer to `anchor` than `far` by `margin` in cosine distance (mean hinge)"""
-    if not anchor.is_cuda:
-        raise _lib.SlicError("margin_cosine_loss needs device tensors (no CPU fallback)")
-    return _MarginCos.apply(anchor, near, far, margin)
+    return margin_distance_loss(anchor, near, far, margin, 'cosine')
+
+
+class _NTXentEuclid(torch.autograd.Function):
+    """'noise_contrastive' on euclidean distances (loss/triplet_loss.py:97-116 with dist_metric='euclidean'): the logits are
+    (1 - ||e_i - e_j||) / T with the diagonal set to 0, the target of row i is (n / 2 + i) mod n"""
+
+    @staticmethod
+    def forward(ctx, emb, temperature):
+        if not emb.is_cuda:
+            raise _lib.SlicError("noise_contrastive loss needs device embeddings (no CPU fallback)")
+        e = emb.contiguous().float()
+        n, D = e.shape
+        buf = torch.empty(2 * n * n + n + 1, dtype=torch.float32, device=e.device)
+        dist, wm, rowloss, loss = buf[:n * n], buf[n * n:2 * n * n], buf[2 * n * n:2 * n * n + n], buf[-1]
+        call("slic_ntxent_euclid_fwd", ptr(e), n, D, float(temperature), ptr(dist), ptr(wm), ptr(rowloss), ptr(loss), stream())
+        ctx.save_for_backward(e)
+        ctx.keep = (dist, wm)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (e,) = ctx.saved_tensors
+        dist, wm = ctx.keep
+        n, D = e.shape
+        dE = torch.empty_like(e)
+        call("slic_ntxent_euclid_bwd", ptr(e), ptr(dist), ptr(wm), n, D, ptr(g.contiguous().float()), ptr(dE), stream())
+        return dE, None
 
 
 class _InfoNCERows(torch.autograd.Function):
@@ -166,8 +204,7 @@ def get_triplets(embeddings, labels, margin, sampling_strategy, dist_metric='cos
     """NegativeTripletSelector.get_triplets (loss/triplet_loss.py:275-309): [anchor idx], [positive idx], [negative idx]
     as int64 device tensors.  Pairs = combinations of the rows of every label with >= 2 rows, labels in ascending order
     (torch.unique), rows ascending — the reference's enumeration order."""
-    if dist_metric != 'cosine':
-        raise NotImplementedError("triplet mining with euclidean distances is not used by any SLIC config")
+    assert dist_metric in ('cosine', 'euclidean')
     lab_h = labels.detach().cpu().numpy()
     assert -1 not in lab_h                           # the reference's assert (:285)
     n = len(lab_h)
@@ -198,8 +235,8 @@ class OnlineTripletLoss(nn.Module):
     # embeddings: [(batch_size * 2), dim_embedding] = cat(anchors, positives); labels: [(batch_size * 2)]
     def forward(self, embeddings, labels, sampling_strategy="random_negative"):
         if sampling_strategy == 'noise_contrastive':
-            if self.dist_metric != 'cosine':
-                raise NotImplementedError("noise_contrastive with euclidean pdist is not used by any SLIC config")
+            if self.dist_metric == 'euclidean':
+                return _NTXentEuclid.apply(embeddings, NCE_TEMPERATURE), 0
             return ntxent_loss(embeddings), 0
         if sampling_strategy == 'all_semi_hard':
             if self.dist_metric != 'cosine':
@@ -223,8 +260,9 @@ class OnlineTripletLoss(nn.Module):
             if a.numel() == 0:
                 return torch.zeros(1, requires_grad=True).mean(), 0          # loss/triplet_loss.py:222-223
             e = embeddings.float()
-            # relu(ap_dists - an_dists + margin).mean() on 1 - cos (:216-227); index_select's backward scatters the grads
-            loss = margin_cosine_loss(e.index_select(0, a), e.index_select(0, p), e.index_select(0, n), self.margin)
+            # relu(ap_dists - an_dists + margin).mean() on 1 - cos or F.pairwise_distance (:212-227); index_select's backward
+            # scatters the grads
+            loss = margin_distance_loss(e.index_select(0, a), e.index_select(0, p), e.index_select(0, n), self.margin, self.dist_metric)
             return loss, int(a.numel())
         raise NotImplementedError(f"sampling_strategy={sampling_strategy!r} ('adapted_hard' belongs to MemTripletLoss)")
 
@@ -281,8 +319,7 @@ class MemTripletLoss(nn.Module):
         self.queue_ptr[0] = (ptr_ + batch_size) % self.K
 
     def forward(self, embeddings, labels, sampling_strategy="adapted_hard"):
-        if self.dist_metric != 'cosine':
-            raise NotImplementedError("MemTripletLoss with euclidean distances is not used by any SLIC config")
+        assert self.dist_metric in ('cosine', 'euclidean')
         if sampling_strategy not in _SELECT_MODES:
             raise NotImplementedError(f"sampling_strategy={sampling_strategy!r}")
         if not embeddings.is_cuda:
@@ -319,6 +356,6 @@ class MemTripletLoss(nn.Module):
         self.last_triplets = (anc_d.long(), pos_d.long(), neg_d.long())
         e = embeddings.float()
         q = self.queue.detach()
-        loss = margin_cosine_loss(e.index_select(0, anc_d.long()), q.index_select(0, pos_d.long()), q.index_select(0, neg_d.long()),
-                                  self.margin)
+        loss = margin_distance_loss(e.index_select(0, anc_d.long()), q.index_select(0, pos_d.long()), q.index_select(0, neg_d.long()),
+                                    self.margin, self.dist_metric)
         return loss, P

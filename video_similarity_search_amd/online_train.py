@@ -24,7 +24,7 @@ import time
 
 import torch
 
-from .loss.triplet_loss import margin_cosine_loss          # the LLC term shares the margin-triplet kernel
+from .loss.triplet_loss import margin_cosine_loss, margin_distance_loss   # the LLC / RSP / intra-negative terms share the margin kernels
 from .misc import distributed_helper as du_helper
 
 modality = 'res'        # module-level switch of the reference (online_train.py:36)
@@ -67,12 +67,15 @@ def triplet_train_epoch(train_loader, model, criterion, optimizer, epoch, cfg, c
     start = time.time()
     pending = []        # (loss tensor, batch_size_world tensor) kept on the device until the next log line
     for batch_idx, (inputs, targets, idx) in enumerate(train_loader):
-        if _flag(cfg.LOSS, "RELATIVE_SPEED_PERCEPTION") or _flag(cfg.LOSS, "INTRA_NEGATIVE"):
-            raise NotImplementedError("RELATIVE_SPEED_PERCEPTION / INTRA_NEGATIVE are off in every shipped SLIC config")
-        llc = _flag(cfg.LOSS, "LOCAL_LOCAL_CONTRAST")
-        if llc:
-            anchor, positive, anchor2 = inputs
-            anchor2 = anchor2.to(device)
+        # a third clip per sample and a margin term on it (online_train.py:256-360), in the reference's order of precedence:
+        #   RELATIVE_SPEED_PERCEPTION: fast positive, d(anc, pos) + 0.1 < d(anc, fast_pos), weight 1
+        #   LOCAL_LOCAL_CONTRAST     : second anchor clip, d(anc, anc2) + LOCAL_LOCAL_MARGIN < d(anc, pos), weight LOCAL_LOCAL_WEIGHT
+        #   INTRA_NEGATIVE           : intra-video negative, d(anc, intra_neg) + 0.04 < d(anc, pos), weight 0.4 (as the reference has it)
+        third = ("rsp" if _flag(cfg.LOSS, "RELATIVE_SPEED_PERCEPTION") else "llc" if _flag(cfg.LOSS, "LOCAL_LOCAL_CONTRAST") else
+                 "intra" if _flag(cfg.LOSS, "INTRA_NEGATIVE") else None)
+        if third:
+            anchor, positive, extra = inputs
+            extra = extra.to(device)
         else:
             anchor, positive = inputs
         anchor, positive = anchor.to(device), positive.to(device)
@@ -80,16 +83,20 @@ def triplet_train_epoch(train_loader, model, criterion, optimizer, epoch, cfg, c
         batch_size = torch.tensor(anchor.size(0)).to(device)
         targets = torch.cat((a_target, p_target), 0).to(device)
         b = anchor.size(0)
-        if llc:
-            outputs = model(torch.cat((anchor, positive, anchor2), 0))      # ONE forward: BN stats over all 3b clips
+        if third:
+            outputs = model(torch.cat((anchor, positive, extra), 0))        # ONE forward: BN stats over all 3b clips
             out_anchor_positive = outputs[:b * 2]
-            out_anc, out_pos, out_anc2 = outputs[:b], outputs[b:2 * b], outputs[2 * b:3 * b]
+            out_anc, out_pos, out_extra = outputs[:b], outputs[b:2 * b], outputs[2 * b:3 * b]
             triplet_loss, n_triplets = criterion(out_anchor_positive, targets, sampling_strategy=cfg.DATASET.SAMPLING_STRATEGY)
-            if cfg.LOSS.DIST_METRIC != 'cosine':
-                raise NotImplementedError("LLC with euclidean distances is not used by the shipped configs")
-            # dist_ap = 1 - cos(anc, anc2), dist_an = 1 - cos(anc, pos); MarginRankingLoss(margin)(ap, an, -1)
-            llc_loss = margin_cosine_loss(out_anc, out_anc2, out_pos, cfg.LOSS.LOCAL_LOCAL_MARGIN)
-            loss = triplet_loss + llc_loss * cfg.LOSS.LOCAL_LOCAL_WEIGHT
+            metric = cfg.LOSS.DIST_METRIC
+            # MarginRankingLoss(margin)(dist_ap, dist_an, -1) = mean max(0, dist_ap - dist_an + margin)
+            if third == "rsp":
+                loss = triplet_loss + margin_distance_loss(out_anc, out_pos, out_extra, 0.1, metric) * 1.0
+            elif third == "llc":
+                loss = triplet_loss + margin_distance_loss(out_anc, out_extra, out_pos, cfg.LOSS.LOCAL_LOCAL_MARGIN, metric) * \
+                    cfg.LOSS.LOCAL_LOCAL_WEIGHT
+            else:
+                loss = triplet_loss + margin_distance_loss(out_anc, out_extra, out_pos, 0.04, metric) * 0.4
         else:
             outputs = model(torch.cat((anchor, positive), 0))
             loss, n_triplets = criterion(outputs, targets, sampling_strategy=cfg.DATASET.SAMPLING_STRATEGY)
