@@ -368,6 +368,14 @@ int slic_bn_bwd_fused(const float* partial, int R, const float* g, const float* 
 /* AdaptiveAvgPool3d(1): y[b,c] = mean_s x[b,s,c]; backward dx = dy / S */
 int slic_avgpool_fwd(const float* x, int B, int S, int C, float* y, void* stream);
 int slic_avgpool_bwd(const float* dy, int B, int S, int C, float* dx, void* stream);
+/* the stem's nn.MaxPool3d(kernel_size=3, stride=2, padding=1) (models/resnet.py:123, 262-263; `no_max_pool=False`) on an NDHWC
+ * tensor: y [B, To, Ho, Wo, C] with To = (T - 1) / 2 + 1 ...; arg (optional) = the winning input position per output element
+ * (first maximum in (t, h, w) order), which the backward gathers from */
+int slic_maxpool3d_fwd(const float* x, int B, int T, int H, int W, int C, float* y, int32_t* arg, void* stream);
+int slic_maxpool3d_bwd(const float* dy, const int32_t* arg, int B, int T, int H, int W, int C, float* dx, void* stream);
+/* shortcut_type 'A' (models/resnet.py:213-222): every stride-th position of x [B, T, H, W, C], channels zero-padded to C_out.
+ * The reference concatenates `out.data`, so the branch carries no gradient: there is no backward entry */
+int slic_shortcut_a(const float* x, int B, int T, int H, int W, int C, int stride, int C_out, float* y, void* stream);
 /* out[c] = sum_m x[m,c] (rows ascending, double accumulator): nn.Linear bias gradient */
 int slic_colsum(const float* x, int64_t M, int C, float* out, void* stream);
 

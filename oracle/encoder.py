@@ -90,7 +90,7 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None, relu_masks=None):
+def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None, relu_masks=None, max_pool=False):
     """x: [B, C, T, H, W].  sd: dict of torch tensors (running stats are updated in place when training).
     taps (optional dict) receives intermediate activations by name.
     relu_masks (optional dict name -> bool tensor, names 'stem', 'layer{L}.{b}.a1', 'layer{L}.{b}', 'head'): the branch every
@@ -106,6 +106,8 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
     x = relu(_bn(x, sd, "bn1", training), "stem")
     if taps is not None:
         taps["stem"] = x
+    if max_pool:                                   # `if not self.no_max_pool: x = self.maxpool(x)` (models/resnet.py:123, 262-263)
+        x = F.max_pool3d(x, kernel_size=3, stride=2, padding=1)
     li = 1
     while f"layer{li}.0.conv1.weight" in sd:
         b = 0
@@ -124,6 +126,11 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
             if pre + ".downsample.0.weight" in sd:
                 res = F.conv3d(x, sd[pre + ".downsample.0.weight"], None, stride, 0)
                 res = _bn(res, sd, pre + ".downsample.1", training)
+            elif stride != 1 or res.shape[1] != out.shape[1]:
+                # shortcut_type 'A' (models/resnet.py:213-222; a state_dict without downsample weights): avg_pool3d(kernel 1,
+                # stride) + zero channels, concatenated through `.data` — the branch carries no gradient
+                res = F.avg_pool3d(x, kernel_size=1, stride=stride).detach()
+                res = torch.cat([res, res.new_zeros((res.shape[0], out.shape[1] - res.shape[1]) + tuple(res.shape[2:]))], 1)
             x = relu(out + res, pre)
             if taps is not None:
                 taps[pre] = x

@@ -390,6 +390,39 @@ def test_tiny_encoder_train_step_vs_reference_golden(gpu, golden_dir):
     np.testing.assert_allclose(ev.cpu().numpy(), enc["eval/emb"], atol=1e-4, rtol=0)
 
 
+def test_encoder_options_maxpool_and_shortcut_a_vs_reference_golden(gpu, golden_dir):
+    """generate_model(18, no_max_pool=False, shortcut_type='A' | 'B') (models/resnet.py:123, 213-231, 262-263): embeddings, loss,
+    every gradient (strided samples), running statistics and the eval forward against the reference's own outputs"""
+    from test_oracle_encoder import _options_cases
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    for tag, shortcut, no_pool, sd, x, g, strided in _options_cases(golden_dir):
+        kw = dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32, shortcut_type=shortcut, no_max_pool=no_pool)
+        m = generate_model(18, **kw)
+        assert sorted(m.state_dict()) == sorted(sd), tag
+        _load_into(m, sd)
+        m = m.cuda().train()
+        xt = torch.from_numpy(x).cuda()
+        emb = m(xt)
+        loss, _ = OnlineTripletLoss(0.2, 'cosine')(emb, torch.arange(2).repeat(2).cuda(), sampling_strategy='noise_contrastive')
+        loss.backward()
+        np.testing.assert_allclose(emb.detach().cpu().numpy(), g[f"{tag}/train_emb"], atol=1e-4, rtol=0, err_msg=tag)
+        assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-4
+        for k, p in m.named_parameters():
+            ref = g[f"{tag}/grad/{k}"]
+            assert p.grad is not None, k
+            np.testing.assert_allclose(strided(p.grad.cpu().numpy()), ref, atol=1e-6 + 5e-4 * np.abs(ref).max(), rtol=0, err_msg=f"{tag} {k}")
+        after = m.state_dict()
+        for k in after:
+            if k.endswith(("running_mean", "running_var")):
+                ref = g[f"{tag}/after/{k}"]
+                np.testing.assert_allclose(after[k].cpu().numpy(), ref, atol=1e-5 + 1e-4 * np.abs(ref).max(), rtol=0, err_msg=f"{tag} {k}")
+        m.eval()
+        with torch.no_grad():
+            ev = m(xt)
+        np.testing.assert_allclose(ev.cpu().numpy(), g[f"{tag}/eval_emb"], atol=1e-4, rtol=0, err_msg=tag)
+
+
 def test_two_live_forward_passes_fused_equals_unfused(gpu, monkeypatch):
     """Tripletnet-style use: two train-mode passes of the SAME module are alive when backward runs.  The BatchNorm-backward
     fusion side channel is keyed by pass, so it must give the gradients of the unfused path (SLIC_BN_FUSE=0)."""

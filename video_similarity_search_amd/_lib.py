@@ -87,6 +87,9 @@ SIGNATURES = {
     "slic_bn_bwd_fused": (I, [P, I, P, P, P, P, P, L, I, P, P, P, P, P]),
     "slic_avgpool_fwd": (I, [P, I, I, I, P, P]),
     "slic_avgpool_bwd": (I, [P, I, I, I, P, P]),
+    "slic_maxpool3d_fwd": (I, [P, I, I, I, I, I, P, P, P]),
+    "slic_maxpool3d_bwd": (I, [P, P, I, I, I, I, I, P, P]),
+    "slic_shortcut_a": (I, [P, I, I, I, I, I, I, I, P, P]),
     "slic_colsum": (I, [P, L, I, P, P]),
     # losses
     "slic_ntxent_workspace_bytes": (c_size_t, [I, I]),

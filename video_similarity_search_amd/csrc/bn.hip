@@ -623,6 +623,105 @@ extern "C" int slic_avgpool_bwd(const float* dy, int B, int S, int C, float* dx,
   return SLIC_OK;
 }
 
+// ---- the stem's MaxPool3d(kernel 3, stride 2, padding 1) (models/resnet.py:123, 262-263: `if not self.no_max_pool`), NDHWC.
+// One thread per (output position, channel); window positions in (t, h, w) order, the first maximum wins (`>`; a NaN is taken and
+// kept, as torch's kernel does); arg = the winning INPUT position (t * H + h) * W + w, kept for the backward.
+__global__ void maxpool3d_fwd_kernel(const float* __restrict__ x, int B, int T, int H, int W, int C, int To, int Ho, int Wo,
+                                     float* __restrict__ y, int32_t* __restrict__ arg) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot = (int64_t)B * To * Ho * Wo * C;
+  if (e >= tot) return;
+  const int c = (int)(e % C);
+  int64_t q = e / C;
+  const int wo = (int)(q % Wo); q /= Wo;
+  const int ho = (int)(q % Ho); q /= Ho;
+  const int to = (int)(q % To);
+  const int64_t b = q / To;
+  float best = -INFINITY;
+  int bi = -1;
+  for (int dt = 0; dt < 3; ++dt) {
+    const int t = 2 * to - 1 + dt;
+    if ((unsigned)t >= (unsigned)T) continue;
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = 2 * ho - 1 + dh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = 2 * wo - 1 + dw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const int pos = (t * H + h) * W + w;
+        const float v = x[((b * T * H * W) + pos) * C + c];
+        if (bi < 0 || v > best || v != v) { best = v; bi = pos; }
+      }
+    }
+  }
+  y[e] = best;
+  if (arg) arg[e] = bi;
+}
+// dx[pos] = sum of dy over the (at most eight) windows that cover pos and chose it — gather form: deterministic, no atomics
+__global__ void maxpool3d_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, int B, int T, int H, int W, int C,
+                                     int To, int Ho, int Wo, float* __restrict__ dx) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot = (int64_t)B * T * H * W * C;
+  if (e >= tot) return;
+  const int c = (int)(e % C);
+  int64_t q = e / C;
+  const int pos = (int)(q % ((int64_t)T * H * W));
+  const int64_t b = q / ((int64_t)T * H * W);
+  const int w = pos % W, h = (pos / W) % H, t = pos / (W * H);
+  float a = 0.f;
+  // windows o with 2 o - 1 <= p <= 2 o + 1:  o in [ceil((p - 1) / 2), floor((p + 1) / 2)]
+  for (int to = t >> 1; to <= (t + 1) >> 1; ++to) {
+    if (to >= To) continue;
+    for (int ho = h >> 1; ho <= (h + 1) >> 1; ++ho) {
+      if (ho >= Ho) continue;
+      for (int wo = w >> 1; wo <= (w + 1) >> 1; ++wo) {
+        if (wo >= Wo) continue;
+        const int64_t o = (((b * To + to) * Ho + ho) * Wo + wo) * C + c;
+        if (arg[o] == pos) a += dy[o];
+      }
+    }
+  }
+  dx[e] = a;
+}
+// shortcut 'A' (models/resnet.py:213-222): F.avg_pool3d(x, kernel_size=1, stride=s) — every s-th position — then zero channels
+// up to `Co`.  (The reference concatenates `out.data`: no gradient flows back through this branch, so there is no backward.)
+__global__ void shortcut_a_kernel(const float* __restrict__ x, int B, int T, int H, int W, int C, int s, int To, int Ho, int Wo, int Co,
+                                  float* __restrict__ y) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t tot = (int64_t)B * To * Ho * Wo * Co;
+  if (e >= tot) return;
+  const int c = (int)(e % Co);
+  int64_t q = e / Co;
+  const int wo = (int)(q % Wo); q /= Wo;
+  const int ho = (int)(q % Ho); q /= Ho;
+  const int to = (int)(q % To);
+  const int64_t b = q / To;
+  y[e] = c < C ? x[((((b * T + (int64_t)to * s) * H + (int64_t)ho * s) * W) + (int64_t)wo * s) * C + c] : 0.f;
+}
+
+extern "C" int slic_maxpool3d_fwd(const float* x, int B, int T, int H, int W, int C, float* y, int32_t* arg, void* stream) {
+  SLIC_REQUIRE(x && y && B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && (int64_t)T * H * W < (1ll << 31), "slic_maxpool3d_fwd: bad args");
+  const int To = (T - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  maxpool3d_fwd_kernel<<<dim3((unsigned)slic_cdiv((int64_t)B * To * Ho * Wo * C, 256)), dim3(256), 0, S_(stream)>>>(x, B, T, H, W, C, To, Ho, Wo, y, arg);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_maxpool3d_bwd(const float* dy, const int32_t* arg, int B, int T, int H, int W, int C, float* dx, void* stream) {
+  SLIC_REQUIRE(dy && arg && dx && B > 0 && T > 0 && H > 0 && W > 0 && C > 0, "slic_maxpool3d_bwd: bad args");
+  const int To = (T - 1) / 2 + 1, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  maxpool3d_bwd_kernel<<<dim3((unsigned)slic_cdiv((int64_t)B * T * H * W * C, 256)), dim3(256), 0, S_(stream)>>>(dy, arg, B, T, H, W, C, To, Ho, Wo, dx);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+extern "C" int slic_shortcut_a(const float* x, int B, int T, int H, int W, int C, int stride, int C_out, float* y, void* stream) {
+  SLIC_REQUIRE(x && y && B > 0 && T > 0 && H > 0 && W > 0 && C > 0 && stride >= 1 && C_out >= C, "slic_shortcut_a: bad args");
+  const int To = (T - 1) / stride + 1, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  shortcut_a_kernel<<<dim3((unsigned)slic_cdiv((int64_t)B * To * Ho * Wo * C_out, 256)), dim3(256), 0, S_(stream)>>>(x, B, T, H, W, C, stride, To, Ho, Wo,
+                                                                                                 C_out, y);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 extern "C" int slic_colsum(const float* x, int64_t M, int C, float* out, void* stream) {
   SLIC_REQUIRE(x && out && M > 0 && C > 0, "slic_colsum: bad args");
   colsum_kernel<<<dim3((unsigned)slic_cdiv(C, 64)), dim3(64), 0, S_(stream)>>>(x, M, C, out);

@@ -20,6 +20,7 @@ import weakref
 
 import torch
 import torch.nn as nn
+from functools import partial
 
 from .. import _lib
 from .._lib import call, ptr, stream
@@ -95,9 +96,11 @@ class _Engine:
         c1 = net.conv1
         self.stem = ConvPlan(C, c1.out_channels, c1.kernel_size, c1.stride, c1.padding, (T, H, W), device)
         dims = self.stem.out_dims
-        if not net.no_max_pool:
-            raise NotImplementedError("no_max_pool=False: every shipped SLIC config sets RESNET.NO_MAX_POOl true "
-                                      "(config/custom_configs/resnet_ucf_itercluster_flow.yaml:29-37)")
+        # nn.MaxPool3d(3, 2, 1) behind the stem (models/resnet.py:262-263) unless no_max_pool (what every shipped config sets)
+        self.pool_in = None if net.no_max_pool else tuple(dims)
+        if self.pool_in is not None:
+            dims = tuple((d - 1) // 2 + 1 for d in dims)
+        self.short_a = {}          # block -> (stride, planes): shortcut_type 'A' (strided positions, zero channels; no parameters)
         self.blocks = []
         self.layer_blocks = []
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
@@ -110,9 +113,11 @@ class _Engine:
                 p2 = ConvPlan(blk.conv2.in_channels, blk.conv2.out_channels, blk.conv2.kernel_size, blk.conv2.stride,
                               blk.conv2.padding, p1.out_dims, device)
                 pd = None
-                if blk.downsample is not None:
-                    if not (hasattr(blk.downsample, "__getitem__") and len(blk.downsample) == 2):
-                        raise NotImplementedError("shortcut_type 'A' is never selected by the shipped configs")
+                if blk.downsample is not None and not isinstance(blk.downsample, nn.Module):
+                    kw = blk.downsample.keywords                       # functools.partial(_downsample_basic_block, planes, stride)
+                    self.short_a[blk] = (int(kw["stride"]), int(kw["planes"]))
+                    assert tuple((d - 1) // kw["stride"] + 1 for d in dims) == tuple(p2.out_dims)
+                elif blk.downsample is not None:
                     dc = blk.downsample[0]
                     pd = ConvPlan(dc.in_channels, dc.out_channels, dc.kernel_size, dc.stride, dc.padding, dims, device)
                     assert pd.out_dims == p2.out_dims
@@ -330,7 +335,14 @@ class _Engine:
         if si == 0:
             x4 = self.stem.make_source(inp)          # NCDHW clip -> the stem plan's operand layout (W-run for RGB)
             z0, a, bn0 = self._conv_bn_act(self.stem, x4, net.conv1.weight, net.bn1, None, True, training, B, keep=save)
-            return a, (dict(x4=x4, z0=z0, a0=a, bn0=bn0) if save else None)
+            if self.pool_in is None:
+                return a, (dict(x4=x4, z0=z0, a0=a, bn0=bn0) if save else None)
+            T, H, W = self.pool_in
+            C = a.shape[-1]
+            pooled = torch.empty((B,) + tuple((d - 1) // 2 + 1 for d in self.pool_in) + (C,), dtype=torch.float32, device=dev)
+            arg = torch.empty(pooled.shape, dtype=torch.int32, device=dev) if save else None
+            call("slic_maxpool3d_fwd", ptr(a), B, T, H, W, C, ptr(pooled), ptr(arg), stream())
+            return pooled, (dict(x4=x4, z0=z0, a0=a, bn0=bn0, pool_arg=arg) if save else None)
         self._await_packs()
         if si <= 4:
             a = inp
@@ -340,6 +352,12 @@ class _Engine:
                 z1, a1, b1 = self._conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True, training, B, keep=save)
                 if pd is not None:
                     zd, r, bd = self._conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False, training, B, keep=save)
+                elif blk in self.short_a:
+                    stride, planes = self.short_a[blk]
+                    T, H, W = p1.in_dims
+                    r = torch.empty((B,) + tuple(p2.out_dims) + (planes,), dtype=torch.float32, device=dev)
+                    call("slic_shortcut_a", ptr(xin), B, T, H, W, xin.shape[-1], stride, planes, ptr(r), stream())
+                    zd, bd = None, None
                 else:
                     zd, r, bd = None, xin, None
                 z2, out, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True, training, B, keep=save)
@@ -488,7 +506,8 @@ class _Engine:
                 elif fuse and bi == 0:
                     prev = self._live_ctx(pid, si - 1)
                     if prev is not None and si - 1 == 0:
-                        below = (prev["a0"], prev["z0"], prev["bn0"])
+                        if self.pool_in is None:           # with the max-pool between, dx does not reach the stem's ReLU directly
+                            below = (prev["a0"], prev["z0"], prev["bn0"])
                     elif prev is not None:
                         pb = prev["blocks"][-1]
                         below = (pb["out"], pb["z2"], pb["b2"])
@@ -502,6 +521,9 @@ class _Engine:
                     grads[blk.downsample[0].weight] = wgrad_async(pd, s["x"], dzd, blk.downsample[0].weight)
                     dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B)
                     res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx, **kw)
+                elif blk in self.short_a:
+                    # the reference's shortcut 'A' concatenates `out.data` (models/resnet.py:220): no gradient through the branch
+                    res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, **kw)
                 else:
                     res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=g, **kw)
                 if below is not None and bi > 0:
@@ -514,7 +536,12 @@ class _Engine:
                     dout = res
             join()
             return dout, grads
-        # stem: a0 = relu(bn1(conv1(x4))); the clip needs no gradient
+        # stem: a0 = relu(bn1(conv1(x4))) (-> max-pool); the clip needs no gradient
+        if self.pool_in is not None:
+            T, H, W = self.pool_in
+            da0 = torch.empty_like(ctx["a0"])
+            call("slic_maxpool3d_bwd", ptr(dout), ptr(ctx["pool_arg"]), B, T, H, W, da0.shape[-1], ptr(da0), stream())
+            dout = da0
         pf = self._prefused.pop((pid, 0), None)
         if pf is not None and pf[0] == dout.data_ptr() and pf[1] == tuple(dout.shape):
             dz0, dg0, db0 = self._bn_bwd_fused(pf[2], dout, ctx["z0"], ctx["bn0"])
@@ -572,9 +599,9 @@ class _SegmentFn(torch.autograd.Function):
         out, saved = engine.seg_forward(si, inp, training=training, save=True)
         # the saved context must not hold the output OBJECT (output -> grad_fn -> ctx -> output would be a reference
         # cycle that pins HBM until Python's cycle collector runs): keep a detached alias of the same storage
-        if si == 0:
+        if si == 0 and engine.pool_in is None:
             saved["a0"] = out.detach()
-        elif si <= 4:
+        elif 1 <= si <= 4:
             saved["blocks"][-1]["out"] = out.detach()
         ctx.engine, ctx.si, ctx.saved, ctx.params = engine, si, saved, params
         if si == 0:
@@ -648,14 +675,20 @@ class ResNet(nn.Module):
         downsample = None
         if stride != 1 or self.in_planes != planes * block.expansion:
             if shortcut_type == 'A':
-                raise NotImplementedError("shortcut_type 'A' is never selected by the shipped configs")
-            downsample = nn.Sequential(conv1x1x1(self.in_planes, planes * block.expansion, stride),
-                                       nn.BatchNorm3d(planes * block.expansion))
+                downsample = partial(self._downsample_basic_block, planes=planes * block.expansion, stride=stride)
+            else:
+                downsample = nn.Sequential(conv1x1x1(self.in_planes, planes * block.expansion, stride),
+                                           nn.BatchNorm3d(planes * block.expansion))
         layers = [block(in_planes=self.in_planes, planes=planes, stride=stride, downsample=downsample)]
         self.in_planes = planes * block.expansion
         for _ in range(1, blocks):
             layers.append(block(self.in_planes, planes))
         return nn.Sequential(*layers)
+
+    def _downsample_basic_block(self, x, planes, stride):
+        """shortcut 'A' (models/resnet.py:213-222): every stride-th position, channels zero-padded to `planes`; the engine runs it
+        as one kernel (slic_shortcut_a) from the keywords of the partial that _make_layer stores in the block"""
+        raise RuntimeError("the shortcut runs inside ResNet.forward's HIP plan")
 
     def __getstate__(self):
         # copy.deepcopy(model) / torch.save(model): the execution plans (device tables, streams, events) are rebuilt on demand
