@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 
 def make_state_dict(rng, layers=(2, 2, 2, 2), widen=1.0, n_in=3, conv1_t=7, hidden=2048, out_dim=128,
-                    projection_head=True, dtype=np.float32):
+                    projection_head=True, dtype=np.float32, bottleneck=False):
     """weights by the reference's init RULES (models/resnet.py:203-210: Conv3d kaiming_normal_(fan_out, relu),
     BN3d gamma=1 beta=0; Linear / BN1d PyTorch defaults) drawn from a numpy Generator so the GPU box
     regenerates them without torch's RNG.  Keys/shapes = the reference's state_dict."""
@@ -53,6 +53,18 @@ def make_state_dict(rng, layers=(2, 2, 2, 2), widen=1.0, n_in=3, conv1_t=7, hidd
         for b in range(nb):
             stride = 2 if (li > 1 and b == 0) else 1
             pre = f"layer{li}.{b}"
+            if bottleneck:                       # models/resnet.py:58-72: 1x1x1 -> 3x3x3 (stride) -> 1x1x1 to 4 p channels
+                conv(pre + ".conv1.weight", p, inp, (1, 1, 1))
+                bn(pre + ".bn1", p)
+                conv(pre + ".conv2.weight", p, p, (3, 3, 3))
+                bn(pre + ".bn2", p)
+                conv(pre + ".conv3.weight", 4 * p, p, (1, 1, 1))
+                bn(pre + ".bn3", 4 * p)
+                if stride != 1 or inp != 4 * p:
+                    conv(pre + ".downsample.0.weight", 4 * p, inp, (1, 1, 1))
+                    bn(pre + ".downsample.1", 4 * p)
+                inp = 4 * p
+                continue
             conv(pre + ".conv1.weight", p, inp, (3, 3, 3))
             bn(pre + ".bn1", p)
             conv(pre + ".conv2.weight", p, p, (3, 3, 3))
@@ -62,7 +74,7 @@ def make_state_dict(rng, layers=(2, 2, 2, 2), widen=1.0, n_in=3, conv1_t=7, hidd
                 bn(pre + ".downsample.1", p)
             inp = p
     if projection_head:
-        linear("fc1", hidden, planes[3])
+        linear("fc1", hidden, inp)
         bn("bn_proj", hidden)
         linear("fc2", out_dim, hidden)
     return sd
@@ -115,14 +127,22 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
             pre = f"layer{li}.{b}"
             stride = 2 if (li > 1 and b == 0) else 1
             res = x
-            out = F.conv3d(x, sd[pre + ".conv1.weight"], None, stride, 1)
-            out = relu(_bn(out, sd, pre + ".bn1", training), pre + ".a1")
-            if taps is not None:
-                taps[pre + ".a1"] = out
-            out = F.conv3d(out, sd[pre + ".conv2.weight"], None, 1, 1)
-            if taps is not None:
-                taps[pre + ".z2"] = out
-            out = _bn(out, sd, pre + ".bn2", training)
+            if pre + ".conv3.weight" in sd:          # Bottleneck.forward (models/resnet.py:74-96)
+                out = F.conv3d(x, sd[pre + ".conv1.weight"], None, 1, 0)
+                out = relu(_bn(out, sd, pre + ".bn1", training), pre + ".a1")
+                out = F.conv3d(out, sd[pre + ".conv2.weight"], None, stride, 1)
+                out = relu(_bn(out, sd, pre + ".bn2", training), pre + ".a2")
+                out = F.conv3d(out, sd[pre + ".conv3.weight"], None, 1, 0)
+                out = _bn(out, sd, pre + ".bn3", training)
+            else:
+                out = F.conv3d(x, sd[pre + ".conv1.weight"], None, stride, 1)
+                out = relu(_bn(out, sd, pre + ".bn1", training), pre + ".a1")
+                if taps is not None:
+                    taps[pre + ".a1"] = out
+                out = F.conv3d(out, sd[pre + ".conv2.weight"], None, 1, 1)
+                if taps is not None:
+                    taps[pre + ".z2"] = out
+                out = _bn(out, sd, pre + ".bn2", training)
             if pre + ".downsample.0.weight" in sd:
                 res = F.conv3d(x, sd[pre + ".downsample.0.weight"], None, stride, 0)
                 res = _bn(res, sd, pre + ".downsample.1", training)

@@ -1,7 +1,7 @@
 """
 Generates tests/golden/encoder_options.npz in the BUILD container by importing the reference's models/resnet.py with the two
 constructor options no shipped config selects: the stem's max-pool (`no_max_pool=False`, models/resnet.py:123, 262-263) and
-`shortcut_type='A'` (:213-231).  A tiny-width R3D-18: train-mode forward + noise_contrastive loss + backward, then an eval forward.
+`shortcut_type='A'` (:213-231).  and the Bottleneck depth 50 (:58-96, 449-450).  Tiny-width models: train-mode forward + noise_contrastive loss + backward, then an eval forward.
     python tests/golden/make_goldens_encoder_options.py
 Kept small: the weights and the clips are NOT stored — `draw_case` below (numpy PCG64, oracle.encoder.make_state_dict) is what the
 test calls to regenerate them, a checksum of each is stored — and a gradient is stored as at most 4096 evenly strided elements.
@@ -21,34 +21,39 @@ if __name__ == "__main__":
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 WIDEN, HIDDEN, OUT_DIM = 0.125, 64, 32
-CASES = (("poolA", "A", False), ("poolB", "B", False))
+CASES = (("poolA", "A", False, 18), ("poolB", "B", False, 18), ("r50", "B", True, 50))     # tag, shortcut, no_max_pool, depth
+LAYERS = {18: (2, 2, 2, 2), 50: (3, 4, 6, 3)}
 
 
-def draw_case(rng, shortcut):
+def draw_case(rng, shortcut, depth=18):
     """the weights (reference init rules, BN affine perturbed) and the clip batch of one case, in the generator's draw order"""
-    sd = oe.make_state_dict(rng, widen=WIDEN, hidden=HIDDEN, out_dim=OUT_DIM)
+    sd = oe.make_state_dict(rng, layers=LAYERS[depth], widen=WIDEN, hidden=HIDDEN, out_dim=OUT_DIM, bottleneck=depth >= 50)
     if shortcut == "A":
         sd = {k: v for k, v in sd.items() if ".downsample." not in k}
     for k in sd:
-        if k.endswith(("bn1.weight", "bn2.weight", "downsample.1.weight")) or k == "bn_proj.weight":
+        if k.endswith(("bn1.weight", "bn2.weight", "bn3.weight", "downsample.1.weight")) or k == "bn_proj.weight":
             sd[k] = (1.0 + 0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
-        if k.endswith(("bn1.bias", "bn2.bias", "downsample.1.bias")) or k == "bn_proj.bias":
+        if k.endswith(("bn1.bias", "bn2.bias", "bn3.bias", "downsample.1.bias")) or k == "bn_proj.bias":
             sd[k] = (0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
     x = rng.standard_normal((4, 3, 8, 48, 48)).astype(np.float32)
     return sd, x
 
 
 def strided(a, limit=4096):
+    """at most ~limit evenly strided elements; the step is kept coprime with 27 (a multiple of 3 would walk one tap of a 3 x 3 x 3 filter)"""
     a = np.asarray(a).reshape(-1)
-    return a[::max(1, -(-a.size // limit))].copy()
+    step = max(1, -(-a.size // limit))
+    while step > 1 and step % 3 == 0:
+        step += 1
+    return a[::step].copy()
 
 
 def main():
     rng = np.random.default_rng(57)
     out = {}
-    for tag, shortcut, no_pool in CASES:
-        sd, x = draw_case(rng, shortcut)
-        m = generate_model(18, hidden_layer=HIDDEN, out_dim=OUT_DIM, num_classes=101, n_input_channels=3, shortcut_type=shortcut,
+    for tag, shortcut, no_pool, depth in CASES:
+        sd, x = draw_case(rng, shortcut, depth)
+        m = generate_model(depth, hidden_layer=HIDDEN, out_dim=OUT_DIM, num_classes=101, n_input_channels=3, shortcut_type=shortcut,
                            conv1_t_size=7, conv1_t_stride=1, no_max_pool=no_pool, widen_factor=WIDEN, projection_head=True,
                            predict_temporal_ds=False, spatio_temporal_attention=False, classifier=False, dropout=None)
         assert sorted(m.state_dict()) == sorted(sd), set(m.state_dict()) ^ set(sd)

@@ -40,6 +40,8 @@ def _gpu_relu_masks(m, xc):
             elif si <= 4:
                 for b, blk in enumerate(ctx["blocks"]):
                     masks[f"layer{si}.{b}.a1"] = ncdhw(blk["a1"])
+                    if "a2" in blk:                                   # Bottleneck
+                        masks[f"layer{si}.{b}.a2"] = ncdhw(blk["a2"])
                     masks[f"layer{si}.{b}"] = ncdhw(blk["out"])
             elif "ah" in ctx:
                 masks["head"] = (ctx["ah"] > 0).view(xc.shape[0], -1).cpu()
@@ -60,6 +62,11 @@ CONV_CASES = [
     (64, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), 1, (4, 14, 14)),
     (128, 256, (3, 3, 3), (2, 2, 2), (1, 1, 1), 3, (3, 7, 7)),     # odd sizes
     (256, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), 5, (1, 1, 1)),     # linear
+    (32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), 4, (2, 6, 6)),      # Bottleneck conv3 / conv1 (depth 50+): 1 x 1 x 1, stride 1
+    (128, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), 4, (2, 6, 6)),
+    (8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), 2, (4, 12, 12)),
+    (32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), 4, (2, 6, 6)),       # Bottleneck conv2 at layer3 of the tiny model
+    (16, 16, (3, 3, 3), (2, 2, 2), (1, 1, 1), 4, (4, 12, 12)),
 ]
 
 
@@ -391,26 +398,48 @@ def test_tiny_encoder_train_step_vs_reference_golden(gpu, golden_dir):
 
 
 def test_encoder_options_maxpool_and_shortcut_a_vs_reference_golden(gpu, golden_dir):
-    """generate_model(18, no_max_pool=False, shortcut_type='A' | 'B') (models/resnet.py:123, 213-231, 262-263): embeddings, loss,
-    every gradient (strided samples), running statistics and the eval forward against the reference's own outputs"""
+    """generate_model(18, no_max_pool=False, shortcut_type='A' | 'B') (models/resnet.py:123, 213-231, 262-263) and the Bottleneck
+    depth generate_model(50) (:58-96): embeddings, loss, every gradient (strided samples), running statistics and the eval forward
+    against the reference's own outputs"""
     from test_oracle_encoder import _options_cases
     from video_similarity_search_amd.models import generate_model
     from video_similarity_search_amd.loss import OnlineTripletLoss
-    for tag, shortcut, no_pool, sd, x, g, strided in _options_cases(golden_dir):
+    for tag, shortcut, no_pool, depth, sd, x, g, strided in _options_cases(golden_dir):
         kw = dict(R3D18_KW, widen_factor=0.125, hidden_layer=64, out_dim=32, shortcut_type=shortcut, no_max_pool=no_pool)
-        m = generate_model(18, **kw)
+        m = generate_model(depth, **kw)
         assert sorted(m.state_dict()) == sorted(sd), tag
         _load_into(m, sd)
         m = m.cuda().train()
         xt = torch.from_numpy(x).cuda()
+        masks = None
+        if depth >= 50:
+            # Sixteen Bottleneck blocks at this width with BatchNorm over 36-288 samples are ill-conditioned: the reference's own
+            # fp32 gradients sit 2-11 % from an fp64 run of the same graph (a ReLU input within rounding of zero takes the other
+            # branch), so its gradients cannot gate a third arithmetic.  As in the full-size tests: the oracle in fp64 with the
+            # device's ReLU branches imposed, max-norm 1e-3; embeddings, loss and the eval forward stay on the reference's golden.
+            masks = _gpu_relu_masks(m, xt)
+            _load_into(m, sd)
         emb = m(xt)
         loss, _ = OnlineTripletLoss(0.2, 'cosine')(emb, torch.arange(2).repeat(2).cuda(), sampling_strategy='noise_contrastive')
         loss.backward()
-        np.testing.assert_allclose(emb.detach().cpu().numpy(), g[f"{tag}/train_emb"], atol=1e-4, rtol=0, err_msg=tag)
+        np.testing.assert_allclose(emb.detach().cpu().numpy(), g[f"{tag}/train_emb"], atol=1e-4 if masks is None else 2e-4, rtol=0, err_msg=tag)
         assert abs(loss.item() - float(g[f"{tag}/loss"])) < 1e-4
+        if masks is not None:
+            from oracle import encoder as oe
+            t64 = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
+            l64 = oe.ntxent_loss(oe.encoder_forward(t64, torch.from_numpy(x).double(), training=True, relu_masks=masks))
+            p64 = {k: v for k, v in t64.items() if v.requires_grad}
+            g64 = dict(zip(p64, torch.autograd.grad(l64, list(p64.values()))))
+            assert abs(loss.item() - float(l64)) < 1e-4
         for k, p in m.named_parameters():
-            ref = g[f"{tag}/grad/{k}"]
             assert p.grad is not None, k
+            if masks is not None:
+                ref = g64[k].numpy()
+                if np.abs(ref).max() < 1e-5:
+                    continue                                   # a bias in front of a BatchNorm: its gradient is rounding noise
+                np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=1e-3 * np.abs(ref).max(), rtol=0, err_msg=f"{tag} {k}")
+                continue
+            ref = g[f"{tag}/grad/{k}"]
             np.testing.assert_allclose(strided(p.grad.cpu().numpy()), ref, atol=1e-6 + 5e-4 * np.abs(ref).max(), rtol=0, err_msg=f"{tag} {k}")
         after = m.state_dict()
         for k in after:
@@ -421,6 +450,40 @@ def test_encoder_options_maxpool_and_shortcut_a_vs_reference_golden(gpu, golden_
         with torch.no_grad():
             ev = m(xt)
         np.testing.assert_allclose(ev.cpu().numpy(), g[f"{tag}/eval_emb"], atol=1e-4, rtol=0, err_msg=tag)
+
+
+def test_r3d50_full_width_vs_oracle(gpu):
+    """generate_model(50) at full width (Bottleneck blocks up to 2048 channels, models/resnet.py:58-96, 449-450): eval-mode and
+    train-mode embeddings against the CPU oracle at 1e-4 of the embedding scale, and a backward pass that reaches every parameter"""
+    from oracle import encoder as oe
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    rng = np.random.default_rng(50)
+    sd = oe.make_state_dict(rng, layers=(3, 4, 6, 3), hidden=512, out_dim=128, bottleneck=True)
+    x = rng.standard_normal((4, 3, 8, 64, 64)).astype(np.float32)       # four clips: BatchNorm1d over two samples is a sign function
+    m = generate_model(50, **dict(R3D18_KW, hidden_layer=512, out_dim=128))
+    assert sorted(m.state_dict()) == sorted(sd)
+    _load_into(m, sd)
+    m = m.cuda().eval()
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        ev = m(xt).cpu().numpy()
+    t = oe.to_torch(sd)
+    with torch.no_grad():
+        ref_ev = oe.encoder_forward(t, torch.from_numpy(x), training=False).numpy()
+        ref_tr = oe.encoder_forward(t, torch.from_numpy(x), training=True).numpy()
+        ref_tr64 = oe.encoder_forward(oe.to_torch(sd, dtype=torch.float64), torch.from_numpy(x).double(), training=True).numpy()
+    np.testing.assert_allclose(ev, ref_ev, atol=1e-4 * max(1.0, np.abs(ref_ev).max()), rtol=0)
+    m.train()
+    emb = m(xt)
+    # train mode: fifty layers of batch statistics over as few as 16 samples — the CPU's own fp32 pass sits 2.6e-4 from its fp64
+    # pass here, so the gate is the fp64 pass at max(1e-4, twice that distance)
+    noise = float(np.abs(ref_tr - ref_tr64).max())
+    np.testing.assert_allclose(emb.detach().cpu().numpy(), ref_tr64, atol=max(1e-4, 2 * noise) * max(1.0, np.abs(ref_tr64).max()), rtol=0)
+    ntxent_loss(emb).backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert float(m.layer1[0].conv3.weight.grad.abs().max()) > 0 and float(m.conv1.weight.grad.abs().max()) > 0
 
 
 def test_two_live_forward_passes_fused_equals_unfused(gpu, monkeypatch):

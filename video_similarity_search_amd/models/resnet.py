@@ -56,6 +56,26 @@ class BasicBlock(nn.Module):
         raise RuntimeError("BasicBlock is a parameter holder; the encoder runs through ResNet.forward (HIP plan)")
 
 
+class Bottleneck(nn.Module):
+    """parameter holder with the reference's attribute names (models/resnet.py:58-96): 1x1x1 -> 3x3x3 (stride) -> 1x1x1 (x 4)"""
+    expansion = 4
+
+    def __init__(self, in_planes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv1x1x1(in_planes, planes)
+        self.bn1 = nn.BatchNorm3d(planes)
+        self.conv2 = conv3x3x3(planes, planes, stride)
+        self.bn2 = nn.BatchNorm3d(planes)
+        self.conv3 = conv1x1x1(planes, planes * self.expansion)
+        self.bn3 = nn.BatchNorm3d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("Bottleneck is a parameter holder; the encoder runs through ResNet.forward (HIP plan)")
+
+
 # ------------------------------------------------------------------------------------------------
 class _Bn:
     """per-call view of one BatchNorm layer: parameters + the statistics this pass produced"""
@@ -100,37 +120,42 @@ class _Engine:
         self.pool_in = None if net.no_max_pool else tuple(dims)
         if self.pool_in is not None:
             dims = tuple((d - 1) // 2 + 1 for d in dims)
+        self.p3 = {}               # Bottleneck block -> plan of its conv3
         self.short_a = {}          # block -> (stride, planes): shortcut_type 'A' (strided positions, zero channels; no parameters)
         self.blocks = []
         self.layer_blocks = []
         for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
             self.layer_blocks.append([])
             for blk in layer:
-                if not all(hasattr(blk, a) for a in ("conv1", "bn1", "conv2", "bn2", "downsample")) or hasattr(blk, "conv3"):
-                    raise NotImplementedError("Bottleneck depths (50+) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
+                assert all(hasattr(blk, a) for a in ("conv1", "bn1", "conv2", "bn2", "downsample"))
                 p1 = ConvPlan(blk.conv1.in_channels, blk.conv1.out_channels, blk.conv1.kernel_size, blk.conv1.stride,
                               blk.conv1.padding, dims, device)
                 p2 = ConvPlan(blk.conv2.in_channels, blk.conv2.out_channels, blk.conv2.kernel_size, blk.conv2.stride,
                               blk.conv2.padding, p1.out_dims, device)
+                plast = p2
+                if hasattr(blk, "conv3"):                              # Bottleneck (depths 50+): a third, 1x1x1 convolution
+                    plast = ConvPlan(blk.conv3.in_channels, blk.conv3.out_channels, blk.conv3.kernel_size, blk.conv3.stride,
+                                     blk.conv3.padding, p2.out_dims, device)
+                    self.p3[blk] = plast
                 pd = None
-                if blk.downsample is not None and not isinstance(blk.downsample, nn.Module):
+                if isinstance(blk.downsample, partial):
                     kw = blk.downsample.keywords                       # functools.partial(_downsample_basic_block, planes, stride)
                     self.short_a[blk] = (int(kw["stride"]), int(kw["planes"]))
-                    assert tuple((d - 1) // kw["stride"] + 1 for d in dims) == tuple(p2.out_dims)
+                    assert tuple((d - 1) // kw["stride"] + 1 for d in dims) == tuple(plast.out_dims)
                 elif blk.downsample is not None:
                     dc = blk.downsample[0]
                     pd = ConvPlan(dc.in_channels, dc.out_channels, dc.kernel_size, dc.stride, dc.padding, dims, device)
-                    assert pd.out_dims == p2.out_dims
+                    assert pd.out_dims == plast.out_dims
                 self.blocks.append((blk, p1, p2, pd))
                 self.layer_blocks[-1].append((blk, p1, p2, pd))
-                dims = p2.out_dims
+                dims = plast.out_dims
         self.final_dims = dims
         # Side channel between the autograd nodes of ONE forward pass (keys carry the pass id, so several passes of the same
         # module that are alive at once — Tripletnet's three, gradient accumulation — never see each other's tensors):
         self._pass_id = 0
         self._live = {}        # (pass, si) -> weakref to the saved context of that segment's pending backward
         self._prefused = {}    # (pass, si) -> (data_ptr, shape, partial sums) of a gradient whose ReLU mask + BN sums are done
-        self.feat = self.blocks[-1][2].N
+        self.feat = self.p3.get(self.blocks[-1][0], self.blocks[-1][2]).N
         if net.projection_head:
             self.fc1 = ConvPlan(net.fc1.in_features, net.fc1.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
             self.fc2 = ConvPlan(net.fc2.in_features, net.fc2.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
@@ -150,7 +175,8 @@ class _Engine:
         conversion and the stem convolution instead.  The stem packs its own weights inline so that it can start at once;
         everything else waits for the side stream's event the first time a packed operand is needed (_await_packs)."""
         jobs = [(p, m.weight) for blk, p1, p2, pd in self.blocks
-                for p, m in ((p1, blk.conv1), (p2, blk.conv2)) + (((pd, blk.downsample[0]),) if pd is not None else ())]
+                for p, m in ((p1, blk.conv1), (p2, blk.conv2)) + (((pd, blk.downsample[0]),) if pd is not None else ()) +
+                (((self.p3[blk], blk.conv3),) if blk in self.p3 else ())]
         if self.net.projection_head:
             jobs += [(self.fc1, self.net.fc1.weight), (self.fc2, self.net.fc2.weight)]
         self.stem.drop_packs()
@@ -349,20 +375,28 @@ class _Engine:
             saved = []
             for blk, p1, p2, pd in self.layer_blocks[si - 1]:
                 xin = a
+                p3 = self.p3.get(blk)
                 z1, a1, b1 = self._conv_bn_act(p1, xin, blk.conv1.weight, blk.bn1, None, True, training, B, keep=save)
+                if p3 is not None:
+                    z2, a2, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, None, True, training, B, keep=save)
                 if pd is not None:
                     zd, r, bd = self._conv_bn_act(pd, xin, blk.downsample[0].weight, blk.downsample[1], None, False, training, B, keep=save)
                 elif blk in self.short_a:
                     stride, planes = self.short_a[blk]
                     T, H, W = p1.in_dims
-                    r = torch.empty((B,) + tuple(p2.out_dims) + (planes,), dtype=torch.float32, device=dev)
+                    r = torch.empty((B,) + tuple((p3 or p2).out_dims) + (planes,), dtype=torch.float32, device=dev)
                     call("slic_shortcut_a", ptr(xin), B, T, H, W, xin.shape[-1], stride, planes, ptr(r), stream())
                     zd, bd = None, None
                 else:
                     zd, r, bd = None, xin, None
-                z2, out, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True, training, B, keep=save)
-                if save:
-                    saved.append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, out=out, b2=b2, zd=zd, bd=bd))
+                if p3 is not None:
+                    z3, out, b3 = self._conv_bn_act(p3, a2, blk.conv3.weight, blk.bn3, r, True, training, B, keep=save)
+                    if save:     # zl / bl: the block's LAST convolution output and BatchNorm (what the layer above fuses into its dgrad)
+                        saved.append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, a2=a2, b2=b2, z3=z3, b3=b3, out=out, zd=zd, bd=bd, zl=z3, bl=b3))
+                else:
+                    z2, out, b2 = self._conv_bn_act(p2, a1, blk.conv2.weight, blk.bn2, r, True, training, B, keep=save)
+                    if save:
+                        saved.append(dict(x=xin, z1=z1, a1=a1, b1=b1, z2=z2, out=out, b2=b2, zd=zd, bd=bd, zl=z2, bl=b2))
                 a = out
             return a, (dict(blocks=saved) if save else None)
         # head: pool -> fc2(relu(bn_proj(fc1(x))))   (models/resnet.py:286-299)
@@ -474,13 +508,32 @@ class _Engine:
                 pre = (dout, pf[2])
             for bi in reversed(range(len(blocks))):
                 (blk, p1, p2, pd), s = blocks[bi]
-                # out = relu(bn2(conv2(a1)) + r)
+                p3 = self.p3.get(blk)
+                # out = relu(bn_l(conv_l(.)) + r), l = the block's last convolution (conv2; conv3 of a Bottleneck)
                 if pre is not None:
                     g, part = pre
-                    dz2, dg2, db2 = self._bn_bwd_fused(part, g, s["z2"], s["b2"])
+                    dzl, dgl, dbl = self._bn_bwd_fused(part, g, s["zl"], s["bl"])
                     pre = None
                 else:
-                    dz2, g, dg2, db2 = self._bn_bwd(dout, s["out"], s["z2"], s["b2"], True)
+                    dzl, g, dgl, dbl = self._bn_bwd(dout, s["out"], s["zl"], s["bl"], True)
+                if p3 is not None:
+                    grads[blk.bn3.weight], grads[blk.bn3.bias] = dgl, dbl
+                    grads[blk.conv3.weight] = wgrad_async(p3, s["a2"], dzl, blk.conv3.weight)
+                    # a2 = relu(bn2(conv2(a1))): mask + BatchNorm-backward sums on conv3's dgrad epilogue
+                    b2 = s["b2"]
+                    if fuse:
+                        g2, part2 = p3.dgrad(dzl, p3.pack_dgrad(blk.conv3.weight), B, mask=s["a2"], bwd=(s["z2"], b2.mean, b2.invstd))
+                        del dzl
+                        dz2, dg2, db2 = self._bn_bwd_fused(part2, g2, s["z2"], b2)
+                        del g2
+                    else:
+                        da2 = p3.dgrad(dzl, p3.pack_dgrad(blk.conv3.weight), B)
+                        del dzl
+                        dz2, _, dg2, db2 = self._bn_bwd(da2, s["a2"], s["z2"], b2, False)
+                        del da2
+                else:
+                    dz2, dg2, db2 = dzl, dgl, dbl
+                    del dzl
                 grads[blk.bn2.weight], grads[blk.bn2.bias] = dg2, db2
                 grads[blk.conv2.weight] = wgrad_async(p2, s["a1"], dz2, blk.conv2.weight)
                 # a1 = relu(bn1(conv1(x))): the ReLU mask and the BatchNorm-backward sums ride on conv2's dgrad epilogue
@@ -502,7 +555,7 @@ class _Engine:
                 below = None
                 if fuse and bi > 0:
                     pb = blocks[bi - 1][1]
-                    below = (pb["out"], pb["z2"], pb["b2"])
+                    below = (pb["out"], pb["zl"], pb["bl"])
                 elif fuse and bi == 0:
                     prev = self._live_ctx(pid, si - 1)
                     if prev is not None and si - 1 == 0:
@@ -510,7 +563,7 @@ class _Engine:
                             below = (prev["a0"], prev["z0"], prev["bn0"])
                     elif prev is not None:
                         pb = prev["blocks"][-1]
-                        below = (pb["out"], pb["z2"], pb["b2"])
+                        below = (pb["out"], pb["zl"], pb["bl"])
                 kw = {}
                 if below is not None:
                     kw = dict(mask=below[0], bwd=(below[1], below[2].mean, below[2].invstd))
@@ -739,4 +792,10 @@ def generate_model(model_depth, **kwargs):
         return ResNet(BasicBlock, [2, 2, 2, 2], get_inplanes(), **kwargs)
     if model_depth == 34:
         return ResNet(BasicBlock, [3, 4, 6, 3], get_inplanes(), **kwargs)
-    raise NotImplementedError("Bottleneck depths (50/101/152/200) are not on the SLIC hot path (RESNET.MODEL_DEPTH: 18)")
+    if model_depth == 50:
+        return ResNet(Bottleneck, [3, 4, 6, 3], get_inplanes(), **kwargs)
+    if model_depth == 101:
+        return ResNet(Bottleneck, [3, 4, 23, 3], get_inplanes(), **kwargs)
+    if model_depth == 152:
+        return ResNet(Bottleneck, [3, 8, 36, 3], get_inplanes(), **kwargs)
+    return ResNet(Bottleneck, [3, 24, 36, 3], get_inplanes(), **kwargs)
