@@ -1,8 +1,9 @@
 #!/bin/bash
-# layer4 Winograd weight gradient: tile-slice count sweep (GPU box)
+# Winograd weight gradient: workgroup budget sweep (tile slices = budget / blocks) at layers 1-3 (GPU box)
 cd "$(dirname "$0")/../.."
-export SLIC_WINO_SPLIT=4
-for s in 1 2 3 4 5 6 7 8 14; do
-  export SLIC_WINO_WGRAD_WGS=$((576 * s))
-  echo "l4 wgrad slices $s: $(python scripts/bench_conv.py 32 'c10 l4' 2>/dev/null | sed 's/.*| wino/wino/')"
+for wgs in 512 768 1024 1536 2048; do
+  export SLIC_WINO_WGRAD_WGS=$wgs
+  for sh in "c2 l1" "c4 l2" "c7 l3"; do
+    echo "wgs $wgs $sh: $(python scripts/bench_conv.py 32 "$sh" 2>/dev/null | sed 's/.*| wino/wino/')"
+  done
 done

@@ -124,7 +124,8 @@ def test_conv_fwd_dgrad_wgrad(gpu, C, N, k, s, p, B, dims):
 @pytest.mark.parametrize("C,N,B,dims", [(64, 64, 2, (4, 10, 12)), (128, 64, 1, (3, 6, 8)), (64, 128, 2, (2, 5, 4)),
                                         (64, 64, 1, (16, 56, 56)), (128, 128, 3, (2, 28, 28)),
                                         (64, 64, 2, (3, 9, 14)), (128, 64, 3, (2, 5, 7)), (256, 256, 2, (4, 14, 14)),      # ragged last tile
-                                        (64, 128, 1, (2, 3, 5)), (64, 64, 2, (2, 4, 1)), (512, 512, 2, (2, 7, 7))])
+                                        (64, 128, 1, (2, 3, 5)), (64, 64, 2, (2, 4, 1)), (512, 512, 2, (2, 7, 7)),
+                                        (64, 64, 43, (4, 28, 28))])     # 527 workgroups on 512 slots: whole blocks + a K-split tail
 def test_conv_winograd_f43(gpu, C, N, B, dims):
     """slic_conv_gemm variant 30 — Winograd F(4, 3) along W (3 x 3 x 3 / stride 1 / pad 1, layer1 / layer2 of R3D-18) — forward and
     data gradient vs fp64 F.conv3d at the gather-GEMM's own tolerance, the fused epilogues (BatchNorm partials per 128 rows;

@@ -1237,7 +1237,7 @@ constexpr int wino_stage_floats(int TG) { return 12 * 32 * TG * 4 + (TG == 4 ? 1
 
 template <int STAGES, bool WPAD, int TG>
 __global__ __launch_bounds__(128 * TG) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int st_per_split) {
+void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int st_per_split, const int mb_off, const int mb_cnt) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMAs' LDS bases (M0) then need no v_readfirstlane
@@ -1253,7 +1253,10 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   constexpr int STAGE_FLOATS = wino_stage_floats(TG);
   constexpr int UP = TG == 4 ? 2 : 3;                         // U pieces per thread (TG = 4: 1024 chunk slots for 768 chunks)
   constexpr int NPC = 3 + UP;                                 // DMA pieces per thread and stage
-  const int64_t tile0 = (int64_t)mb * TW;
+  // this launch covers tile blocks [mb_off, mb_off + mb_cnt): all of them, or — a launch whose last dispatch round would be partly
+  // filled — the whole rounds (K loop in one piece) and then the remaining blocks with the K loop cut (launch_wino)
+  if (mb >= mb_cnt) return;
+  const int64_t tile0 = (int64_t)(mb_off + mb) * TW;
   if (tile0 >= Mt) return;
   const int nb = blockIdx.y, n0 = nb * 64;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
@@ -1438,7 +1441,9 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
     acc[3] = d12 + 8.f * d34 + acc[5];
   }
   if (slab) {
-    float* out = slab + (int64_t)blockIdx.z * p.M * p.N;
+    // slab[piece][GEMM row - first row of this launch][n]  (a tail launch exists on widths that are multiples of 4 only: 4 rows per tile)
+    const int64_t row_off = (int64_t)mb_off * TW * 4;
+    float* out = slab + ((int64_t)blockIdx.z * (p.M - row_off) - row_off) * p.N;
     const int n = n0 + wn * 32 + r;
     const int64_t bth_all = p.M / W;
 #pragma unroll
@@ -1512,7 +1517,7 @@ __global__ void pack_w_wino(const float* __restrict__ Wt, int N, int C, int dgra
 }
 
 template <int STAGES, bool WPAD, int TG>
-static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr) {
+static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, float* slab = nullptr, int nfull = 0) {
   constexpr size_t ring = (size_t)STAGES * wino_stage_floats(TG) * sizeof(float), epi = (size_t)conv_epi_lds_floats(128, 64, 2 * TG) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static bool attr_set = false;
@@ -1521,22 +1526,27 @@ static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, fl
     attr_set = true;
   }
   const int64_t tiles = (a.M / a.Ws) * ((a.Ws + 3) / 4);
-  const unsigned gx = (unsigned)slic_cdiv(tiles, 32 * TG);
+  const int gx = (int)slic_cdiv(tiles, 32 * TG);               // tile blocks
+  const unsigned ny = (unsigned)(a.N / 64);
   if (splits > 1) {
+    // the first `nfull` tile blocks run whole (the launch's full dispatch rounds), the rest cut the K loop `splits` ways
+    if (nfull > 0) {
+      conv_wino_kernel<STAGES, WPAD, TG><<<dim3((unsigned)((nfull + 7) / 8 * 8), ny), dim3(128 * TG), lds, st>>>(a, nullptr, 0, 0, nfull);
+      SLIC_LAUNCH_CHECK();
+    }
+    const int tail = gx - nfull;
     const int ns = 9 * (a.Cs / 8);
     int per = (ns + splits - 1) / splits;
     per = (per + STAGES - 1) / STAGES * STAGES;              // whole ring turns per piece
     const int S = (ns + per - 1) / per;
-    dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64), (unsigned)S);
-    conv_wino_kernel<STAGES, WPAD, TG><<<grid, dim3(128 * TG), lds, st>>>(a, slab, per);
+    conv_wino_kernel<STAGES, WPAD, TG><<<dim3((unsigned)((tail + 7) / 8 * 8), ny, (unsigned)S), dim3(128 * TG), lds, st>>>(a, slab, per, nfull, tail);
     SLIC_LAUNCH_CHECK();
-    conv_splitk_finish<128, 64, 2, 2><<<dim3((unsigned)slic_cdiv(a.M, 128), (unsigned)(a.N / 64)), dim3(256), 0, st>>>(
-        a, slab, S, 0, a.M * (int64_t)a.N);
+    const int64_t row0 = (int64_t)nfull * 32 * TG * 4, rows = a.M - row0;          // nfull > 0: W % 4 == 0, four GEMM rows per tile
+    conv_splitk_finish<128, 64, 2, 2><<<dim3((unsigned)slic_cdiv(rows, 128), ny), dim3(256), 0, st>>>(a, slab, S, (int)(row0 / 128), rows * (int64_t)a.N);
     SLIC_LAUNCH_CHECK();
     return SLIC_OK;
   }
-  dim3 grid((gx + 7) / 8 * 8, (unsigned)(a.N / 64));
-  conv_wino_kernel<STAGES, WPAD, TG><<<grid, dim3(128 * TG), lds, st>>>(a, nullptr, 0);
+  conv_wino_kernel<STAGES, WPAD, TG><<<dim3((unsigned)((gx + 7) / 8 * 8), ny), dim3(128 * TG), lds, st>>>(a, nullptr, 0, 0, gx);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1544,9 +1554,9 @@ static int launch_wino(const SlicConvArgs& a, hipStream_t st, int splits = 1, fl
 // Workgroup shape: 256 threads (TG = 2).  The 512-thread form (TG = 4: one workgroup per CU, the U stage fetched once per 128
 // tiles — a quarter less L2 -> LDS traffic) measured no faster at the layer1 shape (218.7 against 220.2 effective TFLOP/s) and slower
 // at layer2's (188 against 213: the barrier then spans eight waves); it is not instantiated.
-static int launch_wino_pick(const SlicConvArgs& a, hipStream_t st, int splits, float* slab) {
-  if (a.Ws % 4 != 0) return launch_wino<3, true, 2>(a, st, splits, slab);
-  return launch_wino<3, false, 2>(a, st, splits, slab);
+static int launch_wino_pick(const SlicConvArgs& a, hipStream_t st, int splits, float* slab, int nfull = 0) {
+  if (a.Ws % 4 != 0) return launch_wino<3, true, 2>(a, st, splits, slab, 0);
+  return launch_wino<3, false, 2>(a, st, splits, slab, nfull);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1989,7 +1999,10 @@ extern "C" int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant
 
 extern "C" size_t slic_conv_gemm_tailsplit_workspace_bytes(const SlicConvArgs* a, int variant, int nfull_rb, int splits) {
   if (!a || splits < 1 || nfull_rb < 0) return 0;
-  if (variant == 30) return slic_align_up((size_t)splits * a->M * a->N * sizeof(float), 256);      // plain split-K: whole outputs per piece
+  if (variant == 30) {                                         // pieces hold whole outputs of the rows behind the first nfull_rb 64-tile blocks
+    const int64_t row0 = a->Ws % 4 == 0 ? (int64_t)nfull_rb * 256 : 0;
+    return row0 < a->M ? slic_align_up((size_t)splits * (a->M - row0) * a->N * sizeof(float), 256) : 0;
+  }
   const int BM = variant == 22 ? 128 : 64;
   const int64_t tail_rb = slic_cdiv(a->M, BM) - nfull_rb;
   if (tail_rb <= 0) return 0;
@@ -2003,15 +2016,19 @@ extern "C" int slic_conv_gemm_tailsplit(const SlicConvArgs* a, int variant, int 
     // Winograd with the K loop (the 9 x Cs / 8 stages) cut `splits` ways: the few-tile layers (layer4 at B = 32: 112 workgroups of
     // 576 stages).  Pieces write transformed outputs to workspace[piece][M][N]; the finish pass adds them in piece order and runs
     // the epilogue with slab rows of 128 GEMM rows (also on a ragged width).
-    if (splits <= 1) return slic_conv_gemm(a, variant, stream);
-    SLIC_REQUIRE(nfull_rb == 0 && workspace, "slic_conv_gemm_tailsplit: variant 30 is plain split-K (nfull_rb = 0)");
+    // nfull_rb > 0 (widths that are multiples of 4): the first nfull_rb 64-tile blocks — the launch's full dispatch rounds — run whole,
+    // only the blocks behind them cut their K loop (layer2 at B = 32: 1568 workgroups on 512 slots, 218 -> 236 TFLOP/s without the tail)
+    const int64_t gx = slic_cdiv((a->M / a->Ws) * ((a->Ws + 3) / 4), 64);
+    if (splits <= 1 || nfull_rb >= gx) return slic_conv_gemm(a, variant, stream);
+    SLIC_REQUIRE(nfull_rb >= 0 && workspace && (nfull_rb == 0 || a->Ws % 4 == 0),
+                 "slic_conv_gemm_tailsplit: variant 30: whole blocks in front of the split need a width that is a multiple of 4");
     SLIC_REQUIRE(a->wgt && a->dst && a->Cs % 8 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
                      a->Gb == a->Hs && a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len && ((a->Cs / 8) & (a->Cs / 8 - 1)) == 0,
                  "slic_conv_gemm_tailsplit: variant 30 geometry (see slic_conv_gemm)");
     SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)9 * a->Cs * a->N * 6 * 4, "slic_conv_gemm_tailsplit: variant 30: wgt_bytes != 9 * Cs * N * 6 floats");
     SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                  "slic_conv_gemm_tailsplit: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
-    return launch_wino_pick(*a, S_(stream), splits, (float*)workspace);
+    return launch_wino_pick(*a, S_(stream), splits, (float*)workspace, nfull_rb);
   }
   SLIC_REQUIRE(variant == 20 || variant == 22, "slic_conv_gemm_tailsplit: variants 20, 22 (tail split) and 30 (split-K) only");
   const int BM = variant == 22 ? 128 : 64;

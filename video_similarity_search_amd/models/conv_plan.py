@@ -325,11 +325,23 @@ class ConvPlan:
             if os.environ.get("SLIC_WINO_SPLIT", "1") == "0":
                 return None
             Wd = a.Ws
-            wgs = ((a.M // Wd) * ((Wd + 3) // 4) + 63) // 64 * (a.N // 64)
+            gx, ny = ((a.M // Wd) * ((Wd + 3) // 4) + 63) // 64, a.N // 64
+            wgs = gx * ny
             ns = 9 * (a.Cs // 8)
-            if wgs >= int(os.environ.get("SLIC_WINO_MIN_WGS", cls.WINO_MIN_WGS)):
-                return None
             forced = os.environ.get("SLIC_WINO_SPLIT", "1")
+            if wgs >= int(os.environ.get("SLIC_WINO_MIN_WGS", cls.WINO_MIN_WGS)):
+                # More than a round: a partly filled LAST dispatch round costs most of a round's time (layer2 at B = 32: 1568
+                # workgroups on 512 slots = 3.06 rounds, 218 / 224 TFLOP/s against 236 / 237 at B = 31's 2.97 rounds).  The blocks
+                # of the full rounds run whole; the few behind them cut their K loop so that they fill the slots once more.
+                # Widths that are multiples of 4 (four GEMM rows per tile: the tail is a whole number of 128-row blocks).
+                # Pieces of >= 36 stages (layer2: 4 x 36, 231 / 234; 6 x 24 and 3 x 48 gained less); launches of many rounds are
+                # left alone (layer1: 12.25 rounds — cutting its 72-stage K loop cost the data gradient 3 %).
+                rem = wgs % 512
+                if forced == "0" or os.environ.get("SLIC_WINO_TAIL", "1") == "0" or Wd % 4 or rem == 0 or rem > 256 or wgs > 6 * 512:
+                    return None
+                tail_x = -(-rem // ny)
+                s = min(512 // (tail_x * ny), ns // int(os.environ.get("SLIC_WINO_TAIL_MIN", "36")))
+                return (gx - tail_x, s) if s >= 2 else None
             s = int(forced) if forced not in ("0", "1") else min(512 // wgs, ns // 48)
             return (0, s) if s >= 2 else None
         if variant not in (20, 22) or os.environ.get("SLIC_CONV_TAIL", "1") == "0":
@@ -454,7 +466,7 @@ class ConvPlan:
     @staticmethod
     def _wino_wgrad_slices(blocks, mt):
         """tile slices of the transposed-Winograd weight gradient: `blocks` = 9 (kt, kh) x 64 x 64 blocks, `mt` W-tiles.
-        Up to 512 blocks: ~2 residency rounds of the 512 slots (2 workgroups / CU), at least 64 tiles per slice.  More blocks than
+        Up to 512 blocks: one or two residency rounds of the 512 slots (2 workgroups / CU), at least 64 tiles per slice.  More blocks than
         slots (layer4: 576 = one round and an eighth): each slice costs a 6-point slab of 2 x the weight's size to write and re-read,
         so only 1-3 slices are weighed — how full the rounds are x the main loop's share of a workgroup's time, less the slab traffic
         (measured at layer4, B = 32: 1 slice 128 TFLOP/s, 2 143, 3 144, 4 131, 7 106; scripts/r3/ab_split.sh)."""
@@ -462,7 +474,10 @@ class ConvPlan:
         if forced is not None:
             return max(1, min(int(forced) // blocks, mt // 64))
         if blocks <= 512:
-            return max(1, min(1024 // blocks, mt // 64))
+            # ONE residency round when the slices fill it (layer1: 9 blocks x 56 slices = 504 workgroups, layer2: 36 x 14 — half the
+            # slab traffic of two rounds, +1-2 %), else two (layer3: 144 x 7 = 1008; one round would be 3 slices = 432, 170 against 191)
+            one = 512 // blocks
+            return max(1, min(one if one * blocks >= 486 else 1024 // blocks, mt // 64))
         best, best_score = 1, -1.0
         for s in (1, 2, 3):
             if mt // s < 64:
