@@ -326,6 +326,12 @@ def main():
         # the job aborts after five minutes instead of hanging (the headline line is printed before the secondary rows start)
         torch.distributed.init_process_group(backend="nccl", timeout=datetime.timedelta(minutes=5))
         pg = torch.distributed.group.WORLD
+        if world > 1:
+            # The sharded k-means row's ONE all-reduce per iteration: through torch's RCCL process group, whose collectives carry
+            # the timeout above — the library's own communicator (slic_allreduce_f64, include/slic_hip.h) has run on hardware on
+            # one-rank groups only (1-GPU boxes), and a collective of its own that waits for a lost peer would hang the whole run.
+            # SLIC_KMEANS_COMM=slic selects it.
+            os.environ.setdefault("SLIC_KMEANS_COMM", "torch")
 
     from video_similarity_search_amd import _lib
     _lib.check(_lib.load().slic_device_check(), "slic_device_check")
