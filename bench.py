@@ -341,7 +341,9 @@ def main():
     model = model.cuda().train()
     net = model
     if use_dist:
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+        ddp_kw = dict(gradient_as_bucket_view=os.environ.get("SLIC_DDP_BUCKET_VIEW", "1") != "0",
+                      bucket_cap_mb=int(os.environ.get("SLIC_DDP_BUCKET_MB", "25")))
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], **ddp_kw)
     crit = OnlineTripletLoss(0.2, 'cosine')
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.5)
     B = args.batch
