@@ -1,0 +1,29 @@
+"""where the reference-shaped KMeans(n_init=10) call spends its wall time (GPU box): synchronised phase timers"""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np, torch
+from video_similarity_search_amd.clustering import fit_cluster
+from video_similarity_search_amd.clustering import kmeans_hip as kh
+N, D, K = 100000, 512, 500
+rng = np.random.default_rng(1)
+cent = rng.standard_normal((K, D)); cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+X = (cent[rng.integers(0, K, N)] + 0.35 * rng.standard_normal((N, D)) / np.sqrt(D)).astype(np.float32)
+Xd = torch.from_numpy(X).cuda()
+acc = {}
+def timed(name, fn):
+    def w(*a, **k):
+        torch.cuda.synchronize(); t0 = time.time()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); acc[name] = acc.get(name, 0.0) + time.time() - t0
+        return r
+    return w
+for name in ("_kmeans_plusplus_all", "_lloyd_single", "_col_stats", "_permuted", "_row_norms", "_relocate", "_inertia"):
+    if hasattr(kh.KMeans, name):
+        setattr(kh.KMeans, name, timed(name, getattr(kh.KMeans, name)))
+np.random.seed(1)
+fit_cluster(Xd, 'kmeans', k=K, l2normalize=True, n_init=1)
+acc.clear()
+torch.cuda.synchronize(); t0 = time.time()
+fit_cluster(Xd, 'kmeans', k=K, l2normalize=True, n_init=10)
+torch.cuda.synchronize()
+print("wall", round(time.time() - t0, 4), {k: round(v, 4) for k, v in acc.items()}, "relocations", fit_cluster.last_model.n_relocations_)

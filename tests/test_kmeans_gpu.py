@@ -210,6 +210,27 @@ def test_kmeanspp_helpers(gpu):
     assert np.all(np.abs(got - exp) <= 1), (got, exp)      # chunked double sums vs np.cumsum: boundary +-1
 
 
+@pytest.mark.parametrize("N,D,K,R", [(6000, 64, 24, 4), (20000, 128, 100, 10), (30000, 512, 500, 10), (3000, 32, 6, 3)])
+def test_kmeanspp_batch_equals_sequential(gpu, monkeypatch, N, D, K, R):
+    """KMeans(n_init = R): the R k-means++ seedings taken in lock-step (slic_kmeanspp_run_batch: one pass over X per centre for all
+    runs, 1-3 MFMA row tiles of candidates) pick exactly the rows the run-by-run loop picks from the same RNG stream, and the fit
+    ends on the same labels, centres and inertia"""
+    from video_similarity_search_amd.clustering import KMeans
+    rng = np.random.default_rng(N + K)
+    cen = rng.standard_normal((K, D)).astype(np.float32)
+    X = (cen[rng.integers(0, K, N)] + 0.7 * rng.standard_normal((N, D))).astype(np.float32)
+    Xd = torch.from_numpy(X).cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SLIC_KPP_BATCH", mode)
+        km = KMeans(n_clusters=K, n_init=R, max_iter=5, random_state=3).fit(Xd)
+        res[mode] = (np.stack(km.init_indices_log_), km.labels_.copy(), km.cluster_centers_.copy(), km.inertia_)
+    assert res["1"][0].shape == (R, K)
+    assert np.array_equal(res["1"][0], res["0"][0])
+    assert len(set(map(tuple, res["1"][0]))) == R                    # the runs differ from each other (one stream, not R copies)
+    assert np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["1"][2], res["0"][2]) and res["1"][3] == res["0"][3]
+
+
 @pytest.mark.parametrize("N,D,K", [(6000, 64, 24), (1000, 40, 8), (333, 8, 5)])
 def test_kmeanspp_run_matches_stepwise(gpu, N, D, K):
     """the single-sequence k-means++ (slic_kmeanspp_run) picks the rows the stepwise host loop picks from the same

@@ -48,6 +48,8 @@ SIGNATURES = {
     "slic_l2norm_rows": (I, [P, L, I, I, P, I, P]),
     "slic_kmeanspp_run_workspace_bytes": (c_size_t, [L, I]),
     "slic_kmeanspp_run": (I, [P, L, I, I, I, I, I, P, P, P, P, P, P]),
+    "slic_kmeanspp_run_batch_workspace_bytes": (c_size_t, [L, I, I]),
+    "slic_kmeanspp_run_batch": (I, [P, P, L, I, I, I, P, I, I, P, P, P, P]),
     "slic_kmeanspp_step_workspace_bytes": (c_size_t, [L, I]),
     "slic_kmeanspp_step": (I, [P, L, I, I, P, I, P, P, P, P, P]),
     "slic_cumsum_search_workspace_bytes": (c_size_t, [L]),

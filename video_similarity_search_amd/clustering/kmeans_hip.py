@@ -120,6 +120,16 @@ class HipKernels:
         call("slic_kmeanspp_run", ptr(X), N, Dp, X.stride(0), int(first), int(K), int(T), ptr(uniforms), ptr(idx_out),
              ptr(Xp), ptr(xnorm), ptr(ws), stream())
 
+    def kpp_run_batch(self, Xp, xnorm, firsts, K, T, uniforms, idx_out):
+        """all R = len(firsts) initialisations of an n_init loop in lock-step (slic_kmeanspp_run_batch)"""
+        import ctypes
+        N, Dp = Xp.shape
+        R = len(firsts)
+        arr = (ctypes.c_int32 * R)(*[int(f) for f in firsts])
+        ws = _lib.workspace(_lib.load().slic_kmeanspp_run_batch_workspace_bytes(N, T, R), Xp.device, "kpp_batch")
+        call("slic_kmeanspp_run_batch", ptr(Xp), ptr(xnorm), N, Dp, Xp.stride(0), R, arr, int(K), int(T), ptr(uniforms), ptr(idx_out),
+             ptr(ws), stream())
+
     def accumulate(self, X, labels, K, sums, counts):
         N, Dp = X.shape
         ws = _lib.workspace(_lib.load().slic_kmeans_accumulate_workspace_bytes(N, K), X.device, "km_accum")
@@ -220,11 +230,14 @@ class KMeans:
 
     # ------------------------------------------------------------------ helpers
     def _rng(self):
+        """check_random_state(self.random_state), ONCE per fit (KMeans.fit, _kmeans.py:1467: the n_init runs share the stream)"""
         rs = self.random_state
         if rs is None:
             return np.random.mtrand._rand     # sklearn check_random_state(None): numpy's global RandomState
         if isinstance(rs, (int, np.integer)):
-            return np.random.RandomState(rs)
+            if getattr(self, "_fit_rs", None) is None:
+                self._fit_rs = np.random.RandomState(rs)
+            return self._fit_rs
         return rs
 
     def _gather(self, t):
@@ -247,6 +260,8 @@ class KMeans:
 
     # ------------------------------------------------------------------ fit
     def fit(self, X):
+        self._fit_rs = None
+        self.init_indices_log_ = []
         self.k.check()
         X = self.k.to_device(X)
         N, D = X.shape
@@ -305,8 +320,11 @@ class KMeans:
         n_runs = self.n_init if inits is None else len(inits)
 
         best = None
+        seeded = self._kmeans_plusplus_all(Xc, K, n_runs) if (inits is None and n_runs > 1) else None
         for run in range(n_runs):
-            if inits is None:
+            if seeded is not None:
+                C0 = seeded[run]
+            elif inits is None:
                 C0 = self._kmeans_plusplus(Xc, K)          # rows of the centred matrix
             else:
                 c = np.zeros((K, Dp), np.float32)
@@ -563,6 +581,33 @@ class KMeans:
         return True
 
     # ------------------------------------------------------------------ k-means++
+    def _kmeans_plusplus_all(self, Xc, K, R):
+        """the k-means++ seeding of ALL R initialisations of the n_init loop at once, or None when the lock-step kernel does not
+        apply (then the loop seeds run by run).  sklearn's loop draws, per run, the first row and then (K - 1) x T uniforms from
+        ONE RNG stream; neither depends on the data, and Lloyd draws nothing, so the draws are made here in that order and the R
+        runs — independent of each other from then on — take each step as one pass over X (slic_kmeanspp_run_batch)."""
+        k = self.k
+        T = 2 + int(np.log(K))
+        if (self._sharded or not hasattr(k, "kpp_run_batch") or not getattr(k, "uses_perm", False) or T > 16 or R * T > 160
+                or os.environ.get("SLIC_KPP_BATCH", "1") == "0"):
+            return None
+        N, Dp = Xc.shape
+        if N * Xc.stride(0) * 4 >= (1 << 31):
+            return None
+        dev = Xc.device
+        rs = self._rng()
+        firsts, us = [], []
+        for _ in range(R):
+            firsts.append(int(rs.choice(N, p=np.full(N, 1.0 / N))))
+            us.append(rs.uniform(size=(K - 1, T)) if K > 1 else np.zeros((0, T)))
+        ud = torch.from_numpy(np.ascontiguousarray(np.stack(us, 0), dtype=np.float64)).to(dev)
+        idx_d = torch.empty(R, K, dtype=torch.int32, device=dev)
+        k.kpp_run_batch(self._permuted(Xc), self._row_norms(Xc), firsts, K, T, ud, idx_d)
+        ih = idx_d.cpu().numpy().astype(np.int64)
+        self.init_indices_log_ = [ih[r] for r in range(R)]          # every run's picks (the sequential loop appends run by run)
+        self.init_indices_ = ih[-1]
+        return [Xc.index_select(0, idx_d[r].long()).contiguous() for r in range(R)]
+
     def _kmeans_plusplus(self, Xc, K):
         """_kmeans_plusplus (_kmeans.py:174-277): RNG draws on the host from numpy's legacy RandomState (as
         sklearn), distances / potentials / cumsum-search on the device.  In sharded runs every rank seeds on the
@@ -612,6 +657,7 @@ class KMeans:
                 xn = self._row_norms(Xs)
             k.kpp_run(Xs, first, K, T, ud, idx_d, Xp, xn)
             self.init_indices_ = idx_d.cpu().numpy().astype(np.int64)
+            self.init_indices_log_.append(self.init_indices_)
             return Xs.index_select(0, idx_d.long()).contiguous()
         idx[0] = first
         cand[0] = first
@@ -628,4 +674,5 @@ class KMeans:
             closest.copy_(newdist[b])
             idx[c] = int(cand[b].item())
         self.init_indices_ = idx
+        self.init_indices_log_.append(idx)
         return Xs.index_select(0, torch.from_numpy(idx).to(dev)).contiguous()

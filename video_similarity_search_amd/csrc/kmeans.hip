@@ -1632,6 +1632,190 @@ __global__ void kpp_search(const float* __restrict__ prev, const int32_t* __rest
   if (lane == 0) idx[t] = (int32_t)res;
 }
 
+// ---- the R initialisations of KMeans(n_init = R) side by side ---------------------------------------------------------------
+// sklearn runs them one after the other, but the only thing they share is the RNG stream, and k-means++'s draws do not depend on
+// the data: with the uniforms drawn up front (in the order the sequential loop draws them) the R runs are independent.  Step c of
+// ALL of them is then ONE pass over X — R x T candidate rows as NG tiles of 32 MFMA rows per workgroup instead of one pass per
+// run (the single-run pass is HBM-bound at T = 8 rows: 46 us per centre and run) — and one selection launch of R workgroups.
+// Row q = r * T + t of the candidate matrix belongs to run r; every run keeps its own closest-distance arrays, potentials,
+// chunk sums and picks, with exactly the arithmetic (and order) of the single-run kernels above: the results are bit-identical.
+template <int NG>
+__global__ __launch_bounds__(256) void kpp_dist_mfma_batch(const float* __restrict__ Xp, const float* __restrict__ xnorm, int64_t N,
+                                                           int D, int ldx, const int32_t* __restrict__ cand, int RT, int T, int Tprev,
+                                                           const float* __restrict__ prev, const int32_t* __restrict__ sel,
+                                                           float* __restrict__ newdist, double* __restrict__ bpart, int64_t nchunk) {
+  extern __shared__ __attribute__((aligned(16))) float km_lds[];
+  constexpr int BP = 128, CR = 32 * NG;
+  constexpr int STAGE_FLOATS = (BP + CR) * KM_BK;
+  __shared__ float cn[CR];
+  __shared__ double wp[4][CR];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t pblock = (int64_t)blockIdx.x * BP;
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);
+  const int64_t xrows = (N - pblock) < BP ? (N - pblock) : BP;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(Xp + pblock * (int64_t)ldx), 0, (int)(((xrows - 1) * (int64_t)ldx + D) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)Xp, 0, (int)(((N - 1) * (int64_t)ldx + D) * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned xoff[4], coff[NG];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xoff[i] = (srow + 32 * i) < xrows ? ((unsigned)(srow + 32 * i) * (unsigned)ldx + cq * 4) * 4u : OOB;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) coff[g] = (srow + 32 * g) < RT ? ((unsigned)cand[srow + 32 * g] * (unsigned)ldx + cq * 4) * 4u : OOB;
+  for (int q = tid; q < CR; q += 256) cn[q] = q < RT ? xnorm[cand[q]] : 0.f;
+  const int klim = D - cq * 4;
+  const int nk = (D + KM_BK - 1) / KM_BK;
+  auto issue = [&](int kt, int stage) {
+    float* Xs = km_lds + stage * STAGE_FLOATS;
+    float* Cs = Xs + BP * KM_BK;
+    const bool kin = kt * KM_BK < klim;
+    const unsigned kb = (unsigned)kt * (KM_BK * 4u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(Xs + (8 * wave + 32 * i) * KM_BK),
+                                               16, (int)((kin && xoff[i] != OOB) ? xoff[i] + kb : OOB), 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (__attribute__((address_space(3))) void*)(Cs + (8 * wave + 32 * g) * KM_BK),
+                                               16, (int)((kin && coff[g] != OOB) ? coff[g] + kb : OOB), 0, 0, 0);
+  };
+  f32x16 acc[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[g][v] = 0.f;
+  const int r = lane & 31, h = lane >> 5;
+  issue(0, 0);
+  for (int s0 = 0; s0 < nk; s0 += 2) {
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue(s0 + sidx + 1, sidx ^ 1);
+      const float* Xs = km_lds + sidx * STAGE_FLOATS;
+      const float* Cs = Xs + BP * KM_BK;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *(const f32x4*)&Xs[km_off(32 * wave + r, 2 * q + h)];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const f32x4 a = *(const f32x4*)&Cs[km_off(32 * g + r, 2 * q + h)];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int64_t i = pblock + 32 * wave + r;
+  const bool iv = i < N;
+  const float xn = iv ? xnorm[i] : 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int q = 32 * g + (e & 3) + 8 * (e >> 2) + 4 * h;      // candidate row held in accumulator element e of this lane half
+      if (q < RT) {                                               // uniform per (g, e, h)
+        const int run = q / T;
+        const float cl = (prev && iv) ? prev[((int64_t)run * Tprev + sel[run]) * N + i] : INFINITY;
+        const float d = fmaxf(xn + cn[q] - 2.0f * acc[g][e], 0.f);
+        const float m = fminf(d, cl);
+        if (iv) newdist[(int64_t)q * N + i] = m;
+        double v = iv ? (double)m : 0.0;
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);     // over the 32 points of this wave (the lane half keeps its row)
+        if (r == 0) wp[wave][q] = v;
+      }
+    }
+  __syncthreads();
+  for (int q = tid; q < RT; q += 256) {
+    const int64_t c0 = (int64_t)blockIdx.x * 2;
+    bpart[c0 * RT + q] = wp[0][q] + wp[1][q];
+    if (c0 + 1 < nchunk) bpart[(c0 + 1) * RT + q] = wp[2][q] + wp[3][q];
+  }
+}
+
+// kpp_select for run r = blockIdx.x: its T columns of bpart (row stride RT), its sel / potential / chunk sums / candidates / picks
+__global__ __launch_bounds__(KPP_ST) void kpp_select_batch(const double* __restrict__ bpart_all, int64_t nblk, int T, int RT, int Tn,
+                                                           const int32_t* __restrict__ cand_all, int32_t* __restrict__ cand_next_all,
+                                                           int32_t* __restrict__ sel_all,
+                                                           double* __restrict__ pot_all, double* csum_all,
+                                                           int32_t* __restrict__ idx_out_all, int idx_stride,
+                                                           const float* __restrict__ nd_cur_all, int64_t N,
+                                                           const double* __restrict__ u_next_all, int64_t u_stride) {
+  __shared__ double pots[PP_TMAX];
+  __shared__ double wtot[KPP_ST / 64];
+  __shared__ int s_sel;
+  const int run_id = blockIdx.x;
+  const double* bpart = bpart_all + (int64_t)run_id * T;                 // column base; rows are RT apart
+  const int32_t* cand = cand_all + (int64_t)run_id * T;                  // this step's candidates (T per run)
+  int32_t* cand_next = cand_next_all + (int64_t)run_id * Tn;             // the next step's (Tn per run), in the other buffer: the runs' workgroups are concurrent
+  double* csum = csum_all + (int64_t)run_id * nblk;
+  const float* nd_cur = nd_cur_all + (int64_t)run_id * T * N;
+  const double* u_next = u_next_all ? u_next_all + (int64_t)run_id * u_stride : nullptr;
+  const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
+  if (wave < T) {
+    double a = 0.0;
+    for (int64_t b = lane; b < nblk; b += 64) a += bpart[b * RT + wave];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) pots[wave] = a;
+  }
+  __syncthreads();
+  if (i == 0) {
+    int b = 0;
+    for (int t = 1; t < T; ++t) if (pots[t] < pots[b]) b = t;          // np.argmin: first minimum
+    s_sel = b;
+    sel_all[run_id] = b;
+    pot_all[run_id] = pots[b];
+    idx_out_all[(int64_t)run_id * idx_stride] = cand[b];
+  }
+  __syncthreads();
+  const int b = s_sel;
+  const int64_t per = (nblk + KPP_ST - 1) / KPP_ST;
+  const int64_t c0 = (int64_t)i * per, c1 = c0 + per < nblk ? c0 + per : nblk;
+  double run = 0.0;
+  for (int64_t c = c0; c < c1; ++c) run += bpart[c * RT + b];
+  double inc = run;
+  for (int d = 1; d < 64; d <<= 1) {
+    const double u = __shfl_up(inc, d);
+    if (lane >= d) inc += u;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  double woff = 0.0;
+  for (int w = 0; w < wave; ++w) woff += wtot[w];
+  double a = woff + inc - run;
+  for (int64_t c = c0; c < c1; ++c) { a += bpart[c * RT + b]; csum[c] = a; }
+  if (!u_next) return;
+  __syncthreads();
+  if (wave >= Tn) return;
+  const float* v = nd_cur + (int64_t)b * N;
+  const double x = u_next[wave] * pots[b];
+  int64_t lo = 0, hi = nblk;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (csum[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  int64_t res = N;
+  if (lo < nblk) {
+    const double base = lo ? csum[lo - 1] : 0.0;
+    const int64_t e = lo * KPP_CH + lane;
+    const double part = e < N ? (double)v[e] : 0.0;
+    double runs = base, incl = 0.0;
+    for (int l = 0; l < 64; ++l) {
+      runs += __shfl(part, l);
+      if (l == lane) incl = runs;
+    }
+    const unsigned long long m = __ballot(incl >= x && e < N);
+    res = m ? lo * KPP_CH + (__ffsll((long long)m) - 1) : ((lo + 1) * KPP_CH < N ? (lo + 1) * KPP_CH : N);
+  }
+  if (res > N - 1) res = N - 1;
+  if (lane == 0) cand_next[wave] = (int32_t)res;
+}
+
 // ------------------------------------ C ABI ------------------------------------------------
 static inline hipStream_t S(void* s) { return (hipStream_t)s; }
 
@@ -2108,6 +2292,80 @@ extern "C" int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int 
     kpp_select<<<dim3(1), dim3(KPP_ST), 0, st>>>(bpart, nblk, T, cand, sel, cur_pot, csum, idx_out + c, cur, N,
                                                  c + 1 < K ? uniforms + (size_t)c * T : nullptr, T);
     SLIC_LAUNCH_CHECK();
+  }
+  return SLIC_OK;
+}
+
+// All R initialisations of KMeans(n_init = R) in lock-step (kpp_dist_mfma_batch / kpp_select_batch above): firsts[r] = run r's
+// uniformly drawn first row, uniforms [R][K - 1][T] (host-drawn in the sequential loop's order), idx_out [R][K].
+// Needs the k-permuted copy and the row norms (the matrix-pipe distance kernel); R * T <= 160.
+extern "C" size_t slic_kmeanspp_run_batch_workspace_bytes(int64_t N, int T, int R) {
+  const int64_t nblk = slic_cdiv(N, KPP_CH);
+  return slic_align_up((size_t)2 * R * T * N * 4, 256) + slic_align_up((size_t)nblk * R * T * 8, 256) +
+         slic_align_up((size_t)R * nblk * 8, 256) + slic_align_up((size_t)R * 8, 256) + 2 * slic_align_up((size_t)R * T * 4, 256) +
+         slic_align_up((size_t)R * 4, 256);
+}
+
+extern "C" int slic_kmeanspp_run_batch(const float* Xp, const float* xnorm, int64_t N, int D, int ldx, int R, const int32_t* firsts,
+                                       int K, int T, const double* uniforms, int32_t* idx_out, void* workspace, void* stream) {
+  SLIC_REQUIRE(Xp && xnorm && firsts && uniforms && idx_out && workspace, "slic_kmeanspp_run_batch: null pointer");
+  SLIC_REQUIRE(N > 0 && K > 0 && K <= N && R >= 1 && T >= 1 && T <= PP_TMAX && R * T <= 160 && D % 8 == 0 && ldx % 4 == 0 &&
+               (int64_t)N * ldx * 4 < (1ll << 31), "slic_kmeanspp_run_batch: need 1 <= T <= %d, R * T <= 160, D %% 8 == 0, N * ldx * 4 < 2 GiB", PP_TMAX);
+  for (int r = 0; r < R; ++r) SLIC_REQUIRE(firsts[r] >= 0 && firsts[r] < N, "slic_kmeanspp_run_batch: firsts[%d] out of range", r);
+  hipStream_t st = S(stream);
+  const int64_t nblk = slic_cdiv(N, KPP_CH);
+  SlicCarver w(workspace);
+  float* nd = w.take<float>((size_t)2 * R * T * N);
+  double* bpart = w.take<double>((size_t)nblk * R * T);
+  double* csum = w.take<double>((size_t)R * nblk);
+  double* pot = w.take<double>(R);
+  int32_t* candA = w.take<int32_t>((size_t)R * T);
+  int32_t* candB = w.take<int32_t>((size_t)R * T);
+  int32_t* sel = w.take<int32_t>(R);
+  const unsigned nblk_m = (unsigned)slic_cdiv(N, 128);
+  auto dist = [&](int RT, int Tc, int Tprev, const int32_t* cand, const float* prev, float* cur) -> int {
+    const int ng = (RT + 31) / 32;
+    const size_t lds = (size_t)2 * (128 + 32 * ng) * KM_BK * sizeof(float);
+#define KPP_BATCH(NG)                                                                                                              \
+    {                                                                                                                              \
+      static bool attr_set = false;                                                                                                \
+      if (!attr_set) {                                                                                                             \
+        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)kpp_dist_mfma_batch<NG>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                           (int)((size_t)2 * (128 + 32 * NG) * KM_BK * sizeof(float))));                           \
+        attr_set = true;                                                                                                           \
+      }                                                                                                                            \
+      kpp_dist_mfma_batch<NG><<<dim3(nblk_m), dim3(256), lds, st>>>(Xp, xnorm, N, D, ldx, cand, RT, Tc, Tprev, prev, sel, cur,     \
+                                                                   bpart, nblk);                                                   \
+    }
+    switch (ng) {
+      case 1: KPP_BATCH(1) break;
+      case 2: KPP_BATCH(2) break;
+      case 3: KPP_BATCH(3) break;
+      case 4: KPP_BATCH(4) break;
+      default: KPP_BATCH(5) break;
+    }
+#undef KPP_BATCH
+    SLIC_LAUNCH_CHECK();
+    return SLIC_OK;
+  };
+  // centre 0 of every run: one candidate each (the uniformly drawn row), no closest yet
+  SLIC_HIP_CHECK(hipMemcpyAsync(candA, firsts, (size_t)R * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  int rc = dist(R, 1, 1, candA, nullptr, nd);
+  if (rc) return rc;
+  const int64_t ustride = (int64_t)(K - 1) * T;
+  kpp_select_batch<<<dim3(R), dim3(KPP_ST), 0, st>>>(bpart, nblk, 1, R, T, candA, candB, sel, pot, csum, idx_out, K, nd, N,
+                                                     K > 1 ? uniforms : nullptr, ustride);
+  SLIC_LAUNCH_CHECK();
+  int32_t *cc = candB, *cn2 = candA;
+  for (int c = 1; c < K; ++c) {
+    const float* prev = nd + (size_t)((c - 1) & 1) * R * T * N;
+    float* cur = nd + (size_t)(c & 1) * R * T * N;
+    rc = dist(R * T, T, c == 1 ? 1 : T, cc, prev, cur);
+    if (rc) return rc;
+    kpp_select_batch<<<dim3(R), dim3(KPP_ST), 0, st>>>(bpart, nblk, T, R * T, T, cc, cn2, sel, pot, csum, idx_out + c, K, cur, N,
+                                                       c + 1 < K ? uniforms + (size_t)c * T : nullptr, ustride);
+    SLIC_LAUNCH_CHECK();
+    int32_t* t = cc; cc = cn2; cn2 = t;
   }
   return SLIC_OK;
 }
