@@ -194,7 +194,9 @@ size_t slic_kmeanspp_run_workspace_bytes(int64_t N, int T);
 int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int first, int K, int T, const double* uniforms,
                       int32_t* idx_out,
                       const float* Xp /* optional: slic_kmeans_permute_k8(X), same ldx */,
-                      const float* xnorm /* optional: [N] squared row norms;
+                      const float* xnorm /* optional: [N] squared row norms; with Xp the distances run on the matrix
+                                            pipe as |x|^2 + |c|^2 - 2 x.c (sklearn's euclidean_distances form) */,
+                      void* workspace, void* stream);
 /* The R initialisations of KMeans(n_init = R) (the n_init loop of KMeans.fit, _kmeans.py:1500-1530, as
  * clustering/cluster_masks.py:70-71 calls it) seeded in lock-step: firsts[r] (HOST array) = run r's first row, uniforms (device,
  * [R][K-1][T] doubles: the host RNG's draws in the order the sequential loop makes them), idx_out (device, [R][K]).  One pass
@@ -202,9 +204,7 @@ int slic_kmeanspp_run(const float* X, int64_t N, int D, int ldx, int first, int 
  * k-permuted copy (slic_kmeans_permute_k8), xnorm = its squared row norms; R * T <= 160. */
 size_t slic_kmeanspp_run_batch_workspace_bytes(int64_t N, int T, int R);
 int slic_kmeanspp_run_batch(const float* Xp, const float* xnorm, int64_t N, int D, int ldx, int R, const int32_t* firsts, int K, int T,
-                            const double* uniforms, int32_t* idx_out, void* workspace, void* stream); with Xp the distances run on the matrix
-                                            pipe as |x|^2 + |c|^2 - 2 x.c (sklearn's euclidean_distances form) */,
-                      void* workspace, void* stream);
+                            const double* uniforms, int32_t* idx_out, void* workspace, void* stream);
 
 /* inclusive prefix sum of v (float) in double, and searchsorted(cumsum, vals[t], 'left')
  * clipped to N-1  (stable_cumsum + np.searchsorted, _kmeans.py:243-248). */

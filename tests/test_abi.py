@@ -58,3 +58,17 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "libslic_oracle" in t:
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_header_is_valid_c():
+    """include/slic_hip.h compiles on its own as C11 (what a cgo / ctypes-gen / JNI binding would feed it to) — and a stray edit
+    inside a declaration cannot hide behind a library that was built before it"""
+    import os, shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([gcc, "-fsyntax-only", "-x", "c", "-std=c11", "-Wall", "-Werror=comment", os.path.join(root, "include", "slic_hip.h")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
