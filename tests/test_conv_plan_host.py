@@ -19,3 +19,36 @@ def test_plan_split_rules():
     assert ConvPlan._plan_split(args(25088, 256, 6912), 20) == (320, 4)
     assert ConvPlan._plan_split(args(3136, 512, 13824), 20) == (0, 3)
     assert ConvPlan._plan_split(args(3136, 512, 13824), 0) is None
+
+
+def test_winograd_split_rules(monkeypatch):
+    """host-side rules of the Winograd launches at R3D-18's shapes, B = 32 (models/conv_plan.py: _plan_split variant 30,
+    _wino_wgrad_slices): layer1 (12.25 dispatch rounds) is left alone, layer2 (3.06 rounds) runs three whole rounds and cuts the 16
+    tile blocks behind them 4 ways, layer3 (448 workgroups, under a round, ragged width) is left alone, layer4 (112 workgroups) cuts
+    its K loop into 4 even pieces; weight-gradient slices fill one round where they can (layers 1, 2), two otherwise (layer3), and
+    layer4's 576 blocks take 2 slices"""
+    for k in ("SLIC_WINO_SPLIT", "SLIC_WINO_TAIL", "SLIC_WINO_TAIL_MIN", "SLIC_WINO_MIN_WGS", "SLIC_WINO_WGRAD_WGS"):
+        monkeypatch.delenv(k, raising=False)
+
+    def args(M, W, N, C):
+        a = SlicConvArgs()
+        a.M, a.Ws, a.N, a.Cs = M, W, N, C
+        return a
+    B = 32
+    assert ConvPlan._plan_split(args(B * 16 * 56 * 56, 56, 64, 64), 30) is None
+    assert ConvPlan._plan_split(args(B * 8 * 28 * 28, 28, 128, 128), 30) == (768, 4)
+    assert ConvPlan._plan_split(args(B * 4 * 14 * 14, 14, 256, 256), 30) is None
+    assert ConvPlan._plan_split(args(B * 2 * 7 * 7, 7, 512, 512), 30) == (0, 4)
+    # a batch whose layer2 launch is two rounds and five workgroups: the three tile blocks behind the two rounds are cut
+    nfull, s = ConvPlan._plan_split(args(21 * 8 * 28 * 28, 28, 128, 128), 30)
+    assert nfull == 512 and 2 <= s <= 4
+    monkeypatch.setenv("SLIC_WINO_TAIL", "0")
+    assert ConvPlan._plan_split(args(B * 8 * 28 * 28, 28, 128, 128), 30) is None
+    monkeypatch.delenv("SLIC_WINO_TAIL")
+    monkeypatch.setenv("SLIC_WINO_SPLIT", "0")
+    assert ConvPlan._plan_split(args(B * 2 * 7 * 7, 7, 512, 512), 30) is None
+    monkeypatch.delenv("SLIC_WINO_SPLIT")
+    assert [ConvPlan._wino_wgrad_slices(b, mt) for b, mt in ((9, 401408), (36, 50176), (144, 7168), (576, 896))] == [56, 14, 7, 2]
+    assert ConvPlan._wino_wgrad_slices(9, 200) == 3            # never fewer than 64 tiles per slice
+    monkeypatch.setenv("SLIC_WINO_WGRAD_WGS", "1024")
+    assert ConvPlan._wino_wgrad_slices(9, 401408) == 113
