@@ -1227,7 +1227,8 @@ static __device__ __forceinline__ void wino_bt6(const f32x2 (&d)[6], f32x2 (&V)[
 }
 
 #ifndef SLIC_WINO_ABL
-#define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier
+#define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier, 4 = cache-resident input,
+                          // 8 = pre-transformed operand emulation (no transform, no validity VALU), 16 = with 8: record-contiguous operand layout
 #endif
 
 // TG = groups of 32 W-tiles per workgroup (two waves each, one per n half): 2 (256 threads, 2 workgroups / CU) or 4 (512 threads, ONE
@@ -1338,13 +1339,40 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
   };
   auto issue_piece = [&](const StageRec& q, int toff, int d) {
     if (d < 3) {
+#if SLIC_WINO_ABL & 8
+      // diagnostic build (wrong results, right timing): what a kernel reading a PRE-TRANSFORMED, zero-padded operand would issue —
+      // a per-lane constant offset + the stage's offset in the instruction's scalar operand, no vector instruction per piece.
+      // & 16: the operand laid out [row (b, t, h)][C / 8][W-tile][6 points][8 ch] (a stage's 64 tiles are whole 192-byte records,
+      // contiguous along a row) instead of today's 32-byte pieces at channel stride
+#if SLIC_WINO_ABL & 16
+      const unsigned qd = (unsigned)(d * NT + tid), tl_ = qd / 12u, within = qd % 12u;
+      const unsigned rowrel = (unsigned)(((tile0 % Wq) + tl_) / (unsigned)Wq), wt_ = (unsigned)(((tile0 % Wq) + tl_) % (unsigned)Wq);
+      const unsigned voff = ((rowrel * (unsigned)CCH) * (unsigned)Wq + wt_) * 192u + within * 16u;
+      const unsigned row0 = (unsigned)((tile0 / Wq) * 2 / 3);
+      const int tap9_ = q.tap == 9 ? 0 : q.tap;
+      const int kt_ = (tap9_ * 11) >> 5, kh_ = tap9_ - 3 * kt_;
+      const unsigned cc_ = (q.delta >> 5) & (unsigned)(CCH - 1);
+      const unsigned soff = (q.tap == 9) ? 0xFFFFFF00u : ((row0 + (unsigned)(kt_ * H + kh_)) * (unsigned)CCH + cc_) * (unsigned)Wq * 192u;
+#else
+      const unsigned voff = avalid[d] ? aoff[d] : 0u;
+      const unsigned soff = (q.tap == 9) ? 0xFFFFFF00u : q.delta + (unsigned)((H * W + W) * C * 4);
+#endif
 #if SLIC_WINO_ABL & 1
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * NT + wave * 64) * 4),
+                                               16, (int)(OOB + 0 * voff), (int)(0 * soff), 0, 0);
+#else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * NT + wave * 64) * 4),
+                                               16, (int)voff, (int)soff, 0, 0);
+#endif
+#elif SLIC_WINO_ABL & 1
       const unsigned off = OOB + 0 * (aoff[d] + q.delta);     // diagnostic build: DMAs issued, no memory traffic
 #else
       const unsigned off = (aoff[d] + q.delta) | (unsigned)__builtin_amdgcn_sbfe(inv9[d], q.tap, 1);
 #endif
+#if !(SLIC_WINO_ABL & 8)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * NT + wave * 64) * 4),
                                                16, (int)off, 0, 0, 0);
+#endif
     } else {
       const int i = d - 3;
 #if SLIC_WINO_ABL & 1
@@ -1412,11 +1440,16 @@ void conv_wino_kernel(const SlicConvArgs p, float* __restrict__ slab, const int 
       // consume it, closed by the two wait states.
       const f32x2 dl[6] = {{d0[0], d0[1]}, {d1[0], d1[1]}, {d2[0], d2[1]}, {d3[0], d3[1]}, {d4[0], d4[1]}, {d5[0], d5[1]}};
       const f32x2 dh[6] = {{d0[2], d0[3]}, {d1[2], d1[3]}, {d2[2], d2[3]}, {d3[2], d3[3]}, {d4[2], d4[3]}, {d5[2], d5[3]}};
+#if SLIC_WINO_ABL & 8
+#pragma unroll
+      for (int pp = 0; pp < 6; ++pp) { Vl[pp] = dl[pp]; Vh[pp] = dh[pp]; }
+#else
       __builtin_amdgcn_sched_barrier(0);
       wino_bt6(dl, Vl, c2, c4, c5);
       wino_bt6(dh, Vh, c2, c4, c5);
       asm volatile("s_nop 1" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+#endif
       const f32x4 b2 = *(const f32x4*)&St[bro + 2 * 512], b3 = *(const f32x4*)&St[bro + 3 * 512];
       mfma_pair(0, 1, b0, b1);
 #pragma unroll

@@ -62,10 +62,13 @@ class ConvPlan:
         Wp = (Wd + 3) // 4 * 4
         # forward / data gradient: a width that is not a multiple of 4 runs with a ragged last tile per row (padded width must
         # divide 128: 14 -> 16, 7 -> 8); a launch of few workgroups cuts its K loop across workgroups (_plan_split)
-        eligible = base and (Wd % 4 == 0 or 128 % Wp == 0)
+        # and the kernel's K loop addresses 8-channel stages with a shift: C / 8 (forward) and N / 8 (data gradient, whose source
+        # channels are N) must be powers of two — widths such as 192 or 384 (RESNET.WIDEN_FACTOR 1.5 / 3) stay on the direct kernels
+        pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
+        eligible = base and (Wd % 4 == 0 or 128 % Wp == 0) and pow2(self.C // 8) and pow2(self.N // 8)
         on = os.environ.get("SLIC_WINO", "1") != "0"
         self.wino = (eligible and on) if wino is None else bool(wino)
-        assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N multiples of 64, W % 4 == 0 or 4 ceil(W/4) | 128"
+        assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N 64 x a power of two, W % 4 == 0 or 4 ceil(W/4) | 128"
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
         self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
         self._wu = self._wud = None

@@ -776,6 +776,12 @@ def run_engine(eng, module, x):
         for si in range(eng.N_SEG):
             a = _SegmentFn.apply(a, eng, si, bool(module.training), *eng.seg_params(si))
         return a
+    if torch.is_grad_enabled() and x.requires_grad:
+        # a fully frozen encoder under an input that wants a gradient: the reference would back-propagate to the clip
+        # (models/resnet.py:255-312 is an ordinary autograd graph); the stem here has no data gradient — say so instead of
+        # handing back a graph-less tensor
+        raise _lib.SlicError("ResNet.forward: the input requires a gradient but no encoder parameter does; the stem has no data "
+                             "gradient on this path (detach the clip, or leave at least one parameter trainable)")
     with torch.no_grad():
         return eng.forward(x, training=module.training, save=False)[0]
 
