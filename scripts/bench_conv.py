@@ -57,4 +57,13 @@ for name, C, N, k, s, p, dims in SHAPES:
         line += f" dg {fl/t/1e9:6.1f}"
         t = timeit(lambda: wplan.wgrad(x, dz, B, dW))
         line += f" wg {fl/t/1e9:6.1f}"
+        try:
+            w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True)    # F(4,3) x F(2,3) over (W, H)
+            wu, wud = w2.pack_fwd(w), w2.pack_dgrad(w)
+            t = timeit(lambda: w2.forward(x, wu, B, want_stats=True))
+            line += f" | wino2 fwd {fl/t/1e9:6.1f}"
+            t = timeit(lambda: w2.dgrad(dz, wud, B))
+            line += f" dg {fl/t/1e9:6.1f}"
+        except AssertionError:
+            pass
     print(line, flush=True)

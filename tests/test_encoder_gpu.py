@@ -209,6 +209,77 @@ def test_conv_winograd_f43(gpu, C, N, B, dims):
     assert torch.allclose(z2, 2 * z, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("C,N,B,dims", [(64, 64, 2, (4, 8, 8)), (64, 64, 2, (3, 6, 12)), (128, 64, 3, (2, 10, 20)),
+                                        (64, 128, 2, (2, 4, 14)),        # ragged last tile of a row pair: ceil(14 / 4) = 4 | 64
+                                        (128, 64, 2, (2, 7, 7)),         # odd height and ragged width: 4 x 2 tiles per frame | 64
+                                        (64, 64, 1, (16, 56, 56)), (128, 128, 2, (3, 28, 28)), (256, 256, 2, (4, 14, 14))])
+def test_conv_winograd_2d(gpu, C, N, B, dims):
+    """slic_conv_gemm variant 31 — Winograd F(4, 3) along W x F(2, 3) along H (csrc/conv_wino2.hip) — forward and data gradient vs
+    fp64 F.conv3d at the one-dimensional kernel's tolerances, the fused epilogues (BatchNorm partials per block of 64 tiles; affine +
+    addend + ReLU; addend + mask + BatchNorm-backward sums), agreement with variant 30, run-to-run bit equality"""
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(C + N + dims[2] + 1)
+    k, s, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    x = torch.from_numpy(rng.standard_normal((B, C) + dims).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((N, C) + k) / np.sqrt(C * 27)).astype(np.float32))
+    x64, w64 = x.double().requires_grad_(True), w.double()
+    y64 = F.conv3d(x64, w64, None, s, p)
+    dy = torch.from_numpy(rng.standard_normal(tuple(y64.shape)).astype(np.float32))
+    gx64, = torch.autograd.grad(y64, [x64], dy.double())
+    w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True)
+    w1 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=False)
+    assert w2.wino2 and not w1.wino2
+    wd_ = w.cuda().contiguous()
+    xd = _ndhwc(x, C).cuda()
+    dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    tol = 2e-6 * np.sqrt(C * 27) + 1e-6
+    z, (part, rows) = w2.forward(xd, w2.pack_fwd(wd_), B, want_stats=True)
+    T, H, W = dims
+    Hq, Wq = (H + 1) // 2, (W + 3) // 4
+    assert rows == (512 if (H % 2 == 0 and W % 4 == 0) else (64 // Wq) * 2 * W if H % 2 == 0 else 64 // (Hq * Wq) * H * W)
+    got = z.cpu().permute(0, 4, 1, 2, 3)
+    assert (got - y64.float()).abs().max() <= tol * max(1.0, y64.abs().max().item())
+    z1, _ = w1.forward(xd, w1.pack_fwd(wd_), B)
+    assert (z - z1).abs().max().item() <= 2e-5 * max(1.0, y64.abs().max().item())
+    # BatchNorm partials: block r holds the outputs of tiles [64 r, 64 r + 64) — tiles count (b, t, h2, wt) with wt fastest
+    yv = y64.detach().permute(0, 2, 3, 4, 1)                   # [B, T, H, W, N]
+    tiles = [(b, t, h2, wt) for b in range(B) for t in range(T) for h2 in range(Hq) for wt in range(Wq)]
+    assert part.shape[0] == (len(tiles) + 63) // 64
+    for rr in range(part.shape[0]):
+        vals = [yv[b, t, h, 4 * wt:4 * wt + 4].reshape(-1, N) for (b, t, h2, wt) in tiles[64 * rr:64 * rr + 64]
+                for h in (2 * h2, 2 * h2 + 1) if h < H]
+        blk = torch.cat(vals, 0)
+        assert blk.shape[0] == min(rows, B * T * H * W - rr * rows)
+        assert torch.allclose(part[rr, 0].double().cpu(), blk.sum(0), atol=1e-4, rtol=1e-4)
+        assert torch.allclose(part[rr, 1].double().cpu(), ((blk - blk.mean(0)) ** 2).sum(0), atol=1e-4, rtol=1e-4)
+    # eval-mode epilogue: affine + addend + ReLU
+    sc, sh = [torch.from_numpy(rng.standard_normal(N).astype(np.float32)) for _ in range(2)]
+    res = torch.from_numpy(rng.standard_normal((B, N) + dims).astype(np.float32))
+    ref = F.relu(y64.detach() * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1) + res.double())
+    y, _ = w2.forward(xd, w2.pack_fwd(wd_), B, scale=sc.cuda(), shift=sh.cuda(), addend=_ndhwc(res, N).cuda(), relu=True)
+    assert (y.cpu().permute(0, 4, 1, 2, 3).double() - ref).abs().max() <= 4 * tol * max(1.0, ref.abs().max().item())
+    # data gradient, plain and with the fused mask + BatchNorm-backward sums
+    dx = w2.dgrad(dyd, w2.pack_dgrad(wd_), B)
+    assert (dx.cpu().permute(0, 4, 1, 2, 3) - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item())
+    assert torch.equal(dx, w2.dgrad(dyd, w2.pack_dgrad(wd_), B))
+    shp = (B,) + dims + (C,)
+    mask, zz, add = [torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda() for _ in range(3)]
+    mean = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda()
+    invstd = torch.from_numpy((0.5 + rng.random(C)).astype(np.float32)).cuda()
+    refg = w2.dgrad(dyd, w2.pack_dgrad(wd_), B, addend=add)
+    assert torch.allclose(refg, dx + add, atol=1e-6, rtol=0)
+    refg = torch.where(mask > 0, refg, torch.zeros_like(refg))
+    g, bpart = w2.dgrad(dyd, w2.pack_dgrad(wd_), B, addend=add, mask=mask, bwd=(zz, mean, invstd))
+    assert torch.equal(g, refg)
+    s1 = refg.double().reshape(-1, C).sum(0)
+    s2 = (refg.double() * ((zz.double() - mean.double()) * invstd.double())).reshape(-1, C).sum(0)
+    assert torch.allclose(bpart[:, 0].double().sum(0), s1, atol=2e-3, rtol=1e-4)
+    assert torch.allclose(bpart[:, 1].double().sum(0), s2, atol=2e-3, rtol=1e-4)
+    # the weight gradient of a two-dimensional plan is the transposed one-dimensional algorithm's
+    dW = w2.wgrad(xd, dyd, B, torch.empty_like(wd_))
+    assert torch.equal(dW, w1.wgrad(xd, dyd, B, torch.empty_like(wd_)))
+
+
 @pytest.mark.parametrize("variant,slots,want", [(20, 8, (4, 4)), (20, 64, (0, 6)), (22, 4, (2, 2)), (22, 64, (0, 10))])
 def test_conv_tailsplit_matches_single_pass(gpu, monkeypatch, variant, slots, want):
     """tail-split launch (full row blocks whole, the remainder cut along K into the same grid, then the finish pass over those

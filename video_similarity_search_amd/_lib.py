@@ -67,6 +67,7 @@ SIGNATURES = {
     "slic_pack_weight_fwd_runs": (I, [P, I, I, I, I, I, I, P, P]),
     "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
     "slic_pack_weight_wino": (I, [P, I, I, I, P, P]),
+    "slic_pack_weight_wino2": (I, [P, I, I, I, P, P]),
     "slic_conv_wgrad_wino_workspace_bytes": (c_size_t, [P, I]),
     "slic_conv_wino_tile_table": (I, [P, P, P]),
     "slic_conv_wgrad_wino": (I, [P, P, I, P, P, P, P]),

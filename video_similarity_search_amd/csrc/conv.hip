@@ -22,6 +22,7 @@
 // and split-K forms, conv_gemm_kernel (register-staged; stem), conv_wgrad_dma_kernel (+ row table).
 #include "common.h"
 #include "conv_common.h"
+#include "conv_internal.h"
 #include <type_traits>
 #ifndef SLIC_WG_ILVQ
 #define SLIC_WG_ILVQ 7   // same for the weight gradient's eight MFMA groups per tile
@@ -55,188 +56,7 @@ extern "C" int slic_debug_set_stamps(unsigned long long* buf) {
 #define SLIC_STAMP_ID(wg)
 #endif
 
-// Shared epilogue of the gather-GEMM kernels: bias / affine / addend / mask / ReLU store + deterministic BatchNorm partials.
-//
-// The accumulators leave the registers through an LDS image of the output tile ([BM][BN] floats, row-major), so that every
-// global access of the epilogue is a 16-byte-per-lane buffer op on a contiguous run of a dst row (CPR = BN / 4 lanes cover one
-// row: 256-byte runs for BN = 64) — the MFMA accumulator layout itself (a lane owns ONE column, 16 scattered rows) would
-// make each of them a 4-byte access in 128-byte pieces, four times the instruction count for the store and for each of the
-// addend / mask / bwd_z loads.  Thread t owns chunk cq = t % CPR of rows rr + RPP * pass (RPP = 256 / CPR rows per pass).
-// All tensor accesses are range-checked buffer ops with 32-bit byte offsets: a row past M, a chunk past N (N % 4 == 0) or an
-// absent optional operand (resource of size 0) is an out-of-range access — loads return 0, stores are dropped.
-// Reductions have a fixed order: rows ascending inside a thread, an xor butterfly over the row groups of a wave, then the four
-// waves ascending; one slab row per workgroup.
-constexpr int conv_epi_lds_floats(int BM, int BN, int NW = 4) { return BM * BN + 2 * NW * BN + BN; }
-
-// Part 2 of the epilogue: everything after the accumulators have been written to the LDS image [BM][BN] (and a barrier passed).
-// Also called on its own by kernels that build the image themselves (the Winograd kernel: its image rows are the four outputs
-// of each W-tile).  m0 = first GEMM row of the image, a multiple of BM.
-// WPAD (the Winograd kernels on a width that is not a multiple of 4): the image rows live in a W-PADDED row space — image row
-// m' = (b, t, h) * Wp + w' with Wp = 4 ceil(W / 4) a power of two dividing BM; rows with w' >= W do not exist.  m0 is then the
-// padded index of the first row; the GEMM row of image row m' is (m' / Wp) * W + w', and a block holds BM / Wp * W real rows.
-// NTHR = threads of the workgroup (256; the 512-thread Winograd workgroup passes 512: more rows per pass, eight wave partials)
-template <int BM, int BN, bool WPAD = false, int NTHR = 256>
-__device__ __forceinline__ void conv_epilogue_rows(const SlicConvArgs& p, float* lds, int64_t m0, int n0, int tid) {
-  const int64_t mblk = m0 / BM;   // row-block index of this workgroup (its slab row in stat_partial / bwd_partial)
-  [[maybe_unused]] const int wp_shift = WPAD ? 31 - __builtin_clz((p.Ws + 3) & ~3) : 0;
-  [[maybe_unused]] const int64_t bth_all = WPAD ? p.M / p.Ws : 0;
-  // image row -> (exists, GEMM row)
-  auto row_of = [&](int row, int64_t& m) -> bool {
-    if constexpr (WPAD) {
-      const int64_t mp = m0 + row;
-      const int64_t bth = mp >> wp_shift;
-      const int wq = (int)(mp - (bth << wp_shift));
-      m = bth * p.Ws + wq;
-      return wq < p.Ws && bth < bth_all;
-    } else {
-      m = m0 + row;
-      return m < p.M;
-    }
-  };
-  constexpr int CPR = BN / 4;       // 16-byte chunks per tile row
-  constexpr int RPP = NTHR / CPR;   // rows per pass of the workgroup's threads
-  constexpr int NW = NTHR / 64;     // waves
-  constexpr int NPASS = BM / RPP;
-  static_assert(NTHR % CPR == 0 && BM % RPP == 0, "tile shape");
-  float* tile = lds;                       // [BM][BN]: acc + bias
-  float* red1 = lds + BM * BN;             // [NW waves][BN]
-  float* red2 = red1 + NW * BN;            // [NW waves][BN]
-  float* bmean = red2 + NW * BN;           // [BN]
-  const int ewave = tid >> 6, elane = tid & 63;
-  // sum over the row groups a wave holds for one chunk column (lanes elane, elane ^ CPR, elane ^ 2 CPR, ...): every lane ends up
-  // with the same value, added in the same order
-  auto wave_rows_sum = [&](f32x4 v) {
-#pragma unroll
-    for (int off = CPR; off < 64; off <<= 1) {
-      f32x4 o;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) o[c] = __shfl_xor(v[c], off);
-      v += o;
-    }
-    return v;
-  };
-  const bool want_stats = p.stat_partial != nullptr;
-  const bool want_bwd = p.bwd_partial != nullptr;
-  // ---- 2. row-major pass: thread = (row group rr, chunk cq)
-  constexpr unsigned OOBE = 0xFFFFFF00u;
-  const int64_t dst_rows = p.dst_strided ? (p.M / ((int64_t)p.Ga * p.Gb * p.Gc)) * p.Da * p.Db * p.Dc : p.M;
-  const unsigned dst_bytes = (unsigned)(((dst_rows - 1) * (int64_t)p.ldo + p.N) * 4);
-  const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dst_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void*)p.addend, 0, p.addend ? dst_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_src, 0, p.mask_src ? dst_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_bz = __builtin_amdgcn_make_buffer_rsrc((void*)p.bwd_z, 0, p.bwd_z ? dst_bytes : 0, 0x00020000);
-  const bool has_mask = p.mask_src != nullptr, do_relu = p.relu != 0;
-  const int cq = tid % CPR, rr = tid / CPR;
-  const int n = n0 + cq * 4;
-  const bool nv = n < p.N;                       // N % 4 == 0: a chunk is inside or outside as a whole
-  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bmu = sh, bis = sh;
-  if (nv) {
-    if (p.scale) sc = *(const f32x4*)(p.scale + n);
-    if (p.shift) sh = *(const f32x4*)(p.shift + n);
-    if (want_bwd) { bmu = *(const f32x4*)(p.bwd_mean + n); bis = *(const f32x4*)(p.bwd_invstd + n); }
-  }
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, fs = s1;
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int row = ps * RPP + rr;
-    int64_t m;
-    const bool ok = row_of(row, m) && nv;
-    unsigned ro;
-    if (p.dst_strided) {
-      unsigned q = (unsigned)m;
-      const unsigned gc = q % (unsigned)p.Gc; q /= (unsigned)p.Gc;
-      const unsigned gbb = q % (unsigned)p.Gb; q /= (unsigned)p.Gb;
-      const unsigned gaa = q % (unsigned)p.Ga; q /= (unsigned)p.Ga;
-      ro = ((((q * p.Da + gaa * p.da + p.ea) * p.Db + gbb * p.db + p.eb) * p.Dc + gc * p.dc + p.ec) * (unsigned)p.ldo) * 4u;
-    } else {
-      ro = (unsigned)m * (unsigned)(p.ldo * 4);
-    }
-    const unsigned off = ok ? ro + (unsigned)n * 4u : OOBE;
-    f32x4 v = *(const f32x4*)&tile[row * BN + cq * 4];
-    if (ok) fs += v;
-    v = v * sc + sh;
-    v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0));
-    const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_msk, off, 0, 0));
-    const f32x4 zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bz, off, 0, 0));
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float x = v[c];
-      x = (has_mask && !(mk[c] > 0.f)) ? 0.f : x;
-      x = do_relu ? fmaxf(x, 0.f) : x;
-      v[c] = x;
-    }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs_dst, off, 0, 0);
-    if (ok) {
-      s1 += v;
-      s2 += v * ((zz - bmu) * bis);
-    }
-  }
-  if (want_bwd) {
-    // BatchNorm-backward partials of the stored gradient: (sum v, sum v * xhat) per channel over this row block
-    s1 = wave_rows_sum(s1);
-    s2 = wave_rows_sum(s2);
-    if (elane < CPR) {
-      *(f32x4*)&red1[ewave * BN + cq * 4] = s1;
-      *(f32x4*)&red2[ewave * BN + cq * 4] = s2;
-    }
-    __syncthreads();
-    if (tid < BN) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) { t1 += red1[w * BN + tid]; t2 += red2[w * BN + tid]; }
-      const int nn = n0 + tid;
-      if (nn < p.N) {
-        p.bwd_partial[(mblk * 2 + 0) * p.N + nn] = t1;
-        p.bwd_partial[(mblk * 2 + 1) * p.N + nn] = t2;
-      }
-    }
-  }
-  if (want_stats) {
-    // BatchNorm partials of v = acc + bias over this workgroup's valid rows, per channel:
-    //   slab[blk][0][n] = sum v          slab[blk][1][n] = sum (v - mean_blk)^2   (second pass over the LDS image,
-    // so the variance never comes from E[x^2] - mean^2); bn_finalize merges workgroups with Chan's formula in double.
-    int64_t left = p.M - m0, full = BM;
-    if constexpr (WPAD) {
-      full = (BM >> wp_shift) * p.Ws;                 // real rows of a full block
-      left = p.M - mblk * full;
-    }
-    const float inv_rows = 1.0f / (float)(left < full ? left : full);
-    if (want_bwd) __syncthreads();             // red1 is still being read by the block above
-    fs = wave_rows_sum(fs);
-    if (elane < CPR) *(f32x4*)&red1[ewave * BN + cq * 4] = fs;
-    __syncthreads();
-    if (tid < BN) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t += red1[w * BN + tid];
-      bmean[tid] = t * inv_rows;
-      const int nn = n0 + tid;
-      if (nn < p.N) p.stat_partial[(mblk * 2 + 0) * p.N + nn] = t;
-    }
-    __syncthreads();
-    const f32x4 mu = *(const f32x4*)&bmean[cq * 4];
-    f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = ps * RPP + rr;
-      int64_t mm;
-      if (row_of(row, mm)) {
-        const f32x4 d = *(const f32x4*)&tile[row * BN + cq * 4] - mu;
-        q2 += d * d;
-      }
-    }
-    q2 = wave_rows_sum(q2);
-    if (elane < CPR) *(f32x4*)&red2[ewave * BN + cq * 4] = q2;
-    __syncthreads();
-    if (tid < BN) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t += red2[w * BN + tid];
-      const int nn = n0 + tid;
-      if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
-    }
-  }
-}
+#include "conv_epilogue.h"
 
 template <int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&acc)[TM][TN], float* lds, int64_t m0, int n0,
@@ -1178,53 +998,7 @@ static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 //   Epilogue: the 256 x 64 outputs leave through the shared LDS-image epilogue in two 128-row halves (conv_epilogue_rows: store /
 //   addend / mask / BatchNorm partials with slab rows of 128 GEMM rows, as variant 22).
 // ------------------------------------------------------------------------------------------
-// Packed fp32 VALU ops as inline assembly: measured on this kernel family, wave time = MFMA cycles + VALU cycles (a diagnostic build
-// with no memory traffic and no barrier ran the forward kernel at 74 % of the matrix pipe with ~130 VALU instructions per stage,
-// the weight gradient at 66 % with ~46 per k-step — both what 64 cycles per MFMA plus 4 per VALU instruction predict), and left to
-// itself the compiler scalarises the transforms (it schedules element j of every point towards MFMA j).  Two floats per instruction:
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {        // a * b + c
-  f32x2 d;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b), "v"(c));
-  return d;
-}
-static __device__ __forceinline__ f32x2 pk_fnma(f32x2 a, f32x2 b, f32x2 c) {       // c - a * b
-  f32x2 d;
-  asm volatile("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(b), "v"(c));
-  return d;
-}
-static __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
-  f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-static __device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {                 // a - b
-  f32x2 d;
-  asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
-  return d;
-}
-// Two LDS words 256-byte units apart into ONE register pair (the compiler pairs neighbouring loads its own way and then moves
-// registers around to build the pairs the packed ops need).  The compiler does not track the result of an inline-assembly load:
-// the reader issues `s_waitcnt lgkmcnt(0)` itself before the first use.
-template <int O0, int O1>
-static __device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
-  static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2st64_b32 offsets are 8 bits of 256-byte units");
-  f32x2 d;
-  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(O0), "n"(O1));
-  return d;
-}
-// V = B^T d for two floats at a time,  B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-// (c2 / c4 / c5: the constants 2, 4, 5 in both halves of a scalar register pair): 12 instructions for 12 outputs
-static __device__ __forceinline__ void wino_bt6(const f32x2 (&d)[6], f32x2 (&V)[6], f32x2 c2, f32x2 c4, f32x2 c5) {
-  const f32x2 t1 = pk_fnma(d[2], c4, d[4]), t2 = pk_fnma(d[1], c4, d[3]);
-  const f32x2 t3 = pk_sub(d[4], d[2]), u = pk_sub(d[3], d[1]);
-  V[0] = pk_fma(d[0], c4, pk_fnma(d[2], c5, d[4]));
-  V[1] = pk_add(t1, t2);
-  V[2] = pk_sub(t1, t2);
-  V[3] = pk_fma(u, c2, t3);
-  V[4] = pk_fnma(u, c2, t3);
-  V[5] = pk_fma(d[1], c4, pk_fnma(d[3], c5, d[5]));
-}
+#include "wino_common.h"
 
 #ifndef SLIC_WINO_ABL
 #define SLIC_WINO_ABL 0   // diagnostic builds only (csrc/_exp/, scripts/r3/ab_wino.sh): 1 = DMAs out of range, 2 = no stage barrier, 4 = cache-resident input,
@@ -1945,9 +1719,12 @@ static int launch_gemm_dma_tail(const SlicConvArgs& a, hipStream_t st, int nfull
 //   0   register-staged 64 x 64 tiles — any source channel count (the W-run stem, tiny-channel layers, plain GEMMs)
 //   20  LDS-DMA ring, 64 x 64 tiles, 5 workgroups / CU   (source channels % 32 == 0)
 //   22  LDS-DMA ring, 128 x 64 tiles, 3 workgroups / CU  (N <= 64 and many rows: layer1)
+//   30  Winograd F(4, 3) along W (3 x 3 x 3 / stride 1 / pad 1)
+//   31  Winograd F(4, 3) x F(2, 3) over (W, H) (conv_wino2.hip; the same layers where they have many tiles)
 extern "C" int slic_conv_tile_m(const SlicConvArgs* a, int variant) {
   // rows per slab row (callers size stat_partial / bwd_partial with it).  Variant 30 on a width that is not a multiple of 4: a
   // block of 128 image rows holds 128 / Wp * W real rows (conv_epilogue_rows, WPAD)
+  if (variant == 31) return a ? slic_wino2_full_rows(a) : 512;   // two-dimensional Winograd: the real outputs of 64 tiles (0: not eligible)
   if (variant == 30 && a && a->Ws % 4 != 0) return 128 / ((a->Ws + 3) / 4 * 4) * a->Ws;
   return (variant == 22 || variant == 30) ? 128 : 64;
 }
@@ -1960,8 +1737,10 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(a->wgt_bytes > 0 && a->wgt_bytes < 0xFFFFFF00u, "slic_conv_gemm: wgt_bytes must be set and < 4 GiB");
   SLIC_REQUIRE(!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial),
                "slic_conv_gemm: bwd_partial needs bwd_z, bwd_mean, bwd_invstd (and excludes stat_partial)");
-  SLIC_REQUIRE(variant == 0 || variant == 20 || variant == 22 || variant == 30, "slic_conv_gemm: variant must be 0, 20, 22 or 30");
+  SLIC_REQUIRE(variant == 0 || variant == 20 || variant == 22 || variant == 30 || variant == 31,
+               "slic_conv_gemm: variant must be 0, 20, 22, 30 or 31");
   hipStream_t st = S_(stream);
+  if (variant == 31) return slic_conv_wino2_launch(a, st);   // Winograd F(4, 3) x F(2, 3) over (W, H): wgt = the operand of slic_pack_weight_wino2
   if (variant == 30) {
     // Winograd F(4, 3) along W: wgt = the operand of slic_pack_weight_wino; 3 x 3 x 3, stride 1, pad 1 geometry only
     SLIC_REQUIRE(a->Cs % 8 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&

@@ -1,0 +1,586 @@
+// Two-dimensional Winograd for the 3 x 3 x 3, stride-1, pad-1 convolutions: F(4, 3) along W x F(2, 3) along H.
+//
+// Replaces the cuDNN calls behind nn.Conv3d of the BasicBlock convolutions (/root/reference/models/resnet.py:11-17, 41-57) —
+// forward and, with the flipped / transposed operand, data gradient — on the layers with many tiles (layer1 / layer2 / layer3).
+// A tile is 2 output rows x 4 output columns; per kt and channel its 4 x 6 input patch d becomes 24 points V = Bh^T d Bw, each
+// point is its own fp32-MFMA GEMM against U = Gh w Gw^T (packed once per step by pack_w_wino2), and the 8 outputs are
+// Y = Ah^T M Aw.  24 multiplies per (kt, c, n) and tile where the direct form has 72 and the one-dimensional F(4, 3) kernel 36:
+// exact fp32 arithmetic (v_mfma_f32_32x32x2_f32), a third of the direct form's matrix work.
+//
+// Why two dimensions and not a leaner one-dimensional kernel: on gfx950 a wave's vector and vector-memory instructions do not run
+// beside fp32 MFMAs of the same SIMD — the fp32 MFMA holds the vector issue for its 64 cycles (scripts/micro/mfma_valu_coexec.hip:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0 in every build, +3-6 cycles per vector instruction, ~25 per LDS-DMA piece) — so the one-dimensional
+// kernel's 0.73-0.75 of the pipe is within a few points of what its instruction mix allows, and the remaining lever is fewer MFMAs.
+//
+// Workgroup = 512 threads = 8 waves, 64 tiles x 64 n.  The 24 accumulator sets do not fit one wave, so the POINTS are split:
+// wave (j, th) owns H-point j (0..3) of tiles 32 th .. 32 th + 31 for all 64 columns: 6 W-points x 2 column halves = 12
+// accumulators of 16 registers.  Its H-transform needs TWO of the patch's four rows (Bh^T rows: d0 - d2, d1 + d2, d2 - d1,
+// d1 - d3; row 2 is taken as d1 - d2 with U negated), one packed op per pixel, then the F(4, 3) input transform along W:
+// 18 packed instructions per stage and wave for 24 MFMAs.
+// K loop = 3 kt x C / 4 stages of 4 channels; a stage = 24 KB of raw pixels [row 4][pixel 6][tile 64][4 ch] + 24 KB of U
+// [j 4][p 6][n 64][4 ch], both by LDS-DMA in the order the lanes read them (lane (r, hh) of the MFMA reads channels 2 hh, 2 hh + 1
+// of tile / column r with ONE ds_read_b64 per pixel / point: element e goes to MFMA e); 3-stage ring (144 KB: one workgroup per
+// CU, two waves per SIMD), counted vmcnt, one barrier per stage.
+// Epilogue: every wave applies Aw^T to its own accumulators (4 W-outputs), the four H-points of a tile meet in an LDS image
+// [tile 64][row 2][col 4][n 64] in a fixed order (row 0 = (Y0 + Y1) + Y2, row 1 = (-Y3 - Y2) + Y1), and the image leaves through
+// w2_epilogue (store / affine / addend / ReLU mask / BatchNorm partials as conv_epilogue_rows computes them, one slab row per block).
+#include "common.h"
+#include "conv_epilogue.h"
+#include "conv_internal.h"
+#include "wino_common.h"
+
+#ifndef SLIC_PRIO_EDGE
+#define SLIC_PRIO_EDGE 3
+#endif
+#ifndef SLIC_W2_ABL
+#define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range, 2 = no stage barrier
+#endif
+#ifndef SLIC_W2_STAGGER
+#define SLIC_W2_STAGGER 1 // waves 4-7 (tile half 1) run half a stage behind waves 0-3: TWO barriers per stage, and while one wave of a SIMD
+                          // transforms (vector instructions, which an fp32 MFMA of the SAME wave never hides) its partner multiplies
+#endif
+#ifndef SLIC_W2_TAIL
+#define SLIC_W2_TAIL 1    // the last two W-points of a stage are multiplied after the NEXT stage's barrier, under the latency of its LDS reads
+#endif
+
+constexpr int W2_A_FLOATS = 24 * 64 * 4;                       // pixel image of a stage
+constexpr int W2_U_FLOATS = 24 * 64 * 4;                       // U block of a stage
+constexpr int W2_STAGE_FLOATS = W2_A_FLOATS + W2_U_FLOATS;     // 48 KB
+constexpr int W2_NPC = 6;                                      // DMA pieces per thread and stage: 3 pixel + 3 U
+
+
+// Epilogue of the two-dimensional kernel, one call per column half nh.  The four H-point waves of a tile have written their W-outputs
+// Yw_j to LDS side by side, buf[j 4][tile 64][col o 4][n 32] (no read-modify-write: 128 accumulate steps per wave through LDS ran at one
+// LDS round trip each and cost 13 % of the kernel); this pass reads, for output row (tile, hp, o), the three contributions it is made
+// of — Ah^T = [1 1 1 0; 0 1 -1 -1]: row 0 = (Y0 + Y1) + Y2, row 1 = (Y1 - Y2) - Y3 — and does what conv_epilogue_rows does with an
+// image row: store / affine / addend / ReLU-backward mask / ReLU / BatchNorm partials (same formulas, fixed reduction order: rows
+// ascending in a thread, xor butterfly over a wave's row groups, the eight waves ascending; one slab row per block).  Thread = (row
+// group rr = tid / 8, 16-byte chunk cq = tid % 8), 64 rows = 8 tiles per pass, 8 passes.  The vector work is kept small — every
+// vector instruction stops the matrix pipe of its SIMD, and with ONE workgroup per CU nothing else runs meanwhile: the tile's
+// coordinates are decoded once and stepped (no division per row), absent operands are not loaded (workgroup-uniform branches), the
+// combined values stay in registers for the second statistics pass.
+__device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, int64_t tile0, int n0h, int tid, int full_rows) {
+  constexpr int BNH = 32, CPR = 8, RPP = 64, NW = 8, NPASS = 8;
+  constexpr int JSTRIDE = 64 * 4 * BNH;                        // floats between buf[j] and buf[j + 1]
+  const int64_t mblk = tile0 >> 6;
+  const int H = p.Hs, W = p.Ws;
+  const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
+  const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;
+  float* red1 = lds + 4 * JSTRIDE;
+  float* red2 = red1 + NW * BNH;
+  float* bmean = red2 + NW * BNH;
+  const int ewave = tid >> 6, elane = tid & 63;
+  auto wave_rows_sum = [&](f32x4 v) {
+#pragma unroll
+    for (int off = CPR; off < 64; off <<= 1) {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = __shfl_xor(v[c], off);
+      v += o;
+    }
+    return v;
+  };
+  const bool want_stats = p.stat_partial != nullptr, want_bwd = p.bwd_partial != nullptr;
+  const bool has_add = p.addend != nullptr, has_mask = p.mask_src != nullptr, has_bz = p.bwd_z != nullptr, do_relu = p.relu != 0;
+  const bool has_affine = p.scale != nullptr || p.shift != nullptr;
+  constexpr unsigned OOBE = 0xFFFFFF00u;
+  const unsigned dst_bytes = (unsigned)(((p.M - 1) * (int64_t)p.ldo + p.N) * 4);
+  const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dst_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void*)p.addend, 0, has_add ? dst_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_src, 0, has_mask ? dst_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bz = __builtin_amdgcn_make_buffer_rsrc((void*)p.bwd_z, 0, has_bz ? dst_bytes : 0, 0x00020000);
+  const int cq = tid & 7, rr = tid >> 3;
+  const int n = n0h + cq * 4;
+  const bool nv = n < p.N;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bmu = sh, bis = sh;
+  if (nv) {
+    if (p.scale) sc = *(const f32x4*)(p.scale + n);
+    if (p.shift) sh = *(const f32x4*)(p.shift + n);
+    if (want_bwd) { bmu = *(const f32x4*)(p.bwd_mean + n); bis = *(const f32x4*)(p.bwd_invstd + n); }
+  }
+  // this thread's rows: tile tile0 + 8 ps + rr / 8, row hp, column o — decoded once, stepped by eight tiles per pass
+  const int hp = (rr >> 2) & 1, o = rr & 3;
+  const float sgn = hp ? -1.f : 1.f;
+  const float* src = lds + hp * JSTRIDE + (((rr >> 3) * 4 + o) * BNH + cq * 4);      // + ps * 8 tiles; contributions j = hp, hp + 1, hp + 2
+  int64_t tl = tile0 + (rr >> 3);
+  unsigned q = (unsigned)(tl < Mt ? tl : 0);
+  int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+  int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;       // q = frame (b, t)
+  unsigned okmask = 0;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, fs = s1;
+  f32x4 keep[NPASS];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int hr = 2 * h2 + hp, wc = 4 * wt + o;
+    const bool ok = tl < Mt && hr < H && wc < W && nv;
+    okmask |= (ok ? 1u : 0u) << ps;
+    const unsigned m = (q * (unsigned)H + (unsigned)hr) * (unsigned)W + (unsigned)wc;
+    const unsigned off = ok ? (m * (unsigned)p.ldo + (unsigned)n) * 4u : OOBE;
+    const float* sp = src + ps * (8 * 4 * BNH);
+    const f32x4 ya = *(const f32x4*)sp, yb = *(const f32x4*)(sp + JSTRIDE), yc = *(const f32x4*)(sp + 2 * JSTRIDE);
+    f32x4 v = (ya + sgn * yb) + sgn * yc;
+    keep[ps] = v;
+    if (ok) fs += v;
+    if (has_affine) v = v * sc + sh;
+    if (has_add) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0));
+    if (has_mask) {
+      const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_msk, off, 0, 0));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = !(mk[c] > 0.f) ? 0.f : v[c];
+    }
+    if (do_relu) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs_dst, off, 0, 0);
+    if (want_bwd) {
+      const f32x4 zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bz, off, 0, 0));
+      if (ok) {
+        s1 += v;
+        s2 += v * ((zz - bmu) * bis);
+      }
+    }
+    // next pass: eight tiles on
+    tl += 8;
+    wt += 8;
+    while (wt >= Wq) {
+      wt -= Wq;
+      if (++h2 == Hq) { h2 = 0; ++q; }
+    }
+  }
+  if (want_bwd) {
+    s1 = wave_rows_sum(s1);
+    s2 = wave_rows_sum(s2);
+    if (elane < CPR) {
+      *(f32x4*)&red1[ewave * BNH + cq * 4] = s1;
+      *(f32x4*)&red2[ewave * BNH + cq * 4] = s2;
+    }
+    __syncthreads();
+    if (tid < BNH) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { t1 += red1[w * BNH + tid]; t2 += red2[w * BNH + tid]; }
+      const int nn = n0h + tid;
+      if (nn < p.N) {
+        p.bwd_partial[(mblk * 2 + 0) * p.N + nn] = t1;
+        p.bwd_partial[(mblk * 2 + 1) * p.N + nn] = t2;
+      }
+    }
+  }
+  if (want_stats) {
+    // BatchNorm partials over this block's real outputs, per channel: (sum v, sum (v - mean_blk)^2), the second from the kept values
+    const int64_t left = p.M - mblk * (int64_t)full_rows;
+    const float inv_rows = 1.0f / (float)(left < full_rows ? left : full_rows);
+    if (want_bwd) __syncthreads();
+    fs = wave_rows_sum(fs);
+    if (elane < CPR) *(f32x4*)&red1[ewave * BNH + cq * 4] = fs;
+    __syncthreads();
+    if (tid < BNH) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red1[w * BNH + tid];
+      bmean[tid] = t * inv_rows;
+      const int nn = n0h + tid;
+      if (nn < p.N) p.stat_partial[(mblk * 2 + 0) * p.N + nn] = t;
+    }
+    __syncthreads();
+    const f32x4 mu = *(const f32x4*)&bmean[cq * 4];
+    f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      if ((okmask >> ps) & 1u) {
+        const f32x4 d = keep[ps] - mu;
+        q2 += d * d;
+      }
+    }
+    q2 = wave_rows_sum(q2);
+    if (elane < CPR) *(f32x4*)&red2[ewave * BNH + cq * 4] = q2;
+    __syncthreads();
+    if (tid < BNH) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red2[w * BNH + tid];
+      const int nn = n0h + tid;
+      if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
+    }
+  }
+}
+
+template <int STAGES>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = wave & 3, th = wave >> 2;
+  const int r = lane & 31, hh = lane >> 5;
+  const int bx = blockIdx.x, gdx = gridDim.x;
+  const int mb = (bx & 7) * (gdx >> 3) + (bx >> 3);          // XCD-aware order: neighbouring tile blocks share an L2
+  const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
+  const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
+  const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;     // tiles
+  const int64_t tile0 = (int64_t)mb * 64;
+  if (tile0 >= Mt) return;
+  const int nb = blockIdx.y, n0 = nb * 64;
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two: checked on the host)
+  const int cch_shift = 31 - __builtin_clz(CCH);
+  const int NS = 3 * CCH;
+  const int NB = p.N >> 6;
+  // ---- DMA roles: chunk q = i * 512 + tid of the pixel image [ab 24][tile 64][4 ch]: thread = (tile tid % 64, ab = 8 i + wave)
+  const int64_t mytile = tile0 + (tid & 63);
+  const bool tvalid = mytile < Mt;
+  unsigned q = (unsigned)(tvalid ? mytile : 0);
+  const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+  const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;  // q = frame (b, t)
+  const int tt = (int)(q % (unsigned)T);
+  unsigned aoff[3], inv[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int ab = 8 * i + wave;
+    const int a = (ab * 11) >> 6, b = ab - 6 * a;             // ab / 6 for ab < 24
+    const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
+    const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
+    aoff[i] = (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4);
+    // bit kt of an INVALID mask (v_bfe_i32 of one bit gives 0 / -1, and offset | -1 is out of range); bit 3 = a dead stage
+    unsigned m = 1u << 3;
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) m |= ((ok && (unsigned)(tt + kt - 1) < (unsigned)T) ? 0u : 1u) << kt;
+    inv[i] = m;
+  }
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  const unsigned uvoff = (unsigned)tid * 16u;
+  // A stage's DMA pieces cost NO vector instruction: the pixel pieces' per-lane offset (aoffk: the pixel's address at this kt, or an
+  // out-of-range offset where the pixel does not exist) changes only with kt — three times per workgroup, behind a scalar branch —
+  // and the stage's channel group rides in the instruction's scalar offset; U = a per-lane constant + the stage's block as scalar offset.
+  struct StageRec { unsigned coff, ublk; int kt, cc; };
+  auto stage_rec = [&](int s) {
+    StageRec g;
+    const bool live = s < NS;
+    const int sc = live ? s : 0;
+    const int kt = sc >> cch_shift, cc = sc & (CCH - 1);
+    g.kt = live ? kt : 3;
+    g.cc = cc;
+    g.coff = (unsigned)(cc * 16);
+    g.ublk = (unsigned)((kt * CCH + cc) * NB + nb) * (unsigned)(W2_U_FLOATS * 4);
+    return g;
+  };
+  unsigned aoffk[3] = {0x80000000u, 0x80000000u, 0x80000000u};
+  // aoff / inv are needed three times per workgroup: they wait in LDS behind the ring (24 bytes per thread), not in registers
+  unsigned* stash = (unsigned*)(lds + STAGES * W2_STAGE_FLOATS) + tid * 6;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { stash[i] = aoff[i]; stash[3 + i] = inv[i]; }
+  auto set_kt = [&](int kt) {
+    const unsigned kd = (unsigned)((kt - 1) * H * W * C * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) aoffk[i] = ((stash[3 + i] >> kt) & 1u) ? 0x80000000u : stash[i] + kd;
+  };
+  auto issue_piece = [&](const StageRec& g, int toff, int d) {
+#if SLIC_W2_ABL & 8
+    return;
+#endif
+    if (d < 3) {
+#if SLIC_W2_ABL & 1
+      const unsigned off = 0xFFFFFF00u + 0 * aoffk[d];
+#else
+      const unsigned off = aoffk[d];
+#endif
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 512 + wave * 64) * 4),
+                                               16, (int)off, (int)g.coff, 0, 0);
+    } else {
+      const int i = d - 3;
+#if SLIC_W2_ABL & 1
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + W2_A_FLOATS + (i * 512 + wave * 64) * 4),
+                                               16, (int)(0xFFFFFF00u + 0 * uvoff), (int)(0 * g.ublk), 0, 0);
+#else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + W2_A_FLOATS + (i * 512 + wave * 64) * 4),
+                                               16, (int)uvoff, (int)(g.ublk + (unsigned)(i * 8192)), 0, 0);
+#endif
+    }
+  };
+  f32x16 acc[6][2];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
+#pragma unroll
+  for (int t = 0; t < STAGES - 1; ++t) {
+    const StageRec g = stage_rec(t);
+    if (g.cc == 0) set_kt(g.kt);
+#pragma unroll
+    for (int d = 0; d < W2_NPC; ++d) issue_piece(g, t * W2_STAGE_FLOATS, d);
+  }
+  __builtin_amdgcn_s_setprio(0);
+  // reader offsets (floats): pixel (a, b) of this lane's tile, its channel pair; point (j, p) of column half nh
+  const int a1 = j == 0 ? 0 : 1, a2 = j == 3 ? 3 : 2;
+  const int ar1 = (a1 * 6 * 64 + th * 32 + r) * 4 + 2 * hh;   // + b * 256
+  const int ar2 = (a2 * 6 * 64 + th * 32 + r) * 4 + 2 * hh;
+  const int bro = W2_A_FLOATS + (j * 6 * 64 + r) * 4 + 2 * hh; // + p * 256 + nh * 128
+  const float sg = j == 1 ? 1.f : -1.f;                       // H-point: d[a1] + sg * d[a2]  (j = 2 as d1 - d2: its U is negated)
+  const f32x2 sgn = {sg, sg};
+  const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
+  f32x2 V[6], ut[2][2];                                       // ut: U of points 4, 5 (kept across the stage barrier with V[4], V[5])
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) V[pp] = (f32x2){0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) ut[k][nh] = (f32x2){0.f, 0.f};
+  // the eight MFMAs of points p0, p1: element e of the lane's channel pair goes to MFMA e
+  auto mfma_pair = [&](const int p0, const int p1, const f32x2 (&u)[2][2]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        acc[p0][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p0][e], u[0][nh][e], acc[p0][nh], 0, 0, 0);
+        acc[p1][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p1][e], u[1][nh][e], acc[p1][nh], 0, 0, 0);
+      }
+  };
+  auto read_u = [&](const float* St, const int p0, f32x2 (&u)[2][2]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+#if SLIC_W2_ABL & 16
+        u[k][nh] = (f32x2){(float)(p0 + k), (float)nh};
+#else
+        u[k][nh] = *(const f32x2*)&St[bro + (p0 + k) * 256 + nh * 128];
+#endif
+      }
+  };
+  // Stagger (SLIC_W2_STAGGER): the workgroup passes TWO barriers per stage, 2 s and 2 s + 1.  Waves 0-3 (th = 0) start stage s at
+  // barrier 2 s, waves 4-7 (th = 1: the SIMD partners of 0-3) at barrier 2 s + 1; a wave's stage is X = {LDS reads, the previous
+  // stage's last 8 MFMAs, transform} | barrier | Y = {16 MFMAs, the DMAs of stage s + 2}.  So while one wave of a SIMD is in X its
+  // partner is in Y: 24 MFMAs per SIMD and phase either way, and the transform's vector instructions slip between the partner's
+  // MFMAs instead of stopping the pipe for both waves at once (in lock-step the kernel reached 0.64 of the pipe with no memory
+  // traffic at all).  Ring discipline: slot (s % 3) is read during phases 2 s .. 2 s + 2 and refilled (stage s + 3) by DMAs issued
+  // in Y (s + 1), i.e. behind barrier 2 s + 3 at the earliest; the pieces of stage s are complete before barrier 2 s on every wave —
+  // th = 0 waits for them in front of its stage barrier (one younger stage outstanding), th = 1 in front of its mid-stage barrier
+  // (nothing younger outstanding yet).  th = 1 passes one barrier before its first stage, th = 0 one behind its last.
+  constexpr unsigned WAIT_VM6_LGKM0 = ((STAGES - 2) * W2_NPC) | 0x70, WAIT_VM0_LGKM0 = 0x70, WAIT_LGKM0 = 0xC07F;
+  static_assert((STAGES - 2) * W2_NPC < 16, "vmcnt field");
+#if SLIC_W2_STAGGER
+  if (th == 1) {
+    __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
+#if !(SLIC_W2_ABL & 2)
+    __builtin_amdgcn_s_barrier();
+#endif
+  }
+#endif
+  for (int s0 = 0; s0 < NS; s0 += STAGES) {
+#pragma unroll
+    for (int sidx = 0; sidx < STAGES; ++sidx) {
+      const int sgl = s0 + sidx;
+      // stage sgl has landed; this wave's LDS reads of stage sgl - 1 are complete before the barrier frees that slot
+      // (the builtin, not inline assembly: the compiler's own wait-count pass then knows that the registers loaded from LDS in the
+      // previous stage — ut — are in, and does not put an lgkmcnt(0) between this stage's reads and the MFMAs that cover them)
+#if SLIC_W2_STAGGER
+      if (th == 0) __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
+      else __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
+#else
+      __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
+#endif
+#if !(SLIC_W2_ABL & 2)
+      __builtin_amdgcn_s_barrier();
+#endif
+      const float* St = lds + sidx * W2_STAGE_FLOATS;
+      const int toffn = ((sidx + STAGES - 1) % STAGES) * W2_STAGE_FLOATS;
+      const StageRec gn = stage_rec(sgl + STAGES - 1);
+      // A: the stage's LDS reads that the transform and the first MFMAs need, all issued at once
+      f32x2 d1[6], d2[6], cmb[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+#if SLIC_W2_ABL & 16
+        d1[b] = (f32x2){(float)sgl, 1.f}; d2[b] = d1[b];
+#else
+        d1[b] = *(const f32x2*)&St[ar1 + b * 256];
+        d2[b] = *(const f32x2*)&St[ar2 + b * 256];
+#endif
+      }
+      f32x2 u01[2][2], u23[2][2];
+      __builtin_amdgcn_sched_barrier(0);
+      // B: the previous stage's last two points (V[4], V[5], ut still hold them), under the latency of those reads
+#if SLIC_W2_TAIL
+      mfma_pair(4, 5, ut);
+#endif
+      if (gn.cc == 0) set_kt(gn.kt);                          // scalar branch, three times per workgroup
+      __builtin_amdgcn_sched_barrier(0);
+      read_u(St, 0, u01);                                      // lands under the transform
+      __builtin_amdgcn_sched_barrier(0);
+      // C: H-point, then V = B^T (.) along W.  The packed ops are inline assembly, which the compiler's hazard recogniser does not see
+      // as VALU (an MFMA reading a register within two instructions of the op that wrote it would read the OLD value): one fenced
+      // block closed by the two wait states.
+#if SLIC_W2_ABL & 4
+#pragma unroll
+      for (int b = 0; b < 6; ++b) V[b] = d1[b];
+#else
+#pragma unroll
+      for (int b = 0; b < 6; ++b) cmb[b] = pk_fma(d2[b], sgn, d1[b]);
+      wino_bt6(cmb, V, c2, c4, c5);
+      asm volatile("s_nop 1" ::: "memory");
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#if SLIC_W2_STAGGER
+      // mid-stage barrier: the partner group starts its stage here
+      if (th == 1) __builtin_amdgcn_s_waitcnt(WAIT_VM0_LGKM0);
+      else __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
+#if !(SLIC_W2_ABL & 2)
+      __builtin_amdgcn_s_barrier();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // D: the stage's MFMAs, the next-but-one stage's DMAs between them
+      read_u(St, 2, u23);
+      mfma_pair(0, 1, u01);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) issue_piece(gn, toffn, d);
+      read_u(St, 4, ut);
+      mfma_pair(2, 3, u23);
+#pragma unroll
+      for (int d = 3; d < W2_NPC; ++d) issue_piece(gn, toffn, d);
+#if !SLIC_W2_TAIL
+      mfma_pair(4, 5, ut);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#if SLIC_W2_TAIL
+  mfma_pair(4, 5, ut);
+#endif
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#if SLIC_W2_STAGGER && !(SLIC_W2_ABL & 2)
+  if (th == 0) __builtin_amdgcn_s_barrier();
+#endif
+  __syncthreads();
+#if SLIC_W2_ABL & 32
+  if (acc[0][0][0] != 12345.678f) return;                      // diagnostic build: no epilogue
+#endif
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  // Y = A^T M along W,  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]   (in place: acc[0..3] become the four columns)
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    const f32x16 s12 = acc[1][nh] + acc[2][nh], d12 = acc[1][nh] - acc[2][nh];
+    const f32x16 s34 = acc[3][nh] + acc[4][nh], d34 = acc[3][nh] - acc[4][nh];
+    acc[0][nh] = acc[0][nh] + s12 + s34;
+    acc[1][nh] = d12 + 2.f * d34;
+    acc[2][nh] = s12 + 4.f * s34;
+    acc[3][nh] = d12 + 8.f * d34 + acc[5][nh];
+  }
+  // The four H-points of a tile meet in LDS, one column half at a time: every wave writes its W-outputs to buf[j][tile][o][n 32]
+  // (lanes r = consecutive n: 128-byte runs), a barrier, and w2_epilogue combines them row by row
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    if (nh) __syncthreads();                                   // the first half's readers are done with buf and the reduction rows
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int tl = th * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+        lds[((j * 64 + tl) * 4 + o) * 32 + r] = acc[o][nh][g];
+      }
+    __syncthreads();
+#if SLIC_W2_ABL & 256
+    if (tid < 64) p.dst[(tile0 * 8) * p.ldo + n0 + tid] = lds[tid * 97];      // diagnostic build: no row-major epilogue at all
+#else
+    w2_epilogue(p, lds, tile0, n0 + nh * 32, tid, full_rows);
+#endif
+  }
+}
+
+// U2[((((kt * C/4 + cc) * N/64 + nb) * 4 + j) * 6 + p) * 64 + nl][e] = sum_kh sum_kw Gh[j][kh] Gw[p][kw] w(n = 64 nb + nl, c = 4 cc + e, kt, kh, kw)
+//   forward : w(n, c, kt, kh, kw) = W[n][c][kt][kh][kw]                    (N_ = out channels N, C_ = in channels C)
+//   dgrad   : w(n, c, kt, kh, kw) = W[c][n][2 - kt][2 - kh][2 - kw]        (N_ = C: channels of dx, C_ = N: channels of dy)
+// Gw (F(4, 3)) = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+// Gh (F(2, 3)) = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], row 2 NEGATED (the kernel forms H-point 2 as d1 - d2)
+__global__ void pack_w_wino2(const float* __restrict__ Wt, int N, int C, int dgrad, float* __restrict__ U) {
+  const int N_ = dgrad ? C : N, C_ = dgrad ? N : C;
+  const int64_t tot = (int64_t)3 * C_ * N_;
+  const int64_t e0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e0 >= tot) return;
+  // e0 = (((kt * CCH + cc) * NB + nb) * 64 + nl) * 4 + e
+  int64_t q = e0;
+  const int e = (int)(q & 3); q >>= 2;
+  const int nl = (int)(q & 63); q >>= 6;
+  const int NB = N_ >> 6, CCH = C_ >> 2;
+  const int nb = (int)(q % NB); q /= NB;
+  const int cc = (int)(q % CCH); q /= CCH;
+  const int kt = (int)q;
+  const int n = nb * 64 + nl, c = cc * 4 + e;
+  float w[3][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      if (dgrad) w[kh][kw] = Wt[((int64_t)c * C + n) * 27 + (2 - kt) * 9 + (2 - kh) * 3 + (2 - kw)];
+      else w[kh][kw] = Wt[((int64_t)n * C + c) * 27 + kt * 9 + kh * 3 + kw];
+    }
+  // along H first: g[j][kw]
+  float g[4][3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const float s02 = w[0][kw] + w[2][kw];
+    g[0][kw] = w[0][kw];
+    g[1][kw] = 0.5f * (s02 + w[1][kw]);
+    g[2][kw] = -(0.5f * (s02 - w[1][kw]));
+    g[3][kw] = w[2][kw];
+  }
+  const int64_t blk = ((int64_t)(kt * CCH + cc) * NB + nb) * (24 * 64 * 4);
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const float s02 = g[jj][0] + g[jj][2];
+    float u[6];
+    u[0] = 0.25f * g[jj][0];
+    u[1] = (-1.f / 6.f) * (s02 + g[jj][1]);
+    u[2] = (-1.f / 6.f) * (s02 - g[jj][1]);
+    u[3] = (1.f / 24.f) * g[jj][0] + (1.f / 12.f) * g[jj][1] + (1.f / 6.f) * g[jj][2];
+    u[4] = (1.f / 24.f) * g[jj][0] - (1.f / 12.f) * g[jj][1] + (1.f / 6.f) * g[jj][2];
+    u[5] = g[jj][2];
+#pragma unroll
+    for (int pp = 0; pp < 6; ++pp) U[blk + ((jj * 6 + pp) * 64 + nl) * 4 + e] = u[pp];
+  }
+}
+
+// real outputs in a full block of 64 tiles, or 0 when the blocks of this geometry do not all hold the same number
+int slic_wino2_full_rows(const SlicConvArgs* a) {
+  const int W = a->Ws, H = a->Hs;
+  const int Wq = (W + 3) / 4, Hq = (H + 1) / 2;
+  if (W % 4 == 0 && H % 2 == 0) return 512;
+  if (H % 2 == 0) return 64 % Wq == 0 ? (64 / Wq) * 2 * W : 0;
+  return 64 % (Hq * Wq) == 0 ? (64 / (Hq * Wq)) * H * W : 0;
+}
+
+int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st) {
+  constexpr int STAGES = 3;
+  constexpr size_t ring = (size_t)STAGES * W2_STAGE_FLOATS * sizeof(float) + 512 * 6 * 4, epi = (size_t)conv_epi_lds_floats(512, 64, 8) * sizeof(float);
+  constexpr size_t lds = ring > epi ? ring : epi;
+  static_assert(lds <= 160 * 1024, "LDS");
+  SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts && a->Gb == a->Hs &&
+                   a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len,
+               "slic_conv_gemm: variant 31 needs a stride-1 same-size geometry, Cs %% 64 == 0, N %% 64 == 0, no bias");
+  SLIC_REQUIRE(((a->Cs / 4) & (a->Cs / 4 - 1)) == 0, "slic_conv_gemm: variant 31 needs Cs / 4 to be a power of two");
+  SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)3 * 24 * a->Cs * a->N * 4, "slic_conv_gemm: variant 31: wgt_bytes != 3 * 24 * Cs * N floats");
+  const int full = slic_wino2_full_rows(a);
+  SLIC_REQUIRE(full > 0, "slic_conv_gemm: variant 31: blocks of 64 tiles hold different numbers of outputs at H=%d W=%d", a->Hs, a->Ws);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
+  SLIC_REQUIRE(tiles < (1ll << 31) && (int64_t)a->M * a->Cs * 4 < 0xFFFFFF00ll, "slic_conv_gemm: variant 31: tensor too large");
+  const int gx = (int)slic_cdiv(tiles, 64);
+  conv_wino2_kernel<STAGES><<<dim3((unsigned)((gx + 7) / 8 * 8), (unsigned)(a->N / 64)), dim3(512), lds, st>>>(*a, full);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, float* U, void* stream) {
+  SLIC_REQUIRE(W && U && N % 64 == 0 && C % 64 == 0, "slic_pack_weight_wino2: N and C must be multiples of 64");
+  const int64_t tot = (int64_t)3 * C * N;
+  pack_w_wino2<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream>>>(W, N, C, dgrad, U);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}

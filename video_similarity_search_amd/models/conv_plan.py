@@ -38,7 +38,9 @@ class ConvPlan:
 
     WINO_MIN_WGS = 384     # forward / data gradient: a launch of fewer 64-tile x 64-n workgroups than this (layer4 at B = 32: 112) cuts its K loop
 
-    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None):
+    WINO2_MIN_WGS = 200    # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (one workgroup / CU)
+
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, wino2=None, batch=None):
         self.C, self.N = int(C), int(N)
         self.Cs = (self.C + 3) // 4 * 4
         self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
@@ -69,6 +71,20 @@ class ConvPlan:
         on = os.environ.get("SLIC_WINO", "1") != "0"
         self.wino = (eligible and on) if wino is None else bool(wino)
         assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N 64 x a power of two, W % 4 == 0 or 4 ceil(W/4) | 128"
+        # Winograd in two dimensions, F(4, 3) along W x F(2, 3) along H (variant 31, csrc/conv_wino2.hip): a third of the direct form's
+        # multiplies instead of half.  Forward and data gradient of a Winograd plan whose blocks of 64 tiles (2 x 4 outputs each) all
+        # hold the same number of real outputs (H even and W % 4 == 0; or H even and ceil(W / 4) | 64; or ceil(H / 2) ceil(W / 4) | 64)
+        # and whose launch fills the chip: wino2=None decides from `batch` (the engine passes it), SLIC_WINO2=0 switches it off.
+        Hd = self.in_dims[1]
+        Hq2, Wq2 = (Hd + 1) // 2, (Wd + 3) // 4
+        uniform = (Wd % 4 == 0 and Hd % 2 == 0) or (Hd % 2 == 0 and 64 % Wq2 == 0) or (64 % (Hq2 * Wq2) == 0)
+        elig2 = eligible and uniform
+        if wino2 is None:
+            wgs = 0 if batch is None else -(-(int(batch) * self.in_dims[0] * Hq2 * Wq2) // 64) * (max(self.C, self.N) // 64)
+            wino2 = (elig2 and self.wino and os.environ.get("SLIC_WINO2", "1") != "0" and
+                     wgs >= int(os.environ.get("SLIC_WINO2_MIN_WGS", self.WINO2_MIN_WGS)))
+        self.wino2 = bool(wino2)
+        assert (elig2 and self.wino) or not self.wino2, "Winograd F(4,3) x F(2,3): a Winograd plan with uniform 64-tile blocks"
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
         self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
         self._wu = self._wud = None
@@ -212,8 +228,8 @@ class ConvPlan:
             if not fresh and self._wp_key is not None and self._wp_key == self._wkey(weight):
                 return self._wu
             if self._wu is None:
-                self._wu = torch.empty(9 * self.C * self.N * 6, dtype=torch.float32, device=self.device)
-            call("slic_pack_weight_wino", ptr(weight), self.N, self.C, 0, ptr(self._wu), stream())
+                self._wu = torch.empty((72 if self.wino2 else 54) * self.C * self.N, dtype=torch.float32, device=self.device)
+            call("slic_pack_weight_wino2" if self.wino2 else "slic_pack_weight_wino", ptr(weight), self.N, self.C, 0, ptr(self._wu), stream())
             self._wp_key = self._wkey(weight)
             return self._wu
         if not fresh and self._wp_key is not None and self._wp_key == self._wkey(weight):
@@ -235,8 +251,8 @@ class ConvPlan:
             if not fresh and self._wd_key is not None and self._wd_key == self._wkey(weight):
                 return self._wud
             if self._wud is None:
-                self._wud = torch.empty(9 * self.C * self.N * 6, dtype=torch.float32, device=self.device)
-            call("slic_pack_weight_wino", ptr(weight), self.N, self.C, 1, ptr(self._wud), stream())
+                self._wud = torch.empty((72 if self.wino2 else 54) * self.C * self.N, dtype=torch.float32, device=self.device)
+            call("slic_pack_weight_wino2" if self.wino2 else "slic_pack_weight_wino", ptr(weight), self.N, self.C, 1, ptr(self._wud), stream())
             self._wd_key = self._wkey(weight)
             return self._wud
         if not fresh and self._wd_key is not None and self._wd_key == self._wkey(weight):
@@ -273,8 +289,8 @@ class ConvPlan:
         lib = _lib.load()
         a = self._fwd_args(x, B)
         if self.wino:
-            assert variant in (0, 30) and bias is None, "a Winograd plan runs variant 30 only (build the plan with wino=False)"
-            variant = 30
+            assert variant in (0, 30, 31) and bias is None, "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
+            variant = 31 if self.wino2 else 30
         z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
         a.wgt = wp.data_ptr()
         a.wgt_bytes = _lib.u32_bytes(wp, 'packed weights')
@@ -300,8 +316,8 @@ class ConvPlan:
         """variant 0 = auto: the LDS-DMA kernel wherever a per-tap table exists (source channels % 32 == 0) — 128 x 64 tiles
         for the tall N <= 64 layers (layer1: 52 % of the FLOPs), 64 x 64 tiles (5 workgroups / CU) otherwise — else the
         register-staged kernel (W-run stem, tiny-channel layers).  Measured with scripts/bench_conv.py."""
-        if variant == 30:
-            return 30
+        if variant in (30, 31):
+            return variant
         if not a.tap_tab:
             return 0
         if variant == 0:
@@ -389,8 +405,8 @@ class ConvPlan:
         (sum dx, sum dx * xhat) as a [R, 2, Cs] slab for slic_bn_bwd_fused -> returns (dx, partial)."""
         lib = _lib.load()
         if self.wino:
-            assert variant in (0, 30), "a Winograd plan runs variant 30 only (build the plan with wino=False)"
-            variant = 30
+            assert variant in (0, 30, 31), "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
+            variant = 31 if self.wino2 else 30
         T, H, W = self.in_dims
         To, Ho, Wo = self.out_dims
         dx = out if out is not None else torch.empty((B, T, H, W, self.Cs), dtype=torch.float32, device=dz.device)

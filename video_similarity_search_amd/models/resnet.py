@@ -129,9 +129,9 @@ class _Engine:
             for blk in layer:
                 assert all(hasattr(blk, a) for a in ("conv1", "bn1", "conv2", "bn2", "downsample"))
                 p1 = ConvPlan(blk.conv1.in_channels, blk.conv1.out_channels, blk.conv1.kernel_size, blk.conv1.stride,
-                              blk.conv1.padding, dims, device)
+                              blk.conv1.padding, dims, device, batch=B)
                 p2 = ConvPlan(blk.conv2.in_channels, blk.conv2.out_channels, blk.conv2.kernel_size, blk.conv2.stride,
-                              blk.conv2.padding, p1.out_dims, device)
+                              blk.conv2.padding, p1.out_dims, device, batch=B)
                 plast = p2
                 if hasattr(blk, "conv3"):                              # Bottleneck (depths 50+): a third, 1x1x1 convolution
                     plast = ConvPlan(blk.conv3.in_channels, blk.conv3.out_channels, blk.conv3.kernel_size, blk.conv3.stride,
