@@ -84,6 +84,12 @@ def cpu_baseline_encoder(sd, seconds_budget=25.0):
                        f"{dt:.2f} s/step, torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}")
 
 
+def _exec_factor(p):
+    """share of the direct form's multiplies a plan's forward / data-gradient kernel executes: Winograd F(4,3) x F(2,3) over (W, H)
+    a third, F(4,3) along W a half"""
+    return (1.0 / 3.0) if getattr(p, "wino2", False) else (0.5 if p.wino else 1.0)
+
+
 def step_flops(eng, B):
     """(algorithmic, executed) matrix FLOPs of one training step on B clips, from the engine's own plans: forward + data gradient
     (every layer but the stem) + weight gradient of every convolution / linear layer.  A Winograd F(4,3) launch executes half of
@@ -97,7 +103,7 @@ def step_flops(eng, B):
     for p, has_dgrad in plans:
         f = 2.0 * B * float(np.prod(p.out_dims)) * p.N * p.C * p.ntaps
         alg += f * (2 + has_dgrad)
-        exe += f * ((0.5 if p.wino else 1.0) * (1 + has_dgrad) + (0.5 if p.wino_wgrad else 1.0))
+        exe += f * (_exec_factor(p) * (1 + has_dgrad) + (0.5 if p.wino_wgrad else 1.0))
     return alg, exe
 
 
@@ -110,7 +116,7 @@ def fwd_flops(eng, B):
     for p in plans:
         f = 2.0 * B * float(np.prod(p.out_dims)) * p.N * p.C * p.ntaps
         alg += f
-        exe += f * (0.5 if p.wino else 1.0)
+        exe += f * _exec_factor(p)
     return alg, exe
 
 
@@ -422,7 +428,8 @@ def main():
     M = B * 16 * 56 * 56
     flops_launch = 2.0 * M * 64 * 1728                                 # ALGORITHMIC: the direct convolution's 2 M N K
     wino = bool(getattr(l1[0], "wino", False))
-    executed = flops_launch * 0.5 if wino else flops_launch          # F(4,3): 6 multiplies where the direct form has 12
+    wino2 = bool(getattr(l1[0], "wino2", False))
+    executed = flops_launch * _exec_factor(l1[0])                    # F(4,3): 6 multiplies where the direct form has 12; x F(2,3): 4
     # `achieved` / `frac` = what the matrix pipe really EXECUTES (fp32 MFMA FLOPs of the launch / its duration / the pipe's peak):
     # a fraction of a hardware peak, <= 1 by construction.  The direct-form FLOP count of the same convolution over the same time is
     # reported beside it as algorithmic_tflops; the two differ by the Winograd factor (algorithmic_speedup_vs_direct).
@@ -456,7 +463,9 @@ def main():
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
                              traffic_source=traffic_src,
-                             kernel=("conv_wino_kernel<3,false,2> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
+                             kernel=("conv_wino2_kernel<3> (64->64 3x3x3 convolution as Winograd F(4,3) x F(2,3) over (W, H): 24 fp32-MFMA GEMMs per kt "
+                                     "over tiles of 2 x 4 outputs, H-points split over the waves, LDS-DMA 3-stage ring; fwd + dgrad of layer1)" if wino2 else
+                                     "conv_wino_kernel<3,false,2> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
                                      "over W-tiles, LDS-DMA 3-stage ring, transforms in registers; fwd + dgrad of layer1)" if wino else
                                      "conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring; fwd + dgrad of layer1)"),
                              ms_per_launch=ms_k, launches_timed=len(ev),
@@ -469,7 +478,7 @@ def main():
                                executed_tflops=exe_step / (dt / args.steps) / 1e12,
                                frac_of_fp32_mfma_peak_executed=exe_step / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                algorithmic_tflops=alg_step / (dt / args.steps) / 1e12,
-                               note="per GPU; executed = the convolutions' MFMA FLOPs as run (Winograd layers count half), "
+                               note="per GPU; executed = the convolutions' MFMA FLOPs as run (Winograd layers count a half or a third), "
                                     "algorithmic = the direct form's (SURVEY §8a: 248.9 GFLOP per clip)"))
     def all_ranks_ok(ok):
         """every rank reports; False anywhere -> False everywhere (the rows after this point run collectives on all ranks)"""

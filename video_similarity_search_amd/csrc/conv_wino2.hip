@@ -35,18 +35,9 @@
 #ifndef SLIC_W2_ABL
 #define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range, 2 = no stage barrier
 #endif
-#ifndef SLIC_W2_STAGGER
-#define SLIC_W2_STAGGER 1 // waves 4-7 (tile half 1) run half a stage behind waves 0-3: TWO barriers per stage, and while one wave of a SIMD
-                          // transforms (vector instructions, which an fp32 MFMA of the SAME wave never hides) its partner multiplies
-#endif
-#ifndef SLIC_W2_TAIL
-#define SLIC_W2_TAIL 1    // the last two W-points of a stage are multiplied after the NEXT stage's barrier, under the latency of its LDS reads
-#endif
-
-constexpr int W2_A_FLOATS = 24 * 64 * 4;                       // pixel image of a stage
-constexpr int W2_U_FLOATS = 24 * 64 * 4;                       // U block of a stage
-constexpr int W2_STAGE_FLOATS = W2_A_FLOATS + W2_U_FLOATS;     // 48 KB
-constexpr int W2_NPC = 6;                                      // DMA pieces per thread and stage: 3 pixel + 3 U
+constexpr int W2_PX_FLOATS = 24 * 64 * 8;                      // pixel image of a DOUBLE stage (8 channels): 48 KB
+constexpr int W2_U_FLOATS = 24 * 64 * 4;                       // U block of a stage (4 channels): 24 KB
+constexpr int W2_RING_FLOATS = 2 * W2_PX_FLOATS + 2 * W2_U_FLOATS;   // two pixel slots + two U slots = 144 KB
 
 
 // Epilogue of the two-dimensional kernel, one call per column half nh.  The four H-point waves of a tile have written their W-outputs
@@ -60,7 +51,7 @@ constexpr int W2_NPC = 6;                                      // DMA pieces per
 // coordinates are decoded once and stepped (no division per row), absent operands are not loaded (workgroup-uniform branches), the
 // combined values stay in registers for the second statistics pass.
 __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, int64_t tile0, int n0h, int tid, int full_rows) {
-  constexpr int BNH = 32, CPR = 8, RPP = 64, NW = 8, NPASS = 8;
+  constexpr int BNH = 32, CPR = 8, NW = 8, NPASS = 8;          // 64 rows per pass
   constexpr int JSTRIDE = 64 * 4 * BNH;                        // floats between buf[j] and buf[j + 1]
   const int64_t mblk = tile0 >> 6;
   const int H = p.Hs, W = p.Ws;
@@ -206,7 +197,6 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
   }
 }
 
-template <int STAGES>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -223,79 +213,94 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
   if (tile0 >= Mt) return;
   const int nb = blockIdx.y, n0 = nb * 64;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
-  const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two: checked on the host)
+  const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two >= 16: checked on the host)
   const int cch_shift = 31 - __builtin_clz(CCH);
   const int NS = 3 * CCH;
   const int NB = p.N >> 6;
-  // ---- DMA roles: chunk q = i * 512 + tid of the pixel image [ab 24][tile 64][4 ch]: thread = (tile tid % 64, ab = 8 i + wave)
-  const int64_t mytile = tile0 + (tid & 63);
+  // ---- DMA roles.  Pixels: a DOUBLE stage (8 channels) at a time — piece pc = 8 i + wave (i = 0..5) is patch pixel ab = pc / 2 of
+  // tile half pc % 2; lane L serves tile 32 (pc % 2) + L % 32, 16-byte half L / 32 of the pixel's 8 channels: lanes L and L + 32 fetch
+  // the two halves of ONE 32-byte piece of a cache line (16-byte pieces from 64 different lines per instruction cost 8 % of the
+  // kernel), and the LDS image [ab][tile half][channel half][tile 32][4 ch] hands each stage of the pair its own conflict pattern-free
+  // half.  A thread thus serves ONE tile (wave % 2 picks the half) at six patch positions ab = 4 i + wave / 2.
+  const int64_t mytile = tile0 + (wave & 1) * 32 + (lane & 31);
   const bool tvalid = mytile < Mt;
   unsigned q = (unsigned)(tvalid ? mytile : 0);
   const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
   const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;  // q = frame (b, t)
   const int tt = (int)(q % (unsigned)T);
-  unsigned aoff[3], inv[3];
+  // Per-thread state waits in LDS behind the rings (32 bytes per thread): the tile's base offset, the packed invalid masks (4 bits
+  // per piece: bit kt = the pixel does not exist at that kt; bit 3 = a dead stage) and the six piece offsets RESOLVED for the current
+  // kt (the pixel's address, or an out-of-range offset) — rewritten three times per workgroup behind a scalar branch, read back by
+  // every double stage: LDS instructions cost the matrix pipe nothing, six registers held through the loop would spill.  A stage's
+  // DMA pieces then cost NO vector instruction: the channel group rides in the instruction's scalar offset; U = a per-lane constant
+  // + the stage's block as scalar offset.
+  unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid * 8;
+  {
+    unsigned invp = 0;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int ab = 8 * i + wave;
-    const int a = (ab * 11) >> 6, b = ab - 6 * a;             // ab / 6 for ab < 24
-    const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
-    const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
-    aoff[i] = (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4);
-    // bit kt of an INVALID mask (v_bfe_i32 of one bit gives 0 / -1, and offset | -1 is out of range); bit 3 = a dead stage
-    unsigned m = 1u << 3;
+    for (int i = 0; i < 6; ++i) {
+      const int ab = 4 * i + (wave >> 1);
+      const int a = (ab * 11) >> 6, b = ab - 6 * a;           // ab / 6 for ab < 24
+      const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
+      const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
+      unsigned m = 1u << 3;
 #pragma unroll
-    for (int kt = 0; kt < 3; ++kt) m |= ((ok && (unsigned)(tt + kt - 1) < (unsigned)T) ? 0u : 1u) << kt;
-    inv[i] = m;
+      for (int kt = 0; kt < 3; ++kt) m |= ((ok && (unsigned)(tt + kt - 1) < (unsigned)T) ? 0u : 1u) << kt;
+      invp |= m << (4 * i);
+    }
+    stash[6] = (unsigned)(((((int64_t)q * H + 2 * h2) * W + 4 * wt) * C) * 4) + (unsigned)(lane >> 5) * 16u;
+    stash[7] = invp;
   }
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
   const unsigned uvoff = (unsigned)tid * 16u;
-  // A stage's DMA pieces cost NO vector instruction: the pixel pieces' per-lane offset (aoffk: the pixel's address at this kt, or an
-  // out-of-range offset where the pixel does not exist) changes only with kt — three times per workgroup, behind a scalar branch —
-  // and the stage's channel group rides in the instruction's scalar offset; U = a per-lane constant + the stage's block as scalar offset.
-  struct StageRec { unsigned coff, ublk; int kt, cc; };
-  auto stage_rec = [&](int s) {
-    StageRec g;
+  auto set_kt = [&](int kt) {
+    const unsigned base = stash[6], invp = stash[7];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int ab = 4 * i + (wave >> 1);
+      const int a = (ab * 11) >> 6, b = ab - 6 * a;
+      const unsigned kd = (unsigned)((((kt - 1) * H + (a - 1)) * W + (b - 1)) * C * 4);       // scalar
+      stash[i] = ((invp >> (4 * i + kt)) & 1u) ? 0x80000000u : base + kd;
+    }
+  };
+  // pixel double stage ds (stages 2 ds, 2 ds + 1) into pixel slot `slot`
+  // (in two parts of three pieces — part 0 also resolves the offsets when kt changes — so that three offset registers are live at a time)
+  auto issue_px = [&](int ds, int slot, int part) {
+    const int s = 2 * ds;
+    const bool live = s < NS;
+    const int sc = live ? s : 0;
+    const int kt = live ? (sc >> cch_shift) : 3, cc = sc & (CCH - 1);
+    if (part == 0 && cc == 0) set_kt(kt);                     // scalar branch
+    const unsigned coff = (unsigned)(cc * 16);                // 8 channels = 32 bytes per double stage: cc is even
+#pragma unroll
+    for (int i = 3 * part; i < 3 * part + 3; ++i) {
+#if SLIC_W2_ABL & 1
+      const unsigned off = 0xFFFFFF00u + 0 * stash[i];
+#else
+      const unsigned off = stash[i];
+#endif
+      // piece pc = 8 i + wave = (ab, tile half): image [ab 24][slot 2][tile half 2][channel half 2][tile 32][4 ch] — the two ring slots
+      // are INTERLEAVED per patch pixel, so that one lane address per patch row reaches both slots with immediate offsets
+      const int pc = 8 * i + wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + (((pc >> 1) * 2 + slot) * 2 + (pc & 1)) * 256),
+                                               16, (int)off, (int)coff, 0, 0);
+    }
+  };
+  // U block of stage s into U slot `slot`
+  auto issue_u = [&](int s, int slot) {
     const bool live = s < NS;
     const int sc = live ? s : 0;
     const int kt = sc >> cch_shift, cc = sc & (CCH - 1);
-    g.kt = live ? kt : 3;
-    g.cc = cc;
-    g.coff = (unsigned)(cc * 16);
-    g.ublk = (unsigned)((kt * CCH + cc) * NB + nb) * (unsigned)(W2_U_FLOATS * 4);
-    return g;
-  };
-  unsigned aoffk[3] = {0x80000000u, 0x80000000u, 0x80000000u};
-  // aoff / inv are needed three times per workgroup: they wait in LDS behind the ring (24 bytes per thread), not in registers
-  unsigned* stash = (unsigned*)(lds + STAGES * W2_STAGE_FLOATS) + tid * 6;
+    const unsigned ublk = (unsigned)((kt * CCH + cc) * NB + nb) * (unsigned)(W2_U_FLOATS * 4);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { stash[i] = aoff[i]; stash[3 + i] = inv[i]; }
-  auto set_kt = [&](int kt) {
-    const unsigned kd = (unsigned)((kt - 1) * H * W * C * 4);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) aoffk[i] = ((stash[3 + i] >> kt) & 1u) ? 0x80000000u : stash[i] + kd;
-  };
-  auto issue_piece = [&](const StageRec& g, int toff, int d) {
-#if SLIC_W2_ABL & 8
-    return;
-#endif
-    if (d < 3) {
+    for (int i = 0; i < 3; ++i) {
 #if SLIC_W2_ABL & 1
-      const unsigned off = 0xFFFFFF00u + 0 * aoffk[d];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + 2 * W2_PX_FLOATS + slot * W2_U_FLOATS + (i * 512 + wave * 64) * 4),
+                                               16, (int)(0xFFFFFF00u + 0 * uvoff), (int)(0 * ublk), 0, 0);
 #else
-      const unsigned off = aoffk[d];
-#endif
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + toff + (d * 512 + wave * 64) * 4),
-                                               16, (int)off, (int)g.coff, 0, 0);
-    } else {
-      const int i = d - 3;
-#if SLIC_W2_ABL & 1
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + W2_A_FLOATS + (i * 512 + wave * 64) * 4),
-                                               16, (int)(0xFFFFFF00u + 0 * uvoff), (int)(0 * g.ublk), 0, 0);
-#else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + toff + W2_A_FLOATS + (i * 512 + wave * 64) * 4),
-                                               16, (int)uvoff, (int)(g.ublk + (unsigned)(i * 8192)), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + 2 * W2_PX_FLOATS + slot * W2_U_FLOATS + (i * 512 + wave * 64) * 4),
+                                               16, (int)uvoff, (int)(ublk + (unsigned)(i * 8192)), 0, 0);
 #endif
     }
   };
@@ -306,154 +311,106 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
     for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
-#pragma unroll
-  for (int t = 0; t < STAGES - 1; ++t) {
-    const StageRec g = stage_rec(t);
-    if (g.cc == 0) set_kt(g.kt);
-#pragma unroll
-    for (int d = 0; d < W2_NPC; ++d) issue_piece(g, t * W2_STAGE_FLOATS, d);
-  }
+  // prologue: pixel double stage 0, U of stage 0 — in the order of the steady state (per stage U first, then pixels)
+  issue_u(0, 0);
+  issue_px(0, 0, 0);
+  issue_px(0, 0, 1);
   __builtin_amdgcn_s_setprio(0);
-  // reader offsets (floats): pixel (a, b) of this lane's tile, its channel pair; point (j, p) of column half nh
+  // reader offsets (floats): pixel (a, b) of this lane's tile, channel half e2 of the double stage, its channel pair:
+  //   (((ab * 2 + slot) * 2 + th) * 2 + e2) * 128 + r * 4 + 2 hh;   point (j, p) of column half nh: ((j * 6 + p) * 64 + nh * 32 + r) * 4 + 2 hh
   const int a1 = j == 0 ? 0 : 1, a2 = j == 3 ? 3 : 2;
-  const int ar1 = (a1 * 6 * 64 + th * 32 + r) * 4 + 2 * hh;   // + b * 256
-  const int ar2 = (a2 * 6 * 64 + th * 32 + r) * 4 + 2 * hh;
-  const int bro = W2_A_FLOATS + (j * 6 * 64 + r) * 4 + 2 * hh; // + p * 256 + nh * 128
+  // THREE lane addresses (bytes) serve every LDS read of the loop with immediate offsets; they are made opaque to the compiler, which
+  // otherwise re-associates the large constants into one address register per read and spills them (a scratch reload in the loop
+  // also drains the DMA queue: vmcnt counts it)
+  typedef __attribute__((address_space(3))) const char* lds_cptr;
+  const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  unsigned ar1 = lbase + (unsigned)(a1 * 6144 + th * 256 + r * 4 + 2 * hh) * 4u;      // + (b * 1024 + slot * 512 + e2 * 128) * 4
+  unsigned ar2 = lbase + (unsigned)(a2 * 6144 + th * 256 + r * 4 + 2 * hh) * 4u;
+  unsigned bro = lbase + (unsigned)(2 * W2_PX_FLOATS + (j * 6 * 64 + r) * 4 + 2 * hh) * 4u;   // + (slot * W2_U_FLOATS + p * 256 + nh * 128) * 4
+  asm volatile("" : "+v"(ar1), "+v"(ar2), "+v"(bro));
   const float sg = j == 1 ? 1.f : -1.f;                       // H-point: d[a1] + sg * d[a2]  (j = 2 as d1 - d2: its U is negated)
   const f32x2 sgn = {sg, sg};
   const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
-  f32x2 V[6], ut[2][2];                                       // ut: U of points 4, 5 (kept across the stage barrier with V[4], V[5])
+  f32x2 V[6], ut[2];                                          // ut: U of point 5 (kept across the stage barrier with V[5])
 #pragma unroll
   for (int pp = 0; pp < 6; ++pp) V[pp] = (f32x2){0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) ut[k][nh] = (f32x2){0.f, 0.f};
-  // the eight MFMAs of points p0, p1: element e of the lane's channel pair goes to MFMA e
-  auto mfma_pair = [&](const int p0, const int p1, const f32x2 (&u)[2][2]) {
+  for (int nh = 0; nh < 2; ++nh) ut[nh] = (f32x2){0.f, 0.f};
+  // the four MFMAs of point pp: element e of the lane's channel pair goes to MFMA e (the two column halves alternate: the same
+  // accumulator comes round every other MFMA, 128 cycles apart)
+  auto mfma_point = [&](const int pp, const f32x2 (&u)[2]) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        acc[p0][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p0][e], u[0][nh][e], acc[p0][nh], 0, 0, 0);
-        acc[p1][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[p1][e], u[1][nh][e], acc[p1][nh], 0, 0, 0);
-      }
+      for (int nh = 0; nh < 2; ++nh) acc[pp][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][e], u[nh][e], acc[pp][nh], 0, 0, 0);
   };
-  auto read_u = [&](const float* St, const int p0, f32x2 (&u)[2][2]) {
+  auto read_u = [&](const int uslot, const int pp, f32x2 (&u)[2]) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-#if SLIC_W2_ABL & 16
-        u[k][nh] = (f32x2){(float)(p0 + k), (float)nh};
-#else
-        u[k][nh] = *(const f32x2*)&St[bro + (p0 + k) * 256 + nh * 128];
-#endif
-      }
+    for (int nh = 0; nh < 2; ++nh) u[nh] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)bro + (uslot * W2_U_FLOATS + pp * 256 + nh * 128) * 4);
   };
-  // Stagger (SLIC_W2_STAGGER): the workgroup passes TWO barriers per stage, 2 s and 2 s + 1.  Waves 0-3 (th = 0) start stage s at
-  // barrier 2 s, waves 4-7 (th = 1: the SIMD partners of 0-3) at barrier 2 s + 1; a wave's stage is X = {LDS reads, the previous
-  // stage's last 8 MFMAs, transform} | barrier | Y = {16 MFMAs, the DMAs of stage s + 2}.  So while one wave of a SIMD is in X its
-  // partner is in Y: 24 MFMAs per SIMD and phase either way, and the transform's vector instructions slip between the partner's
-  // MFMAs instead of stopping the pipe for both waves at once (in lock-step the kernel reached 0.64 of the pipe with no memory
-  // traffic at all).  Ring discipline: slot (s % 3) is read during phases 2 s .. 2 s + 2 and refilled (stage s + 3) by DMAs issued
-  // in Y (s + 1), i.e. behind barrier 2 s + 3 at the earliest; the pieces of stage s are complete before barrier 2 s on every wave —
-  // th = 0 waits for them in front of its stage barrier (one younger stage outstanding), th = 1 in front of its mid-stage barrier
-  // (nothing younger outstanding yet).  th = 1 passes one barrier before its first stage, th = 0 one behind its last.
-  constexpr unsigned WAIT_VM6_LGKM0 = ((STAGES - 2) * W2_NPC) | 0x70, WAIT_VM0_LGKM0 = 0x70, WAIT_LGKM0 = 0xC07F;
-  static_assert((STAGES - 2) * W2_NPC < 16, "vmcnt field");
-#if SLIC_W2_STAGGER
-  if (th == 1) {
-    __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
-#if !(SLIC_W2_ABL & 2)
-    __builtin_amdgcn_s_barrier();
-#endif
-  }
-#endif
-  for (int s0 = 0; s0 < NS; s0 += STAGES) {
+  // Ring discipline.  Pixel slots: 2 x 48 KB, double stage ds in slot ds % 2, issued WHOLE (six pieces) in stage 2 ds - 2, i.e.
+  // two stages ahead, behind the barrier that ends the last reads of double stage ds - 2.  U slots: 2 x 24 KB, stage s in slot s % 2,
+  // issued first thing in stage s - 1.  vmcnt retires in order, so the wait in front of an odd stage leaves the six pixel pieces
+  // in flight (vmcnt(6)) and the one in front of an even stage takes everything (vmcnt(0): the pixels issued two stages ago, the U
+  // issued one stage ago).  Four stage bodies per loop turn: (double-stage parity, channel half) fix every LDS slot at compile time.
+  constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
+  for (int s0 = 0; s0 < NS; s0 += 4) {
 #pragma unroll
-    for (int sidx = 0; sidx < STAGES; ++sidx) {
+    for (int sidx = 0; sidx < 4; ++sidx) {
       const int sgl = s0 + sidx;
-      // stage sgl has landed; this wave's LDS reads of stage sgl - 1 are complete before the barrier frees that slot
+      const int e2 = sidx & 1, pslot = (sidx >> 1) & 1, uslot = sidx & 1;
       // (the builtin, not inline assembly: the compiler's own wait-count pass then knows that the registers loaded from LDS in the
       // previous stage — ut — are in, and does not put an lgkmcnt(0) between this stage's reads and the MFMAs that cover them)
-#if SLIC_W2_STAGGER
-      if (th == 0) __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
-      else __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
-#else
-      __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
-#endif
+      if (e2) __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
+      else __builtin_amdgcn_s_waitcnt(WAIT_VM0_LGKM0);
 #if !(SLIC_W2_ABL & 2)
       __builtin_amdgcn_s_barrier();
 #endif
-      const float* St = lds + sidx * W2_STAGE_FLOATS;
-      const int toffn = ((sidx + STAGES - 1) % STAGES) * W2_STAGE_FLOATS;
-      const StageRec gn = stage_rec(sgl + STAGES - 1);
-      // A: the stage's LDS reads that the transform and the first MFMAs need, all issued at once
+      const int pso = (pslot * 512 + e2 * 128) * 4;            // bytes
+      // A: the stage's pixel reads, all issued at once
       f32x2 d1[6], d2[6], cmb[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-#if SLIC_W2_ABL & 16
-        d1[b] = (f32x2){(float)sgl, 1.f}; d2[b] = d1[b];
-#else
-        d1[b] = *(const f32x2*)&St[ar1 + b * 256];
-        d2[b] = *(const f32x2*)&St[ar2 + b * 256];
-#endif
+        d1[b] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)ar1 + pso + b * 4096);
+        d2[b] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)ar2 + pso + b * 4096);
       }
-      f32x2 u01[2][2], u23[2][2];
+      f32x2 ua[2], ub[2];
       __builtin_amdgcn_sched_barrier(0);
-      // B: the previous stage's last two points (V[4], V[5], ut still hold them), under the latency of those reads
-#if SLIC_W2_TAIL
-      mfma_pair(4, 5, ut);
-#endif
-      if (gn.cc == 0) set_kt(gn.kt);                          // scalar branch, three times per workgroup
+      // B: the next stage's U, then the previous stage's last point (V[5], ut still hold it) under the latency of A
+      issue_u(sgl + 1, uslot ^ 1);
+      mfma_point(5, ut);
       __builtin_amdgcn_sched_barrier(0);
-      read_u(St, 0, u01);                                      // lands under the transform
+      read_u(uslot, 0, ua);                                       // lands under the transform
       __builtin_amdgcn_sched_barrier(0);
       // C: H-point, then V = B^T (.) along W.  The packed ops are inline assembly, which the compiler's hazard recogniser does not see
       // as VALU (an MFMA reading a register within two instructions of the op that wrote it would read the OLD value): one fenced
       // block closed by the two wait states.
-#if SLIC_W2_ABL & 4
-#pragma unroll
-      for (int b = 0; b < 6; ++b) V[b] = d1[b];
-#else
 #pragma unroll
       for (int b = 0; b < 6; ++b) cmb[b] = pk_fma(d2[b], sgn, d1[b]);
       wino_bt6(cmb, V, c2, c4, c5);
       asm volatile("s_nop 1" ::: "memory");
-#endif
       __builtin_amdgcn_sched_barrier(0);
-#if SLIC_W2_STAGGER
-      // mid-stage barrier: the partner group starts its stage here
-      if (th == 1) __builtin_amdgcn_s_waitcnt(WAIT_VM0_LGKM0);
-      else __builtin_amdgcn_s_waitcnt(WAIT_LGKM0);
-#if !(SLIC_W2_ABL & 2)
-      __builtin_amdgcn_s_barrier();
-#endif
+      // D: the stage's MFMAs point by point, the next point's U fetched one point ahead (two points' fragments live at a time);
+      // an even stage issues the pixel double stage two stages ahead between them
+      read_u(uslot, 1, ub);
+      mfma_point(0, ua);
+      read_u(uslot, 2, ua);
+      mfma_point(1, ub);
       __builtin_amdgcn_sched_barrier(0);
-#endif
-      // D: the stage's MFMAs, the next-but-one stage's DMAs between them
-      read_u(St, 2, u23);
-      mfma_pair(0, 1, u01);
-#pragma unroll
-      for (int d = 0; d < 3; ++d) issue_piece(gn, toffn, d);
-      read_u(St, 4, ut);
-      mfma_pair(2, 3, u23);
-#pragma unroll
-      for (int d = 3; d < W2_NPC; ++d) issue_piece(gn, toffn, d);
-#if !SLIC_W2_TAIL
-      mfma_pair(4, 5, ut);
-#endif
+      if (!e2) issue_px((sgl >> 1) + 1, pslot ^ 1, 0);
+      read_u(uslot, 3, ub);
+      mfma_point(2, ua);
+      read_u(uslot, 4, ua);
+      mfma_point(3, ub);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!e2) issue_px((sgl >> 1) + 1, pslot ^ 1, 1);
+      read_u(uslot, 5, ut);
+      mfma_point(4, ua);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-#if SLIC_W2_TAIL
-  mfma_pair(4, 5, ut);
-#endif
+  mfma_point(5, ut);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#if SLIC_W2_STAGGER && !(SLIC_W2_ABL & 2)
-  if (th == 0) __builtin_amdgcn_s_barrier();
-#endif
   __syncthreads();
 #if SLIC_W2_ABL & 32
   if (acc[0][0][0] != 12345.678f) return;                      // diagnostic build: no epilogue
@@ -553,8 +510,7 @@ int slic_wino2_full_rows(const SlicConvArgs* a) {
 }
 
 int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st) {
-  constexpr int STAGES = 3;
-  constexpr size_t ring = (size_t)STAGES * W2_STAGE_FLOATS * sizeof(float) + 512 * 6 * 4, epi = (size_t)conv_epi_lds_floats(512, 64, 8) * sizeof(float);
+  constexpr size_t ring = (size_t)W2_RING_FLOATS * sizeof(float) + 512 * 8 * 4, epi = (size_t)conv_epi_lds_floats(512, 64, 8) * sizeof(float);
   constexpr size_t lds = ring > epi ? ring : epi;
   static_assert(lds <= 160 * 1024, "LDS");
   SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts && a->Gb == a->Hs &&
@@ -566,13 +522,13 @@ int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st) {
   SLIC_REQUIRE(full > 0, "slic_conv_gemm: variant 31: blocks of 64 tiles hold different numbers of outputs at H=%d W=%d", a->Hs, a->Ws);
   static bool attr_set = false;
   if (!attr_set) {
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_kernel<STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
   SLIC_REQUIRE(tiles < (1ll << 31) && (int64_t)a->M * a->Cs * 4 < 0xFFFFFF00ll, "slic_conv_gemm: variant 31: tensor too large");
   const int gx = (int)slic_cdiv(tiles, 64);
-  conv_wino2_kernel<STAGES><<<dim3((unsigned)((gx + 7) / 8 * 8), (unsigned)(a->N / 64)), dim3(512), lds, st>>>(*a, full);
+  conv_wino2_kernel<<<dim3((unsigned)((gx + 7) / 8 * 8), (unsigned)(a->N / 64)), dim3(512), lds, st>>>(*a, full);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
