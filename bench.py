@@ -160,6 +160,25 @@ def kmeans_secondary(rank, world, pg, run_cpu):
                ms_per_iter=dt / iters * 1e3, iters=iters, n_gpus=world, whole_fit_seconds=dt_fit,
                whole_iteration_frac_of_fp32_mfma=flops_iter / (dt / iters) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
                config=dict(workload=f"Lloyd, N=100000 D=512 K=500 fp32, explicit init, tol=0, 20 fixed iterations; {layout}"))
+    if pg is not None:
+        # the same iteration WEAK-scaled (100k rows on every GPU, N = 100k x ranks): per-GPU work fixed, so the curve shows what the one
+        # collective per iteration costs; the strong-scaled row above divides 100k rows over the ranks (per-rank E-step of ~50 us at 8)
+        Xw = torch.from_numpy(X).cuda() if world > 1 else Xd
+        kmw = KMeans(n_clusters=K, init=init, n_init=1, max_iter=iters, tol=0.0, fixed_iters=True, process_group=pg)
+        kmw.fit(Xw)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        kmw.fit(Xw)
+        torch.cuda.synchronize()
+        dtw = kmw.lloyd_seconds_
+        if world > 1:
+            tw = torch.tensor([dtw], device="cuda")
+            torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+            dtw = float(tw.item())
+        out["weak_scaled"] = dict(value=N * world * iters / dtw, unit="embeddings/s", ms_per_iter=dtw / iters * 1e3, n_gpus=world,
+                                  rows_per_gpu=N, scaling="weak")
+        del Xw, kmw
     # E-step kernel alone (dominant kernel of this path): HIP events on the launch stream
     from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
     k = HipKernels()
@@ -362,12 +381,9 @@ def main():
         # the job aborts after five minutes instead of hanging (the headline line is printed before the secondary rows start)
         torch.distributed.init_process_group(backend="nccl", timeout=datetime.timedelta(minutes=5))
         pg = torch.distributed.group.WORLD
-        if world > 1:
-            # The sharded k-means row's ONE all-reduce per iteration: through torch's RCCL process group, whose collectives carry
-            # the timeout above — the library's own communicator (slic_allreduce_f64, include/slic_hip.h) has run on hardware on
-            # one-rank groups only (1-GPU boxes), and a collective of its own that waits for a lost peer would hang the whole run.
-            # SLIC_KMEANS_COMM=slic selects it.
-            os.environ.setdefault("SLIC_KMEANS_COMM", "torch")
+        # The sharded k-means row's ONE all-reduce per iteration goes through torch's RCCL process group (the product default:
+        # its collectives carry the timeout above); SLIC_KMEANS_COMM=slic selects the library's own communicator
+        # (slic_allreduce_f64, include/slic_hip.h), whose waits are bounded by SLIC_COMM_TIMEOUT_MS.
 
     from video_similarity_search_amd import _lib
     _lib.check(_lib.load().slic_device_check(), "slic_device_check")
@@ -550,6 +566,55 @@ def main():
                                                  frac_of_fp32_mfma_peak_executed=exe128 / dt128 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                                  algorithmic_tflops=alg128 / dt128 / 1e12)
             del x128
+            # north_star's wording ("synthetic 8 x 3 x 16 x 112 x 112 batches") and the shipped configs' own step (BASELINE configs[3],
+            # online_train.py:255-392: 13 anchors + 13 positives + 13 second anchors through ONE forward, random_semi_hard mining + the LLC
+            # margin term): small batches run the few-tile launch rules (K splits, one-dimensional Winograd where the 2-D form has too
+            # few workgroups) that the B = 32 headline never reaches
+            from video_similarity_search_amd.loss.triplet_loss import margin_cosine_loss
+
+            def timed_steps(fn, n_warm, n):
+                for _ in range(n_warm):
+                    fn()
+                torch.cuda.synchronize()
+                t1 = time.time()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.time() - t1) / n
+
+            x8 = torch.from_numpy(np.random.default_rng(13 + rank).standard_normal((8, 3, 16, 112, 112)).astype(np.float32)).cuda()
+            lab8 = torch.arange(4).repeat(2).cuda()
+
+            def step8():
+                emb = model(x8)
+                l8, _ = crit(emb, lab8, sampling_strategy='noise_contrastive')
+                opt.zero_grad(set_to_none=True)
+                l8.backward()
+                opt.step()
+            dt8 = timed_steps(step8, 3, 10)
+            alg8, exe8 = step_flops(net._engine(x8), 8)
+            res["secondary"]["train_b8"] = dict(metric="clips/sec R3D-18+NT-Xent training step at B = 8 x 3x16x112x112, per GPU", value=8 / dt8,
+                                                unit="clips/s", ms_per_step=dt8 * 1e3,
+                                                frac_of_fp32_mfma_peak_executed=exe8 / dt8 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                                algorithmic_tflops=alg8 / dt8 / 1e12)
+            del x8
+            x39 = torch.from_numpy(np.random.default_rng(17 + rank).standard_normal((39, 3, 16, 112, 112)).astype(np.float32)).cuda()
+            lab26 = torch.arange(13).repeat(2).cuda()
+
+            def step39():
+                out = model(x39)
+                l39, _ = crit(out[:26], lab26, sampling_strategy="random_semi_hard")
+                l39 = l39 + 1.0 * margin_cosine_loss(out[:13], out[26:39], out[13:26], 0.04)
+                opt.zero_grad(set_to_none=True)
+                l39.backward()
+                opt.step()
+            dt39 = timed_steps(step39, 2, 5)
+            alg39, exe39 = step_flops(net._engine(x39), 39)
+            res["secondary"]["train_configs3_b39"] = dict(
+                metric="clips/sec R3D-18 training step of BASELINE configs[3]: 39 clips (13 anchors + 13 positives + 13 second anchors), "
+                       "random_semi_hard + LLC margin term, per GPU", value=39 / dt39, unit="clips/s", ms_per_step=dt39 * 1e3,
+                frac_of_fp32_mfma_peak_executed=exe39 / dt39 / 1e12 / FP32_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg39 / dt39 / 1e12)
+            del x39
             if world == 1:
                 # the reference-shaped clustering call end to end: KMeans(n_clusters=500, n_init=10) = 10 x (k-means++ + Lloyd, tol 1e-4)
                 from video_similarity_search_amd.clustering import fit_cluster

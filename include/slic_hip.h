@@ -35,6 +35,7 @@ extern "C" {
 #define SLIC_EINVAL -1   /* bad argument / unsupported shape */
 #define SLIC_EHIP -2     /* HIP runtime error (launch, memset, ...) */
 #define SLIC_ENODEV -3   /* no gfx950 device visible */
+#define SLIC_ETIMEOUT -4 /* a bounded wait on a collective ran out (slic_comm_create_timeout, slic_comm_wait): the communicator is aborted */
 
 /* library */
 int slic_version(void);                 /* (major<<16)|(minor<<8)|patch */
@@ -159,8 +160,20 @@ int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, i
 typedef struct slic_comm slic_comm;
 int slic_comm_unique_id(void* id_out /* SLIC_COMM_ID_BYTES */);
 int slic_comm_create(const void* id, int world, int rank, slic_comm** out);
+/* The same with a deadline (milliseconds; 0 = none): the communicator is created non-blocking and polled; if the peers have not all
+ * joined in time — a rank died before the rendezvous, a wrong world size — it is aborted and SLIC_ETIMEOUT comes back instead of a
+ * hang.  The deadline also bounds the enqueue of every later slic_allreduce_* of this communicator. */
+int slic_comm_create_timeout(const void* id, int world, int rank, int timeout_ms, slic_comm** out);
 int slic_allreduce_f32(slic_comm* comm, float* buf, int64_t n, void* stream);
 int slic_allreduce_f64(slic_comm* comm, double* buf, int64_t n, void* stream);
+/* Bounded wait for the collectives already enqueued: returns when everything enqueued on `stream` so far has run (SLIC_OK), when RCCL
+ * reports an asynchronous error (SLIC_EHIP), or when timeout_ms (0 = none) has passed (SLIC_ETIMEOUT: a peer never joined) — in the two
+ * failure cases the communicator has been ABORTED (its stuck kernel is released, every later call on it fails) so that the rank can
+ * exit non-zero instead of hanging its peers' job.  What torch.distributed's process-group timeout is to the reference's collectives
+ * (misc/distributed_helper.py:30-64). */
+int slic_comm_wait(slic_comm* comm, void* stream, int timeout_ms);
+/* give up on a communicator at once (ncclCommAbort) and free the handle */
+int slic_comm_abort(slic_comm* comm);
 int slic_comm_destroy(slic_comm* comm);
 
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in

@@ -102,15 +102,26 @@ def _bn(x, sd, name, training, momentum=0.1, eps=1e-5):
     return y
 
 
-def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None, relu_masks=None, max_pool=False):
+def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=True, taps=None, relu_masks=None, max_pool=False,
+                    mask_report=None):
     """x: [B, C, T, H, W].  sd: dict of torch tensors (running stats are updated in place when training).
     taps (optional dict) receives intermediate activations by name.
     relu_masks (optional dict name -> bool tensor, names 'stem', 'layer{L}.{b}.a1', 'layer{L}.{b}', 'head'): the branch every
     ReLU takes is IMPOSED (y = x * mask) instead of decided by the sign of x — a ReLU input within rounding noise of zero goes
-    either way in any fp32 run, and a gradient comparison is only well posed between runs that took the same branches."""
+    either way in any fp32 run, and a gradient comparison is only well posed between runs that took the same branches.
+    mask_report (optional dict, with relu_masks): per ReLU, how the imposed branches differ from the ones THIS run's own
+    pre-activation v would take — {numel, flipped = #(mask != (v > 0)), worst = max |v| over the flipped elements, scale = rms(v)} —
+    so that a test can bound the imposed masks: a few elements, all within rounding noise of zero (assert_masks_benign)."""
     def relu(v, name):
         if relu_masks is not None and name in relu_masks:
-            return v * relu_masks[name].to(v.dtype)
+            m = relu_masks[name]
+            if mask_report is not None:
+                with torch.no_grad():
+                    diff = (v > 0) != m
+                    n = int(diff.sum())
+                    mask_report[name] = dict(numel=v.numel(), flipped=n, worst=float(v[diff].abs().max()) if n else 0.0,
+                                             scale=float(v.double().pow(2).mean().sqrt()))
+            return v * m.to(v.dtype)
         return F.relu(v)
 
     kt = sd["conv1.weight"].shape[2]
@@ -164,6 +175,19 @@ def encoder_forward(sd, x, training, conv1_stride=(1, 2, 2), projection_head=Tru
     h = F.linear(x, sd["fc1.weight"], sd["fc1.bias"])
     h = relu(_bn(h, sd, "bn_proj", training), "head")
     return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def assert_masks_benign(report, max_frac=2e-5, max_rel=1e-4, floor=2):
+    """the imposed ReLU branches (encoder_forward(relu_masks=..., mask_report=report)) may differ from the run's own only in a
+    handful of elements per layer (at most max(floor, max_frac * numel)) and only where the pre-activation is within rounding
+    noise of zero (|v| <= max_rel * rms of the layer's pre-activations).  Returns (total flipped, total elements) for the log."""
+    tot = cnt = 0
+    for name, r in report.items():
+        assert r["flipped"] <= max(floor, max_frac * r["numel"]), (name, r)
+        assert r["worst"] <= max_rel * r["scale"], (name, r)
+        tot += r["flipped"]
+        cnt += r["numel"]
+    return tot, cnt
 
 
 def r3d_to_resnet_keys(sd):

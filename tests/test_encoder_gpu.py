@@ -499,7 +499,10 @@ def test_encoder_options_maxpool_and_shortcut_a_vs_reference_golden(gpu, golden_
         if masks is not None:
             from oracle import encoder as oe
             t64 = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
-            l64 = oe.ntxent_loss(oe.encoder_forward(t64, torch.from_numpy(x).double(), training=True, relu_masks=masks))
+            rep = {}
+            l64 = oe.ntxent_loss(oe.encoder_forward(t64, torch.from_numpy(x).double(), training=True, relu_masks=masks, mask_report=rep))
+            # tiny layers (a few hundred to a few thousand elements each): at most two flipped branches per layer, all within noise
+            print(f"{tag}: imposed ReLU branches differ from the fp64 run's own in {oe.assert_masks_benign(rep)} elements")
             p64 = {k: v for k, v in t64.items() if v.requires_grad}
             g64 = dict(zip(p64, torch.autograd.grad(l64, list(p64.values()))))
             assert abs(loss.item() - float(l64)) < 1e-4
@@ -625,7 +628,11 @@ def test_r3d18_full_size_eval_and_train_vs_oracle(gpu):
     # branches have the same derivative).  Max-norm, relative to the tensor's largest entry.
     masks = _gpu_relu_masks(m, xt.cuda())
     t64g = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
-    l64 = oe.ntxent_loss(oe.encoder_forward(t64g, xt.double(), training=True, relu_masks=masks))
+    rep = {}
+    l64 = oe.ntxent_loss(oe.encoder_forward(t64g, xt.double(), training=True, relu_masks=masks, mask_report=rep))
+    # the imposed branches are the fp64 run's own but for a handful of elements per layer, every one of them within rounding noise of
+    # zero (|pre-activation| <= 1e-4 of the layer's rms): a wrong-but-self-consistent device mask cannot hide behind the imposition
+    print("B = 4: imposed ReLU branches differ from the fp64 run's own in (elements, of)", oe.assert_masks_benign(rep))
     g64 = dict(zip(names, torch.autograd.grad(l64, [t64g[k] for k in names])))
     for k in names:
         ref = g64[k]
@@ -684,7 +691,9 @@ def test_eval_mode_backward_frozen_batchnorm_vs_oracle(gpu):
                 masks["head"] = (ctx["ah"] > 0).view(4, -1).cpu()
     t64 = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
     names = [k for k, v in t64.items() if v.requires_grad]
-    e64 = oe.encoder_forward(t64, x.double(), training=False, relu_masks=masks)
+    rep = {}
+    e64 = oe.encoder_forward(t64, x.double(), training=False, relu_masks=masks, mask_report=rep)
+    print("eval-mode backward: imposed ReLU branches differ from the fp64 run's own in (elements, of)", oe.assert_masks_benign(rep))
     l64 = oe.ntxent_loss(e64)
     g64 = dict(zip(names, torch.autograd.grad(l64, [t64[k] for k in names])))
     assert (emb.detach().cpu().double() - e64.detach()).abs().max().item() <= 1e-4
@@ -838,19 +847,28 @@ def test_config1_bench_batch_b32_train_step_vs_oracle(gpu):
     # pre-activation within rounding noise of zero — the head's BatchNorm1d output nearest to zero is 3.5e-6 away with this seed —
     # goes either way in any fp32 run), where the host has the memory (the fp64 autograd graph holds ~30 GB at B = 32); otherwise
     # the fp32 oracle is the reference and the gate is loose.
-    if psutil.virtual_memory().available > 90 * 2 ** 30:
+    avail = psutil.virtual_memory().available / 2 ** 30
+    if avail > 90 or os.environ.get("SLIC_TEST_B32_FP64") == "1":
+        print(f"configs[1] gradient gate: fp64 oracle on the device's ReLU branches, 1e-3 ({avail:.0f} GiB of host memory free)")
         t64 = oe.to_torch(sd, dtype=torch.float64, requires_grad=True)
-        l64 = oe.ntxent_loss(oe.encoder_forward(t64, x.double(), training=True, relu_masks=masks))
+        rep = {}
+        l64 = oe.ntxent_loss(oe.encoder_forward(t64, x.double(), training=True, relu_masks=masks, mask_report=rep))
+        print("B = 32: imposed ReLU branches differ from the fp64 run's own in (elements, of)", oe.assert_masks_benign(rep))
         g64 = dict(zip(names, torch.autograd.grad(l64, [t64[k] for k in names])))
         for k in names:
             ref = g64[k]
             d_gpu = (g_gpu[k].double() - ref).abs().max().item() / ref.abs().max().item()
             assert d_gpu <= 1e-3, (k, d_gpu)
-    else:
+    elif os.environ.get("SLIC_TEST_B32_LOOSE") == "1":
+        # explicit opt-in only: the fp32 oracle as the gradient reference (its own ReLU branches), 5e-3
+        print(f"configs[1] gradient gate: LOOSE branch (fp32 oracle, 5e-3) — {avail:.0f} GiB of host memory free, SLIC_TEST_B32_LOOSE=1")
         for k in names:
             ref = g32[k]
             d = (g_gpu[k] - ref).abs().max().item() / ref.abs().max().item()
             assert d <= 5e-3, (k, d)
+    else:
+        pytest.fail(f"configs[1] gradient gate needs ~90 GiB of free host memory for the fp64 oracle graph ({avail:.0f} GiB free); "
+                    "set SLIC_TEST_B32_LOOSE=1 to accept the fp32-oracle gate (5e-3) instead")
 
 
 def test_bench_configuration_properties_b32(gpu, monkeypatch):

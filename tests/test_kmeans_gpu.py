@@ -385,4 +385,58 @@ def test_slic_comm_one_rank_allreduce(gpu):
     torch.cuda.synchronize()
     assert torch.equal(a, a0) and torch.equal(b, b0)
     assert lib.slic_allreduce_f32(comm, None, 4, None) != 0 and b"bad args" in lib.slic_last_error()
+    _lib.check(lib.slic_comm_wait(comm, stream(), 5000), "slic_comm_wait")          # everything enqueued has run: returns at once
     _lib.check(lib.slic_comm_destroy(comm), "slic_comm_destroy")
+
+
+def test_slic_comm_missing_peer_times_out(gpu):
+    """a communicator whose peer never shows up (world = 2 joined by ONE process — what a rank lost before the rendezvous looks
+    like) must not hang: slic_comm_create_timeout gives up after its deadline with SLIC_ETIMEOUT, the communicator is aborted and
+    the process goes on (here: a fresh one-rank communicator works right after)"""
+    import ctypes
+    import time
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd._lib import call, ptr, stream
+    lib = _lib.load()
+    buf = (ctypes.c_ubyte * 128)()
+    _lib.check(lib.slic_comm_unique_id(buf), "slic_comm_unique_id")
+    comm = ctypes.c_void_p()
+    t0 = time.time()
+    rc = lib.slic_comm_create_timeout(bytes(buf), 2, 0, 3000, ctypes.byref(comm))
+    dt = time.time() - t0
+    assert rc == -4 and not comm.value, (rc, lib.slic_last_error())               # SLIC_ETIMEOUT
+    assert 2.5 <= dt < 30 and b"aborted" in lib.slic_last_error(), (dt, lib.slic_last_error())
+    # the process is intact: a one-rank communicator with a deadline, an all-reduce, a bounded wait, an explicit abort
+    _lib.check(lib.slic_comm_unique_id(buf), "slic_comm_unique_id")
+    _lib.check(lib.slic_comm_create_timeout(bytes(buf), 1, 0, 10000, ctypes.byref(comm)), "slic_comm_create_timeout")
+    b = torch.arange(4096, dtype=torch.float64, device="cuda") / 7
+    b0 = b.clone()
+    call("slic_allreduce_f64", comm, ptr(b), b.numel(), stream())
+    _lib.check(lib.slic_comm_wait(comm, stream(), 10000), "slic_comm_wait")
+    assert torch.equal(b, b0)
+    _lib.check(lib.slic_comm_abort(comm), "slic_comm_abort")
+
+
+def test_sharded_kmeans_through_the_library_communicator(gpu, monkeypatch):
+    """SLIC_KMEANS_COMM=slic (opt-in): the sharded iteration's one all-reduce through slic_allreduce_f64 on a one-rank RCCL group,
+    every status read behind slic_comm_wait's deadline — same labels as the default route through torch.distributed"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import os, numpy as np, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', RANK='0', WORLD_SIZE='1')\n"
+        "dist.init_process_group('nccl'); torch.cuda.set_device(0)\n"
+        "from video_similarity_search_amd.clustering import KMeans\n"
+        "rng = np.random.default_rng(3); X = rng.standard_normal((4096, 64)).astype(np.float32)\n"
+        "init = X[rng.choice(4096, 16, replace=False)].copy(); Xd = torch.from_numpy(X).cuda()\n"
+        "out = []\n"
+        "for route in ('torch', 'slic'):\n"
+        "    os.environ['SLIC_KMEANS_COMM'] = route\n"
+        "    km = KMeans(16, init=init, n_init=1, max_iter=15, process_group=dist.group.WORLD).fit(Xd)\n"
+        "    out.append((km.labels_.copy(), km.n_iter_, km.cluster_centers_.copy()))\n"
+        "assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])\n"
+        "dist.destroy_process_group(); print('routes agree', out[0][1])\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "routes agree" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

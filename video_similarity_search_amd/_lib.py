@@ -39,6 +39,9 @@ SIGNATURES = {
     "slic_kmeans_lloyd_global": (I, [P, I, L, I, P, I, I, P, P, P, P, P, P, I, P, P]),
     "slic_comm_unique_id": (I, [P]),
     "slic_comm_create": (I, [P, I, I, P]),
+    "slic_comm_create_timeout": (I, [P, I, I, I, P]),
+    "slic_comm_wait": (I, [P, P, I]),
+    "slic_comm_abort": (I, [P]),
     "slic_allreduce_f32": (I, [P, P, L, P]),
     "slic_allreduce_f64": (I, [P, P, L, P]),
     "slic_comm_destroy": (I, [P]),

@@ -173,16 +173,42 @@ class HipKernels:
         call("slic_cumsum_search", ptr(v), v.numel(), ptr(vals), T, ptr(idx_out), ptr(ws), stream())
 
 
-_COMMS = {}        # process group -> slic_comm* (an RCCL communicator of the library's own, created once per group)
+# process group -> slic_comm* (an RCCL communicator of the library's own, created once per group).  Keyed on the group OBJECT through
+# weak references: a destroyed group's id() may be re-used by a new group with other members, and a stale communicator would hang or
+# reduce over the wrong ranks; when the group goes away its communicator is destroyed with it.
+import weakref
+
+_COMMS = weakref.WeakKeyDictionary()
+
+
+class _CommHandle:
+    """owns one slic_comm*: slic_comm_destroy when the handle dies (the group was collected) or at interpreter exit"""
+
+    def __init__(self, ptr_):
+        self.ptr = ptr_
+        self._fin = weakref.finalize(self, _CommHandle._close, ptr_)
+
+    @staticmethod
+    def _close(ptr_):
+        try:
+            _lib.load().slic_comm_destroy(ptr_)
+        except Exception:
+            pass
+
+
+def comm_timeout_ms():
+    """deadline of the library communicator's waits (SLIC_COMM_TIMEOUT_MS, default five minutes — torch.distributed's own collectives
+    default to ten): a peer that never joins makes every rank raise instead of hang"""
+    return int(os.environ.get("SLIC_COMM_TIMEOUT_MS", "300000"))
 
 
 def _slic_comm(pg, dev):
-    """the C-ABI communicator for the sharded iteration's all-reduce (include/slic_hip.h: slic_comm_create): rank 0 of the group
-    draws the unique id, torch.distributed carries it to the others, every rank joins on its device"""
+    """the C-ABI communicator for the sharded iteration's all-reduce (include/slic_hip.h: slic_comm_create_timeout): rank 0 of the
+    group draws the unique id, torch.distributed carries it to the others, every rank joins on its device — under a deadline"""
     import ctypes
-    key = id(pg)
-    if key in _COMMS:
-        return _COMMS[key]
+    h = _COMMS.get(pg)
+    if h is not None:
+        return h.ptr
     lib = _lib.load()
     W, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
     idt = torch.zeros(128, dtype=torch.uint8, device=dev)
@@ -193,8 +219,8 @@ def _slic_comm(pg, dev):
     torch.distributed.broadcast(idt, src=torch.distributed.get_global_rank(pg, 0), group=pg)
     raw = bytes(idt.cpu().numpy().tobytes())
     comm = ctypes.c_void_p()
-    _lib.check(lib.slic_comm_create(raw, W, rank, ctypes.byref(comm)), "slic_comm_create")
-    _COMMS[key] = comm
+    _lib.check(lib.slic_comm_create_timeout(raw, W, rank, comm_timeout_ms(), ctypes.byref(comm)), "slic_comm_create_timeout")
+    _COMMS[pg] = _CommHandle(comm)
     return comm
 
 
@@ -383,11 +409,13 @@ class KMeans:
                 parts = [torch.empty(W, PL, dtype=torch.float32, device=dev) for _ in range(2)]
             gsums = [torch.empty(K * Dp, dtype=torch.float32, device=dev) for _ in range(2)]
             gcounts = [torch.empty(K, dtype=torch.float32, device=dev) for _ in range(2)]
-            # the all-reduce goes through the library's own RCCL communicator (slic_allreduce_f64 on the compute stream) when
-            # the group runs on RCCL; under gloo (the CPU tests' kernel provider) through torch.distributed
+            # the all-reduce goes through torch.distributed's process group (RCCL on the GPU, gloo in the CPU tests): its
+            # collectives carry the group's timeout and it is the path every multi-rank test runs.  SLIC_KMEANS_COMM=slic opts
+            # into the library's own RCCL communicator (slic_allreduce_f64 on the compute stream, the C ABI's collective for
+            # callers without torch.distributed); its waits are bounded too (slic_comm_create_timeout / slic_comm_wait)
             comm = None
             if (self.exchange == "allreduce" and on_gpu and torch.distributed.get_backend(self.process_group) == "nccl"
-                    and os.environ.get("SLIC_KMEANS_COMM", "slic") != "torch"):
+                    and os.environ.get("SLIC_KMEANS_COMM", "torch") == "slic"):
                 comm = _slic_comm(self.process_group, dev)
         else:
             gsums = [p[: K * Dp] for p in part]
@@ -444,6 +472,9 @@ class KMeans:
 
         def read(it):
             if on_gpu:
+                if comm is not None:
+                    # bounded: a peer that never joined the iteration's all-reduce aborts the communicator and raises here
+                    call("slic_comm_wait", comm, stream(), comm_timeout_ms())
                 ev[it & 1].synchronize()
             return host[it & 1].tolist()
 

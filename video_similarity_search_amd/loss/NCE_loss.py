@@ -192,16 +192,17 @@ class _FusedContrastStep(torch.autograd.Function):
              K1, ptr(stat[0]), ptr(stat[1]), ptr(loss), stream())
         ctx.mark_non_differentiable(scores)
         ctx.T, ctx.shape = float(T), (B, K1, D)
-        ctx.keep = (rows, scores, stat)
+        # through save_for_backward: the scores handed back for logging are the buffer the backward reads, and a caller's in-place
+        # edit must trip autograd's version check instead of corrupting the gradients; a second backward (retain_graph) works
+        ctx.save_for_backward(rows, scores, stat)
         return loss, scores
 
     @staticmethod
     def backward(ctx, g, _gs):
         B, K1, D = ctx.shape
-        rows, scores, stat = ctx.keep
+        rows, scores, stat = ctx.saved_tensors
         df = torch.empty(2, B, D, dtype=torch.float32, device=g.device)
         call("slic_nce_fused_bwd", ptr(rows), ptr(scores), ptr(stat[0]), B, K1, D, ctx.T, ptr(g.contiguous().float()), ptr(df), stream())
-        ctx.keep = None
         return df[1], df[0], None, None, None, None, None, None
 
 

@@ -117,14 +117,12 @@ class _NTXentEuclid(torch.autograd.Function):
         buf = torch.empty(2 * n * n + n + 1, dtype=torch.float32, device=e.device)
         dist, wm, rowloss, loss = buf[:n * n], buf[n * n:2 * n * n], buf[2 * n * n:2 * n * n + n], buf[-1]
         call("slic_ntxent_euclid_fwd", ptr(e), n, D, float(temperature), ptr(dist), ptr(wm), ptr(rowloss), ptr(loss), stream())
-        ctx.save_for_backward(e)
-        ctx.keep = (dist, wm)
+        ctx.save_for_backward(e, dist, wm)
         return loss.clone()
 
     @staticmethod
     def backward(ctx, g):
-        (e,) = ctx.saved_tensors
-        dist, wm = ctx.keep
+        e, dist, wm = ctx.saved_tensors
         n, D = e.shape
         dE = torch.empty_like(e)
         call("slic_ntxent_euclid_bwd", ptr(e), ptr(dist), ptr(wm), n, D, ptr(g.contiguous().float()), ptr(dE), stream())
