@@ -398,6 +398,7 @@ class KMeans:
         ev = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
         done = [torch.cuda.Event() if on_gpu else None for _ in range(2)]
         side = self._side_stream(dev) if on_gpu else None
+        comm = None
         if self._sharded:
             W = torch.distributed.get_world_size(self.process_group)
             PL = K * Dp + K + 2                                          # [sums | counts | n_changed lo, hi]
@@ -413,7 +414,6 @@ class KMeans:
             # collectives carry the group's timeout and it is the path every multi-rank test runs.  SLIC_KMEANS_COMM=slic opts
             # into the library's own RCCL communicator (slic_allreduce_f64 on the compute stream, the C ABI's collective for
             # callers without torch.distributed); its waits are bounded too (slic_comm_create_timeout / slic_comm_wait)
-            comm = None
             if (self.exchange == "allreduce" and on_gpu and torch.distributed.get_backend(self.process_group) == "nccl"
                     and os.environ.get("SLIC_KMEANS_COMM", "torch") == "slic"):
                 comm = _slic_comm(self.process_group, dev)
