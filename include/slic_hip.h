@@ -324,6 +324,17 @@ int slic_pack_weight_wino(const float* W, int N, int C, int dgrad, float* U, voi
  * same number of real outputs — slic_conv_tile_m(args, 31) returns it (the slab rows' size) or 0 when the geometry does not allow
  * it: H even and W % 4 == 0, or H even and ceil(W / 4) | 64, or ceil(H / 2) * ceil(W / 4) | 64. */
 int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, float* U, void* stream);
+/* Weight gradient by the transposed TWO-dimensional algorithm, dW = Gh^T [sum over tiles of (Bh^T x Bw) . (Ah dY Aw^T)] Gw: 24
+ * multiplies per (kt, c, n) and tile of 2 x 4 outputs (slic_conv_wgrad_wino: 36, the direct form: 72); replaces slic_conv_wgrad_wino
+ * where variant 31 runs the forward (any H, W: ragged tiles are masked).  args as slic_conv_wgrad_wino; tile_tab: (M / (Hs Ws)) *
+ * ceil(Hs / 2) * ceil(Ws / 4) records of 8 bytes written once per geometry by slic_conv_wino2_tile_table; `splits` slices of the
+ * tiles, reduced in slice order (deterministic); workspace: splits x 3 x 24 x Cs x N floats.  One workgroup per (kt, pair of H-points,
+ * 64 x 64 block, slice): 6 x Cs / 64 x N / 64 x splits workgroups of 512 threads, one per CU.  Stands in for the same autograd weight
+ * gradient of nn.Conv3d (models/resnet.py:11-17) as slic_conv_wgrad. */
+size_t slic_conv_wgrad_wino2_workspace_bytes(const SlicConvArgs* args, int splits);
+int slic_conv_wino2_tile_table(const SlicConvArgs* args, uint32_t* tile_tab, void* stream);
+int slic_conv_wgrad_wino2(const SlicConvArgs* args, const float* dy, int splits, const uint32_t* tile_tab, float* dW,
+                          void* workspace, void* stream);
 /* Weight gradient of the same layers by the transposed F(4, 3) algorithm, dW[kw] = sum over W-tiles of G^T[(B^T x) . (A dy)]
  * (six multiplies per (kt, kh, c, n) and tile of four outputs instead of twelve); replaces slic_conv_wgrad where variant 30 runs the
  * forward.  args: the forward geometry (src = x, 3 x 3 x 3 / stride 1 / pad 1, Cs % 64 == 0, N % 64 == 0, any Ws: the last tile of a

@@ -58,12 +58,15 @@ for name, C, N, k, s, p, dims in SHAPES:
         t = timeit(lambda: wplan.wgrad(x, dz, B, dW))
         line += f" wg {fl/t/1e9:6.1f}"
         try:
-            w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True)    # F(4,3) x F(2,3) over (W, H)
+            w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True, wino2_wgrad=6 * (C // 64) * (N // 64) <= 128)    # F(4,3) x F(2,3) over (W, H)
             wu, wud = w2.pack_fwd(w), w2.pack_dgrad(w)
             t = timeit(lambda: w2.forward(x, wu, B, want_stats=True))
             line += f" | wino2 fwd {fl/t/1e9:6.1f}"
             t = timeit(lambda: w2.dgrad(dz, wud, B))
             line += f" dg {fl/t/1e9:6.1f}"
+            if w2.wino2_wgrad:
+                t = timeit(lambda: w2.wgrad(x, dz, B, dW))
+                line += f" wg {fl/t/1e9:6.1f}"
         except AssertionError:
             pass
     print(line, flush=True)

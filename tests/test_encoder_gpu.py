@@ -226,9 +226,9 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     y64 = F.conv3d(x64, w64, None, s, p)
     dy = torch.from_numpy(rng.standard_normal(tuple(y64.shape)).astype(np.float32))
     gx64, = torch.autograd.grad(y64, [x64], dy.double())
-    w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True)
+    w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True, wino2_wgrad=6 * (C // 64) * (N // 64) <= 128)
     w1 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=False)
-    assert w2.wino2 and not w1.wino2
+    assert w2.wino2 and not w1.wino2 and not w1.wino2_wgrad
     wd_ = w.cuda().contiguous()
     xd = _ndhwc(x, C).cuda()
     dyd = dy.permute(0, 2, 3, 4, 1).contiguous().cuda()
@@ -275,9 +275,17 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     s2 = (refg.double() * ((zz.double() - mean.double()) * invstd.double())).reshape(-1, C).sum(0)
     assert torch.allclose(bpart[:, 0].double().sum(0), s1, atol=2e-3, rtol=1e-4)
     assert torch.allclose(bpart[:, 1].double().sum(0), s2, atol=2e-3, rtol=1e-4)
-    # the weight gradient of a two-dimensional plan is the transposed one-dimensional algorithm's
-    dW = w2.wgrad(xd, dyd, B, torch.empty_like(wd_))
-    assert torch.equal(dW, w1.wgrad(xd, dyd, B, torch.empty_like(wd_)))
+    # weight gradient by the transposed two-dimensional algorithm (slic_conv_wgrad_wino2) where the plan uses it (the layers with
+    # few 64 x 64 blocks), vs fp64 and vs the one-dimensional kernel; default slicing, three slices, one slice; bit-equal run to run
+    x64w, w64w = x.double(), w.double().requires_grad_(True)
+    gw64, = torch.autograd.grad(F.conv3d(x64w, w64w, None, s, p), [w64w], dy.double())
+    dW1 = w1.wgrad(xd, dyd, B, torch.empty_like(wd_)).cpu()
+    assert w2.wino2_wgrad == (6 * (C // 64) * (N // 64) <= 128)
+    for splits in (None, 3, 1):
+        dW = w2.wgrad(xd, dyd, B, torch.empty_like(wd_), splits=splits).cpu()
+        assert (dW - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item()), splits
+    assert (dW - dW1).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
+    assert torch.equal(w2.wgrad(xd, dyd, B, torch.empty_like(wd_)), w2.wgrad(xd, dyd, B, torch.empty_like(wd_)))
 
 
 @pytest.mark.parametrize("variant,slots,want", [(20, 8, (4, 4)), (20, 64, (0, 6)), (22, 4, (2, 2)), (22, 64, (0, 10))])

@@ -71,6 +71,9 @@ SIGNATURES = {
     "slic_pack_weight_dgrad": (I, [P, I, I, I, I, I, P, P]),
     "slic_pack_weight_wino": (I, [P, I, I, I, P, P]),
     "slic_pack_weight_wino2": (I, [P, I, I, I, P, P]),
+    "slic_conv_wgrad_wino2_workspace_bytes": (c_size_t, [P, I]),
+    "slic_conv_wino2_tile_table": (I, [P, P, P]),
+    "slic_conv_wgrad_wino2": (I, [P, P, I, P, P, P, P]),
     "slic_conv_wgrad_wino_workspace_bytes": (c_size_t, [P, I]),
     "slic_conv_wino_tile_table": (I, [P, P, P]),
     "slic_conv_wgrad_wino": (I, [P, P, I, P, P, P, P]),

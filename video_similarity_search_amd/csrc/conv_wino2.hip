@@ -28,6 +28,7 @@
 #include "conv_epilogue.h"
 #include "conv_internal.h"
 #include "wino_common.h"
+#include <type_traits>
 
 #ifndef SLIC_PRIO_EDGE
 #define SLIC_PRIO_EDGE 3
@@ -537,6 +538,407 @@ extern "C" int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, f
   SLIC_REQUIRE(W && U && N % 64 == 0 && C % 64 == 0, "slic_pack_weight_wino2: N and C must be multiples of 64");
   const int64_t tot = (int64_t)3 * C * N;
   pack_w_wino2<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, (hipStream_t)stream>>>(W, N, C, dgrad, U);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the same layers by the TRANSPOSED two-dimensional algorithm: with Y = Ah^T [(Gh w Gw^T) . (Bh^T x Bw)] Aw per tile,
+//   dL/dw = Gh^T [ sum over tiles of (Bh^T x Bw) . (Ah dY Aw^T) ] Gw
+// — the forward's input transform V (24 points from the tile's 4 x 6 patch), the output transform run backwards Z (24 points from the
+// tile's 2 x 4 output gradients), one 64 x 64 product-sum per point, kt and tile, and Gh^T .. Gw once at the very end: 24 multiplies per
+// (kt, c, n) and tile of 8 outputs where the one-dimensional transposed algorithm has 36 and the direct form 72.
+//   Workgroup = 512 threads = one kt, one PAIR of H-points (j = 2 jp, 2 jp + 1: they share three of the patch's four rows), one
+//   64 c x 64 n block, one slice of the tiles.  Waves 0-3 take j = 2 jp, waves 4-7 j = 2 jp + 1, each group 2 x 2 waves of 32 c x 32 n
+//   with six accumulators (the W-points).  The MFMA's k dimension is the TILE: lane (r, hh) reads its channel's pixels of tile
+//   2 ks + hh (two patch rows x 6) and its column's gradients (two output rows x 4) with ds_read2st64_b32 — two k-steps per
+//   instruction, and every vector instruction below works on such a pair — forms the H-point (one packed op per pixel / gradient), runs
+//   the F(4, 3) transforms along W in registers and feeds one MFMA per W-point.
+//   Stage = 8 tiles, ONE WAVE PER TILE for the DMA: 512 bytes of the patch's last two pixels (a half piece, issued first: its dead lanes'
+//   zeros land where the wave's own next piece then writes), 2 KB of gradients, 4 KB of pixels — 6.5 KB per tile, 52 KB per stage,
+//   3-stage ring (156 KB: one workgroup per CU), counted vmcnt, one barrier per stage; per-tile records {pixel index, invalid bits}
+//   from slic_conv_wino2_tile_table, loaded a stage ahead.
+//   Slabs [slice][kt][j][p][c][n]; conv_wgrad_wino2_reduce adds the slices in order and applies Gh^T .. Gw.
+// ------------------------------------------------------------------------------------------
+constexpr int WG2_TILE_BYTES = 6656;                           // [2 pixels 512][8 gradients 2048][16 pixels 4096]
+constexpr int WG2_STAGE_BYTES = 8 * WG2_TILE_BYTES;            // 53248
+constexpr int WG2_RING_OFF = 1024;                             // the ring starts 1 KB into LDS (a lane address below reaches back 1 KB)
+constexpr int WG2_STAGES = 3;
+
+// tab[tile] = {pixel index of (b, t, 2 h2, 4 wt); bits 0-23: patch pixel (a, b) = (2 h2 - 1 + a, 4 wt - 1 + b) is OUTSIDE the frame
+//              (bit a * 6 + b); bits 24-26: frame t - 1 + kt is outside the clip; bit 27: always set (the dead half of a piece)}
+__global__ void conv_wino2_tile_table_kernel(const SlicConvArgs p, uint2* __restrict__ tab) {
+  const int Wq = (p.Ws + 3) >> 2, Hq = (p.Hs + 1) >> 1;
+  const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= (p.M / ((int64_t)p.Hs * p.Ws)) * Hq * Wq) return;
+  unsigned q = (unsigned)tile;
+  const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+  const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;
+  const int tt = (int)(q % (unsigned)p.Ts);
+  unsigned mk = 1u << 27;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const bool in = (unsigned)(2 * h2 - 1 + a) < (unsigned)p.Hs && (unsigned)(4 * wt - 1 + b) < (unsigned)p.Ws;
+      mk |= (in ? 0u : 1u) << (a * 6 + b);
+    }
+#pragma unroll
+  for (int kt = 0; kt < 3; ++kt) mk |= ((unsigned)(tt + kt - 1) < (unsigned)p.Ts ? 0u : 1u) << (24 + kt);
+  tab[tile] = make_uint2((unsigned)(((int64_t)q * p.Hs + 2 * h2) * p.Ws + 4 * wt), mk);
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy, unsigned dy_bytes, const uint2* __restrict__ tile_tab,
+                             float* __restrict__ slab, int tiles_per_split, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int js = wave >> 2, wc = (wave >> 1) & 1, wn = wave & 1;
+  const int r = lane & 31, hh = lane >> 5;
+  const int C = p.Cs, N = p.N, H = p.Hs, W = p.Ws;
+  const int CB = C >> 6, NBk = N >> 6;
+  const int per_slice = 6 * CB * NBk;
+  const int bx = blockIdx.x, gdx = gridDim.x;
+  const int v = (bx & 7) * (gdx >> 3) + (bx >> 3);            // XCD-aware: the workgroups of a slice (same tiles) share an L2
+  if (v >= per_slice * nsplit) return;
+  const int z = v / per_slice;
+  int rest = v - z * per_slice;
+  const int kj = rest / (CB * NBk); rest -= kj * (CB * NBk);
+  const int cb = rest / NBk, nb = rest - cb * NBk;
+  const int kt = kj >> 1, jp = kj & 1;
+  const int j = 2 * jp + js;
+  const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
+  const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;
+  const int64_t tbeg = (int64_t)z * tiles_per_split;
+  const int64_t tend = min(tbeg + tiles_per_split, Mt);
+  const int nst = tend > tbeg ? (int)((tend - tbeg + 7) / 8) : 0;
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)tile_tab, 0, (int)(tend * 8), 0x00020000);
+  // ---- DMA roles: wave w serves tile w of the stage with seven 1 KB pieces, in this order:
+  //   piece 0: patch pixels rho = 2, b = 4, 5 (slots 16, 17 of the three stored rows x 6; lanes 32-63 dead)      -> tile bytes [0, 512)
+  //   pieces 1, 2: the 2 x 4 gradients (slot = hp * 4 + o)                                                          -> [512, 2560)
+  //   pieces 3-6: patch pixels slots 0..15 (slot = rho * 6 + b, stored row rho = patch row jp + rho)                -> [2560, 6656)
+  // lane = (slot within the piece lane / 16, 16-byte chunk lane % 16 of the slot's 64 channels / columns)
+  unsigned pos[7], cst[7], mul[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int sub = lane >> 4, chunk = lane & 15;
+    if (i == 1 || i == 2) {
+      const int slot = (i - 1) * 4 + sub, hp = slot >> 2, o = slot & 3;
+      pos[i] = (unsigned)((hp + 1) * 6 + (o + 1));              // output (hp, o) is patch pixel (hp + 1, o + 1)
+      cst[i] = (unsigned)(((hp * W + o) * N + nb * 64 + chunk * 4) * 4);
+      mul[i] = (unsigned)(N * 4);
+    } else {
+      const int slot = i == 0 ? 16 + sub : (i - 3) * 4 + sub;   // piece 0: sub 0, 1 live
+      const int rho = slot / 6, b = slot - 6 * rho, a = jp + rho;
+      pos[i] = (i == 0 && sub >= 2) ? 27u : (unsigned)(a * 6 + b);
+      cst[i] = (unsigned)(((((kt - 1) * H + (a - 1)) * W + (b - 1)) * C + cb * 64 + chunk * 4) * 4);
+      mul[i] = (unsigned)(C * 4);
+    }
+  }
+  // Fast path (most tiles: every pixel the workgroup needs exists): a wave serves ONE tile, so the tile's base offset is wave-uniform
+  // and rides in the DMA's SCALAR offset — no vector instruction per piece.  The per-lane constants are biased to be non-negative
+  // (B0x: one frame for kt = 0, one row for jp = 0, one pixel), the scalar part carries the rest (never negative when the pixels exist).
+  const unsigned B0x = (unsigned)((((kt == 0 ? H * W : 0) + (jp == 0 ? W : 0) + 1) * C) * 4);
+  unsigned cstb[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) cstb[i] = (i == 1 || i == 2) ? cst[i] : ((i == 0 && (lane >> 4) >= 2) ? 0x80000000u : cst[i] + B0x);
+  unsigned needx = (1u << (24 + kt));
+#pragma unroll
+  for (int e = 0; e < 18; ++e) needx |= 1u << (jp * 6 + e);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto load_rec = [&](int s) -> u32x2 {
+    const int64_t tile = tbeg + (int64_t)s * 8 + wave;
+    u32x2 rc = __builtin_amdgcn_raw_buffer_load_b64(rs_tab, (int)(tile * 8), 0, 0);      // past the slice: zeros -> made invalid below
+    return rc;
+  };
+  const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds) + WG2_RING_OFF;
+  auto issue_piece = [&](int slot_, int d, const u32x2 rec, const unsigned xmask) {
+    // invalid -> offset | -1 (out of range: zeros).  A record past the slice reads {0, 0}: bit 27 is clear there, so `live` marks it dead
+    const unsigned m = (d == 1 || d == 2) ? rec.y : xmask;
+    const unsigned off = (__umul24(rec.x, mul[d]) + cst[d]) | (unsigned)__builtin_amdgcn_sbfe((int)m, pos[d], 1);
+    const int dst = slot_ * WG2_STAGE_BYTES + wave * WG2_TILE_BYTES + (d == 0 ? 0 : (d <= 2 ? 512 + (d - 1) * 1024 : 2560 + (d - 3) * 1024));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((d == 1 || d == 2) ? rs_dy : rs_src,
+                                             (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + WG2_RING_OFF + dst),
+                                             16, (int)off, 0, 0, 0);
+  };
+  auto issue_fast = [&](int slot_, int d, const unsigned sx_, const unsigned sy_) {
+    const int dst = slot_ * WG2_STAGE_BYTES + wave * WG2_TILE_BYTES + (d == 0 ? 0 : (d <= 2 ? 512 + (d - 1) * 1024 : 2560 + (d - 3) * 1024));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((d == 1 || d == 2) ? rs_dy : rs_src,
+                                             (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + WG2_RING_OFF + dst),
+                                             16, (int)cstb[d], (int)((d == 1 || d == 2) ? sy_ : sx_), 0, 0);
+  };
+  // all seven pieces of the tile whose record is rc (wave-uniform): fast when every needed pixel exists
+  // (in two parts, pieces 0-2 and 3-6, so that the caller's MFMAs sit between them outside the branch)
+  auto issue_tile = [&](int slot_, u32x2 rc, const int part) {
+    const unsigned ry = (unsigned)__builtin_amdgcn_readfirstlane((int)rc.y), rx = (unsigned)__builtin_amdgcn_readfirstlane((int)rc.x);
+    if ((ry & needx) == 0 && ((ry >> 27) & 1u)) {
+      const unsigned sxo = rx * (unsigned)(C * 4) - B0x, syo = rx * (unsigned)(N * 4);
+      if (part == 0) {
+        issue_fast(slot_, 0, sxo, syo);
+        issue_fast(slot_, 1, sxo, syo);
+        issue_fast(slot_, 2, sxo, syo);
+      } else {
+        issue_fast(slot_, 3, sxo, syo);
+        issue_fast(slot_, 4, sxo, syo);
+        issue_fast(slot_, 5, sxo, syo);
+        issue_fast(slot_, 6, sxo, syo);
+      }
+    } else {
+      const unsigned tinv = (unsigned)__builtin_amdgcn_sbfe((int)rc.y, 24 + kt, 1);          // -1: frame t - 1 + kt outside
+      const bool dead = !((rc.y >> 27) & 1u);                                                  // zeros record: past the slice
+      const unsigned xm = dead ? 0xFFFFFFFFu : (rc.y | tinv);
+      if (dead) rc.y = 0xFFFFFFFFu;
+      if (part == 0) {
+        issue_piece(slot_, 0, rc, xm);
+        issue_piece(slot_, 1, rc, xm);
+        issue_piece(slot_, 2, rc, xm);
+      } else {
+        issue_piece(slot_, 3, rc, xm);
+        issue_piece(slot_, 4, rc, xm);
+        issue_piece(slot_, 5, rc, xm);
+        issue_piece(slot_, 6, rc, xm);
+      }
+    }
+  };
+  f32x16 acc[6];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
+  u32x2 recn;
+#pragma unroll
+  for (int t = 0; t < WG2_STAGES - 1; ++t) {
+    const u32x2 rc = load_rec(t);
+    issue_tile(t, rc, 0);
+    issue_tile(t, rc, 1);
+    asm volatile("" ::: "memory");
+  }
+  recn = load_rec(WG2_STAGES - 1);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_setprio(0);
+  // ---- readers.  H-point j: V = x[rho1] + sx * x[rho2],  Z = y[ya] + sy * y[1]:
+  //   j = 0: rows (0, 2), sx = -1; Z = y0            j = 1: rows (1, 2), sx = +1; Z = y0 + y1
+  //   j = 2: rows (0, 1), sx = -1 (the point NEGATED); Z = y0 - y1      j = 3: rows (0, 2), sx = -1; Z = y1 (NEGATED)
+  // (stored rows: rho = patch row - jp; the two negations are undone by the reduce kernel's Gh)
+  const int rho1 = j == 1 ? 1 : 0, rho2 = j == 2 ? 1 : 2;
+  const float sxf = j == 1 ? 1.f : -1.f, syf = j == 1 ? 1.f : (j == 2 ? -1.f : 0.f);
+  const f32x2 sx = {sxf, sxf}, sy = {syf, syf};
+  const int ya = j == 3 ? 1 : 0;
+  const bool two_rows = j == 1 || j == 2;
+  // lane addresses (bytes; + stage * WG2_STAGE_BYTES): tile 2 ks + hh of the k-step, this lane's channel / column.  Pixel (rho, b):
+  // slot e = 6 rho + b lives at 2560 + 256 e for e < 16 and at 256 (e - 16) for e = 16, 17 — row rho2 = 2 reaches back for b = 4, 5
+  const unsigned xch = (unsigned)((wc * 32 + r) * 4), ych = (unsigned)((wn * 32 + r) * 4);
+  const unsigned tb = lbase + (unsigned)(hh * WG2_TILE_BYTES);
+  unsigned x1a = tb + 2560u + (unsigned)(rho1 * 1536) + xch;                                   // + 256 b
+  unsigned x2a = tb + 2560u + (unsigned)(rho2 * 1536) + xch;                                   // + 256 b, b < 4 (any b for rho2 = 1)
+  unsigned x2h = (rho2 == 2 ? tb - 1024u : tb + 2560u + 1536u) + xch;                          // + 256 b, b = 4, 5
+  unsigned yfa = tb + 512u + (unsigned)(ya * 1024) + ych;                                      // + 256 o
+  unsigned ysa = tb + 512u + 1024u + ych;                                                      // + 256 o  (row 1)
+  asm volatile("" : "+v"(x1a), "+v"(x2a), "+v"(x2h), "+v"(yfa), "+v"(ysa));
+  const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c8 = {8.f, 8.f};
+  const f32x2 zero2 = {0.f, 0.f};
+  // k-steps 2 kp (.x) and 2 kp + 1 (.y) of ring slot SL: offsets in 256-byte units (tile 26, k-step 52, pair 104, slot 208)
+  auto read_pair = [&](auto sl_, auto kp_, f32x2 (&xa)[6], f32x2 (&xb)[6], f32x2 (&yf)[4], f32x2 (&ys)[4]) {
+    constexpr int SL = decltype(sl_)::value;
+    constexpr int B0 = decltype(kp_)::value * 104;
+    const unsigned so = (unsigned)(SL * WG2_STAGE_BYTES);
+    xa[0] = lds_read2st64<B0 + 0, B0 + 52>(x1a + so);
+    xa[1] = lds_read2st64<B0 + 1, B0 + 53>(x1a + so);
+    xa[2] = lds_read2st64<B0 + 2, B0 + 54>(x1a + so);
+    xa[3] = lds_read2st64<B0 + 3, B0 + 55>(x1a + so);
+    xa[4] = lds_read2st64<B0 + 4, B0 + 56>(x1a + so);
+    xa[5] = lds_read2st64<B0 + 5, B0 + 57>(x1a + so);
+    xb[0] = lds_read2st64<B0 + 0, B0 + 52>(x2a + so);
+    xb[1] = lds_read2st64<B0 + 1, B0 + 53>(x2a + so);
+    xb[2] = lds_read2st64<B0 + 2, B0 + 54>(x2a + so);
+    xb[3] = lds_read2st64<B0 + 3, B0 + 55>(x2a + so);
+    xb[4] = lds_read2st64<B0 + 4, B0 + 56>(x2h + so);
+    xb[5] = lds_read2st64<B0 + 5, B0 + 57>(x2h + so);
+    yf[0] = lds_read2st64<B0 + 0, B0 + 52>(yfa + so);
+    yf[1] = lds_read2st64<B0 + 1, B0 + 53>(yfa + so);
+    yf[2] = lds_read2st64<B0 + 2, B0 + 54>(yfa + so);
+    yf[3] = lds_read2st64<B0 + 3, B0 + 55>(yfa + so);
+    ys[0] = lds_read2st64<B0 + 0, B0 + 52>(ysa + so);
+    ys[1] = lds_read2st64<B0 + 1, B0 + 53>(ysa + so);
+    ys[2] = lds_read2st64<B0 + 2, B0 + 54>(ysa + so);
+    ys[3] = lds_read2st64<B0 + 3, B0 + 55>(ysa + so);
+  };
+  // H-points, then V = B^T (.) and the four inner points of Z = A (.) along W (Z = [c0, c0+c1+c2+c3, c0-c1+c2-c3, c0+2c1+4c2+8c3,
+  // c0-2c1+4c2-8c3, c3]; points 0 and 5 are c0 and c3 themselves): one fenced block closed by the two wait states an MFMA needs behind
+  // the (inline-assembly) VALU instruction that wrote its operand
+  auto transform_pair = [&](const f32x2 (&xa)[6], const f32x2 (&xb)[6], const f32x2 (&yf)[4], const f32x2 (&ys)[4], f32x2 (&V)[6],
+                            f32x2 (&Zi)[4], f32x2 (&cz)[4]) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the pair's (inline-assembly) LDS reads
+    f32x2 cx[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) cx[b] = pk_fma(xb[b], sx, xa[b]);
+    if (two_rows) {                                            // wave-uniform: H-points 1, 2 combine both gradient rows
+#pragma unroll
+      for (int o = 0; o < 4; ++o) cz[o] = pk_fma(ys[o], sy, yf[o]);
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) cz[o] = yf[o];
+    }
+    wino_bt6(cx, V, c2, c4, c5);
+    const f32x2 e = pk_add(cz[0], cz[2]), od = pk_add(cz[1], cz[3]);
+    const f32x2 e4 = pk_fma(cz[2], c4, cz[0]), o4 = pk_fma(cz[3], c8, pk_add(cz[1], cz[1]));
+    Zi[0] = pk_add(e, od);
+    Zi[1] = pk_sub(e, od);
+    Zi[2] = pk_add(e4, o4);
+    Zi[3] = pk_sub(e4, o4);
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the six MFMAs of k-step `sel` (0 / 1) of a transformed pair
+  auto mfma6 = [&](const f32x2 (&V)[6], const f32x2 (&Zi)[4], const f32x2 (&cz)[4], const int sel) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0][sel], cz[0][sel], acc[0], 0, 0, 0);
+#pragma unroll
+    for (int pp = 1; pp < 5; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][sel], Zi[pp - 1][sel], acc[pp], 0, 0, 0);
+    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[5][sel], cz[3][sel], acc[5], 0, 0, 0);
+  };
+  // the stage's second pair stays in registers across the barrier: its odd k-step is multiplied after the NEXT stage's barrier
+  f32x2 Vp[6], Zp[4], czp[4];
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp) Vp[pp] = zero2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { Zp[q] = zero2; czp[q] = zero2; }
+  constexpr int PER = 8;                                       // VMEM ops per stage: seven DMAs + one record load
+  auto stage = [&](const int sg, auto sl_) {
+    constexpr int sidx = decltype(sl_)::value;
+    // stage sg has landed once only the younger ops are outstanding: the record load issued behind its DMAs and the
+    // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (WG2_STAGES - 2) * PER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int slotn = (sidx + WG2_STAGES - 1) % WG2_STAGES;
+    f32x2 xa[6], xb[6], yf[4], ys[4], V[6], Zi[4], cz[4];
+    read_pair(sl_, std::integral_constant<int, 0>{}, xa, xb, yf, ys);
+    mfma6(Vp, Zp, czp, 1);                                     // the previous stage's last k-step, under the latency of these reads
+    transform_pair(xa, xb, yf, ys, V, Zi, cz);
+    read_pair(sl_, std::integral_constant<int, 1>{}, xa, xb, yf, ys);
+    mfma6(V, Zi, cz, 0);
+    issue_tile(slotn, recn, 0);
+    mfma6(V, Zi, cz, 1);
+    issue_tile(slotn, recn, 1);
+    asm volatile("" ::: "memory");                           // the counted vmcnt relies on this order: seven DMAs, then the record
+    recn = load_rec(sg + WG2_STAGES);
+    asm volatile("" ::: "memory");
+    transform_pair(xa, xb, yf, ys, Vp, Zp, czp);
+    mfma6(Vp, Zp, czp, 0);
+  };
+  for (int s0 = 0; s0 < nst; s0 += WG2_STAGES) {
+    stage(s0, std::integral_constant<int, 0>{});
+    stage(s0 + 1, std::integral_constant<int, 1>{});
+    stage(s0 + 2, std::integral_constant<int, 2>{});
+  }
+  mfma6(Vp, Zp, czp, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  // slab[z][kt][j][p][c][n]
+  float* out = slab + (((int64_t)z * 3 + kt) * 4 + j) * 6 * (int64_t)C * N;
+  const int n = nb * 64 + 32 * wn + r;
+#pragma unroll
+  for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
+      out[((int64_t)pp * C + c) * N + n] = acc[pp][g];
+    }
+}
+
+// dW[n][c][kt][kh][kw] = sum_j sum_p Gh[j][kh] Gw[p][kw] * (sum over slices z, ascending, of slab[z][kt][j][p][c][n])
+// Gh as the kernel left the points: rows 2 and 3 negated — [1 0 0; 1/2 1/2 1/2; -1/2 1/2 -1/2; 0 0 -1]
+__global__ __launch_bounds__(256) void conv_wgrad_wino2_reduce(const float* __restrict__ slab, int S, int C, int N, float* __restrict__ dW) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t CN = (int64_t)C * N;
+  if (e >= 3 * CN) return;
+  const int n = (int)(e % N);
+  const int c = (int)((e / N) % C);
+  const int kt = (int)(e / CN);
+  const int64_t zs = 3 * 24 * CN;
+  float t[4][3];      // [j][kw]: the W-points taken back through Gw^T
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    float sp[6];
+#pragma unroll
+    for (int pp = 0; pp < 6; ++pp) {
+      const float* q = slab + (((int64_t)kt * 4 + jj) * 6 + pp) * CN + (int64_t)c * N + n;
+      float a = 0.f;
+      for (int zi = 0; zi < S; ++zi) a += q[zi * zs];
+      sp[pp] = a;
+    }
+    // Gw^T rows: kw 0: [1/4 -1/6 -1/6 1/24 1/24 0], kw 1: [0 -1/6 1/6 1/12 -1/12 0], kw 2: [0 -1/6 -1/6 1/6 1/6 1]
+    const float s12 = sp[1] + sp[2], d12 = sp[2] - sp[1], s34 = sp[3] + sp[4], d34 = sp[3] - sp[4];
+    t[jj][0] = 0.25f * sp[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    t[jj][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+    t[jj][2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + sp[5];
+  }
+  float* o = dW + ((int64_t)n * C + c) * 27 + kt * 9;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    const float h12 = 0.5f * (t[1][kw] - t[2][kw]);            // 1/2 (S1 + S2) with S2 stored negated
+    o[0 * 3 + kw] = t[0][kw] + h12;
+    o[1 * 3 + kw] = 0.5f * (t[1][kw] + t[2][kw]);              // 1/2 (S1 - S2)
+    o[2 * 3 + kw] = h12 - t[3][kw];                            // + S3, stored negated
+  }
+}
+
+static int64_t wino2_tiles(const SlicConvArgs* a) { return (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4); }
+
+static void wino2_wgrad_plan(const SlicConvArgs* a, int splits, int* tps, int* S) {
+  const int64_t Mt = wino2_tiles(a);
+  int64_t per = slic_cdiv(Mt, splits < 1 ? 1 : splits);
+  per = slic_cdiv(per, 8) * 8;
+  *tps = (int)per;
+  *S = (int)slic_cdiv(Mt, per);
+}
+
+extern "C" size_t slic_conv_wgrad_wino2_workspace_bytes(const SlicConvArgs* a, int splits) {
+  if (!a || a->M <= 0) return 0;
+  int tps, S;
+  wino2_wgrad_plan(a, splits, &tps, &S);
+  return slic_align_up((size_t)S * 3 * 24 * a->Cs * a->N * sizeof(float), 256);
+}
+
+extern "C" int slic_conv_wino2_tile_table(const SlicConvArgs* a, uint32_t* tile_tab, void* stream) {
+  SLIC_REQUIRE(a && tile_tab && a->M > 0 && a->Ws > 0 && a->Hs > 0 && a->Ga == a->Ts && a->Gb == a->Hs && a->Gc == a->Ws && a->Cs > 0,
+               "slic_conv_wino2_tile_table: needs a stride-1 same-size geometry");
+  SLIC_REQUIRE(a->M < (1ll << 24), "slic_conv_wino2_tile_table: more than 2^24 output positions (split the batch)");
+  conv_wino2_tile_table_kernel<<<dim3((unsigned)slic_cdiv(wino2_tiles(a), 256)), dim3(256), 0, (hipStream_t)stream>>>(*a, (uint2*)tile_tab);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
+extern "C" int slic_conv_wgrad_wino2(const SlicConvArgs* a, const float* dy, int splits, const uint32_t* tile_tab, float* dW,
+                                     void* workspace, void* stream) {
+  SLIC_REQUIRE(a && a->src && dy && dW && workspace && tile_tab && splits >= 1, "slic_conv_wgrad_wino2: bad args");
+  SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts && a->Gb == a->Hs &&
+                   a->Gc == a->Ws && !a->k_run_len,
+               "slic_conv_wgrad_wino2: needs a 3x3x3 stride-1 same-size geometry, Cs %% 64 == 0, N %% 64 == 0");
+  const int64_t dyb = a->M * (int64_t)a->N * 4;
+  SLIC_REQUIRE(dyb < (int64_t)0xFFFFFF00u && a->M * (int64_t)a->Cs * 4 < (int64_t)0xFFFFFF00u && a->M < (1ll << 24),
+               "slic_conv_wgrad_wino2: tensors larger than 4 GiB / 2^24 positions (split the batch)");
+  int tps, S;
+  wino2_wgrad_plan(a, splits, &tps, &S);
+  hipStream_t st = (hipStream_t)stream;
+  constexpr size_t lds = (size_t)WG2_RING_OFF + (size_t)WG2_STAGES * WG2_STAGE_BYTES;
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int64_t total = (int64_t)6 * (a->Cs / 64) * (a->N / 64) * S;
+  SLIC_REQUIRE(total < (1ll << 30), "slic_conv_wgrad_wino2: grid too large");
+  const unsigned gx = (unsigned)((total + 7) / 8 * 8);
+  conv_wgrad_wino2_kernel<<<dim3(gx), dim3(512), lds, st>>>(*a, dy, (unsigned)dyb, (const uint2*)tile_tab, (float*)workspace, tps, S);
+  SLIC_LAUNCH_CHECK();
+  const int64_t tot = (int64_t)3 * a->Cs * a->N;
+  conv_wgrad_wino2_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>((const float*)workspace, S, a->Cs, a->N, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

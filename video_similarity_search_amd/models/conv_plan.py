@@ -40,7 +40,7 @@ class ConvPlan:
 
     WINO2_MIN_WGS = 200    # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (one workgroup / CU)
 
-    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, wino2=None, batch=None):
+    def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, wino2=None, batch=None, wino2_wgrad=None):
         self.C, self.N = int(C), int(N)
         self.Cs = (self.C + 3) // 4 * 4
         self.kernel, self.stride, self.pad = tuple(kernel), tuple(stride), tuple(pad)
@@ -87,8 +87,21 @@ class ConvPlan:
         assert (elig2 and self.wino) or not self.wino2, "Winograd F(4,3) x F(2,3): a Winograd plan with uniform 64-tile blocks"
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
         self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
+        # ... and by the transposed TWO-dimensional algorithm (slic_conv_wgrad_wino2) where it is the faster one.  Its workgroup loads
+        # 1.3 x the one-dimensional kernel's bytes per MFMA (three patch rows + two gradient rows for a pair of H-points), and both kernels
+        # run at the same L2 -> LDS rate per CU (~21 GB/s), so two thirds of the MFMAs buy little: measured at B = 32 (algorithmic
+        # TFLOP/s, 2-D vs 1-D): layer1 234 vs 228, layer2 255-258 vs 228-231, layer3 187-192 vs 190-192.  wino2_wgrad=None: the
+        # 128-channel layers only (SLIC_WINO2_WGRAD=1 forces it wherever the 6 x C / 64 x N / 64 blocks fit the 256 slots, =0 never).
+        mode = os.environ.get("SLIC_WINO2_WGRAD", "auto")
+        blocks2 = 6 * (self.C // 64) * (self.N // 64)
+        if wino2_wgrad is None:
+            wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= 128 and
+                           (mode == "1" or (self.C == 128 and self.N == 128)))
+        self.wino2_wgrad = bool(wino2_wgrad)
+        assert not self.wino2_wgrad or (base and blocks2 <= 256), "transposed 2-D Winograd weight gradient: a Winograd plan with at most 256 blocks"
         self._wu = self._wud = None
         self._wino_tabs = {}
+        self._wino2_tabs = {}
         if self.wrun:
             self._init_wrun()
             return
@@ -512,6 +525,23 @@ class ConvPlan:
         """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
         lib = _lib.load()
         a = self._fwd_args(x, B)
+        if self.wino2_wgrad:
+            # transposed F(4, 3) x F(2, 3): one workgroup of 512 threads per (kt, H-point pair), 64 x 64 block and slice of the 2 x 4
+            # tiles — ONE residency round of the 256 slots (one workgroup per CU), at least 64 tiles per slice
+            blocks = 6 * (self.C // 64) * (self.N // 64)
+            H2, W2 = self.in_dims[1], self.in_dims[2]
+            mt = (a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)
+            if splits is None:
+                forced = os.environ.get("SLIC_WINO2_WGRAD_WGS")
+                splits = max(1, min((int(forced) if forced else 256) // blocks, mt // 64))
+            tab = self._wino2_tabs.get(B)
+            if tab is None:
+                tab = torch.empty(mt, 2, dtype=torch.int32, device=self.device)
+                call("slic_conv_wino2_tile_table", ctypes.byref(a), ptr(tab), stream())
+                self._wino2_tabs[B] = tab
+            ws = _lib.workspace(lib.slic_conv_wgrad_wino2_workspace_bytes(ctypes.byref(a), splits), x.device, "wgrad")
+            call("slic_conv_wgrad_wino2", ctypes.byref(a), ptr(dz), splits, ptr(tab), ptr(dW), ptr(ws), stream())
+            return dW
         if self.wino_wgrad:
             # transposed F(4, 3): one workgroup per (kt, kh), 64 x 64 block and slice of the W-tiles; ~2 residency rounds of the
             # 512 slots (2 workgroups / CU), at least 64 tiles per slice
