@@ -3,8 +3,8 @@ usage: collect_profiles.py <scratch dir> <out dir> <round tag>"""
 import csv, glob, json, os, sys
 
 scratch, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNEL = "conv_wino_kernel<3, false, 2>"
-GRID = 6272 * 256                       # layer1 shape at B = 32: 401 408 W-tiles / 64 per workgroup (one n block)
+KERNEL = "conv_wino2_kernel"
+GRID = 3136 * 512                       # layer1 shape at B = 32: 200 704 tiles of 2 x 4 outputs / 64 per workgroup of 512 threads (one n block)
 
 
 def find(sub, pat):
@@ -56,13 +56,14 @@ if find("pmc_sq", "*counter_collection.csv"):
             pass
 res = {
     "FETCH_SIZE_KB_mean": fetch, "FETCH_SIZE_launches": nf, "WRITE_SIZE_KB_mean": write, "WRITE_SIZE_launches": nw,
-    "note": f"{KERNEL.replace(', ', ',')} (Winograd F(4,3) along W) at the layer1 shape (grid 6272 x 256 threads: M=1605632 rows = 401408 "
-            "W-tiles, N=64, K=1728; B=32): 4 forward launches (fused BN statistics) + 4 data-gradient launches (fused ReLU mask + "
-            "BN-backward sums: they also read the mask and z tensors) per step. Separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; "
-            "each with --kernel-trace only) over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary`. Units KiB. "
-            "Per MI355X_MICROARCH.md §HBM, gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced read, so "
-            "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024. Algorithmic minimum: 0.82 GB (forward) / 1.64 GB (data gradient "
-            "with mask and z). The kernel executes 177.6 GFLOP on the matrix pipe per launch for 355.1 GFLOP of the direct form.",
+    "note": f"{KERNEL} (Winograd F(4,3) x F(2,3) over (W, H)) at the layer1 shape (grid 3136 x 512 threads: M=1605632 rows = 200704 "
+            "tiles of 2 x 4 outputs, N=64, K=1728; B=32): 4 forward launches (fused BN statistics) + 4 data-gradient launches (fused ReLU "
+            "mask + BN-backward sums: they also read the mask and z tensors) per step. Separate rocprofv3 --pmc passes (FETCH_SIZE, "
+            "WRITE_SIZE; each with --kernel-trace only) over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary`. "
+            "Units KiB. Per MI355X_MICROARCH.md §HBM, gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced read, so "
+            "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (the pixel gather reads 16-byte pieces: the factor 2 is an upper "
+            "bound there). Algorithmic minimum: 0.82 GB (forward) / 1.64 GB (data gradient with mask and z). The kernel executes 118.4 "
+            "GFLOP on the matrix pipe per launch (28.9 M v_mfma_f32_32x32x2_f32) for 355.1 GFLOP of the direct form.",
     "hbm_bytes_per_launch": (2 * fetch + write) * 1024,
     "rocprof_trace_avg_ms": tr, "rocprof_trace_launches": nt,
     "hip_event_avg_ms": p["roofline"]["ms_per_launch"],
@@ -70,7 +71,7 @@ res = {
 }
 if sq.get("SQ_VALU_MFMA_BUSY_CYCLES") and sq.get("GRBM_GUI_ACTIVE"):
     # MFMA pipe busy cycles summed over the 1024 SIMDs / (elapsed cycles x 1024); GRBM_GUI_ACTIVE comes summed over the 8
-    # XCDs, so elapsed = GUI_ACTIVE / 8.  (The busy count equals 64 cycles x the launch's 43.4 M v_mfma_f32_32x32x2_f32.)
+    # XCDs, so elapsed = GUI_ACTIVE / 8.  (The busy count equals 64 cycles x the launch's 28.9 M v_mfma_f32_32x32x2_f32.)
     res["mfma_busy_fraction"] = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     if sq.get("SQ_WAVE_CYCLES"):
         res["wave_cycle_split"] = {k: sq[k] / sq["SQ_WAVE_CYCLES"] for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in sq}

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash scripts/collect_profiles.sh'): default bench, rocprofv3 kernel stats, two PMC passes.
-# Outputs land in gpurun_out/prof_r03/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r03 profiles r03` files them.
+# Outputs land in gpurun_out/prof_r04/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r04 profiles r04` files them.
 set -u
 R="$(pwd)"
-S="$R/gpurun_out/prof_r03"
+S="$R/gpurun_out/prof_r04"
 rm -rf "$S"; mkdir -p "$S"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python "$R/bench.py" > "$S/default.log" 2>&1 < /dev/null
@@ -20,7 +20,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$S/stats_fi
 timeout 300 python "$R/scripts/bench_rows.py" > "$S/rows.log" 2>&1 < /dev/null
 timeout 300 python "$R/scripts/bench_topk_k.py" > "$S/topk_k.log" 2>&1 < /dev/null
 timeout 300 python "$R/scripts/bench_conv.py" 32 > "$S/conv_shapes.log" 2>&1 < /dev/null
-timeout 300 bash "$R/scripts/r3/ab_wino.sh" run > "$S/wino_ablations.log" 2>&1 < /dev/null
 find "$S" -name "*kernel_trace.csv" -path "*stats_*" -delete
 find "$S" -name "*agent_info.csv" -delete
 du -sh "$S"; ls "$S"

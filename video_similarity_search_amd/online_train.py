@@ -224,7 +224,7 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
 
     NUM_GPUS > 1 with k-means (cfg.ITERCLUSTER.SHARDED, default on): the extraction keeps each rank's [N/W, D] rows on
     its GPU (no per-batch all_gather + D2H, evaluate.py:189-193), fit_cluster runs row-sharded over the process group
-    (one [K*D + K] all-gather per Lloyd iteration over RCCL), and the only other exchange is one int32 all-gather of
+    (ONE fp64 all-reduce of [K*D sums | K counts | n_changed] per Lloyd iteration over RCCL), and the only other exchange is one int32 all-gather of
     (label, dataset index, true label).  FINCH — and SHARDED = False — keep the reference's shape: gather to every rank,
     cluster on rank 0, and the dataset-ordered labels are broadcast (which is also the barrier of :662).
     `kmeans_kernels`: another kernel provider for fit_cluster (the tests of the multi-process control flow pass a CPU one
