@@ -455,7 +455,7 @@ def main():
     # HBM traffic of the dominant kernel comes from PMC counters, which need rocprofv3 around the process: the value below is
     # the one committed with the profile of the same command (profiles/), NOT measured in this run — `traffic` stays null
     traffic_prof, traffic_src = None, None
-    for name in (("r03_pmc_conv_wino.json",) if wino else ("r02_pmc_conv_gemm_dma.json", "r01_pmc_conv_gemm_dma.json")):
+    for name in (("r04_pmc_conv_wino.json", "r03_pmc_conv_wino.json") if wino else ("r02_pmc_conv_gemm_dma.json", "r01_pmc_conv_gemm_dma.json")):
         pmc = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pmc):
             try:

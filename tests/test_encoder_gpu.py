@@ -212,7 +212,8 @@ def test_conv_winograd_f43(gpu, C, N, B, dims):
 @pytest.mark.parametrize("C,N,B,dims", [(64, 64, 2, (4, 8, 8)), (64, 64, 2, (3, 6, 12)), (128, 64, 3, (2, 10, 20)),
                                         (64, 128, 2, (2, 4, 14)),        # ragged last tile of a row pair: ceil(14 / 4) = 4 | 64
                                         (128, 64, 2, (2, 7, 7)),         # odd height and ragged width: 4 x 2 tiles per frame | 64
-                                        (64, 64, 1, (16, 56, 56)), (128, 128, 2, (3, 28, 28)), (256, 256, 2, (4, 14, 14))])
+                                        (64, 64, 1, (16, 56, 56)), (128, 128, 2, (3, 28, 28)), (256, 256, 2, (4, 14, 14)),
+                                        (64, 64, 3, (14, 56, 56))])      # 258 workgroups: one whole dispatch round + a K-split tail of two
 def test_conv_winograd_2d(gpu, C, N, B, dims):
     """slic_conv_gemm variant 31 — Winograd F(4, 3) along W x F(2, 3) along H (csrc/conv_wino2.hip) — forward and data gradient vs
     fp64 F.conv3d at the one-dimensional kernel's tolerances, the fused epilogues (BatchNorm partials per block of 64 tiles; affine +
@@ -275,6 +276,27 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     s2 = (refg.double() * ((zz.double() - mean.double()) * invstd.double())).reshape(-1, C).sum(0)
     assert torch.allclose(bpart[:, 0].double().sum(0), s1, atol=2e-3, rtol=1e-4)
     assert torch.allclose(bpart[:, 1].double().sum(0), s2, atol=2e-3, rtol=1e-4)
+    # the K-split launch (the plan cuts the K loop by kt for a partly filled last dispatch round / few workgroups: every shape of this
+    # test but those whose workgroup count is a multiple of 256 or leaves more than half a round) against the one-piece launch
+    split = w2._plan_split(w2._fwd_args(xd, B), 31)
+    gxb = -(-len(tiles) // 64)
+    assert (split is None) == ((gxb * (N // 64)) % 256 == 0 or (gxb * (N // 64)) % 256 > 128)
+    if split is not None:
+        import os as _os
+        _os.environ["SLIC_WINO2_SPLIT"] = "0"
+        try:
+            assert w2._plan_split(w2._fwd_args(xd, B), 31) is None
+            z1p, (p1, r1) = w2.forward(xd, w2.pack_fwd(wd_), B, want_stats=True)
+            dx1 = w2.dgrad(dyd, w2.pack_dgrad(wd_), B)
+            g1, bp1 = w2.dgrad(dyd, w2.pack_dgrad(wd_), B, addend=add, mask=mask, bwd=(zz, mean, invstd))
+        finally:
+            del _os.environ["SLIC_WINO2_SPLIT"]
+        assert r1 == rows and torch.allclose(z1p, z, atol=2e-5 * max(1.0, y64.abs().max().item()), rtol=0)
+        assert (z1p.cpu().permute(0, 4, 1, 2, 3) - y64.float()).abs().max() <= tol * max(1.0, y64.abs().max().item())
+        assert torch.allclose(dx1, dx, atol=2e-5 * max(1.0, gx64.abs().max().item()), rtol=0)
+        assert torch.allclose(p1.double(), part.double(), atol=2e-4, rtol=1e-4)
+        assert torch.allclose(g1, g, atol=2e-5 * max(1.0, gx64.abs().max().item()), rtol=0)
+        assert torch.allclose(bp1[:, 0].double().sum(0), bpart[:, 0].double().sum(0), atol=2e-3, rtol=1e-4)
     # weight gradient by the transposed two-dimensional algorithm (slic_conv_wgrad_wino2) where the plan uses it (the layers with
     # few 64 x 64 blocks), vs fp64 and vs the one-dimensional kernel; default slicing, three slices, one slice; bit-equal run to run
     x64w, w64w = x.double(), w.double().requires_grad_(True)

@@ -175,7 +175,7 @@ extern "C" int slic_comm_wait(slic_comm* c, void* stream, int timeout_ms) {
   SLIC_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t e = hipEventRecord(ev, (hipStream_t)stream);
   if (e != hipSuccess) {
-    hipEventDestroy(ev);
+    (void)hipEventDestroy(ev);
     slic_set_error("slic_comm_wait: hipEventRecord -> %s", hipGetErrorString(e));
     return SLIC_EHIP;
   }
@@ -209,7 +209,7 @@ extern "C" int slic_comm_wait(slic_comm* c, void* stream, int timeout_ms) {
     nap();
   }
   (void)hipGetLastError();                                          // hipErrorNotReady from the queries is not an error of ours
-  hipEventDestroy(ev);
+  (void)hipEventDestroy(ev);
   return rc;
 }
 

@@ -199,7 +199,7 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
 }
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
+void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restrict__ slab, const int mb_off, const int mb_cnt) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,13 +210,20 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
   const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
   const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
   const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;     // tiles
-  const int64_t tile0 = (int64_t)mb * 64;
+  // this launch covers tile blocks [mb_off, mb_off + mb_cnt): all of them, or — a launch whose last dispatch round would be partly
+  // filled, or one of few workgroups — the whole rounds with the K loop in one piece, and then the remaining blocks with the K loop
+  // cut by kt: workgroup z = blockIdx.z of the second launch reduces the C / 4 stages of kt = z only and writes its two output rows'
+  // partial sums to slab[block][kt][column half][row][tile][col][n 32]; conv_wino2_finish adds the three pieces in kt order and runs
+  // the epilogue.  One piece (slab == NULL) covers everything.
+  if (mb >= mb_cnt) return;
+  const int64_t tile0 = (int64_t)(mb_off + mb) * 64;
   if (tile0 >= Mt) return;
   const int nb = blockIdx.y, n0 = nb * 64;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two >= 16: checked on the host)
   const int cch_shift = 31 - __builtin_clz(CCH);
-  const int NS = 3 * CCH;
+  const int sbeg = slab ? (int)blockIdx.z * CCH : 0;           // first stage of this workgroup's range
+  const int NS = slab ? sbeg + CCH : 3 * CCH;                  // END of the range
   const int NB = p.N >> 6;
   // ---- DMA roles.  Pixels: a DOUBLE stage (8 channels) at a time — piece pc = 8 i + wave (i = 0..5) is patch pixel ab = pc / 2 of
   // tile half pc % 2; lane L serves tile 32 (pc % 2) + L % 32, 16-byte half L / 32 of the pixel's 8 channels: lanes L and L + 32 fetch
@@ -313,9 +320,9 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
   // prologue: pixel double stage 0, U of stage 0 — in the order of the steady state (per stage U first, then pixels)
-  issue_u(0, 0);
-  issue_px(0, 0, 0);
-  issue_px(0, 0, 1);
+  issue_u(sbeg, 0);
+  issue_px(sbeg >> 1, 0, 0);
+  issue_px(sbeg >> 1, 0, 1);
   __builtin_amdgcn_s_setprio(0);
   // reader offsets (floats): pixel (a, b) of this lane's tile, channel half e2 of the double stage, its channel pair:
   //   (((ab * 2 + slot) * 2 + th) * 2 + e2) * 128 + r * 4 + 2 hh;   point (j, p) of column half nh: ((j * 6 + p) * 64 + nh * 32 + r) * 4 + 2 hh
@@ -355,7 +362,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
   // in flight (vmcnt(6)) and the one in front of an even stage takes everything (vmcnt(0): the pixels issued two stages ago, the U
   // issued one stage ago).  Four stage bodies per loop turn: (double-stage parity, channel half) fix every LDS slot at compile time.
   constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
-  for (int s0 = 0; s0 < NS; s0 += 4) {
+  for (int s0 = sbeg; s0 < NS; s0 += 4) {
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
       const int sgl = s0 + sidx;
@@ -443,8 +450,51 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows) {
 #if SLIC_W2_ABL & 256
     if (tid < 64) p.dst[(tile0 * 8) * p.ldo + n0 + tid] = lds[tid * 97];      // diagnostic build: no row-major epilogue at all
 #else
-    w2_epilogue(p, lds, tile0, n0 + nh * 32, tid, full_rows);
+    if (slab) {
+      // K-split piece: the two output rows' partial sums, combined as the epilogue combines them, to the slab (16 bytes per lane)
+      float* out = slab + ((((int64_t)mb * gridDim.y + nb) * 3 + blockIdx.z) * 2 + nh) * (2 * 64 * 4 * 32);
+      const int cq = tid & 7, rr = tid >> 3;
+      const int hp = (rr >> 2) & 1, o = rr & 3;
+      const float sgn = hp ? -1.f : 1.f;
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int tl = ps * 8 + (rr >> 3);
+        const float* sp = lds + hp * (64 * 4 * 32) + (tl * 4 + o) * 32 + cq * 4;
+        const f32x4 ya = *(const f32x4*)sp, yb = *(const f32x4*)(sp + 64 * 4 * 32), yc = *(const f32x4*)(sp + 2 * 64 * 4 * 32);
+        *(f32x4*)(out + ((hp * 64 + tl) * 4 + o) * 32 + cq * 4) = (ya + sgn * yb) + sgn * yc;
+      }
+    } else {
+      w2_epilogue(p, lds, tile0, n0 + nh * 32, tid, full_rows);
+    }
 #endif
+  }
+}
+
+// second pass of a K-split launch: one workgroup per (tail block, n block) adds the three kt pieces in order, lays the sums out as the
+// epilogue expects its side-by-side contributions (row 0 as H-point 0, minus row 1 as H-point 3, H-points 1 and 2 zero) and runs it
+__global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, const int full_rows, const float* __restrict__ slab, const int mb_off) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int mb = blockIdx.x, nb = blockIdx.y;
+  const int64_t tile0 = (int64_t)(mb_off + mb) * 64;
+  constexpr int JS = 64 * 4 * 32;                              // floats per H-point region (and per row of a slab piece)
+  for (int nh = 0; nh < 2; ++nh) {
+    if (nh) __syncthreads();
+    const float* base = slab + (((int64_t)mb * gridDim.y + nb) * 3 * 2 + nh) * (2 * JS);
+    for (int e = tid * 4; e < 2 * JS; e += 512 * 4) {          // e < JS: row 0; else row 1
+      f32x4 v = *(const f32x4*)(base + e);
+      v += *(const f32x4*)(base + 2 * (2 * JS) + e);
+      v += *(const f32x4*)(base + 4 * (2 * JS) + e);
+      if (e < JS) {
+        *(f32x4*)(lds + e) = v;
+        *(f32x4*)(lds + JS + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      } else {
+        *(f32x4*)(lds + 3 * JS + (e - JS)) = -v;
+        *(f32x4*)(lds + 2 * JS + (e - JS)) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();
+    w2_epilogue(p, lds, tile0, nb * 64 + nh * 32, tid, full_rows);
   }
 }
 
@@ -510,26 +560,60 @@ int slic_wino2_full_rows(const SlicConvArgs* a) {
   return 64 % (Hq * Wq) == 0 ? (64 / (Hq * Wq)) * H * W : 0;
 }
 
-int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st) {
-  constexpr size_t ring = (size_t)W2_RING_FLOATS * sizeof(float) + 512 * 8 * 4, epi = (size_t)conv_epi_lds_floats(512, 64, 8) * sizeof(float);
-  constexpr size_t lds = ring > epi ? ring : epi;
-  static_assert(lds <= 160 * 1024, "LDS");
+static int wino2_check(const SlicConvArgs* a, int* full) {
   SLIC_REQUIRE(a->Cs % 64 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts && a->Gb == a->Hs &&
                    a->Gc == a->Ws && !a->dst_strided && !a->bias && !a->k_run_len,
                "slic_conv_gemm: variant 31 needs a stride-1 same-size geometry, Cs %% 64 == 0, N %% 64 == 0, no bias");
   SLIC_REQUIRE(((a->Cs / 4) & (a->Cs / 4 - 1)) == 0, "slic_conv_gemm: variant 31 needs Cs / 4 to be a power of two");
   SLIC_REQUIRE((uint64_t)a->wgt_bytes == (uint64_t)3 * 24 * a->Cs * a->N * 4, "slic_conv_gemm: variant 31: wgt_bytes != 3 * 24 * Cs * N floats");
-  const int full = slic_wino2_full_rows(a);
-  SLIC_REQUIRE(full > 0, "slic_conv_gemm: variant 31: blocks of 64 tiles hold different numbers of outputs at H=%d W=%d", a->Hs, a->Ws);
+  *full = slic_wino2_full_rows(a);
+  SLIC_REQUIRE(*full > 0, "slic_conv_gemm: variant 31: blocks of 64 tiles hold different numbers of outputs at H=%d W=%d", a->Hs, a->Ws);
+  const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
+  SLIC_REQUIRE(tiles < (1ll << 31) && (int64_t)a->M * a->Cs * 4 < 0xFFFFFF00ll, "slic_conv_gemm: variant 31: tensor too large");
+  return SLIC_OK;
+}
+
+static constexpr size_t w2_lds_bytes() {
+  constexpr size_t ring = (size_t)W2_RING_FLOATS * sizeof(float) + 512 * 8 * 4, epi = (size_t)conv_epi_lds_floats(512, 64, 8) * sizeof(float);
+  return ring > epi ? ring : epi;
+}
+
+size_t slic_conv_wino2_split_workspace_bytes(const SlicConvArgs* a, int nfull) {
+  const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
+  const int64_t tail = slic_cdiv(tiles, 64) - nfull;
+  return tail <= 0 ? 0 : slic_align_up((size_t)tail * (a->N / 64) * 3 * 2 * (2 * 64 * 4 * 32) * sizeof(float), 256);
+}
+
+// nfull < 0: the plain launch.  nfull >= 0: tile blocks [0, nfull) whole, the rest with the K loop cut by kt + the finish pass.
+int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, float* slab) {
+  int full;
+  int rc = wino2_check(a, &full);
+  if (rc) return rc;
+  constexpr size_t lds = w2_lds_bytes();
+  static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
-  SLIC_REQUIRE(tiles < (1ll << 31) && (int64_t)a->M * a->Cs * 4 < 0xFFFFFF00ll, "slic_conv_gemm: variant 31: tensor too large");
   const int gx = (int)slic_cdiv(tiles, 64);
-  conv_wino2_kernel<<<dim3((unsigned)((gx + 7) / 8 * 8), (unsigned)(a->N / 64)), dim3(512), lds, st>>>(*a, full);
+  const unsigned ny = (unsigned)(a->N / 64);
+  if (nfull < 0 || nfull >= gx) {
+    conv_wino2_kernel<<<dim3((unsigned)((gx + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, 0, gx);
+    SLIC_LAUNCH_CHECK();
+    return SLIC_OK;
+  }
+  SLIC_REQUIRE(slab, "slic_conv_gemm_tailsplit: variant 31 needs a workspace");
+  if (nfull > 0) {
+    conv_wino2_kernel<<<dim3((unsigned)((nfull + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, 0, nfull);
+    SLIC_LAUNCH_CHECK();
+  }
+  const int tail = gx - nfull;
+  conv_wino2_kernel<<<dim3((unsigned)((tail + 7) / 8 * 8), ny, 3), dim3(512), lds, st>>>(*a, full, slab, nfull, tail);
+  SLIC_LAUNCH_CHECK();
+  conv_wino2_finish<<<dim3((unsigned)tail, ny), dim3(512), lds, st>>>(*a, full, slab, nfull);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -665,7 +749,10 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
                                              (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + WG2_RING_OFF + dst),
                                              16, (int)off, 0, 0, 0);
   };
-  auto issue_fast = [&](int slot_, int d, const unsigned sx_, const unsigned sy_) {
+  auto issue_fast = [&](int slot_, int d, unsigned sx_, unsigned sy_) {
+#if SLIC_W2_ABL & 1
+    sx_ = 0xFFFFFF00u; sy_ = 0xFFFFFF00u;                      // diagnostic build: DMAs out of range (no memory traffic)
+#endif
     const int dst = slot_ * WG2_STAGE_BYTES + wave * WG2_TILE_BYTES + (d == 0 ? 0 : (d <= 2 ? 512 + (d - 1) * 1024 : 2560 + (d - 3) * 1024));
     __builtin_amdgcn_raw_ptr_buffer_load_lds((d == 1 || d == 2) ? rs_dy : rs_src,
                                              (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + WG2_RING_OFF + dst),
@@ -774,6 +861,15 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
                             f32x2 (&Zi)[4], f32x2 (&cz)[4]) {
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the pair's (inline-assembly) LDS reads
+#if SLIC_W2_ABL & 4
+#pragma unroll
+    for (int b = 0; b < 6; ++b) V[b] = xa[b];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { cz[o] = yf[o]; Zi[o] = ys[o]; }
+    asm volatile("s_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+#endif
     f32x2 cx[6];
 #pragma unroll
     for (int b = 0; b < 6; ++b) cx[b] = pk_fma(xb[b], sx, xa[b]);
@@ -813,7 +909,9 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
     // stage sg has landed once only the younger ops are outstanding: the record load issued behind its DMAs and the
     // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (WG2_STAGES - 2) * PER) : "memory");
+#if !(SLIC_W2_ABL & 2)
     __builtin_amdgcn_s_barrier();
+#endif
     constexpr int slotn = (sidx + WG2_STAGES - 1) % WG2_STAGES;
     f32x2 xa[6], xb[6], yf[4], ys[4], V[6], Zi[4], cz[4];
     read_pair(sl_, std::integral_constant<int, 0>{}, xa, xb, yf, ys);

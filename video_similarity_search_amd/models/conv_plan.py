@@ -38,7 +38,8 @@ class ConvPlan:
 
     WINO_MIN_WGS = 384     # forward / data gradient: a launch of fewer 64-tile x 64-n workgroups than this (layer4 at B = 32: 112) cuts its K loop
 
-    WINO2_MIN_WGS = 200    # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (one workgroup / CU)
+    WINO2_MIN_WGS = 64     # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (launches of less than
+                           # a dispatch round of the 256 one-per-CU slots cut their K loop by kt: _plan_split)
 
     def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, wino2=None, batch=None, wino2_wgrad=None):
         self.C, self.N = int(C), int(N)
@@ -349,6 +350,20 @@ class ConvPlan:
         layer4 392.  So the tiles of the full rounds run whole, and the remainder — whole row blocks at the end of M — is cut
         along K into as many pieces as fill the slots once more (each piece keeps >= SPLIT_MIN_KTILES k-tiles).  A remainder
         that already fills most of a round is left alone.  SLIC_CONV_TAIL=0 switches the mechanism off (tests compare)."""
+        if variant == 31:
+            # two-dimensional Winograd, ONE workgroup per CU (256 slots): a launch's partly filled last dispatch round — when it is at
+            # most half full — and launches of less than a round cut their K loop by kt (three pieces + a finish pass): layer2 at B = 32
+            # is 784 workgroups = 3.06 rounds, layer4 64
+            if os.environ.get("SLIC_WINO2_SPLIT", "1") == "0":
+                return None
+            H2, W2 = a.Hs, a.Ws
+            gx, ny = -(-((a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)) // 64), a.N // 64
+            wgs = gx * ny
+            rem = wgs % 256
+            if rem == 0 or rem > 128:
+                return None
+            tail_x = -(-rem // ny)
+            return (gx - tail_x, 3)
         if variant == 30:
             # Winograd: few-tile launches cut the K loop (9 x Cs / 8 stages) into as many even pieces as fill ONE residency round of
             # the 512 slots (2 workgroups / CU), each piece keeping >= 48 stages.  Measured at layer4, B = 32 (112 workgroups, 576
