@@ -425,12 +425,16 @@ class ConvPlan:
         e1.record()
         self.prof.append((e0, e1))
 
-    def dgrad(self, dz, wd, B, addend=None, out=None, variant=0, mask=None, bwd=None):
+    def dgrad(self, dz, wd, B, addend=None, out=None, variant=0, mask=None, bwd=None, skip_empty=False, addend_classes=None):
         """dz: [B, To, Ho, Wo, N] -> dx: [B, T, H, W, Cs] = conv_transpose(dz) (+ addend; addend may be `out`
         itself: every element is read and written by the same lane).
         mask (same shape as dx): dx = where(mask > 0, dx, 0) — the ReLU backward of the layer below, fused.
         bwd = (z, mean, invstd) of that layer's BatchNorm: also returns the per-workgroup partial sums
-        (sum dx, sum dx * xhat) as a [R, 2, Cs] slab for slic_bn_bwd_fused -> returns (dx, partial)."""
+        (sum dx, sum dx * xhat) as a [R, 2, Cs] slab for slic_bn_bwd_fused -> returns (dx, partial).
+        skip_empty: parity classes without a tap (a 1x1x1 stride-2 convolution reaches one position in eight) are NOT launched — their
+        positions of dx stay unwritten, for a consumer that reads dx through addend_classes.
+        addend_classes: the parity classes on which `addend` is defined (tap_classes() of the plan that wrote it); the other classes'
+        launches take no addend."""
         lib = _lib.load()
         if self.wino:
             assert variant in (0, 30, 31), "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
@@ -442,6 +446,9 @@ class ConvPlan:
         # longest K loop first: the classes of a stride-2 layer have 1 ... 8 taps, one grid holds them all (blockIdx.z, dispatched
         # in order), and a launch that ends with its longest workgroups ends on a nearly empty chip
         for dc in sorted(self.dgrad_classes, key=lambda d: -d["nchunks"]):
+            if skip_empty and dc["nchunks"] == 0:
+                assert addend is None and mask is None and bwd is None
+                continue
             a = SlicConvArgs()
             a.src = dz.data_ptr()
             a.src_bytes = _lib.u32_bytes(dz, 'dgrad source')
@@ -450,7 +457,7 @@ class ConvPlan:
             a.dst = dx.data_ptr()
             a.tab = dc["tab"].data_ptr()
             a.tap_tab = dc["tap"].data_ptr() if dc["tap"] is not None else None
-            a.addend = addend.data_ptr() if addend is not None else None
+            a.addend = addend.data_ptr() if (addend is not None and (addend_classes is None or dc["cls"] in addend_classes)) else None
             a.mask_src = mask.data_ptr() if mask is not None else None
             ga, gb, gc = dc["grid"]
             a.M = B * ga * gb * gc
@@ -499,6 +506,10 @@ class ConvPlan:
             for a in launches:
                 self._launch(a, variant)
         return dx if bwd is None else (dx, part)
+
+    def tap_classes(self):
+        """the parity classes of the data gradient that have at least one tap (the positions dgrad(skip_empty=True) writes)"""
+        return {dc["cls"] for dc in self.dgrad_classes if dc["nchunks"] > 0}
 
     def _row_table(self, a, B):
         """per-row {source byte offset, in-bounds mask} records of the forward geometry at batch B (8 bytes / row),

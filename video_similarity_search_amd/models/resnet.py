@@ -572,8 +572,13 @@ class _Engine:
                     dzd, _, dgd, dbd = self._bn_bwd(g, None, s["zd"], s["bd"], False)
                     grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dgd, dbd
                     grads[blk.downsample[0].weight] = wgrad_async(pd, s["x"], dzd, blk.downsample[0].weight)
-                    dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B)
-                    res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx, **kw)
+                    # the shortcut's data gradient reaches one input position in stride^3 (1x1x1 kernel): only that parity class is
+                    # launched (seven launches that wrote zeros at layer2.0 / 3.0 / 4.0 before), and conv1's data gradient takes dx as
+                    # its addend on that class alone — with the same strides the classes of the two plans coincide
+                    sparse = pd.stride == p1.stride and pd.stride != (1, 1, 1) and pd.tap_classes() <= p1.tap_classes()
+                    dx = pd.dgrad(dzd, pd.pack_dgrad(blk.downsample[0].weight), B, skip_empty=sparse)
+                    res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, addend=dx, out=dx,
+                                   addend_classes=pd.tap_classes() if sparse else None, **kw)
                 elif blk in self.short_a:
                     # the reference's shortcut 'A' concatenates `out.data` (models/resnet.py:220): no gradient through the branch
                     res = p1.dgrad(dz1, p1.pack_dgrad(blk.conv1.weight), B, **kw)
