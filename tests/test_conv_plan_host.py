@@ -52,3 +52,38 @@ def test_winograd_split_rules(monkeypatch):
     assert ConvPlan._wino_wgrad_slices(9, 200) == 3            # never fewer than 64 tiles per slice
     monkeypatch.setenv("SLIC_WINO_WGRAD_WGS", "1024")
     assert ConvPlan._wino_wgrad_slices(9, 401408) == 113
+
+
+def test_winograd_2d_plan_rules(monkeypatch):
+    """host-side rules of the two-dimensional Winograd plans at R3D-18's shapes (models/conv_plan.py): variant 31 where the blocks of 64
+    tiles are uniform and the launch has at least 64 workgroups; its K split by kt for a partly filled last dispatch round (layer2 at
+    B = 32: 784 workgroups = three rounds + 16) and for launches of less than half a round (layer4: 64); the transposed two-dimensional
+    weight gradient on the 128-channel layers only; channel counts that are not 64 x a power of two stay off the Winograd kernels"""
+    for k in ("SLIC_WINO", "SLIC_WINO2", "SLIC_WINO2_MIN_WGS", "SLIC_WINO2_SPLIT", "SLIC_WINO2_WGRAD", "SLIC_WINO_WGRAD"):
+        monkeypatch.delenv(k, raising=False)
+    k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    shapes = [(64, (16, 56, 56)), (128, (8, 28, 28)), (256, (4, 14, 14)), (512, (2, 7, 7))]
+    plans = {C: ConvPlan(C, C, k3, s1, p1, dims, "cpu", batch=32) for C, dims in shapes}
+    assert [plans[C].wino2 for C, _ in shapes] == [True, True, True, True]
+    assert [plans[C].wino2_wgrad for C, _ in shapes] == [False, True, False, False]
+    assert all(plans[C].wino and plans[C].wino_wgrad for C, _ in shapes)
+
+    def args(B, C, dims):
+        a = SlicConvArgs()
+        T, H, W = dims
+        a.M, a.Ts, a.Hs, a.Ws, a.N, a.Cs = B * T * H * W, T, H, W, C, C
+        return a
+    assert ConvPlan._plan_split(args(32, 64, (16, 56, 56)), 31) is None          # 3136 workgroups: 12.25 rounds, remainder 64 ... of 256
+    assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) == (384, 3)      # 392 tile blocks x 2: the last 8 blocks cut by kt
+    assert ConvPlan._plan_split(args(32, 256, (4, 14, 14)), 31) is None          # 224 workgroups: most of a round
+    assert ConvPlan._plan_split(args(32, 512, (2, 7, 7)), 31) == (0, 3)          # 64 workgroups: all of them cut
+    # small batches: layer3 at B = 8 has 56 workgroups -> the one-dimensional kernel
+    assert not ConvPlan(256, 256, k3, s1, p1, (4, 14, 14), "cpu", batch=8).wino2
+    # no batch hint (a plan built by hand): never variant 31 by default
+    assert not ConvPlan(64, 64, k3, s1, p1, (16, 56, 56), "cpu").wino2
+    # widths 192 / 384 (RESNET.WIDEN_FACTOR 1.5 / 3): the Winograd forward / data gradient address their K loop with shifts
+    for C in (192, 384):
+        pl = ConvPlan(C, C, k3, s1, p1, (4, 14, 14), "cpu", batch=32)
+        assert not pl.wino and not pl.wino2 and pl.wino_wgrad
+    # non-uniform blocks (odd height whose tiles per frame do not divide 64): not eligible
+    assert not ConvPlan(64, 64, k3, s1, p1, (4, 9, 20), "cpu", batch=64).wino2

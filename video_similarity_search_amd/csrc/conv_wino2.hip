@@ -41,6 +41,25 @@ constexpr int W2_U_FLOATS = 24 * 64 * 4;                       // U block of a s
 constexpr int W2_RING_FLOATS = 2 * W2_PX_FLOATS + 2 * W2_U_FLOATS;   // two pixel slots + two U slots = 144 KB
 
 
+constexpr int W2_TREC_FLOATS = 4 * 64 * 4 * 32 + 1024;         // LDS float offset of the 64 tile records, behind buf and the reduction rows
+
+// records of the workgroup's 64 tiles for the epilogue: {GEMM row of the tile's output (0, 0); bit 0: the tile exists, bit 1: its second
+// row is inside the frame, bits 2-5: column o is inside}.  Called by threads 0-63 once the K loop's ring is dead; a barrier follows.
+__device__ __forceinline__ void w2_tile_records(const SlicConvArgs& p, float* lds, int64_t tile0, int tid) {
+  const int H = p.Hs, W = p.Ws;
+  const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
+  const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;
+  const int64_t tl = tile0 + tid;
+  unsigned q = (unsigned)(tl < Mt ? tl : 0);
+  const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+  const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;       // q = frame (b, t)
+  unsigned bits = tl < Mt ? 1u : 0u;
+  bits |= (2 * h2 + 1 < H) ? 2u : 0u;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) bits |= (4 * wt + o < W) ? (4u << o) : 0u;
+  ((uint2*)(lds + W2_TREC_FLOATS))[tid] = make_uint2((q * (unsigned)H + 2u * (unsigned)h2) * (unsigned)W + 4u * (unsigned)wt, bits);
+}
+
 // Epilogue of the two-dimensional kernel, one call per column half nh.  The four H-point waves of a tile have written their W-outputs
 // Yw_j to LDS side by side, buf[j 4][tile 64][col o 4][n 32] (no read-modify-write: 128 accumulate steps per wave through LDS ran at one
 // LDS round trip each and cost 13 % of the kernel); this pass reads, for output row (tile, hp, o), the three contributions it is made
@@ -55,9 +74,7 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
   constexpr int BNH = 32, CPR = 8, NW = 8, NPASS = 8;          // 64 rows per pass
   constexpr int JSTRIDE = 64 * 4 * BNH;                        // floats between buf[j] and buf[j + 1]
   const int64_t mblk = tile0 >> 6;
-  const int H = p.Hs, W = p.Ws;
-  const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
-  const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;
+  const int W = p.Ws;
   float* red1 = lds + 4 * JSTRIDE;
   float* red2 = red1 + NW * BNH;
   float* bmean = red2 + NW * BNH;
@@ -90,23 +107,23 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
     if (p.shift) sh = *(const f32x4*)(p.shift + n);
     if (want_bwd) { bmu = *(const f32x4*)(p.bwd_mean + n); bis = *(const f32x4*)(p.bwd_invstd + n); }
   }
-  // this thread's rows: tile tile0 + 8 ps + rr / 8, row hp, column o — decoded once, stepped by eight tiles per pass
+  // this thread's rows: tile tile0 + 8 ps + rr / 8, row hp, column o.  The tiles' records {GEMM row of output (0, 0), validity bits}
+  // wait in LDS (w2_tile_records: 64 threads decoded them once): a pass reads one — no division, no loop, so the compiler is free to
+  // hoist the passes' global loads (mask, z, addend) above one another instead of paying one memory round trip per pass
   const int hp = (rr >> 2) & 1, o = rr & 3;
   const float sgn = hp ? -1.f : 1.f;
   const float* src = lds + hp * JSTRIDE + (((rr >> 3) * 4 + o) * BNH + cq * 4);      // + ps * 8 tiles; contributions j = hp, hp + 1, hp + 2
-  int64_t tl = tile0 + (rr >> 3);
-  unsigned q = (unsigned)(tl < Mt ? tl : 0);
-  int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
-  int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;       // q = frame (b, t)
+  const uint2* trec = (const uint2*)(lds + W2_TREC_FLOATS) + (rr >> 3);                // + ps * 8
+  const unsigned need = 1u | (hp ? 2u : 0u) | (4u << o);
   unsigned okmask = 0;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, fs = s1;
   f32x4 keep[NPASS];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
-    const int hr = 2 * h2 + hp, wc = 4 * wt + o;
-    const bool ok = tl < Mt && hr < H && wc < W && nv;
+    const uint2 tr = trec[ps * 8];
+    const bool ok = (tr.y & need) == need && nv;
     okmask |= (ok ? 1u : 0u) << ps;
-    const unsigned m = (q * (unsigned)H + (unsigned)hr) * (unsigned)W + (unsigned)wc;
+    const unsigned m = tr.x + (unsigned)(hp * W + o);
     const unsigned off = ok ? (m * (unsigned)p.ldo + (unsigned)n) * 4u : OOBE;
     const float* sp = src + ps * (8 * 4 * BNH);
     const f32x4 ya = *(const f32x4*)sp, yb = *(const f32x4*)(sp + JSTRIDE), yc = *(const f32x4*)(sp + 2 * JSTRIDE);
@@ -131,13 +148,6 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
         s1 += v;
         s2 += v * ((zz - bmu) * bis);
       }
-    }
-    // next pass: eight tiles on
-    tl += 8;
-    wt += 8;
-    while (wt >= Wq) {
-      wt -= Wq;
-      if (++h2 == Hq) { h2 = 0; ++q; }
     }
   }
   if (want_bwd) {
@@ -420,6 +430,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   mfma_point(5, ut);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  if (tid < 64) w2_tile_records(p, lds, tile0, tid);           // visible behind the barrier in front of w2_epilogue
 #if SLIC_W2_ABL & 32
   if (acc[0][0][0] != 12345.678f) return;                      // diagnostic build: no epilogue
 #endif
@@ -478,6 +489,7 @@ __global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, c
   const int mb = blockIdx.x, nb = blockIdx.y;
   const int64_t tile0 = (int64_t)(mb_off + mb) * 64;
   constexpr int JS = 64 * 4 * 32;                              // floats per H-point region (and per row of a slab piece)
+  if (tid < 64) w2_tile_records(p, lds, tile0, tid);
   for (int nh = 0; nh < 2; ++nh) {
     if (nh) __syncthreads();
     const float* base = slab + (((int64_t)mb * gridDim.y + nb) * 3 * 2 + nh) * (2 * JS);

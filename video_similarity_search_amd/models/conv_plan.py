@@ -360,8 +360,8 @@ class ConvPlan:
             gx, ny = -(-((a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)) // 64), a.N // 64
             wgs = gx * ny
             rem = wgs % 256
-            if rem == 0 or rem > 128:
-                return None
+            if rem == 0 or rem > 128 or wgs > 6 * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
+                return None                                  # pass measured no faster there)
             tail_x = -(-rem // ny)
             return (gx - tail_x, 3)
         if variant == 30:
