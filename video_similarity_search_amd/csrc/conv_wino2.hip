@@ -70,7 +70,11 @@ __device__ __forceinline__ void w2_tile_records(const SlicConvArgs& p, float* ld
 // vector instruction stops the matrix pipe of its SIMD, and with ONE workgroup per CU nothing else runs meanwhile: the tile's
 // coordinates are decoded once and stepped (no division per row), absent operands are not loaded (workgroup-uniform branches), the
 // combined values stay in registers for the second statistics pass.
-__device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, int64_t tile0, int n0h, int tid, int full_rows) {
+// LOADS = the pass reads optional operands from memory (addend, ReLU-backward mask, the BatchNorm z): those loads of ALL eight passes are
+// issued first, in one batch, and the passes then consume them — one memory round trip per call instead of one per pass (with one
+// workgroup per CU nothing else covers that latency).  The forward of a training step (statistics only) takes the instantiation without.
+template <bool LOADS>
+__device__ __forceinline__ void w2_epilogue_impl(const SlicConvArgs& p, float* lds, int64_t tile0, int n0h, int tid, int full_rows) {
   constexpr int BNH = 32, CPR = 8, NW = 8, NPASS = 8;          // 64 rows per pass
   constexpr int JSTRIDE = 64 * 4 * BNH;                        // floats between buf[j] and buf[j + 1]
   const int64_t mblk = tile0 >> 6;
@@ -118,32 +122,52 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
   unsigned okmask = 0;
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, fs = s1;
   f32x4 keep[NPASS];
+  unsigned offs[NPASS];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const uint2 tr = trec[ps * 8];
     const bool ok = (tr.y & need) == need && nv;
     okmask |= (ok ? 1u : 0u) << ps;
     const unsigned m = tr.x + (unsigned)(hp * W + o);
-    const unsigned off = ok ? (m * (unsigned)p.ldo + (unsigned)n) * 4u : OOBE;
+    offs[ps] = ok ? (m * (unsigned)p.ldo + (unsigned)n) * 4u : OOBE;
+  }
+  // absent operands have resources of size zero: their loads return zeros at once (and are not issued at all without LOADS)
+  // (in two batches of four passes: 48 registers of loads in flight — all eight at once spilled)
+  constexpr int LB = 4;
+  f32x4 ldadd[LOADS ? LB : 1], ldmsk[LOADS ? LB : 1], ldz[LOADS ? LB : 1];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    if constexpr (LOADS) {
+      if (ps % LB == 0) {
+#pragma unroll
+        for (int q = 0; q < LB; ++q) {
+          ldadd[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, offs[ps + q], 0, 0));
+          ldmsk[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_msk, offs[ps + q], 0, 0));
+          ldz[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bz, offs[ps + q], 0, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const bool ok = (okmask >> ps) & 1u;
+    const unsigned off = offs[ps];
     const float* sp = src + ps * (8 * 4 * BNH);
     const f32x4 ya = *(const f32x4*)sp, yb = *(const f32x4*)(sp + JSTRIDE), yc = *(const f32x4*)(sp + 2 * JSTRIDE);
     f32x4 v = (ya + sgn * yb) + sgn * yc;
     keep[ps] = v;
     if (ok) fs += v;
     if (has_affine) v = v * sc + sh;
-    if (has_add) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, off, 0, 0));
-    if (has_mask) {
-      const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_msk, off, 0, 0));
+    if constexpr (LOADS) {
+      v += ldadd[ps % LB];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = !(mk[c] > 0.f) ? 0.f : v[c];
+      for (int c = 0; c < 4; ++c) v[c] = (has_mask && !(ldmsk[ps % LB][c] > 0.f)) ? 0.f : v[c];
     }
     if (do_relu) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
     }
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs_dst, off, 0, 0);
-    if (want_bwd) {
-      const f32x4 zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bz, off, 0, 0));
+    if (LOADS && want_bwd) {
+      const f32x4 zz = ldz[ps % LB];
       if (ok) {
         s1 += v;
         s2 += v * ((zz - bmu) * bis);
@@ -206,6 +230,11 @@ __device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, i
       if (nn < p.N) p.stat_partial[(mblk * 2 + 1) * p.N + nn] = t;
     }
   }
+}
+
+__device__ __forceinline__ void w2_epilogue(const SlicConvArgs& p, float* lds, int64_t tile0, int n0h, int tid, int full_rows) {
+  if (p.addend || p.mask_src || p.bwd_z) w2_epilogue_impl<true>(p, lds, tile0, n0h, tid, full_rows);      // workgroup-uniform
+  else w2_epilogue_impl<false>(p, lds, tile0, n0h, tid, full_rows);
 }
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
