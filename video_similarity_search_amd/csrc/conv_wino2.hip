@@ -275,70 +275,65 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
   const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;  // q = frame (b, t)
   const int tt = (int)(q % (unsigned)T);
-  // Per-thread state waits in LDS behind the rings (32 bytes per thread): the tile's base offset, the packed invalid masks (4 bits
-  // per piece: bit kt = the pixel does not exist at that kt; bit 3 = a dead stage) and the six piece offsets RESOLVED for the current
-  // kt (the pixel's address, or an out-of-range offset) — rewritten three times per workgroup behind a scalar branch, read back by
-  // every double stage: LDS instructions cost the matrix pipe nothing, six registers held through the loop would spill.  A stage's
-  // DMA pieces then cost NO vector instruction: the channel group rides in the instruction's scalar offset; U = a per-lane constant
-  // + the stage's block as scalar offset.
+  // Stage order: the local stage index sl (0 .. 3 C/4 - 1, or 0 .. C/4 - 1 for a K-split piece, whose kt is blockIdx.z) runs with kt
+  // INNER — double stage d = sl / 2 is (channel group cd = d / 3, kt = d % 3), stage sl its channel half sl % 2: a workgroup touches
+  // the three frames t - 1, t, t + 1 of its patch in consecutive double stages, and the per-lane piece offsets never change (kt rides in
+  // the scalar offset).  Against a kt-outer order (offsets rewritten three times per workgroup) it measured equal in time; FETCH_SIZE
+  // per launch 376 vs 334 MB at layer1, 88 vs 107 MB at layer3 (scripts/r4/pmc_fetch_ab.sh).
+  // Per-thread state: the six piece offsets (the pixel's address in frame t, or an out-of-range offset where the pixel is outside the
+  // frame) wait in LDS behind the rings (LDS instructions cost the matrix pipe nothing; six registers held through the loop would
+  // spill); whether frame t - 1 / t + 1 exists is one flag word per lane.  A double stage then costs ONE vector instruction + one per
+  // piece: kt and the channel group ride in the DMA's SCALAR offset (the resource starts one frame before the tensor, so that the
+  // scalar part is never negative); U = a per-lane constant + the stage's block as scalar offset.
+  const int NSL = NS - sbeg;                                  // stages of this workgroup
+  const unsigned HWC4 = (unsigned)(H * W * C * 4);
   unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid * 8;
-  {
-    unsigned invp = 0;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int ab = 4 * i + (wave >> 1);
-      const int a = (ab * 11) >> 6, b = ab - 6 * a;           // ab / 6 for ab < 24
-      const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
-      const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
-      unsigned m = 1u << 3;
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) m |= ((ok && (unsigned)(tt + kt - 1) < (unsigned)T) ? 0u : 1u) << kt;
-      invp |= m << (4 * i);
-    }
-    stash[6] = (unsigned)(((((int64_t)q * H + 2 * h2) * W + 4 * wt) * C) * 4) + (unsigned)(lane >> 5) * 16u;
-    stash[7] = invp;
+  for (int i = 0; i < 6; ++i) {
+    const int ab = 4 * i + (wave >> 1);
+    const int a = (ab * 11) >> 6, b = ab - 6 * a;             // ab / 6 for ab < 24
+    const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
+    const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
+    stash[i] = ok ? (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4) + (unsigned)(lane >> 5) * 16u : 0x80000000u;
   }
-  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
+  // bit kt: frame t - 1 + kt is outside the clip; bit 3: a dead stage
+  const int tflags = (tt == 0 ? 1 : 0) | (tt == T - 1 ? 4 : 0) | 8;
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - HWC4), 0, p.src_bytes + 2 * HWC4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
   const unsigned uvoff = (unsigned)tid * 16u;
-  auto set_kt = [&](int kt) {
-    const unsigned base = stash[6], invp = stash[7];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int ab = 4 * i + (wave >> 1);
-      const int a = (ab * 11) >> 6, b = ab - 6 * a;
-      const unsigned kd = (unsigned)((((kt - 1) * H + (a - 1)) * W + (b - 1)) * C * 4);       // scalar
-      stash[i] = ((invp >> (4 * i + kt)) & 1u) ? 0x80000000u : base + kd;
-    }
+  const int ktz = slab ? (int)blockIdx.z : -1;
+  // (kt, channel group) of local double stage d
+  auto kt_cd = [&](int d, int& kt, int& cd) {
+    if (ktz >= 0) { kt = ktz; cd = d; }
+    else { cd = (int)(((unsigned)d * 43691u) >> 17); kt = d - 3 * cd; }          // d / 3 for d < 2^16
   };
-  // pixel double stage ds (stages 2 ds, 2 ds + 1) into pixel slot `slot`
-  // (in two parts of three pieces — part 0 also resolves the offsets when kt changes — so that three offset registers are live at a time)
-  auto issue_px = [&](int ds, int slot, int part) {
-    const int s = 2 * ds;
-    const bool live = s < NS;
-    const int sc = live ? s : 0;
-    const int kt = live ? (sc >> cch_shift) : 3, cc = sc & (CCH - 1);
-    if (part == 0 && cc == 0) set_kt(kt);                     // scalar branch
-    const unsigned coff = (unsigned)(cc * 16);                // 8 channels = 32 bytes per double stage: cc is even
+  // pixel double stage d into pixel slot `slot`, in two parts of three pieces (three offset registers live at a time)
+  auto issue_px = [&](int d, int slot, int part) {
+    const bool live = 2 * d < NSL;
+    int kt, cd;
+    kt_cd(live ? d : 0, kt, cd);
+    const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(tflags, live ? kt : 3, 1);          // -1: this frame does not exist
+    const unsigned soff = (unsigned)kt * HWC4 + (unsigned)(cd * 32);      // 8 channels = 32 bytes per double stage
 #pragma unroll
     for (int i = 3 * part; i < 3 * part + 3; ++i) {
 #if SLIC_W2_ABL & 1
-      const unsigned off = 0xFFFFFF00u + 0 * stash[i];
+      const unsigned off = 0xFFFFFF00u + 0 * (stash[i] | inv);
 #else
-      const unsigned off = stash[i];
+      const unsigned off = stash[i] | inv;
 #endif
       // piece pc = 8 i + wave = (ab, tile half): image [ab 24][slot 2][tile half 2][channel half 2][tile 32][4 ch] — the two ring slots
       // are INTERLEAVED per patch pixel, so that one lane address per patch row reaches both slots with immediate offsets
       const int pc = 8 * i + wave;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + (((pc >> 1) * 2 + slot) * 2 + (pc & 1)) * 256),
-                                               16, (int)off, (int)coff, 0, 0);
+                                               16, (int)off, (int)soff, 0, 0);
     }
   };
-  // U block of stage s into U slot `slot`
-  auto issue_u = [&](int s, int slot) {
-    const bool live = s < NS;
-    const int sc = live ? s : 0;
-    const int kt = sc >> cch_shift, cc = sc & (CCH - 1);
+  // U block of local stage sl into U slot `slot`
+  auto issue_u = [&](int sl, int slot) {
+    const bool live = sl < NSL;
+    int kt, cd;
+    kt_cd(live ? (sl >> 1) : 0, kt, cd);
+    const int cc = 2 * cd + (live ? (sl & 1) : 0);
     const unsigned ublk = (unsigned)((kt * CCH + cc) * NB + nb) * (unsigned)(W2_U_FLOATS * 4);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -359,9 +354,9 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
   // prologue: pixel double stage 0, U of stage 0 — in the order of the steady state (per stage U first, then pixels)
-  issue_u(sbeg, 0);
-  issue_px(sbeg >> 1, 0, 0);
-  issue_px(sbeg >> 1, 0, 1);
+  issue_u(0, 0);
+  issue_px(0, 0, 0);
+  issue_px(0, 0, 1);
   __builtin_amdgcn_s_setprio(0);
   // reader offsets (floats): pixel (a, b) of this lane's tile, channel half e2 of the double stage, its channel pair:
   //   (((ab * 2 + slot) * 2 + th) * 2 + e2) * 128 + r * 4 + 2 hh;   point (j, p) of column half nh: ((j * 6 + p) * 64 + nh * 32 + r) * 4 + 2 hh
@@ -401,7 +396,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   // in flight (vmcnt(6)) and the one in front of an even stage takes everything (vmcnt(0): the pixels issued two stages ago, the U
   // issued one stage ago).  Four stage bodies per loop turn: (double-stage parity, channel half) fix every LDS slot at compile time.
   constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
-  for (int s0 = sbeg; s0 < NS; s0 += 4) {
+  for (int s0 = 0; s0 < NSL; s0 += 4) {
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {
       const int sgl = s0 + sidx;
