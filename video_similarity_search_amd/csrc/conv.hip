@@ -34,6 +34,9 @@
 #define SLIC_ILVQ 2      // MFMA groups (of 4 per k-tile) over which the next tile's DMAs are spread (4 -> 2: +0.6 % on the step: the DMAs get half a tile more lead)
 #endif
 #include <stdlib.h>
+#ifndef SLIC_GEMM0_WPE
+#define SLIC_GEMM0_WPE 4   // waves per SIMD of the register-staged kernel, pinned: left to itself the compiler shuttled the accumulator between
+#endif                     // VGPRs and AGPRs every k-tile (32 v_accvgpr moves per 32 MFMAs — vector instructions, which stop the matrix pipe)
 
 // In-kernel time stamps (MI355X_MICROARCH.md, 'In-kernel stamps'): ONLY in the diagnostic build scripts/stamps_conv.py makes
 // (-DSLIC_STAMPS, a separate library under csrc/_exp/); in the shipped library the macro is empty and no stamp executes.
@@ -82,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue(const SlicConvArgs& p, f32x16 (&ac
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const SlicConvArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SLIC_GEMM0_WPE, SLIC_GEMM0_WPE))) void conv_gemm_kernel(const SlicConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;   // 32x32 MFMA tiles per wave
