@@ -259,7 +259,8 @@ __device__ __forceinline__ void conv_gemm_dma_body(const SlicConvArgs& p, const 
   static_assert(BM % RALL == 0 && BN % RALL == 0, "tile rows per DMA pass");
   constexpr int STAGE_FLOATS = TILE_FLOATS;                   // a ring stage holds one k-tile: one barrier per k-tile
   static_assert(WM * WN == 4, "4 waves");
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMAs' LDS bases (M0) then need no v_readfirstlane each
   const int wm = wave / WN, wn = wave % WN;
   // XCD-aware order: consecutive workgroup ids run on different XCDs (id % 8), so hand each XCD a contiguous range of
   // row blocks — neighbouring rows (the taps' halo) are then re-read through the same L2
@@ -584,7 +585,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_dma_kernel(const SlicConvArgs 
   static_assert(!RT || STAGES == 2, "row-table path: the counted waits assume a 2-stage ring");
   constexpr int SUB = 32 * 64;                       // one [32 m][64] sub-tile
   constexpr int STAGE_FLOATS = (G + 1) * SUB;        // G sub-tiles of X and one of dY
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the DMAs' LDS bases (M0) then need no v_readfirstlane each
   const int wk = wave >> 1, wn = wave & 1;
   const int nx = (p.nchunks + 16 * G - 1) / (16 * G), ny = (p.N + 63) / 64;
   const int L = blockIdx.x;
