@@ -88,16 +88,18 @@ class ConvPlan:
         assert (elig2 and self.wino) or not self.wino2, "Winograd F(4,3) x F(2,3): a Winograd plan with uniform 64-tile blocks"
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
         self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
-        # ... and by the transposed TWO-dimensional algorithm (slic_conv_wgrad_wino2) where it is the faster one.  Its workgroup loads
-        # 1.3 x the one-dimensional kernel's bytes per MFMA (three patch rows + two gradient rows for a pair of H-points), and both kernels
-        # run at the same L2 -> LDS rate per CU (~21 GB/s), so two thirds of the MFMAs buy little: measured at B = 32 (algorithmic
-        # TFLOP/s, 2-D vs 1-D): layer1 234 vs 228, layer2 255-258 vs 228-231, layer3 187-192 vs 190-192.  wino2_wgrad=None: the
-        # 128-channel layers only (SLIC_WINO2_WGRAD=1 forces it wherever the 6 x C / 64 x N / 64 blocks fit the 256 slots, =0 never).
-        mode = os.environ.get("SLIC_WINO2_WGRAD", "auto")
+        # ... and by the transposed TWO-dimensional algorithm (slic_conv_wgrad_wino2) wherever the two-dimensional forward runs and its
+        # 6 x C / 64 x N / 64 blocks leave room for tile slices on the 256 one-workgroup-per-CU slots (layers 1-3; layer4's 384 blocks
+        # stay on the one-dimensional kernel).  In isolation it only wins at layer2 (algorithmic TFLOP/s at B = 32, 2-D vs 1-D: layer1
+        # 234 vs 228, layer2 255-258 vs 228-231, layer3 187-192 vs 190-192 — it loads 1.3 x the bytes per MFMA), but IN THE STEP it is
+        # worth 2.4 % (same box: 819.6 against 800.2-800.5 clips/s with it on layer2 only): on the side stream it shares the chip with
+        # the main stream's two-dimensional data gradients better than the one-dimensional kernel's two workgroups per CU did.
+        # SLIC_WINO2_WGRAD=0 switches it off, =2 restricts it to the 128-channel layers (the round's first rule).
+        mode = os.environ.get("SLIC_WINO2_WGRAD", "1")
         blocks2 = 6 * (self.C // 64) * (self.N // 64)
         if wino2_wgrad is None:
             wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= 128 and
-                           (mode == "1" or (self.C == 128 and self.N == 128)))
+                           (mode != "2" or (self.C == 128 and self.N == 128)))
         self.wino2_wgrad = bool(wino2_wgrad)
         assert not self.wino2_wgrad or (base and blocks2 <= 256), "transposed 2-D Winograd weight gradient: a Winograd plan with at most 256 blocks"
         self._wu = self._wud = None
