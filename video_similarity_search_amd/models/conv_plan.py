@@ -303,6 +303,7 @@ class ConvPlan:
                 variant=0):
         """x: [B, T, H, W, Cs] -> z: [B, To, Ho, Wo, N]; returns (z, (stat_partial, rows_per_partial) or None)"""
         lib = _lib.load()
+        self._prof_tag = "fwd"
         a = self._fwd_args(x, B)
         if self.wino:
             assert variant in (0, 30, 31) and bias is None, "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
@@ -425,7 +426,7 @@ class ConvPlan:
         e0.record()                      # torch's current stream == the stream the kernel is launched on
         go()
         e1.record()
-        self.prof.append((e0, e1))
+        self.prof.append((e0, e1, getattr(self, "_prof_tag", "fwd")))
 
     def dgrad(self, dz, wd, B, addend=None, out=None, variant=0, mask=None, bwd=None, skip_empty=False, addend_classes=None):
         """dz: [B, To, Ho, Wo, N] -> dx: [B, T, H, W, Cs] = conv_transpose(dz) (+ addend; addend may be `out`
@@ -438,6 +439,7 @@ class ConvPlan:
         addend_classes: the parity classes on which `addend` is defined (tap_classes() of the plan that wrote it); the other classes'
         launches take no addend."""
         lib = _lib.load()
+        self._prof_tag = "dgrad"
         if self.wino:
             assert variant in (0, 30, 31), "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
             variant = 31 if self.wino2 else 30
@@ -503,7 +505,7 @@ class ConvPlan:
             call("slic_conv_gemm_multi", arr, len(launches), picks[0], stream())
             if self.prof is not None:
                 e1.record()
-                self.prof.append((e0, e1))
+                self.prof.append((e0, e1, "dgrad"))
         else:
             for a in launches:
                 self._launch(a, variant)

@@ -453,10 +453,11 @@ class _Engine:
         # Weight gradients on a side stream: they depend only on (saved activation, dz), nothing downstream in this segment
         # depends on them, and they are MFMA-bound — so they overlap the HBM-bound BatchNorm passes and fill the partial
         # last rounds of the data-gradient launches; the main stream joins before returning.  All segments: +1.3 % clips/s
-        # (70.2 vs 71.2 ms / step, SLIC_WGRAD_STREAM=1).  Default ("auto"): every segment EXCEPT layer1 — with two kernels
-        # sharing the CUs a per-launch duration (HIP events, rocprof) stops describing one kernel, and bench.py's roofline
-        # object is defined on layer1's launches, which therefore keep the GPU to themselves.  "0": off.
-        mode = os.environ.get("SLIC_WGRAD_STREAM", "auto")
+        # (round 1: 70.2 vs 71.2 ms / step; round 4: 829.8 vs 819.3 clips/s).  Default "1": every segment.  "auto": every segment EXCEPT
+        # layer1 (rounds 1-3's default: with two kernels sharing the CUs a per-launch duration stops describing one kernel, and
+        # bench.py's roofline object was defined on all of layer1's launches; it now times layer1's FORWARD launches, which no
+        # side-stream kernel overlaps, and reports the overlapped data-gradient launches beside them).  "0": off.
+        mode = os.environ.get("SLIC_WGRAD_STREAM", "1")
         side = self._side_stream() if (mode == "1" or (mode == "auto" and si != 1)) else None
         main = torch.cuda.current_stream()
 
