@@ -1026,6 +1026,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_wino2_reduce(const float* __re
   }
 }
 
+// slab[0][e] = sum over slices z, ascending, of slab[z][e]  (e over the 72 x C x N point sums, 16 bytes per thread, four slices in
+// flight): the reduce kernel's own slice loop ran on 3 x C x N threads — 48 workgroups at layer1, each thread walking 24 x 42 values —
+// and took 150 us for 50 MB; with the slices summed here by 72 x C x N / 4 threads it is one pass at memory speed
+__global__ __launch_bounds__(256) void conv_wgrad_wino2_sum(float* __restrict__ slab, int S, int64_t n4) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n4) return;
+  f32x4* q = (f32x4*)slab + e;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  int zi = 0;
+  for (; zi + 4 <= S; zi += 4) {
+    const f32x4 s0 = q[zi * n4], s1 = q[(zi + 1) * n4], s2 = q[(zi + 2) * n4], s3 = q[(zi + 3) * n4];
+    a += s0; a += s1; a += s2; a += s3;
+  }
+  for (; zi < S; ++zi) a += q[zi * n4];
+  q[0] = a;
+}
+
 static int64_t wino2_tiles(const SlicConvArgs* a) { return (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4); }
 
 static void wino2_wgrad_plan(const SlicConvArgs* a, int splits, int* tps, int* S) {
@@ -1077,7 +1094,12 @@ extern "C" int slic_conv_wgrad_wino2(const SlicConvArgs* a, const float* dy, int
   conv_wgrad_wino2_kernel<<<dim3(gx), dim3(512), lds, st>>>(*a, dy, (unsigned)dyb, (const uint2*)tile_tab, (float*)workspace, tps, S);
   SLIC_LAUNCH_CHECK();
   const int64_t tot = (int64_t)3 * a->Cs * a->N;
-  conv_wgrad_wino2_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>((const float*)workspace, S, a->Cs, a->N, dW);
+  if (S > 1) {
+    const int64_t n4 = (int64_t)72 * a->Cs * a->N / 4;
+    conv_wgrad_wino2_sum<<<dim3((unsigned)slic_cdiv(n4, 256)), dim3(256), 0, st>>>((float*)workspace, S, n4);
+    SLIC_LAUNCH_CHECK();
+  }
+  conv_wgrad_wino2_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>((const float*)workspace, 1, a->Cs, a->N, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

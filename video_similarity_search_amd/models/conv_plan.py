@@ -98,10 +98,10 @@ class ConvPlan:
         mode = os.environ.get("SLIC_WINO2_WGRAD", "1")
         blocks2 = 6 * (self.C // 64) * (self.N // 64)
         if wino2_wgrad is None:
-            wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= 128 and
+            wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "128")) and
                            (mode != "2" or (self.C == 128 and self.N == 128)))
         self.wino2_wgrad = bool(wino2_wgrad)
-        assert not self.wino2_wgrad or (base and blocks2 <= 256), "transposed 2-D Winograd weight gradient: a Winograd plan with at most 256 blocks"
+        assert not self.wino2_wgrad or base, "transposed 2-D Winograd weight gradient: a Winograd plan"
         self._wu = self._wud = None
         self._wino_tabs = {}
         self._wino2_tabs = {}
