@@ -289,8 +289,9 @@ int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant, void* str
  * finished (pieces added in split order, then the ordinary epilogue) by a second pass over those rows only.  nfull_rb = 0 is plain
  * split-K (raw accumulators to workspace[splits][M][N]); splits <= 1 forwards to slic_conv_gemm.  Deterministic.  Stands in for cuDNN's algorithm choice on
  * the few-tile layers of models/resnet.py:126-131 (layer3 / layer4 at small M).
- * Variant 31 (two-dimensional Winograd): nfull_rb counts 64-TILE blocks; the blocks behind them cut their K loop by kt (three pieces
- * whatever `splits` > 1 says) and a finish pass adds the pieces in kt order and runs the epilogue; splits <= 1 is the plain launch. */
+ * Variant 31 (two-dimensional Winograd): nfull_rb counts 64-TILE blocks; the blocks behind them cut their K loop — the 3 Cs / 8 double
+ * stages in (channel group, kt) order — into `splits` even pieces (splits must divide 3 Cs / 16, 2 .. 16: SLIC_EINVAL otherwise, and a
+ * workspace size of 0) and a finish pass adds the pieces in order and runs the epilogue; splits <= 1 is the plain launch. */
 size_t slic_conv_gemm_tailsplit_workspace_bytes(const SlicConvArgs* args, int variant, int nfull_rb, int splits);
 int slic_conv_gemm_tailsplit(const SlicConvArgs* args, int variant, int nfull_rb, int splits, void* workspace, void* stream);
 

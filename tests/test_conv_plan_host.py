@@ -74,9 +74,9 @@ def test_winograd_2d_plan_rules(monkeypatch):
         a.M, a.Ts, a.Hs, a.Ws, a.N, a.Cs = B * T * H * W, T, H, W, C, C
         return a
     assert ConvPlan._plan_split(args(32, 64, (16, 56, 56)), 31) is None          # 3136 workgroups: 12.25 rounds, remainder 64 ... of 256
-    assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) == (384, 3)      # 392 tile blocks x 2: the last 8 blocks cut by kt
+    assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) == (384, 6)      # 392 tile blocks x 2: the last 8 blocks cut into 6 pieces
     assert ConvPlan._plan_split(args(32, 256, (4, 14, 14)), 31) is None          # 224 workgroups: most of a round
-    assert ConvPlan._plan_split(args(32, 512, (2, 7, 7)), 31) == (0, 3)          # 64 workgroups: all of them cut
+    assert ConvPlan._plan_split(args(32, 512, (2, 7, 7)), 31) == (0, 4)          # 64 workgroups: all of them cut, 4 pieces = one dispatch round
     # small batches: layer3 at B = 8 has 56 workgroups -> the one-dimensional kernel
     assert not ConvPlan(256, 256, k3, s1, p1, (4, 14, 14), "cpu", batch=8).wino2
     # no batch hint (a plan built by hand): never variant 31 by default

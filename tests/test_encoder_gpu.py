@@ -298,6 +298,16 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
         assert torch.allclose(p1.double(), part.double(), atol=2e-4, rtol=1e-4)
         assert torch.allclose(g1, g, atol=2e-5 * max(1.0, gx64.abs().max().item()), rtol=0)
         assert torch.allclose(bp1[:, 0].double().sum(0), bpart[:, 0].double().sum(0), atol=2e-3, rtol=1e-4)
+        # other piece counts than the plan's (any divisor of 3 C / 16): same result within the order of the sums
+        for pieces in ("2", "3", "6"):
+            _os.environ["SLIC_WINO2_PIECES"] = pieces
+            try:
+                assert w2._plan_split(w2._fwd_args(xd, B), 31)[1] == int(pieces)
+                zq, (pq, rq) = w2.forward(xd, w2.pack_fwd(wd_), B, want_stats=True)
+            finally:
+                del _os.environ["SLIC_WINO2_PIECES"]
+            assert rq == rows and torch.allclose(zq, z1p, atol=2e-5 * max(1.0, y64.abs().max().item()), rtol=0), pieces
+            assert torch.allclose(pq.double(), p1.double(), atol=2e-4, rtol=1e-4), pieces
     # weight gradient by the transposed two-dimensional algorithm (slic_conv_wgrad_wino2) where the plan uses it (the layers with
     # few 64 x 64 blocks), vs fp64 and vs the one-dimensional kernel; default slicing, three slices, one slice; bit-equal run to run
     x64w, w64w = x.double(), w.double().requires_grad_(True)

@@ -1745,7 +1745,7 @@ extern "C" int slic_conv_gemm(const SlicConvArgs* a, int variant, void* stream) 
   SLIC_REQUIRE(variant == 0 || variant == 20 || variant == 22 || variant == 30 || variant == 31,
                "slic_conv_gemm: variant must be 0, 20, 22, 30 or 31");
   hipStream_t st = S_(stream);
-  if (variant == 31) return slic_conv_wino2_launch(a, st, -1, nullptr);   // Winograd F(4, 3) x F(2, 3) over (W, H): wgt = the operand of slic_pack_weight_wino2
+  if (variant == 31) return slic_conv_wino2_launch(a, st, -1, nullptr, 1);   // Winograd F(4, 3) x F(2, 3) over (W, H): wgt = the operand of slic_pack_weight_wino2
   if (variant == 30) {
     // Winograd F(4, 3) along W: wgt = the operand of slic_pack_weight_wino; 3 x 3 x 3, stride 1, pad 1 geometry only
     SLIC_REQUIRE(a->Cs % 8 == 0 && a->N % 64 == 0 && a->sa == 1 && a->sb == 1 && a->sc == 1 && a->Ga == a->Ts &&
@@ -1816,7 +1816,7 @@ extern "C" int slic_conv_gemm_multi(const SlicConvArgs* args, int n, int variant
 
 extern "C" size_t slic_conv_gemm_tailsplit_workspace_bytes(const SlicConvArgs* a, int variant, int nfull_rb, int splits) {
   if (!a || splits < 1 || nfull_rb < 0) return 0;
-  if (variant == 31) return slic_conv_wino2_split_workspace_bytes(a, nfull_rb);    // kt pieces of the tile blocks behind the first nfull_rb
+  if (variant == 31) return slic_conv_wino2_split_workspace_bytes(a, nfull_rb, splits);    // pieces of the tile blocks behind the first nfull_rb
   if (variant == 30) {                                         // pieces hold whole outputs of the rows behind the first nfull_rb 64-tile blocks
     const int64_t row0 = a->Ws % 4 == 0 ? (int64_t)nfull_rb * 256 : 0;
     return row0 < a->M ? slic_align_up((size_t)splits * (a->M - row0) * a->N * sizeof(float), 256) : 0;
@@ -1831,13 +1831,13 @@ extern "C" int slic_conv_gemm_tailsplit(const SlicConvArgs* a, int variant, int 
   int rc = validate(a, "slic_conv_gemm_tailsplit");
   if (rc) return rc;
   if (variant == 31) {
-    // two-dimensional Winograd: the first nfull_rb 64-tile blocks whole, the blocks behind them with the K loop cut by kt (three
-    // pieces, whatever `splits` says) + conv_wino2_finish: the partly filled last dispatch round of a launch (layer2 at B = 32: 784
-    // workgroups on 256 slots) and launches of few workgroups (layer4, small batches)
+    // two-dimensional Winograd: the first nfull_rb 64-tile blocks whole, the blocks behind them with the K loop cut into `splits` even
+    // pieces (splits | 3 Cs / 16) + conv_wino2_finish: the partly filled last dispatch round of a launch (layer2 at B = 32: 784
+    // workgroups on 256 slots) and launches of few workgroups (layer4: 64 workgroups x 4 pieces, small batches)
     SLIC_REQUIRE(a->wgt && a->dst && nfull_rb >= 0 && (!a->bwd_partial || (a->bwd_z && a->bwd_mean && a->bwd_invstd && !a->stat_partial)),
                  "slic_conv_gemm_tailsplit: variant 31: bad args");
-    if (splits <= 1) return slic_conv_wino2_launch(a, S_(stream), -1, nullptr);
-    return slic_conv_wino2_launch(a, S_(stream), nfull_rb, (float*)workspace);
+    if (splits <= 1) return slic_conv_wino2_launch(a, S_(stream), -1, nullptr, 1);
+    return slic_conv_wino2_launch(a, S_(stream), nfull_rb, (float*)workspace, splits);
   }
   if (variant == 30) {
     // Winograd with the K loop (the 9 x Cs / 8 stages) cut `splits` ways: the few-tile layers (layer4 at B = 32: 112 workgroups of

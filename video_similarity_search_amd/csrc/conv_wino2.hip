@@ -17,13 +17,17 @@
 // accumulators of 16 registers.  Its H-transform needs TWO of the patch's four rows (Bh^T rows: d0 - d2, d1 + d2, d2 - d1,
 // d1 - d3; row 2 is taken as d1 - d2 with U negated), one packed op per pixel, then the F(4, 3) input transform along W:
 // 18 packed instructions per stage and wave for 24 MFMAs.
-// K loop = 3 kt x C / 4 stages of 4 channels; a stage = 24 KB of raw pixels [row 4][pixel 6][tile 64][4 ch] + 24 KB of U
-// [j 4][p 6][n 64][4 ch], both by LDS-DMA in the order the lanes read them (lane (r, hh) of the MFMA reads channels 2 hh, 2 hh + 1
-// of tile / column r with ONE ds_read_b64 per pixel / point: element e goes to MFMA e); 3-stage ring (144 KB: one workgroup per
-// CU, two waves per SIMD), counted vmcnt, one barrier per stage.
-// Epilogue: every wave applies Aw^T to its own accumulators (4 W-outputs), the four H-points of a tile meet in an LDS image
-// [tile 64][row 2][col 4][n 64] in a fixed order (row 0 = (Y0 + Y1) + Y2, row 1 = (-Y3 - Y2) + Y1), and the image leaves through
-// w2_epilogue (store / affine / addend / ReLU mask / BatchNorm partials as conv_epilogue_rows computes them, one slab row per block).
+// K loop = 3 C / 4 stages of 4 channels, kt inner (double stage d of 8 channels = (channel group d / 3, kt = d % 3)).  Raw pixels come
+// a DOUBLE stage at a time — 48 KB [pixel 24][slot 2][tile half 2][channel half 2][tile 32][4 ch], two slots interleaved per patch
+// pixel, 32-byte pieces of a cache line per lane pair — and U a stage at a time — 24 KB [j 4][p 6][n 64][4 ch], two slots — both by
+// LDS-DMA in the order the lanes read them (lane (r, hh) of the MFMA reads channels 2 hh, 2 hh + 1 of tile / column r with ONE
+// ds_read_b64 per pixel / point: element e goes to MFMA e); 144 KB of rings + 16 KB of per-thread piece offsets: one workgroup per CU,
+// two waves per SIMD, counted vmcnt, one barrier per stage, kt and the channel group in the DMA's scalar offset.
+// Epilogue: every wave applies Aw^T to its own accumulators (4 W-outputs), the four H-points of a tile are written side by side to
+// LDS buf[j 4][tile 64][col 4][n 32] one column half at a time, and w2_epilogue combines them in a fixed order (row 0 = (Y0 + Y1) + Y2,
+// row 1 = (Y1 - Y2) - Y3) and finishes the rows (store / affine / addend / ReLU mask / BatchNorm partials as conv_epilogue_rows
+// computes them, one slab row per block).  Few-workgroup launches and partly filled last rounds cut the K loop into even pieces
+// (slab + conv_wino2_finish).
 #include "common.h"
 #include "conv_epilogue.h"
 #include "conv_internal.h"
@@ -251,9 +255,10 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;     // tiles
   // this launch covers tile blocks [mb_off, mb_off + mb_cnt): all of them, or — a launch whose last dispatch round would be partly
   // filled, or one of few workgroups — the whole rounds with the K loop in one piece, and then the remaining blocks with the K loop
-  // cut by kt: workgroup z = blockIdx.z of the second launch reduces the C / 4 stages of kt = z only and writes its two output rows'
-  // partial sums to slab[block][kt][column half][row][tile][col][n 32]; conv_wino2_finish adds the three pieces in kt order and runs
-  // the epilogue.  One piece (slab == NULL) covers everything.
+  // cut into gridDim.z even pieces: workgroup z = blockIdx.z of the second launch reduces double stages [z, z + 1) * (3 C / 8) / gridDim.z
+  // of the same (channel group, kt) order and writes its two output rows' partial sums to
+  // slab[block][piece][column half][row][tile][col][n 32]; conv_wino2_finish adds the pieces in order and runs the epilogue.
+  // One piece (slab == NULL) covers everything.
   if (mb >= mb_cnt) return;
   const int64_t tile0 = (int64_t)(mb_off + mb) * 64;
   if (tile0 >= Mt) return;
@@ -261,8 +266,6 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two >= 16: checked on the host)
   const int cch_shift = 31 - __builtin_clz(CCH);
-  const int sbeg = slab ? (int)blockIdx.z * CCH : 0;           // first stage of this workgroup's range
-  const int NS = slab ? sbeg + CCH : 3 * CCH;                  // END of the range
   const int NB = p.N >> 6;
   // ---- DMA roles.  Pixels: a DOUBLE stage (8 channels) at a time — piece pc = 8 i + wave (i = 0..5) is patch pixel ab = pc / 2 of
   // tile half pc % 2; lane L serves tile 32 (pc % 2) + L % 32, 16-byte half L / 32 of the pixel's 8 channels: lanes L and L + 32 fetch
@@ -275,7 +278,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
   const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;  // q = frame (b, t)
   const int tt = (int)(q % (unsigned)T);
-  // Stage order: the local stage index sl (0 .. 3 C/4 - 1, or 0 .. C/4 - 1 for a K-split piece, whose kt is blockIdx.z) runs with kt
+  // Stage order: the stage index sl (0 .. 3 C/4 - 1; a K-split piece starts at double stage dbeg and runs 3 C/4 / pieces of them) runs with kt
   // INNER — double stage d = sl / 2 is (channel group cd = d / 3, kt = d % 3), stage sl its channel half sl % 2: a workgroup touches
   // the three frames t - 1, t, t + 1 of its patch in consecutive double stages, and the per-lane piece offsets never change (kt rides in
   // the scalar offset).  Against a kt-outer order (offsets rewritten three times per workgroup) it measured equal in time; FETCH_SIZE
@@ -285,7 +288,8 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   // spill); whether frame t - 1 / t + 1 exists is one flag word per lane.  A double stage then costs ONE vector instruction + one per
   // piece: kt and the channel group ride in the DMA's SCALAR offset (the resource starts one frame before the tensor, so that the
   // scalar part is never negative); U = a per-lane constant + the stage's block as scalar offset.
-  const int NSL = NS - sbeg;                                  // stages of this workgroup
+  const int NSL = slab ? 3 * CCH / (int)gridDim.z : 3 * CCH;   // stages of this workgroup (a multiple of 4: checked on the host)
+  const int dbeg = slab ? (int)blockIdx.z * (NSL >> 1) : 0;   // its first double stage
   const unsigned HWC4 = (unsigned)(H * W * C * 4);
   unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid * 8;
 #pragma unroll
@@ -301,11 +305,11 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - HWC4), 0, p.src_bytes + 2 * HWC4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
   const unsigned uvoff = (unsigned)tid * 16u;
-  const int ktz = slab ? (int)blockIdx.z : -1;
   // (kt, channel group) of local double stage d
   auto kt_cd = [&](int d, int& kt, int& cd) {
-    if (ktz >= 0) { kt = ktz; cd = d; }
-    else { cd = (int)(((unsigned)d * 43691u) >> 17); kt = d - 3 * cd; }          // d / 3 for d < 2^16
+    d += dbeg;
+    cd = (int)(((unsigned)d * 43691u) >> 17);                  // d / 3 for d < 2^16
+    kt = d - 3 * cd;
   };
   // pixel double stage d into pixel slot `slot`, in two parts of three pieces (three offset registers live at a time)
   auto issue_px = [&](int d, int slot, int part) {
@@ -487,7 +491,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
 #else
     if (slab) {
       // K-split piece: the two output rows' partial sums, combined as the epilogue combines them, to the slab (16 bytes per lane)
-      float* out = slab + ((((int64_t)mb * gridDim.y + nb) * 3 + blockIdx.z) * 2 + nh) * (2 * 64 * 4 * 32);
+      float* out = slab + ((((int64_t)mb * gridDim.y + nb) * gridDim.z + blockIdx.z) * 2 + nh) * (2 * 64 * 4 * 32);
       const int cq = tid & 7, rr = tid >> 3;
       const int hp = (rr >> 2) & 1, o = rr & 3;
       const float sgn = hp ? -1.f : 1.f;
@@ -505,9 +509,10 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   }
 }
 
-// second pass of a K-split launch: one workgroup per (tail block, n block) adds the three kt pieces in order, lays the sums out as the
+// second pass of a K-split launch: one workgroup per (tail block, n block) adds the `pieces` pieces in order, lays the sums out as the
 // epilogue expects its side-by-side contributions (row 0 as H-point 0, minus row 1 as H-point 3, H-points 1 and 2 zero) and runs it
-__global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, const int full_rows, const float* __restrict__ slab, const int mb_off) {
+__global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, const int full_rows, const float* __restrict__ slab, const int mb_off,
+                                                          const int pieces) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int mb = blockIdx.x, nb = blockIdx.y;
@@ -516,11 +521,10 @@ __global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, c
   if (tid < 64) w2_tile_records(p, lds, tile0, tid);
   for (int nh = 0; nh < 2; ++nh) {
     if (nh) __syncthreads();
-    const float* base = slab + (((int64_t)mb * gridDim.y + nb) * 3 * 2 + nh) * (2 * JS);
+    const float* base = slab + (((int64_t)mb * gridDim.y + nb) * pieces * 2 + nh) * (2 * JS);
     for (int e = tid * 4; e < 2 * JS; e += 512 * 4) {          // e < JS: row 0; else row 1
       f32x4 v = *(const f32x4*)(base + e);
-      v += *(const f32x4*)(base + 2 * (2 * JS) + e);
-      v += *(const f32x4*)(base + 4 * (2 * JS) + e);
+      for (int z = 1; z < pieces; ++z) v += *(const f32x4*)(base + (int64_t)z * 2 * (2 * JS) + e);
       if (e < JS) {
         *(f32x4*)(lds + e) = v;
         *(f32x4*)(lds + JS + e) = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -614,14 +618,17 @@ static constexpr size_t w2_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-size_t slic_conv_wino2_split_workspace_bytes(const SlicConvArgs* a, int nfull) {
+// a K-split piece is a whole number of loop turns (two double stages): pieces | 3 Cs / 16
+static bool wino2_pieces_ok(const SlicConvArgs* a, int pieces) { return pieces >= 2 && pieces <= 16 && (3 * a->Cs / 16) % pieces == 0; }
+
+size_t slic_conv_wino2_split_workspace_bytes(const SlicConvArgs* a, int nfull, int pieces) {
   const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
   const int64_t tail = slic_cdiv(tiles, 64) - nfull;
-  return tail <= 0 ? 0 : slic_align_up((size_t)tail * (a->N / 64) * 3 * 2 * (2 * 64 * 4 * 32) * sizeof(float), 256);
+  return tail <= 0 || !wino2_pieces_ok(a, pieces) ? 0 : slic_align_up((size_t)tail * (a->N / 64) * pieces * 2 * (2 * 64 * 4 * 32) * sizeof(float), 256);
 }
 
-// nfull < 0: the plain launch.  nfull >= 0: tile blocks [0, nfull) whole, the rest with the K loop cut by kt + the finish pass.
-int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, float* slab) {
+// nfull < 0: the plain launch.  nfull >= 0: tile blocks [0, nfull) whole, the rest with the K loop cut into `pieces` + the finish pass.
+int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, float* slab, int pieces) {
   int full;
   int rc = wino2_check(a, &full);
   if (rc) return rc;
@@ -642,14 +649,15 @@ int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, flo
     return SLIC_OK;
   }
   SLIC_REQUIRE(slab, "slic_conv_gemm_tailsplit: variant 31 needs a workspace");
+  SLIC_REQUIRE(wino2_pieces_ok(a, pieces), "slic_conv_gemm_tailsplit: variant 31: splits = %d must divide 3 Cs / 16 = %d (2 .. 16)", pieces, 3 * a->Cs / 16);
   if (nfull > 0) {
     conv_wino2_kernel<<<dim3((unsigned)((nfull + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, 0, nfull);
     SLIC_LAUNCH_CHECK();
   }
   const int tail = gx - nfull;
-  conv_wino2_kernel<<<dim3((unsigned)((tail + 7) / 8 * 8), ny, 3), dim3(512), lds, st>>>(*a, full, slab, nfull, tail);
+  conv_wino2_kernel<<<dim3((unsigned)((tail + 7) / 8 * 8), ny, (unsigned)pieces), dim3(512), lds, st>>>(*a, full, slab, nfull, tail);
   SLIC_LAUNCH_CHECK();
-  conv_wino2_finish<<<dim3((unsigned)tail, ny), dim3(512), lds, st>>>(*a, full, slab, nfull);
+  conv_wino2_finish<<<dim3((unsigned)tail, ny), dim3(512), lds, st>>>(*a, full, slab, nfull, pieces);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -38,6 +38,7 @@ class ConvPlan:
 
     WINO_MIN_WGS = 384     # forward / data gradient: a launch of fewer 64-tile x 64-n workgroups than this (layer4 at B = 32: 112) cuts its K loop
 
+    WINO2_PIECES = (2, 3, 4, 6)     # K-split pieces of a variant-31 tail (measured at layer4 / layer2, scripts/r4/ab_wino2.sh)
     WINO2_MIN_WGS = 64     # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (launches of less than
                            # a dispatch round of the 256 one-per-CU slots cut their K loop by kt: _plan_split)
 
@@ -355,8 +356,8 @@ class ConvPlan:
         that already fills most of a round is left alone.  SLIC_CONV_TAIL=0 switches the mechanism off (tests compare)."""
         if variant == 31:
             # two-dimensional Winograd, ONE workgroup per CU (256 slots): a launch's partly filled last dispatch round — when it is at
-            # most half full — and launches of less than a round cut their K loop by kt (three pieces + a finish pass): layer2 at B = 32
-            # is 784 workgroups = 3.06 rounds, layer4 64
+            # most half full — and launches of less than a round cut their K loop into as many even pieces as fill the slots once
+            # (pieces | 3 Cs / 16; + a finish pass): layer2 at B = 32 is 784 workgroups = 3.06 rounds (16 in the tail), layer4 64 x 4 pieces
             if os.environ.get("SLIC_WINO2_SPLIT", "1") == "0":
                 return None
             H2, W2 = a.Hs, a.Ws
@@ -366,7 +367,11 @@ class ConvPlan:
             if rem == 0 or rem > 128 or wgs > 6 * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
                 return None                                  # pass measured no faster there)
             tail_x = -(-rem // ny)
-            return (gx - tail_x, 3)
+            forced = int(os.environ.get("SLIC_WINO2_PIECES", "0"))
+            units = 3 * a.Cs // 16
+            fit = [s for s in cls.WINO2_PIECES if units % s == 0 and tail_x * ny * s <= 256]
+            s = forced or (max(fit) if fit else 2)
+            return (gx - tail_x, s)
         if variant == 30:
             # Winograd: few-tile launches cut the K loop (9 x Cs / 8 stages) into as many even pieces as fill ONE residency round of
             # the 512 slots (2 workgroups / CU), each piece keeping >= 48 stages.  Measured at layer4, B = 32 (112 workgroups, 576
