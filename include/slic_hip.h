@@ -322,7 +322,7 @@ int slic_pack_weight_wino(const float* W, int N, int C, int dgrad, float* U, voi
 /* Variant 31 of slic_conv_gemm: Winograd in TWO dimensions, F(4, 3) along W x F(2, 3) along H — 24 multiplies per (kt, c, n) and tile of
  * 2 x 4 outputs where the direct form has 72 and variant 30 has 36, all exact-fp32 MFMA.  Same SlicConvArgs as variant 30 (stride-1
  * same-size 3 x 3 x 3 geometry, no bias, Cs = 64 x a power of two, N % 64 == 0); wgt / wgt_bytes = the operand written here:
- * U2[kt][C/4][N/64][Hpoint 4][Wpoint 6][n 64][4 ch] = Gh w Gw^T, 3 * 24 * C * N floats (dgrad = 1: flipped / transposed for the data
+ * U2[kt][C/4][N/64][Hpoint 4][Wpoint 6][column half 2][channel pair 2][n 32][2 ch] = Gh w Gw^T, 3 * 24 * C * N floats (dgrad = 1: flipped / transposed for the data
  * gradient).  Stands in for the same cuDNN calls as variant 30 (models/resnet.py:11-17, 41-57).  Blocks of 64 tiles must all hold the
  * same number of real outputs — slic_conv_tile_m(args, 31) returns it (the slab rows' size) or 0 when the geometry does not allow
  * it: H even and W % 4 == 0, or H even and ceil(W / 4) | 64, or ceil(H / 2) * ceil(W / 4) | 64. */

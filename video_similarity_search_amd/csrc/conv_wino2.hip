@@ -19,7 +19,7 @@
 // 18 packed instructions per stage and wave for 24 MFMAs.
 // K loop = 3 C / 4 stages of 4 channels, kt inner (double stage d of 8 channels = (channel group d / 3, kt = d % 3)).  Raw pixels come
 // a DOUBLE stage at a time — 48 KB [pixel 24][slot 2][tile half 2][channel half 2][tile 32][4 ch], two slots interleaved per patch
-// pixel, 32-byte pieces of a cache line per lane pair — and U a stage at a time — 24 KB [j 4][p 6][n 64][4 ch], two slots — both by
+// pixel, 32-byte pieces of a cache line per lane pair — and U a stage at a time — 24 KB [j 4][p 6][column half 2][channel pair 2][n 32][2 ch], two slots — both by
 // LDS-DMA in the order the lanes read them (lane (r, hh) of the MFMA reads channels 2 hh, 2 hh + 1 of tile / column r with ONE
 // ds_read_b64 per pixel / point: element e goes to MFMA e); 144 KB of rings + 16 KB of per-thread piece offsets: one workgroup per CU,
 // two waves per SIMD, counted vmcnt, one barrier per stage, kt and the channel group in the DMA's scalar offset.
@@ -291,14 +291,14 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int NSL = slab ? 3 * CCH / (int)gridDim.z : 3 * CCH;   // stages of this workgroup (a multiple of 4: checked on the host)
   const int dbeg = slab ? (int)blockIdx.z * (NSL >> 1) : 0;   // its first double stage
   const unsigned HWC4 = (unsigned)(H * W * C * 4);
-  unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid * 8;
+  unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid;   // word i of thread tid at [i][tid]: conflict-free (a row per thread was 8-way)
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int ab = 4 * i + (wave >> 1);
     const int a = (ab * 11) >> 6, b = ab - 6 * a;             // ab / 6 for ab < 24
     const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
     const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
-    stash[i] = ok ? (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4) + (unsigned)(lane >> 5) * 16u : 0x80000000u;
+    stash[i * 512] = ok ? (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4) + (unsigned)(lane >> 5) * 16u : 0x80000000u;
   }
   // bit kt: frame t - 1 + kt is outside the clip; bit 3: a dead stage
   const int tflags = (tt == 0 ? 1 : 0) | (tt == T - 1 ? 4 : 0) | 8;
@@ -321,9 +321,9 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
 #pragma unroll
     for (int i = 3 * part; i < 3 * part + 3; ++i) {
 #if SLIC_W2_ABL & 1
-      const unsigned off = 0xFFFFFF00u + 0 * (stash[i] | inv);
+      const unsigned off = 0xFFFFFF00u + 0 * (stash[i * 512] | inv);
 #else
-      const unsigned off = stash[i] | inv;
+      const unsigned off = stash[i * 512] | inv;
 #endif
       // piece pc = 8 i + wave = (ab, tile half): image [ab 24][slot 2][tile half 2][channel half 2][tile 32][4 ch] — the two ring slots
       // are INTERLEAVED per patch pixel, so that one lane address per patch row reaches both slots with immediate offsets
@@ -363,7 +363,9 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   issue_px(0, 0, 1);
   __builtin_amdgcn_s_setprio(0);
   // reader offsets (floats): pixel (a, b) of this lane's tile, channel half e2 of the double stage, its channel pair:
-  //   (((ab * 2 + slot) * 2 + th) * 2 + e2) * 128 + r * 4 + 2 hh;   point (j, p) of column half nh: ((j * 6 + p) * 64 + nh * 32 + r) * 4 + 2 hh
+  //   (((ab * 2 + slot) * 2 + th) * 2 + e2) * 128 + r * 4 + 2 hh;   point (j, p) of column half nh: ((j * 6 + p) * 2 + nh) * 128 + hh * 64 + r * 2
+  // (U is stored channel pair major — the 32 lanes of a ds_read_b64's lane group then cover one 256-byte bank row; the pixel image's
+  //  order is the DMA's, 16 bytes per tile: lanes r and r + 16 of a group share banks, two LDS cycles per group instead of one)
   const int a1 = j == 0 ? 0 : 1, a2 = j == 3 ? 3 : 2;
   // THREE lane addresses (bytes) serve every LDS read of the loop with immediate offsets; they are made opaque to the compiler, which
   // otherwise re-associates the large constants into one address register per read and spills them (a scratch reload in the loop
@@ -372,7 +374,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
   unsigned ar1 = lbase + (unsigned)(a1 * 6144 + th * 256 + r * 4 + 2 * hh) * 4u;      // + (b * 1024 + slot * 512 + e2 * 128) * 4
   unsigned ar2 = lbase + (unsigned)(a2 * 6144 + th * 256 + r * 4 + 2 * hh) * 4u;
-  unsigned bro = lbase + (unsigned)(2 * W2_PX_FLOATS + (j * 6 * 64 + r) * 4 + 2 * hh) * 4u;   // + (slot * W2_U_FLOATS + p * 256 + nh * 128) * 4
+  unsigned bro = lbase + (unsigned)(2 * W2_PX_FLOATS + j * 6 * 256 + hh * 64 + r * 2) * 4u;   // + (slot * W2_U_FLOATS + p * 256 + nh * 128) * 4
   asm volatile("" : "+v"(ar1), "+v"(ar2), "+v"(bro));
   const float sg = j == 1 ? 1.f : -1.f;                       // H-point: d[a1] + sg * d[a2]  (j = 2 as d1 - d2: its U is negated)
   const f32x2 sgn = {sg, sg};
@@ -538,7 +540,8 @@ __global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, c
   }
 }
 
-// U2[((((kt * C/4 + cc) * N/64 + nb) * 4 + j) * 6 + p) * 64 + nl][e] = sum_kh sum_kw Gh[j][kh] Gw[p][kw] w(n = 64 nb + nl, c = 4 cc + e, kt, kh, kw)
+// U2[(((((kt * C/4 + cc) * N/64 + nb) * 4 + j) * 6 + p) * 2 + nl / 32) * 2 + e / 2][nl % 32][e % 2]
+//     = sum_kh sum_kw Gh[j][kh] Gw[p][kw] w(n = 64 nb + nl, c = 4 cc + e, kt, kh, kw)      (channel PAIR major inside a column half: see the kernel's reader offsets)
 //   forward : w(n, c, kt, kh, kw) = W[n][c][kt][kh][kw]                    (N_ = out channels N, C_ = in channels C)
 //   dgrad   : w(n, c, kt, kh, kw) = W[c][n][2 - kt][2 - kh][2 - kw]        (N_ = C: channels of dx, C_ = N: channels of dy)
 // Gw (F(4, 3)) = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
@@ -587,7 +590,7 @@ __global__ void pack_w_wino2(const float* __restrict__ Wt, int N, int C, int dgr
     u[4] = (1.f / 24.f) * g[jj][0] - (1.f / 12.f) * g[jj][1] + (1.f / 6.f) * g[jj][2];
     u[5] = g[jj][2];
 #pragma unroll
-    for (int pp = 0; pp < 6; ++pp) U[blk + ((jj * 6 + pp) * 64 + nl) * 4 + e] = u[pp];
+    for (int pp = 0; pp < 6; ++pp) U[blk + ((((jj * 6 + pp) * 2 + (nl >> 5)) * 2 + (e >> 1)) * 32 + (nl & 31)) * 2 + (e & 1)] = u[pp];
   }
 }
 
