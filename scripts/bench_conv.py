@@ -58,7 +58,7 @@ for name, C, N, k, s, p, dims in SHAPES:
         t = timeit(lambda: wplan.wgrad(x, dz, B, dW))
         line += f" wg {fl/t/1e9:6.1f}"
         try:
-            w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True, wino2_wgrad=6 * (C // 64) * (N // 64) <= 128)    # F(4,3) x F(2,3) over (W, H)
+            w2 = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True, wino2_wgrad=3 * (C // 64) * (N // 64) <= 256)    # F(4,3) x F(2,3) over (W, H)
             wu, wud = w2.pack_fwd(w), w2.pack_dgrad(w)
             t = timeit(lambda: w2.forward(x, wu, B, want_stats=True))
             line += f" | wino2 fwd {fl/t/1e9:6.1f}"

@@ -58,14 +58,17 @@ def test_winograd_2d_plan_rules(monkeypatch):
     """host-side rules of the two-dimensional Winograd plans at R3D-18's shapes (models/conv_plan.py): variant 31 where the blocks of 64
     tiles are uniform and the launch has at least 64 workgroups; its K split by kt for a partly filled last dispatch round (layer2 at
     B = 32: 784 workgroups = three rounds + 16) and for launches of less than half a round (layer4: 64); the transposed two-dimensional
-    weight gradient wherever its blocks fit the 256 slots (layers 1-3); channel counts that are not 64 x a power of two stay off the Winograd kernels"""
+    weight gradient wherever its 3 x C/64 x N/64 workgroups per slice fit the 256 slots (all four layers; layer4: 192, one slice); channel counts that are not 64 x a power of two stay off the Winograd kernels"""
     for k in ("SLIC_WINO", "SLIC_WINO2", "SLIC_WINO2_MIN_WGS", "SLIC_WINO2_SPLIT", "SLIC_WINO2_WGRAD", "SLIC_WINO_WGRAD"):
         monkeypatch.delenv(k, raising=False)
     k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     shapes = [(64, (16, 56, 56)), (128, (8, 28, 28)), (256, (4, 14, 14)), (512, (2, 7, 7))]
     plans = {C: ConvPlan(C, C, k3, s1, p1, dims, "cpu", batch=32) for C, dims in shapes}
     assert [plans[C].wino2 for C, _ in shapes] == [True, True, True, True]
-    assert [plans[C].wino2_wgrad for C, _ in shapes] == [True, True, True, False]
+    assert [plans[C].wino2_wgrad for C, _ in shapes] == [True, True, True, True]
+    monkeypatch.setenv("SLIC_WINO2_WGRAD_MAXBLOCKS", "128")
+    assert [ConvPlan(C, C, k3, s1, p1, dims, "cpu", batch=32).wino2_wgrad for C, dims in shapes] == [True, True, True, False]
+    monkeypatch.delenv("SLIC_WINO2_WGRAD_MAXBLOCKS")
     assert all(plans[C].wino and plans[C].wino_wgrad for C, _ in shapes)
 
     def args(B, C, dims):

@@ -679,25 +679,21 @@ extern "C" int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, f
 // — the forward's input transform V (24 points from the tile's 4 x 6 patch), the output transform run backwards Z (24 points from the
 // tile's 2 x 4 output gradients), one 64 x 64 product-sum per point, kt and tile, and Gh^T .. Gw once at the very end: 24 multiplies per
 // (kt, c, n) and tile of 8 outputs where the one-dimensional transposed algorithm has 36 and the direct form 72.
-//   Workgroup = 512 threads = one kt, one PAIR of H-points (j = 2 jp, 2 jp + 1: they share three of the patch's four rows), one
-//   64 c x 64 n block, one slice of the tiles.  Waves 0-3 take j = 2 jp, waves 4-7 j = 2 jp + 1, each group 2 x 2 waves of 32 c x 32 n
-//   with six accumulators (the W-points).  The MFMA's k dimension is the TILE: lane (r, hh) reads its channel's pixels of tile
-//   2 ks + hh (two patch rows x 6) and its column's gradients (two output rows x 4) with ds_read2st64_b32 — two k-steps per
-//   instruction, and every vector instruction below works on such a pair — forms the H-point (one packed op per pixel / gradient), runs
-//   the F(4, 3) transforms along W in registers and feeds one MFMA per W-point.
-//   Stage = 8 tiles, ONE WAVE PER TILE for the DMA: 512 bytes of the patch's last two pixels (a half piece, issued first: its dead lanes'
-//   zeros land where the wave's own next piece then writes), 2 KB of gradients, 4 KB of pixels — 6.5 KB per tile, 52 KB per stage,
-//   3-stage ring (156 KB: one workgroup per CU), counted vmcnt, one barrier per stage; per-tile records {pixel index, invalid bits}
-//   from slic_conv_wino2_tile_table, loaded a stage ahead.
-//   Slabs [slice][kt][j][p][c][n]; conv_wgrad_wino2_reduce adds the slices in order and applies Gh^T .. Gw.
+//   Workgroup = 512 threads = one kt, one 64 c x 64 n block, one slice of the tiles, ALL FOUR H-points: wave (j, wc) owns H-point j of
+//   32 channels for all 64 columns — 6 W-points x 2 column halves = 12 accumulators, the forward kernel's budget.  The MFMA's k dimension
+//   is the TILE: lane (r, hh) reads its channel's pixels of tile 2 ks + hh (two patch rows x 6) and its column's gradients in both column
+//   halves (two output rows x 4, ds_read2_b32), forms the H-point, runs the F(4, 3) transforms along W in registers — V in scalars
+//   (one k-step), Z packed over the two column halves — and feeds two MFMAs per W-point.
+//   Stage = 4 tiles (two k-steps), tile image [24 pixels][64 ch] + [8 gradients][64 n] = 8 KB (whole cache lines: 170 bytes per MFMA),
+//   4-stage ring (128 KB: one workgroup per CU), wave w DMAs four of the eight 1 KB pieces of tile w / 2; counted vmcnt, one barrier per
+//   stage; k-step 1 of a stage is multiplied behind the NEXT stage's barrier, under the latency of its first reads.  Per-tile records
+//   {pixel index, invalid bits} from slic_conv_wino2_tile_table come by SCALAR loads, a stage ahead (a vector load would sit in the
+//   in-order vmcnt queue behind the DMAs: waiting for the record then drains the ring — the round's first kernel, one H-point PAIR per
+//   workgroup with 32 c x 32 n waves, did exactly that and ran at 0.50 of the pipe; this form: 0.64 at layer1).
+//   Slabs [slice][kt][j][p][c][n]; conv_wgrad_wino2_sum adds the slices in order, conv_wgrad_wino2_reduce applies Gh^T .. Gw.
 // ------------------------------------------------------------------------------------------
-constexpr int WG2_TILE_BYTES = 6656;                           // [2 pixels 512][8 gradients 2048][16 pixels 4096]
-constexpr int WG2_STAGE_BYTES = 8 * WG2_TILE_BYTES;            // 53248
-constexpr int WG2_RING_OFF = 1024;                             // the ring starts 1 KB into LDS (a lane address below reaches back 1 KB)
-constexpr int WG2_STAGES = 3;
-
 // tab[tile] = {pixel index of (b, t, 2 h2, 4 wt); bits 0-23: patch pixel (a, b) = (2 h2 - 1 + a, 4 wt - 1 + b) is OUTSIDE the frame
-//              (bit a * 6 + b); bits 24-26: frame t - 1 + kt is outside the clip; bit 27: always set (the dead half of a piece)}
+//              (bit a * 6 + b); bits 24-26: frame t - 1 + kt is outside the clip; bit 27: always set (a record read past the slice is all zeros)}
 __global__ void conv_wino2_tile_table_kernel(const SlicConvArgs p, uint2* __restrict__ tab) {
   const int Wq = (p.Ws + 3) >> 2, Hq = (p.Hs + 1) >> 1;
   const int64_t tile = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -719,207 +715,184 @@ __global__ void conv_wino2_tile_table_kernel(const SlicConvArgs p, uint2* __rest
   tab[tile] = make_uint2((unsigned)(((int64_t)q * p.Hs + 2 * h2) * p.Ws + 4 * wt), mk);
 }
 
+constexpr int WB_TILE_BYTES = 8192;
+constexpr int WB_STAGE_BYTES = 4 * WB_TILE_BYTES;
+#ifndef SLIC_WB_STAGES
+#define SLIC_WB_STAGES 4
+#endif
+constexpr int WB_STAGES = SLIC_WB_STAGES;
+
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy, unsigned dy_bytes, const uint2* __restrict__ tile_tab,
-                             float* __restrict__ slab, int tiles_per_split, int nsplit) {
+                              float* __restrict__ slab, int tiles_per_split, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int js = wave >> 2, wc = (wave >> 1) & 1, wn = wave & 1;
+  const int j = wave & 3, wc = wave >> 2;
   const int r = lane & 31, hh = lane >> 5;
   const int C = p.Cs, N = p.N, H = p.Hs, W = p.Ws;
   const int CB = C >> 6, NBk = N >> 6;
-  const int per_slice = 6 * CB * NBk;
+  const int per_slice = 3 * CB * NBk;
   const int bx = blockIdx.x, gdx = gridDim.x;
   const int v = (bx & 7) * (gdx >> 3) + (bx >> 3);            // XCD-aware: the workgroups of a slice (same tiles) share an L2
   if (v >= per_slice * nsplit) return;
   const int z = v / per_slice;
   int rest = v - z * per_slice;
-  const int kj = rest / (CB * NBk); rest -= kj * (CB * NBk);
+  const int kt = rest / (CB * NBk); rest -= kt * (CB * NBk);
   const int cb = rest / NBk, nb = rest - cb * NBk;
-  const int kt = kj >> 1, jp = kj & 1;
-  const int j = 2 * jp + js;
   const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
   const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;
   const int64_t tbeg = (int64_t)z * tiles_per_split;
   const int64_t tend = min(tbeg + tiles_per_split, Mt);
-  const int nst = tend > tbeg ? (int)((tend - tbeg + 7) / 8) : 0;
+  const int nst = tend > tbeg ? (int)((tend - tbeg + 3) / 4) : 0;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_tab = __builtin_amdgcn_make_buffer_rsrc((void*)tile_tab, 0, (int)(tend * 8), 0x00020000);
-  // ---- DMA roles: wave w serves tile w of the stage with seven 1 KB pieces, in this order:
-  //   piece 0: patch pixels rho = 2, b = 4, 5 (slots 16, 17 of the three stored rows x 6; lanes 32-63 dead)      -> tile bytes [0, 512)
-  //   pieces 1, 2: the 2 x 4 gradients (slot = hp * 4 + o)                                                          -> [512, 2560)
-  //   pieces 3-6: patch pixels slots 0..15 (slot = rho * 6 + b, stored row rho = patch row jp + rho)                -> [2560, 6656)
-  // lane = (slot within the piece lane / 16, 16-byte chunk lane % 16 of the slot's 64 channels / columns)
-  unsigned pos[7], cst[7], mul[7];
+  // ---- DMA roles: wave w serves tile dt = w / 2 of the stage with pieces d = 4 (w % 2) + i, i = 0..3 (d 0-5: patch pixels 4 d .. 4 d + 3,
+  // pixel e = a * 6 + b; d 6, 7: the gradients of output row d - 6); lane = (slot within the piece lane / 16, 16-byte chunk lane % 16 of the
+  // slot's 64 channels / columns); piece d lands at tile byte 1024 d.  Pieces 0, 1 of a wave are always pixels; pieces 2, 3 are pixels
+  // for even waves and gradients for odd ones: their resource, row pitch and bias are wave-uniform selections made once.
+  const int dt = wave >> 1, dh = wave & 1;
+  const int sub = lane >> 4, chunk = lane & 15;
+  // Fast path (every pixel of the patch and frame t - 1 + kt exist): the tile's base offset is wave-uniform and rides in the DMA's SCALAR
+  // offset.  The per-lane constants are biased to be non-negative (B0x: one frame for kt = 0, one row, one pixel), the scalar part
+  // carries the rest (never negative when the pixels exist).
+  const unsigned B0x = (unsigned)((((kt == 0 ? H * W : 0) + W + 1) * C) * 4);
+  const __amdgpu_buffer_rsrc_t rs_23 = __builtin_amdgcn_make_buffer_rsrc(dh ? (void*)dy : (void*)p.src, 0, dh ? (int)dy_bytes : (int)p.src_bytes, 0x00020000);
+  const unsigned pitch23 = (unsigned)((dh ? N : C) * 4), bias23 = dh ? 0u : B0x;
+  unsigned cstb[4];                                            // per-lane constant part of the piece's byte offset, + its bias
+  int spos[4];                                                 // validity bit of the slot = spos + sub (wave-uniform part)
 #pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int sub = lane >> 4, chunk = lane & 15;
-    if (i == 1 || i == 2) {
-      const int slot = (i - 1) * 4 + sub, hp = slot >> 2, o = slot & 3;
-      pos[i] = (unsigned)((hp + 1) * 6 + (o + 1));              // output (hp, o) is patch pixel (hp + 1, o + 1)
-      cst[i] = (unsigned)(((hp * W + o) * N + nb * 64 + chunk * 4) * 4);
-      mul[i] = (unsigned)(N * 4);
+  for (int i = 0; i < 4; ++i) {
+    const int d = 4 * dh + i;
+    if (d >= 6) {
+      const int hp = d - 6, o = sub;
+      spos[i] = (hp + 1) * 6 + 1;                              // output (hp, o) is patch pixel (hp + 1, o + 1)
+      cstb[i] = (unsigned)(((hp * W + o) * N + nb * 64 + chunk * 4) * 4);
     } else {
-      const int slot = i == 0 ? 16 + sub : (i - 3) * 4 + sub;   // piece 0: sub 0, 1 live
-      const int rho = slot / 6, b = slot - 6 * rho, a = jp + rho;
-      pos[i] = (i == 0 && sub >= 2) ? 27u : (unsigned)(a * 6 + b);
-      cst[i] = (unsigned)(((((kt - 1) * H + (a - 1)) * W + (b - 1)) * C + cb * 64 + chunk * 4) * 4);
-      mul[i] = (unsigned)(C * 4);
+      const int e = 4 * d + sub, a = e / 6, b = e - 6 * a;
+      spos[i] = 4 * d;
+      cstb[i] = (unsigned)(((((kt - 1) * H + (a - 1)) * W + (b - 1)) * C + cb * 64 + chunk * 4) * 4) + B0x;
     }
   }
-  // Fast path (most tiles: every pixel the workgroup needs exists): a wave serves ONE tile, so the tile's base offset is wave-uniform
-  // and rides in the DMA's SCALAR offset — no vector instruction per piece.  The per-lane constants are biased to be non-negative
-  // (B0x: one frame for kt = 0, one row for jp = 0, one pixel), the scalar part carries the rest (never negative when the pixels exist).
-  const unsigned B0x = (unsigned)((((kt == 0 ? H * W : 0) + (jp == 0 ? W : 0) + 1) * C) * 4);
-  unsigned cstb[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) cstb[i] = (i == 1 || i == 2) ? cst[i] : ((i == 0 && (lane >> 4) >= 2) ? 0x80000000u : cst[i] + B0x);
-  unsigned needx = (1u << (24 + kt));
-#pragma unroll
-  for (int e = 0; e < 18; ++e) needx |= 1u << (jp * 6 + e);
+  const unsigned needx = 0x00FFFFFFu | (1u << (24 + kt));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  // the record of this wave's tile of stage s — a SCALAR load (the tile is wave-uniform): it does not enter the vector-memory queue, whose
+  // in-order counter would otherwise make the wait for a record a wait for every DMA issued before it
   auto load_rec = [&](int s) -> u32x2 {
-    const int64_t tile = tbeg + (int64_t)s * 8 + wave;
-    u32x2 rc = __builtin_amdgcn_raw_buffer_load_b64(rs_tab, (int)(tile * 8), 0, 0);      // past the slice: zeros -> made invalid below
+    const int64_t tile = tbeg + (int64_t)s * 4 + dt;
+    u32x2 rc = {0u, 0u};                                       // past the slice: zeros -> dead below
+    if (tile < tend) { const uint2 t = tile_tab[tile]; rc.x = t.x; rc.y = t.y; }
     return rc;
   };
-  const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds) + WG2_RING_OFF;
-  auto issue_piece = [&](int slot_, int d, const u32x2 rec, const unsigned xmask) {
-    // invalid -> offset | -1 (out of range: zeros).  A record past the slice reads {0, 0}: bit 27 is clear there, so `live` marks it dead
-    const unsigned m = (d == 1 || d == 2) ? rec.y : xmask;
-    const unsigned off = (__umul24(rec.x, mul[d]) + cst[d]) | (unsigned)__builtin_amdgcn_sbfe((int)m, pos[d], 1);
-    const int dst = slot_ * WG2_STAGE_BYTES + wave * WG2_TILE_BYTES + (d == 0 ? 0 : (d <= 2 ? 512 + (d - 1) * 1024 : 2560 + (d - 3) * 1024));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds((d == 1 || d == 2) ? rs_dy : rs_src,
-                                             (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + WG2_RING_OFF + dst),
-                                             16, (int)off, 0, 0, 0);
+  auto piece_dst = [&](int slot_, int i) {
+    return (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + slot_ * WB_STAGE_BYTES + dt * WB_TILE_BYTES +
+                                                      (4 * dh + i) * 1024);
   };
-  auto issue_fast = [&](int slot_, int d, unsigned sx_, unsigned sy_) {
-#if SLIC_W2_ABL & 1
-    sx_ = 0xFFFFFF00u; sy_ = 0xFFFFFF00u;                      // diagnostic build: DMAs out of range (no memory traffic)
-#endif
-    const int dst = slot_ * WG2_STAGE_BYTES + wave * WG2_TILE_BYTES + (d == 0 ? 0 : (d <= 2 ? 512 + (d - 1) * 1024 : 2560 + (d - 3) * 1024));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds((d == 1 || d == 2) ? rs_dy : rs_src,
-                                             (__attribute__((address_space(3))) void*)((__attribute__((address_space(3))) char*)lds + WG2_RING_OFF + dst),
-                                             16, (int)cstb[d], (int)((d == 1 || d == 2) ? sy_ : sx_), 0, 0);
-  };
-  // all seven pieces of the tile whose record is rc (wave-uniform): fast when every needed pixel exists
-  // (in two parts, pieces 0-2 and 3-6, so that the caller's MFMAs sit between them outside the branch)
-  auto issue_tile = [&](int slot_, u32x2 rc, const int part) {
+  // pieces i0, i0 + 1 (i0 = 0 or 2) of the tile whose record is rc (wave-uniform)
+  auto issue_tile = [&](int slot_, u32x2 rc, const int i0) {
     const unsigned ry = (unsigned)__builtin_amdgcn_readfirstlane((int)rc.y), rx = (unsigned)__builtin_amdgcn_readfirstlane((int)rc.x);
+    const unsigned pitch = i0 ? pitch23 : (unsigned)(C * 4), bias = i0 ? bias23 : B0x;
+    const bool isy = i0 && dh;
     if ((ry & needx) == 0 && ((ry >> 27) & 1u)) {
-      const unsigned sxo = rx * (unsigned)(C * 4) - B0x, syo = rx * (unsigned)(N * 4);
-      if (part == 0) {
-        issue_fast(slot_, 0, sxo, syo);
-        issue_fast(slot_, 1, sxo, syo);
-        issue_fast(slot_, 2, sxo, syo);
-      } else {
-        issue_fast(slot_, 3, sxo, syo);
-        issue_fast(slot_, 4, sxo, syo);
-        issue_fast(slot_, 5, sxo, syo);
-        issue_fast(slot_, 6, sxo, syo);
+      const unsigned so_ = rx * pitch - bias;
+#pragma unroll
+      for (int i = i0; i < i0 + 2; ++i) {
+#if SLIC_W2_ABL & 1
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(i0 ? rs_23 : rs_src, piece_dst(slot_, i), 16, (int)(0xFFFFFF00u + 0 * cstb[i]), 0, 0, 0);
+#else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(i0 ? rs_23 : rs_src, piece_dst(slot_, i), 16, (int)cstb[i], (int)so_, 0, 0);
+#endif
       }
     } else {
-      const unsigned tinv = (unsigned)__builtin_amdgcn_sbfe((int)rc.y, 24 + kt, 1);          // -1: frame t - 1 + kt outside
-      const bool dead = !((rc.y >> 27) & 1u);                                                  // zeros record: past the slice
-      const unsigned xm = dead ? 0xFFFFFFFFu : (rc.y | tinv);
-      if (dead) rc.y = 0xFFFFFFFFu;
-      if (part == 0) {
-        issue_piece(slot_, 0, rc, xm);
-        issue_piece(slot_, 1, rc, xm);
-        issue_piece(slot_, 2, rc, xm);
-      } else {
-        issue_piece(slot_, 3, rc, xm);
-        issue_piece(slot_, 4, rc, xm);
-        issue_piece(slot_, 5, rc, xm);
-        issue_piece(slot_, 6, rc, xm);
+      // invalid slot -> offset | -1 (out of range: zeros).  A record past the slice reads {0, 0}: bit 27 is clear there
+      const bool dead = !((ry >> 27) & 1u);
+      const unsigned tinv = (unsigned)__builtin_amdgcn_sbfe((int)ry, 24 + kt, 1);          // -1: frame t - 1 + kt outside
+      const unsigned m = dead ? 0xFFFFFFFFu : (isy ? ry : (ry | tinv));
+      const unsigned base = rx * pitch - bias;
+#pragma unroll
+      for (int i = i0; i < i0 + 2; ++i) {
+        const unsigned inv = (unsigned)(-(int)((m >> (unsigned)(spos[i] + sub)) & 1u));
+        const unsigned off = (base + cstb[i]) | inv;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(i0 ? rs_23 : rs_src, piece_dst(slot_, i), 16, (int)off, 0, 0, 0);
       }
     }
   };
-  f32x16 acc[6];
+  f32x16 acc[6][2];
 #pragma unroll
   for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) acc[pp][g] = 0.f;
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+      for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
   u32x2 recn;
 #pragma unroll
-  for (int t = 0; t < WG2_STAGES - 1; ++t) {
+  for (int t = 0; t < WB_STAGES - 1; ++t) {
     const u32x2 rc = load_rec(t);
     issue_tile(t, rc, 0);
-    issue_tile(t, rc, 1);
+    issue_tile(t, rc, 2);
     asm volatile("" ::: "memory");
   }
-  recn = load_rec(WG2_STAGES - 1);
+  recn = load_rec(WB_STAGES - 1);
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_setprio(0);
-  // ---- readers.  H-point j: V = x[rho1] + sx * x[rho2],  Z = y[ya] + sy * y[1]:
+  // ---- readers.  H-point j: V = x[a1] + sx * x[a2] (patch rows),  Z = y[ya] + sy * y[1]:
   //   j = 0: rows (0, 2), sx = -1; Z = y0            j = 1: rows (1, 2), sx = +1; Z = y0 + y1
-  //   j = 2: rows (0, 1), sx = -1 (the point NEGATED); Z = y0 - y1      j = 3: rows (0, 2), sx = -1; Z = y1 (NEGATED)
-  // (stored rows: rho = patch row - jp; the two negations are undone by the reduce kernel's Gh)
-  const int rho1 = j == 1 ? 1 : 0, rho2 = j == 2 ? 1 : 2;
-  const float sxf = j == 1 ? 1.f : -1.f, syf = j == 1 ? 1.f : (j == 2 ? -1.f : 0.f);
-  const f32x2 sx = {sxf, sxf}, sy = {syf, syf};
+  //   j = 2: rows (1, 2), sx = -1 (the point NEGATED); Z = y0 - y1      j = 3: rows (1, 3), sx = -1; Z = y1 (NEGATED)
+  // (the two negations are undone by the reduce kernel's Gh)
+  const int a1 = j == 0 ? 0 : 1, a2 = j == 3 ? 3 : 2;
+  const float sxf = j == 1 ? 1.f : -1.f, syf = j == 1 ? 1.f : -1.f;
+  const f32x2 sy = {syf, syf};
   const int ya = j == 3 ? 1 : 0;
   const bool two_rows = j == 1 || j == 2;
-  // lane addresses (bytes; + stage * WG2_STAGE_BYTES): tile 2 ks + hh of the k-step, this lane's channel / column.  Pixel (rho, b):
-  // slot e = 6 rho + b lives at 2560 + 256 e for e < 16 and at 256 (e - 16) for e = 16, 17 — row rho2 = 2 reaches back for b = 4, 5
-  const unsigned xch = (unsigned)((wc * 32 + r) * 4), ych = (unsigned)((wn * 32 + r) * 4);
-  const unsigned tb = lbase + (unsigned)(hh * WG2_TILE_BYTES);
-  unsigned x1a = tb + 2560u + (unsigned)(rho1 * 1536) + xch;                                   // + 256 b
-  unsigned x2a = tb + 2560u + (unsigned)(rho2 * 1536) + xch;                                   // + 256 b, b < 4 (any b for rho2 = 1)
-  unsigned x2h = (rho2 == 2 ? tb - 1024u : tb + 2560u + 1536u) + xch;                          // + 256 b, b = 4, 5
-  unsigned yfa = tb + 512u + (unsigned)(ya * 1024) + ych;                                      // + 256 o
-  unsigned ysa = tb + 512u + 1024u + ych;                                                      // + 256 o  (row 1)
-  asm volatile("" : "+v"(x1a), "+v"(x2a), "+v"(x2h), "+v"(yfa), "+v"(ysa));
-  const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c8 = {8.f, 8.f};
-  const f32x2 zero2 = {0.f, 0.f};
-  // k-steps 2 kp (.x) and 2 kp + 1 (.y) of ring slot SL: offsets in 256-byte units (tile 26, k-step 52, pair 104, slot 208)
-  auto read_pair = [&](auto sl_, auto kp_, f32x2 (&xa)[6], f32x2 (&xb)[6], f32x2 (&yf)[4], f32x2 (&ys)[4]) {
-    constexpr int SL = decltype(sl_)::value;
-    constexpr int B0 = decltype(kp_)::value * 104;
-    const unsigned so = (unsigned)(SL * WG2_STAGE_BYTES);
-    xa[0] = lds_read2st64<B0 + 0, B0 + 52>(x1a + so);
-    xa[1] = lds_read2st64<B0 + 1, B0 + 53>(x1a + so);
-    xa[2] = lds_read2st64<B0 + 2, B0 + 54>(x1a + so);
-    xa[3] = lds_read2st64<B0 + 3, B0 + 55>(x1a + so);
-    xa[4] = lds_read2st64<B0 + 4, B0 + 56>(x1a + so);
-    xa[5] = lds_read2st64<B0 + 5, B0 + 57>(x1a + so);
-    xb[0] = lds_read2st64<B0 + 0, B0 + 52>(x2a + so);
-    xb[1] = lds_read2st64<B0 + 1, B0 + 53>(x2a + so);
-    xb[2] = lds_read2st64<B0 + 2, B0 + 54>(x2a + so);
-    xb[3] = lds_read2st64<B0 + 3, B0 + 55>(x2a + so);
-    xb[4] = lds_read2st64<B0 + 4, B0 + 56>(x2h + so);
-    xb[5] = lds_read2st64<B0 + 5, B0 + 57>(x2h + so);
-    yf[0] = lds_read2st64<B0 + 0, B0 + 52>(yfa + so);
-    yf[1] = lds_read2st64<B0 + 1, B0 + 53>(yfa + so);
-    yf[2] = lds_read2st64<B0 + 2, B0 + 54>(yfa + so);
-    yf[3] = lds_read2st64<B0 + 3, B0 + 55>(yfa + so);
-    ys[0] = lds_read2st64<B0 + 0, B0 + 52>(ysa + so);
-    ys[1] = lds_read2st64<B0 + 1, B0 + 53>(ysa + so);
-    ys[2] = lds_read2st64<B0 + 2, B0 + 54>(ysa + so);
-    ys[3] = lds_read2st64<B0 + 3, B0 + 55>(ysa + so);
+  // lane addresses (bytes; + slot * WB_STAGE_BYTES + ks * 2 * WB_TILE_BYTES): tile 2 ks + hh, this lane's channel / column
+  typedef __attribute__((address_space(3))) const char* lds_cptr;
+  const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  unsigned xr1 = lbase + (unsigned)(hh * WB_TILE_BYTES + a1 * 1536 + (wc * 32 + r) * 4);      // + 256 b
+  unsigned xr2 = lbase + (unsigned)(hh * WB_TILE_BYTES + a2 * 1536 + (wc * 32 + r) * 4);
+  unsigned yr1 = lbase + (unsigned)(hh * WB_TILE_BYTES + 6144 + ya * 1024 + r * 4);             // + 256 o (+ 128: the second column half)
+  unsigned yr2 = lbase + (unsigned)(hh * WB_TILE_BYTES + 6144 + 1024 + r * 4);
+  asm volatile("" : "+v"(xr1), "+v"(xr2), "+v"(yr1), "+v"(yr2));
+  const f32x2 c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+  // operands of one k-step: V (six W-points of this lane's channel) and Z (six W-points of its column in both column halves)
+  struct Ops { float V[6]; f32x2 Z[6]; };
+  auto read_x = [&](const int so, float (&xa)[6], float (&xb)[6]) {
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      xa[b] = *(const __attribute__((address_space(3))) float*)((lds_cptr)xr1 + so + b * 256);
+      xb[b] = *(const __attribute__((address_space(3))) float*)((lds_cptr)xr2 + so + b * 256);
+    }
   };
-  // H-points, then V = B^T (.) and the four inner points of Z = A (.) along W (Z = [c0, c0+c1+c2+c3, c0-c1+c2-c3, c0+2c1+4c2+8c3,
-  // c0-2c1+4c2-8c3, c3]; points 0 and 5 are c0 and c3 themselves): one fenced block closed by the two wait states an MFMA needs behind
-  // the (inline-assembly) VALU instruction that wrote its operand
-  auto transform_pair = [&](const f32x2 (&xa)[6], const f32x2 (&xb)[6], const f32x2 (&yf)[4], const f32x2 (&ys)[4], f32x2 (&V)[6],
-                            f32x2 (&Zi)[4], f32x2 (&cz)[4]) {
+  auto read_y = [&](const int so, f32x2 (&yf)[4], f32x2 (&ys)[4]) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      yf[o][0] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr1 + so + o * 256);
+      yf[o][1] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr1 + so + o * 256 + 128);
+      ys[o][0] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr2 + so + o * 256);
+      ys[o][1] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr2 + so + o * 256 + 128);
+    }
+  };
+  // H-point, then V = B^T (.) along W (scalars: one k-step of this lane's channel)
+  auto transform_x = [&](const float (&xa)[6], const float (&xb)[6], Ops& t) {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the pair's (inline-assembly) LDS reads
-#if SLIC_W2_ABL & 4
+    float d[6];
 #pragma unroll
-    for (int b = 0; b < 6; ++b) V[b] = xa[b];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) { cz[o] = yf[o]; Zi[o] = ys[o]; }
-    asm volatile("s_nop 1" ::: "memory");
+    for (int b = 0; b < 6; ++b) d[b] = __builtin_fmaf(sxf, xb[b], xa[b]);
+    const float t1 = __builtin_fmaf(-4.f, d[2], d[4]), t2 = __builtin_fmaf(-4.f, d[1], d[3]);
+    const float t3 = d[4] - d[2], u = d[3] - d[1];
+    t.V[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
+    t.V[1] = t1 + t2;
+    t.V[2] = t1 - t2;
+    t.V[3] = __builtin_fmaf(2.f, u, t3);
+    t.V[4] = __builtin_fmaf(-2.f, u, t3);
+    t.V[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
     __builtin_amdgcn_sched_barrier(0);
-    return;
-#endif
-    f32x2 cx[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) cx[b] = pk_fma(xb[b], sx, xa[b]);
+  };
+  // H-point, then Z = A (.) along W for both column halves at once (packed): Z = [c0, c0+c1+c2+c3, c0-c1+c2-c3, c0+2c1+4c2+8c3,
+  // c0-2c1+4c2-8c3, c3]; one fenced block closed by the two wait states an MFMA needs behind the (inline-assembly) op that wrote its operand
+  auto transform_y = [&](const f32x2 (&yf)[4], const f32x2 (&ys)[4], Ops& t) {
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 cz[4];
     if (two_rows) {                                            // wave-uniform: H-points 1, 2 combine both gradient rows
 #pragma unroll
       for (int o = 0; o < 4; ++o) cz[o] = pk_fma(ys[o], sy, yf[o]);
@@ -927,71 +900,85 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
 #pragma unroll
       for (int o = 0; o < 4; ++o) cz[o] = yf[o];
     }
-    wino_bt6(cx, V, c2, c4, c5);
     const f32x2 e = pk_add(cz[0], cz[2]), od = pk_add(cz[1], cz[3]);
     const f32x2 e4 = pk_fma(cz[2], c4, cz[0]), o4 = pk_fma(cz[3], c8, pk_add(cz[1], cz[1]));
-    Zi[0] = pk_add(e, od);
-    Zi[1] = pk_sub(e, od);
-    Zi[2] = pk_add(e4, o4);
-    Zi[3] = pk_sub(e4, o4);
+    t.Z[0] = cz[0];
+    t.Z[1] = pk_add(e, od);
+    t.Z[2] = pk_sub(e, od);
+    t.Z[3] = pk_add(e4, o4);
+    t.Z[4] = pk_sub(e4, o4);
+    t.Z[5] = cz[3];
     asm volatile("s_nop 1" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  // the six MFMAs of k-step `sel` (0 / 1) of a transformed pair
-  auto mfma6 = [&](const f32x2 (&V)[6], const f32x2 (&Zi)[4], const f32x2 (&cz)[4], const int sel) {
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[0][sel], cz[0][sel], acc[0], 0, 0, 0);
+  // the MFMAs of W-points [p0, p1) of a transformed k-step (two column halves each)
+  auto mfma_pts = [&](const Ops& t, const int p0, const int p1) {
 #pragma unroll
-    for (int pp = 1; pp < 5; ++pp) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][sel], Zi[pp - 1][sel], acc[pp], 0, 0, 0);
-    acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[5][sel], cz[3][sel], acc[5], 0, 0, 0);
+    for (int pp = p0; pp < p1; ++pp)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) acc[pp][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(t.V[pp], t.Z[pp][nh], acc[pp][nh], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
-  // the stage's second pair stays in registers across the barrier: its odd k-step is multiplied after the NEXT stage's barrier
-  f32x2 Vp[6], Zp[4], czp[4];
+  Ops prev;
 #pragma unroll
-  for (int pp = 0; pp < 6; ++pp) Vp[pp] = zero2;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { Zp[q] = zero2; czp[q] = zero2; }
-  constexpr int PER = 8;                                       // VMEM ops per stage: seven DMAs + one record load
+  for (int pp = 0; pp < 6; ++pp) { prev.V[pp] = 0.f; prev.Z[pp] = (f32x2){0.f, 0.f}; }
+  constexpr int PER = 4;                                       // vector-memory ops per stage and wave: four DMAs
+  constexpr int VMW = (WB_STAGES - 2) * PER;                   // 8
   auto stage = [&](const int sg, auto sl_) {
     constexpr int sidx = decltype(sl_)::value;
-    // stage sg has landed once only the younger ops are outstanding: the record load issued behind its DMAs and the
-    // STAGES - 2 stages after it; and this wave's own LDS reads of the previous stage are complete
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(1 + (WG2_STAGES - 2) * PER) : "memory");
+    // stage sg has landed once only the DMAs of the STAGES - 2 stages after it are outstanding; and this wave's own LDS reads of the
+    // previous stage are complete
+    __builtin_amdgcn_s_waitcnt((VMW & 0xF) | 0x0070 | (((VMW >> 4) & 3) << 14));             // vmcnt(8) lgkmcnt(0) expcnt(7)
 #if !(SLIC_W2_ABL & 2)
     __builtin_amdgcn_s_barrier();
 #endif
-    constexpr int slotn = (sidx + WG2_STAGES - 1) % WG2_STAGES;
-    f32x2 xa[6], xb[6], yf[4], ys[4], V[6], Zi[4], cz[4];
-    read_pair(sl_, std::integral_constant<int, 0>{}, xa, xb, yf, ys);
-    mfma6(Vp, Zp, czp, 1);                                     // the previous stage's last k-step, under the latency of these reads
-    transform_pair(xa, xb, yf, ys, V, Zi, cz);
-    read_pair(sl_, std::integral_constant<int, 1>{}, xa, xb, yf, ys);
-    mfma6(V, Zi, cz, 0);
+    constexpr int slotn = (sidx + WB_STAGES - 1) % WB_STAGES;
+    constexpr int so = sidx * WB_STAGE_BYTES;
+    float xa[6], xb[6];
+    f32x2 yf[4], ys[4];
+    Ops cur;
+    // k-step 0 of this stage: its reads and transforms between the MFMAs of the previous stage's k-step 1
+    read_x(so, xa, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pts(prev, 0, 3);
+    read_y(so, yf, ys);
+    transform_x(xa, xb, cur);
+    mfma_pts(prev, 3, 6);
+    transform_y(yf, ys, cur);
+    // k-step 1: the same between the MFMAs of k-step 0; the stage's DMAs (the slot freed by the barrier above) among them
+    read_x(so + 2 * WB_TILE_BYTES, xa, xb);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pts(cur, 0, 3);
     issue_tile(slotn, recn, 0);
-    mfma6(V, Zi, cz, 1);
-    issue_tile(slotn, recn, 1);
-    asm volatile("" ::: "memory");                           // the counted vmcnt relies on this order: seven DMAs, then the record
-    recn = load_rec(sg + WG2_STAGES);
-    asm volatile("" ::: "memory");
-    transform_pair(xa, xb, yf, ys, Vp, Zp, czp);
-    mfma6(Vp, Zp, czp, 0);
+    read_y(so + 2 * WB_TILE_BYTES, yf, ys);
+    transform_x(xa, xb, prev);
+    mfma_pts(cur, 3, 6);
+    issue_tile(slotn, recn, 2);
+    recn = load_rec(sg + WB_STAGES);
+    transform_y(yf, ys, prev);
   };
-  for (int s0 = 0; s0 < nst; s0 += WG2_STAGES) {
+  for (int s0 = 0; s0 < nst; s0 += WB_STAGES) {
     stage(s0, std::integral_constant<int, 0>{});
     stage(s0 + 1, std::integral_constant<int, 1>{});
     stage(s0 + 2, std::integral_constant<int, 2>{});
+    stage(s0 + 3, std::integral_constant<int, 3>{});
+    if constexpr (WB_STAGES == 5) stage(s0 + 4, std::integral_constant<int, 4>{});
   }
-  mfma6(Vp, Zp, czp, 1);
+  mfma_pts(prev, 0, 6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   // slab[z][kt][j][p][c][n]
   float* out = slab + (((int64_t)z * 3 + kt) * 4 + j) * 6 * (int64_t)C * N;
-  const int n = nb * 64 + 32 * wn + r;
 #pragma unroll
   for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
-      out[((int64_t)pp * C + c) * N + n] = acc[pp][g];
+    for (int nh = 0; nh < 2; ++nh) {
+      const int n = nb * 64 + 32 * nh + r;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
+        out[((int64_t)pp * C + c) * N + n] = acc[pp][nh][g];
+      }
     }
 }
 
@@ -1092,14 +1079,14 @@ extern "C" int slic_conv_wgrad_wino2(const SlicConvArgs* a, const float* dy, int
   int tps, S;
   wino2_wgrad_plan(a, splits, &tps, &S);
   hipStream_t st = (hipStream_t)stream;
-  constexpr size_t lds = (size_t)WG2_RING_OFF + (size_t)WG2_STAGES * WG2_STAGE_BYTES;
+  constexpr size_t lds = (size_t)WB_STAGES * WB_STAGE_BYTES;
   static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wgrad_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int64_t total = (int64_t)6 * (a->Cs / 64) * (a->N / 64) * S;
+  const int64_t total = (int64_t)3 * (a->Cs / 64) * (a->N / 64) * S;
   SLIC_REQUIRE(total < (1ll << 30), "slic_conv_wgrad_wino2: grid too large");
   const unsigned gx = (unsigned)((total + 7) / 8 * 8);
   conv_wgrad_wino2_kernel<<<dim3(gx), dim3(512), lds, st>>>(*a, dy, (unsigned)dyb, (const uint2*)tile_tab, (float*)workspace, tps, S);

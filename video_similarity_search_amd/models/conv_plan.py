@@ -90,16 +90,13 @@ class ConvPlan:
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
         self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
         # ... and by the transposed TWO-dimensional algorithm (slic_conv_wgrad_wino2) wherever the two-dimensional forward runs and its
-        # 6 x C / 64 x N / 64 blocks leave room for tile slices on the 256 one-workgroup-per-CU slots (layers 1-3; layer4's 384 blocks
-        # stay on the one-dimensional kernel).  In isolation it only wins at layer2 (algorithmic TFLOP/s at B = 32, 2-D vs 1-D: layer1
-        # 234 vs 228, layer2 255-258 vs 228-231, layer3 187-192 vs 190-192 — it loads 1.3 x the bytes per MFMA), but IN THE STEP it is
-        # worth 2.4 % (same box: 819.6 against 800.2-800.5 clips/s with it on layer2 only): on the side stream it shares the chip with
-        # the main stream's two-dimensional data gradients better than the one-dimensional kernel's two workgroups per CU did.
-        # SLIC_WINO2_WGRAD=0 switches it off, =2 restricts it to the 128-channel layers (the round's first rule).
+        # 3 x C / 64 x N / 64 workgroups per tile slice fit the 256 one-workgroup-per-CU slots (all four layers at B = 32; layer4: 192
+        # workgroups, one slice).  Algorithmic TFLOP/s at B = 32, 2-D vs 1-D kernel: layer1 303 vs 230, layer2 289 vs 230, layer3 228 vs
+        # 192, layer4 150 vs 143.  SLIC_WINO2_WGRAD=0 switches it off, =2 restricts it to the 128-channel layers.
         mode = os.environ.get("SLIC_WINO2_WGRAD", "1")
-        blocks2 = 6 * (self.C // 64) * (self.N // 64)
+        blocks2 = 3 * (self.C // 64) * (self.N // 64)
         if wino2_wgrad is None:
-            wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "128")) and
+            wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
                            (mode != "2" or (self.C == 128 and self.N == 128)))
         self.wino2_wgrad = bool(wino2_wgrad)
         assert not self.wino2_wgrad or base, "transposed 2-D Winograd weight gradient: a Winograd plan"
@@ -561,9 +558,9 @@ class ConvPlan:
         lib = _lib.load()
         a = self._fwd_args(x, B)
         if self.wino2_wgrad:
-            # transposed F(4, 3) x F(2, 3): one workgroup of 512 threads per (kt, H-point pair), 64 x 64 block and slice of the 2 x 4
+            # transposed F(4, 3) x F(2, 3): one workgroup of 512 threads per kt, 64 x 64 block and slice of the 2 x 4
             # tiles — ONE residency round of the 256 slots (one workgroup per CU), at least 64 tiles per slice
-            blocks = 6 * (self.C // 64) * (self.N // 64)
+            blocks = 3 * (self.C // 64) * (self.N // 64)
             H2, W2 = self.in_dims[1], self.in_dims[2]
             mt = (a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)
             if splits is None:
