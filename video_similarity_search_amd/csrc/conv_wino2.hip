@@ -265,7 +265,6 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int nb = blockIdx.y, n0 = nb * 64;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two >= 16: checked on the host)
-  const int cch_shift = 31 - __builtin_clz(CCH);
   const int NB = p.N >> 6;
   // ---- DMA roles.  Pixels: a DOUBLE stage (8 channels) at a time — piece pc = 8 i + wave (i = 0..5) is patch pixel ab = pc / 2 of
   // tile half pc % 2; lane L serves tile 32 (pc % 2) + L % 32, 16-byte half L / 32 of the pixel's 8 channels: lanes L and L + 32 fetch
@@ -747,7 +746,6 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
   const int nst = tend > tbeg ? (int)((tend - tbeg + 3) / 4) : 0;
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, p.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)dy_bytes, 0x00020000);
   // ---- DMA roles: wave w serves tile dt = w / 2 of the stage with pieces d = 4 (w % 2) + i, i = 0..3 (d 0-5: patch pixels 4 d .. 4 d + 3,
   // pixel e = a * 6 + b; d 6, 7: the gradients of output row d - 6); lane = (slot within the piece lane / 16, 16-byte chunk lane % 16 of the
   // slot's 64 channels / columns); piece d lands at tile byte 1024 d.  Pieces 0, 1 of a wave are always pixels; pieces 2, 3 are pixels
@@ -984,48 +982,53 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
 
 // dW[n][c][kt][kh][kw] = sum_j sum_p Gh[j][kh] Gw[p][kw] * (sum over slices z, ascending, of slab[z][kt][j][p][c][n])
 // Gh as the kernel left the points: rows 2 and 3 negated — [1 0 0; 1/2 1/2 1/2; -1/2 1/2 -1/2; 0 0 -1]
+// Workgroup = 8 channels x 32 columns, all three kt: a thread reads the 72 point sums of its (c, n) — columns fastest: 128-byte runs —
+// and the 27 weights leave through LDS, so that the stores are 864-byte runs of dW's [n][c 8][27] (a thread writing its own 9 values
+// wrote 4 bytes every 27 C floats: 210 us for layer4's 75 MB)
 __global__ __launch_bounds__(256) void conv_wgrad_wino2_reduce(const float* __restrict__ slab, int S, int C, int N, float* __restrict__ dW) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float outs[32 * 217];                               // [n 32][c 8][27], rows padded to 217 floats (bank spread)
+  const int tid = threadIdx.x;
+  const int nl = tid & 31, cl = tid >> 5;
+  const int c0 = blockIdx.x * 8, n0 = blockIdx.y * 32;
+  const int n = n0 + nl, c = c0 + cl;
   const int64_t CN = (int64_t)C * N;
-  if (e >= 3 * CN) return;
-  const int n = (int)(e % N);
-  const int c = (int)((e / N) % C);
-  const int kt = (int)(e / CN);
   const int64_t zs = 3 * 24 * CN;
-  float t[4][3];      // [j][kw]: the W-points taken back through Gw^T
+  for (int kt = 0; kt < 3; ++kt) {
+    float t[4][3];      // [j][kw]: the W-points taken back through Gw^T
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    float sp[6];
+    for (int jj = 0; jj < 4; ++jj) {
+      float sp[6];
 #pragma unroll
-    for (int pp = 0; pp < 6; ++pp) {
-      const float* q = slab + (((int64_t)kt * 4 + jj) * 6 + pp) * CN + (int64_t)c * N + n;
-      float a = 0.f;
-      int zi = 0;
-      for (; zi + 4 <= S; zi += 4) {                           // four slices in flight, added in slice order
-        const float s0 = q[zi * zs], s1 = q[(zi + 1) * zs], s2 = q[(zi + 2) * zs], s3 = q[(zi + 3) * zs];
-        a += s0; a += s1; a += s2; a += s3;
+      for (int pp = 0; pp < 6; ++pp) {
+        const float* q = slab + (((int64_t)kt * 4 + jj) * 6 + pp) * CN + (int64_t)c * N + n;
+        float a = 0.f;
+        for (int zi = 0; zi < S; ++zi) a += q[zi * zs];          // slices in order
+        sp[pp] = a;
       }
-      for (; zi < S; ++zi) a += q[zi * zs];
-      sp[pp] = a;
+      // Gw^T rows: kw 0: [1/4 -1/6 -1/6 1/24 1/24 0], kw 1: [0 -1/6 1/6 1/12 -1/12 0], kw 2: [0 -1/6 -1/6 1/6 1/6 1]
+      const float s12 = sp[1] + sp[2], d12 = sp[2] - sp[1], s34 = sp[3] + sp[4], d34 = sp[3] - sp[4];
+      t[jj][0] = 0.25f * sp[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+      t[jj][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+      t[jj][2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + sp[5];
     }
-    // Gw^T rows: kw 0: [1/4 -1/6 -1/6 1/24 1/24 0], kw 1: [0 -1/6 1/6 1/12 -1/12 0], kw 2: [0 -1/6 -1/6 1/6 1/6 1]
-    const float s12 = sp[1] + sp[2], d12 = sp[2] - sp[1], s34 = sp[3] + sp[4], d34 = sp[3] - sp[4];
-    t[jj][0] = 0.25f * sp[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-    t[jj][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-    t[jj][2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + sp[5];
-  }
-  float* o = dW + ((int64_t)n * C + c) * 27 + kt * 9;
+    float* o = outs + nl * 217 + cl * 27 + kt * 9;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    const float h12 = 0.5f * (t[1][kw] - t[2][kw]);            // 1/2 (S1 + S2) with S2 stored negated
-    o[0 * 3 + kw] = t[0][kw] + h12;
-    o[1 * 3 + kw] = 0.5f * (t[1][kw] + t[2][kw]);              // 1/2 (S1 - S2)
-    o[2 * 3 + kw] = h12 - t[3][kw];                            // + S3, stored negated
+    for (int kw = 0; kw < 3; ++kw) {
+      const float h12 = 0.5f * (t[1][kw] - t[2][kw]);            // 1/2 (S1 + S2) with S2 stored negated
+      o[0 * 3 + kw] = t[0][kw] + h12;
+      o[1 * 3 + kw] = 0.5f * (t[1][kw] + t[2][kw]);              // 1/2 (S1 - S2)
+      o[2 * 3 + kw] = h12 - t[3][kw];                            // + S3, stored negated
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * 216; i += 256) {
+    const int row = i / 216, e = i - row * 216;
+    dW[((int64_t)(n0 + row) * C + c0) * 27 + e] = outs[row * 217 + e];
   }
 }
 
 // slab[0][e] = sum over slices z, ascending, of slab[z][e]  (e over the 72 x C x N point sums, 16 bytes per thread, four slices in
-// flight): the reduce kernel's own slice loop ran on 3 x C x N threads — 48 workgroups at layer1, each thread walking 24 x 42 values —
+// flight at first, eight now): the reduce kernel's own slice loop ran on 3 x C x N threads — 48 workgroups at layer1, each thread walking 24 x 42 values —
 // and took 150 us for 50 MB; with the slices summed here by 72 x C x N / 4 threads it is one pass at memory speed
 __global__ __launch_bounds__(256) void conv_wgrad_wino2_sum(float* __restrict__ slab, int S, int64_t n4) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1033,9 +1036,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_wino2_sum(float* __restrict__ 
   f32x4* q = (f32x4*)slab + e;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   int zi = 0;
-  for (; zi + 4 <= S; zi += 4) {
-    const f32x4 s0 = q[zi * n4], s1 = q[(zi + 1) * n4], s2 = q[(zi + 2) * n4], s3 = q[(zi + 3) * n4];
-    a += s0; a += s1; a += s2; a += s3;
+  for (; zi + 8 <= S; zi += 8) {                                // eight slices in flight, added in slice order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = q[(zi + u) * n4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
   }
   for (; zi < S; ++zi) a += q[zi * n4];
   q[0] = a;
@@ -1091,13 +1097,12 @@ extern "C" int slic_conv_wgrad_wino2(const SlicConvArgs* a, const float* dy, int
   const unsigned gx = (unsigned)((total + 7) / 8 * 8);
   conv_wgrad_wino2_kernel<<<dim3(gx), dim3(512), lds, st>>>(*a, dy, (unsigned)dyb, (const uint2*)tile_tab, (float*)workspace, tps, S);
   SLIC_LAUNCH_CHECK();
-  const int64_t tot = (int64_t)3 * a->Cs * a->N;
   if (S > 1) {
     const int64_t n4 = (int64_t)72 * a->Cs * a->N / 4;
     conv_wgrad_wino2_sum<<<dim3((unsigned)slic_cdiv(n4, 256)), dim3(256), 0, st>>>((float*)workspace, S, n4);
     SLIC_LAUNCH_CHECK();
   }
-  conv_wgrad_wino2_reduce<<<dim3((unsigned)slic_cdiv(tot, 256)), dim3(256), 0, st>>>((const float*)workspace, 1, a->Cs, a->N, dW);
+  conv_wgrad_wino2_reduce<<<dim3((unsigned)(a->Cs / 8), (unsigned)(a->N / 32)), dim3(256), 0, st>>>((const float*)workspace, 1, a->Cs, a->N, dW);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }

@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void km_assign_dma(
 // the 16 k-tiles of a 128 x 128 tile as in km_assign_dma (6256 workgroups of 16 k-tiles each at 100k x 512 x 500), the DMA
 // of step s + 3 is issued at step s and waited for at step s + 2, and the last quarter of a step fetches the first fragments
 // of the next.  Same k order inside every accumulator, same score expression, same tie rule: bit-identical labels.
-// Partial lists: one per 32-centroid group (cb * 4 + wave), as km_combine expects.
+// Partial lists: ONE per 128-centroid block (blockIdx.y) — the four waves' (score, index) pairs of a finished tile meet in 4 KB of LDS
+// behind the ring and wave w combines those of the tile's points 32 w .. 32 w + 31, groups ascending with a strict '<' (what km_combine
+// would do with four separate lists: it now reads a quarter of the bytes).
 #ifdef KM_STAMPS
 __device__ unsigned long long km_cnt[8];
 extern "C" int slic_debug_km_counters(unsigned long long* out, int reset) {
@@ -406,9 +408,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   KMS(unsigned long long kc_[4] = {0, 0, 0, 0}; const unsigned long long kt00_ = km_now();)
   f32x16 acc[4];                                               // 4 point sub-tiles of 32 x this wave's 32 centroids
   f32x4 b[2][4];                                               // point fragments, double-buffered ACROSS k-tiles
-  float obest[4];                                              // the finished tile's results, stored one step later
-  int oidx[4];
-  int64_t op0 = -1;
+  int64_t op0 = -1;                                            // first point of the finished tile (its lists leave one step later)
+  float* xch = km_lds + ST * STAGE_FLOATS;                     // [wave 4][point 128] {score, index} of the finished tile
+  // wave w's quarter of the finished tile: min over the four groups, ascending (first minimum wins: lower centroid index), and out
+  auto flush = [&]() {
+    const int64_t pq = op0 + 32 * wave + r;
+    float best = xch[(0 * 128 + 32 * wave + r) * 2];
+    int bidx = __float_as_int(xch[(0 * 128 + 32 * wave + r) * 2 + 1]);
+#pragma unroll
+    for (int sw = 1; sw < 4; ++sw) {
+      const float sc = xch[(sw * 128 + 32 * wave + r) * 2];
+      const int si = __float_as_int(xch[(sw * 128 + 32 * wave + r) * 2 + 1]);
+      if (sc < best) { best = sc; bidx = si; }
+    }
+    if (h == 0 && pq < pend) { pscore[(int64_t)blockIdx.y * N + pq] = best; pidx[(int64_t)blockIdx.y * N + pq] = bidx; }
+  };
 #pragma unroll
   for (int u = 0; u < ST - 1; ++u) issue(u / NK, u % NK, u);   // steps 0 .. ST - 2
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ST - 2)) : "memory");             // step 0 has landed
@@ -433,16 +447,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int kn = kt + ST - 1;                             // step s + ST - 1
         issue(kn >= NK ? tile + 1 : tile, kn >= NK ? kn - NK : kn, kn % ST);
       }
-      if (kt == 0 && op0 >= 0) {
-        // the previous tile's partial argmin: written HERE, a whole k-tile before the next vmcnt wait, not in front of it
-        if (h == 0 && cbase < K) {                              // a group entirely past K has no list
-#pragma unroll
-          for (int pt = 0; pt < 4; ++pt) {
-            const int64_t p = op0 + 32 * pt + r;
-            if (p < pend) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
-          }
-        }
-      }
+      // the previous tile's partial argmin: combined and written HERE (behind the barrier that makes every wave's pairs visible), a whole
+      // k-tile before the next vmcnt wait, not in front of it
+      if (kt == 0 && op0 >= 0) flush();
       const float* Xs = km_lds + (kt % ST) * STAGE_FLOATS;
       const float* Xn = km_lds + ((kt + 1) % ST) * STAGE_FLOATS;
       __builtin_amdgcn_s_setprio(1);
@@ -480,8 +487,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const float ob = __shfl_xor(best, 32);
       const int oi = __shfl_xor(bidx, 32);
       if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-      obest[pt] = best;
-      oidx[pt] = bidx;
+      if (h == 0) {
+        xch[(wave * 128 + 32 * pt + r) * 2] = best;
+        xch[(wave * 128 + 32 * pt + r) * 2 + 1] = __int_as_float(bidx);
+      }
     }
     op0 = pbeg + (int64_t)tile * BP;
     KMS(kc_[2] += km_now() - kb_;)
@@ -493,12 +502,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else if (npt_last == 2) tile_body(ntile - 1, std::integral_constant<int, 2>{});
     else tile_body(ntile - 1, std::integral_constant<int, 1>{});
   }
-  if (op0 >= 0 && h == 0 && cbase < K) {
-#pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-      const int64_t p = op0 + 32 * pt + r;
-      if (p < pend) { pscore[(int64_t)grp * N + p] = obest[pt]; pidx[(int64_t)grp * N + p] = oidx[pt]; }
-    }
+  if (op0 >= 0) {
+    __syncthreads();
+    flush();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
   KMS(kc_[3] = km_now() - kt00_; if (lane == 0) for (int i_ = 0; i_ < 4; ++i_) atomicAdd(&km_cnt[i_], kc_[i_]);)
@@ -688,7 +694,7 @@ template <typename TOut>
 __global__ __launch_bounds__(128) void km_accumulate(
     const float* __restrict__ X, int D, int ldx, const int32_t* __restrict__ order,
     const int32_t* __restrict__ cnt, TOut* __restrict__ sums, TOut* __restrict__ counts_f,
-    const int32_t* __restrict__ n_changed, TOut* __restrict__ nch_out) {
+    const int32_t* __restrict__ n_changed, TOut* __restrict__ nch_out, int xperm) {
   __shared__ int red[128];
   const int j = blockIdx.x;
   const int c4 = blockIdx.y * 128 + threadIdx.x;
@@ -719,6 +725,14 @@ __global__ __launch_bounds__(128) void km_accumulate(
     for (int u = 0; u < 8; ++u) acc += v[u];
   }
   for (; m < n; ++m) acc += *(const f32x4*)(X + (int64_t)ord[m] * ldx + c4 * 4);
+  if (xperm) {
+    // X is the E-step's k8-permuted copy (km_permute_k8): this thread's four values are natural columns 8 g + {0, 2, 4, 6} (even
+    // chunk) or 8 g + {1, 3, 5, 7} (odd) — the sums are per column, so only the addresses differ
+    TOut* d = sums + (int64_t)j * D + (c4 >> 1) * 8 + (c4 & 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[2 * i] = (TOut)acc[i];
+    return;
+  }
   TOut* d = sums + (int64_t)j * D + c4 * 4;
   if constexpr (sizeof(TOut) == 4) {
     *(f32x4*)d = acc;
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__(128) void km_accumulate_average(
     const float* __restrict__ X, int D, int ldx, const int32_t* __restrict__ order, const int32_t* __restrict__ cnt,
     float* __restrict__ sums, float* __restrict__ counts_f, const float* __restrict__ Co, int K, float* __restrict__ Cn,
     float* shift, float* __restrict__ cnorm_new, float* __restrict__ Cn_perm, int spherical,
-    const int32_t* n_changed, int32_t* done, double* __restrict__ status) {
+    const int32_t* n_changed, int32_t* done, double* __restrict__ status, int xperm) {
   extern __shared__ float km_avg_lds[];
   float* row = km_avg_lds;
   float* tg = km_avg_lds + D;
@@ -1082,7 +1096,13 @@ __global__ __launch_bounds__(128) void km_accumulate_average(
   const int n = cnt[j];
   f32x4 acc = ordered_sum(order + offset_of(j), n);
   if (t == 0) counts_f[j] = (float)n;
-  if (t * 4 < D) *(f32x4*)(sums + (int64_t)j * D + t * 4) = acc;
+  // xperm: X is the E-step's k8-permuted copy (the iteration then streams ONE copy of the data set — 205 MB at 100k x 512, inside the
+  // 256 MB Infinity Cache — instead of two): this thread's four values are natural columns cb + {0, 2, 4, 6}
+  const int cb = xperm ? (t >> 1) * 8 + (t & 1) : t * 4, cs = xperm ? 2 : 1;
+  if (t * 4 < D) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sums[(int64_t)j * D + cb + cs * i] = acc[i];
+  }
   int src = j;
   float alpha;
   if (n > 0) {
@@ -1092,8 +1112,8 @@ __global__ __launch_bounds__(128) void km_accumulate_average(
     acc = ordered_sum(order + offset_of(src), cnt[src]);
   }
   if (t * 4 < D) {
-    const f32x4 r = {acc[0] * alpha, acc[1] * alpha, acc[2] * alpha, acc[3] * alpha};
-    *(f32x4*)(row + t * 4) = r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row[cb + cs * i] = acc[i] * alpha;
   }
   km_average_tail<true>(j, Co, D, Cn, shift, cnorm_new, Cn_perm, spherical, row, tg, mv);
   // ---- the status word, by the last workgroup to get here.  The only cross-workgroup data is shift[] (cnt and *n_changed come
@@ -1924,7 +1944,7 @@ static int km_assign_perm_impl(const float* Xp, int64_t N, int D, int ldx, const
                     tiles >= 4 * (int64_t)slices &&                                              // a few tiles per workgroup
                     (slic_cdiv(tiles, slices) * 128 + 128) * (int64_t)ldx * 4 < (1ll << 31);        // slice inside one resource
   if (creg) {
-    const size_t lds = (size_t)4 * 128 * KM_BK * sizeof(float);
+    const size_t lds = (size_t)4 * 128 * KM_BK * sizeof(float) + 4 * 128 * 2 * sizeof(float);     // the ring + the tile's four pair lists
     static bool attr_set = false;
     if (!attr_set) {
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_assign_creg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1937,7 +1957,7 @@ static int km_assign_perm_impl(const float* Xp, int64_t N, int D, int ldx, const
     else if (D > 128) km_assign_creg<8, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, z0, z1);
     else km_assign_creg<4, 4><<<grid, dim3(256), lds, st>>>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, z0, z1);
     SLIC_LAUNCH_CHECK();
-    G = (int)slic_cdiv(K, 32);                                // groups past K are never written and never read
+    G = ncb;                                                   // one list per 128-centroid block
   } else {
     int rc = launch_assign_dma<128, 2, 1, 2>(Xp, N, D, ldx, Cp, K, ldc, cnorm, pscore, pidx, st, z0, z1);
     if (rc) return rc;
@@ -1986,7 +2006,8 @@ static int32_t* km_accumulate_done_counter(void* workspace, int64_t N, int K) {
 template <typename TOut>
 static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const int32_t* labels, int K, TOut* sums,
                               TOut* counts, const int32_t* n_changed, TOut* nch_out, void* workspace, void* stream,
-                              bool have_hist = false, KmFinish* fin = nullptr) {
+                              bool have_hist = false, KmFinish* fin = nullptr, int xperm = 0) {
+  SLIC_REQUIRE(!xperm || D % 8 == 0, "slic_kmeans_accumulate: a k8-permuted source needs D %% 8 == 0");
   SLIC_REQUIRE(X && labels && sums && counts && workspace, "slic_kmeans_accumulate: null pointer");
   SLIC_REQUIRE(N > 0 && K > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldx >= D,
                "slic_kmeans_accumulate: need D %% 4 == 0 (N=%lld K=%d D=%d ldx=%d)", (long long)N, K, D, ldx);
@@ -2019,7 +2040,7 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
       const size_t lds = ((size_t)D + D / 4 + 4) * sizeof(float);
       km_accumulate_average<<<dim3(K), dim3(128), lds, st>>>(X, D, ldx, order, cnt, sums, counts, fin->C_old, K, fin->C_new, fin->shift,
                                                            fin->cnorm_new, fin->C_new_perm, fin->spherical, n_changed, done,
-                                                           fin->status);
+                                                           fin->status, xperm);
       SLIC_LAUNCH_CHECK();
       fin->done = true;
       return SLIC_OK;
@@ -2027,7 +2048,7 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
   }
   (void)done;
   km_accumulate<TOut><<<dim3(K, (unsigned)slic_cdiv(D / 4, 128)), dim3(128), 0, st>>>(X, D, ldx, order, cnt, sums, counts,
-                                                                                     n_changed, nch_out);
+                                                                                     n_changed, nch_out, xperm);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -2130,7 +2151,8 @@ extern "C" int slic_kmeans_lloyd_step(const float* X, const float* Xp, int64_t N
                                km_accumulate_hist_slab(ws2), n_changed, km_accumulate_done_counter(ws2, N, K));
   if (rc) return rc;
   KmFinish fin = {C_old, C_new, shift, cnorm_new, Cp_new, spherical, status, false};
-  rc = km_accumulate_impl<float>(X, N, D, ldx, labels, K, sums, counts, n_changed, nullptr, ws2, stream, true, &fin);
+  // the M-step gathers its rows from the PERMUTED copy too (column sums do not care; the kernels write them back in natural order)
+  rc = km_accumulate_impl<float>(Xp, N, D, ldx, labels, K, sums, counts, n_changed, nullptr, ws2, stream, true, &fin, 1);
   if (rc || fin.done) return rc;
   return slic_kmeans_finalize(C_old, sums, counts, K, D, C_new, shift, cnorm_new, Cp_new, spherical, n_changed, status, stream);
 }
@@ -2158,10 +2180,10 @@ extern "C" int slic_kmeans_lloyd_local(const float* X, const float* Xp, int64_t 
   const int64_t KD = (int64_t)K * D;
   if (payload_f64) {
     double* p = (double*)payload;
-    return km_accumulate_impl<double>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true);
+    return km_accumulate_impl<double>(Xp, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true, nullptr, 1);
   }
   float* p = (float*)payload;
-  return km_accumulate_impl<float>(X, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true);
+  return km_accumulate_impl<float>(Xp, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true, nullptr, 1);
 }
 
 extern "C" int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, int n_parts, const float* C_old,
