@@ -361,7 +361,7 @@ class ConvPlan:
             gx, ny = -(-((a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)) // 64), a.N // 64
             wgs = gx * ny
             rem = wgs % 256
-            if rem == 0 or rem > 128 or wgs > 6 * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
+            if rem == 0 or rem > 128 or wgs > int(os.environ.get("SLIC_WINO2_TAIL_MAXROUNDS", "6")) * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
                 return None                                  # pass measured no faster there)
             tail_x = -(-rem // ny)
             forced = int(os.environ.get("SLIC_WINO2_PIECES", "0"))
