@@ -321,6 +321,73 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     assert torch.equal(w2.wgrad(xd, dyd, B, torch.empty_like(wd_)), w2.wgrad(xd, dyd, B, torch.empty_like(wd_)))
 
 
+def test_winograd_error_growth_measured(gpu, monkeypatch):
+    """VERDICT round 3 item 9's gate: the error growth of F(4, 3) x F(2, 3) is MEASURED, per convolution and through the whole network,
+    beside the direct kernels' and the one-dimensional F(4, 3) kernels' (printed; DESIGN.md section 2 quotes the numbers).
+    Per convolution: 64 -> 64 channels, 2 x 4 x 28 x 28, x ~ N(0, 1), w ~ N(0, 1 / K), against fp64 conv3d: the largest error of
+    the forward / data gradient / weight gradient relative to the result's largest entry — the two-dimensional kernels within 8 x the
+    direct kernels' and inside the direct kernels' own gates.  Network: R3D-18 eval-mode embeddings of 32 clips at 3 x 16 x 112 x 112
+    (every layer then runs the two-dimensional kernels) against the oracle in fp64: within 1e-4, and within 4 x the direct engine's."""
+    from oracle import encoder as oe
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    for k in ("SLIC_WINO", "SLIC_WINO2", "SLIC_WINO2_WGRAD", "SLIC_WINO_WGRAD"):
+        monkeypatch.delenv(k, raising=False)
+    torch.manual_seed(11)
+    C = N = 64
+    B, dims = 2, (4, 28, 28)
+    k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    K = C * 27
+    x = torch.randn(B, C, *dims)
+    w = torch.randn(N, C, 3, 3, 3) / K ** 0.5
+    dy = torch.randn(B, N, *dims)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, None, s1, p1)
+    gx64, gw64 = torch.autograd.grad(y64, [x64, w64], dy.double())
+    xd, dyd, wd = _ndhwc(x, C).cuda(), _ndhwc(dy, N).cuda(), w.cuda()
+    rows = {}
+    for name, kw in (("direct", dict(wino=False)), ("F(4,3)", dict(wino=True, wino2=False, wino2_wgrad=False)),
+                     ("F(4,3)xF(2,3)", dict(wino=True, wino2=True, wino2_wgrad=True))):
+        pl = ConvPlan(C, N, k3, s1, p1, dims, "cuda", **kw)
+        z, _ = pl.forward(xd, pl.pack_fwd(wd), B)
+        dx = pl.dgrad(dyd, pl.pack_dgrad(wd), B)
+        dW = pl.wgrad(xd, dyd, B, torch.empty_like(wd)).cpu()
+        e_f = ((z.cpu().permute(0, 4, 1, 2, 3).double() - y64.detach()).abs().max() / y64.abs().max()).item()
+        e_d = ((dx.cpu().permute(0, 4, 1, 2, 3).double() - gx64).abs().max() / gx64.abs().max()).item()
+        e_w = ((dW.double() - gw64).abs().max() / gw64.abs().max()).item()
+        rows[name] = (e_f, e_d, e_w)
+        print(f"conv 64->64 3x3x3, K = {K}: {name:14s} max error / max entry  forward {e_f:.2e}  data gradient {e_d:.2e}  weight gradient {e_w:.2e}")
+    for i, gate in enumerate((2e-6 * K ** 0.5 + 1e-6, 5e-5, 1e-4)):
+        assert rows["F(4,3)xF(2,3)"][i] <= gate and rows["F(4,3)xF(2,3)"][i] <= 8 * max(rows["direct"][i], 1e-7), (i, rows)
+    # the whole network, eval mode, 32 clips: direct kernels / one-dimensional / two-dimensional Winograd engines against fp64
+    rng = np.random.default_rng(7)
+    sd = oe.make_state_dict(rng)
+    xc = torch.from_numpy(rng.standard_normal((32, 3, 16, 112, 112)).astype(np.float32))
+    with torch.no_grad():
+        ref = oe.encoder_forward(oe.to_torch(sd, dtype=torch.float64), xc.double(), training=False)
+    dist = {}
+    for name, env in (("direct", {"SLIC_WINO": "0"}), ("F(4,3)", {"SLIC_WINO2": "0"}), ("F(4,3)xF(2,3)", {})):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        m = generate_model(18, **R3D18_KW)
+        _load_into(m, sd)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            emb = m(xc.cuda()).cpu().double()
+        eng = m._engine(xc.cuda())
+        convs = [p_ for _, p1, p2, _ in eng.blocks for p_ in (p1, p2) if p_.stride == (1, 1, 1)]
+        want = {"direct": (False, False), "F(4,3)": (True, False), "F(4,3)xF(2,3)": (True, True)}[name]
+        assert all((p_.wino, p_.wino2) == want for p_ in convs), (name, [(p_.wino, p_.wino2) for p_ in convs])
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        dist[name] = ((emb - ref).abs().max().item(), ((emb - ref) ** 2).mean().sqrt().item() / (ref ** 2).mean().sqrt().item())
+        print(f"R3D-18 eval embeddings, 32 clips: {name:14s} max |error| {dist[name][0]:.2e}  rms error / rms {dist[name][1]:.2e}   (largest entry {ref.abs().max().item():.2f})")
+        del m
+        torch.cuda.empty_cache()
+    assert dist["F(4,3)xF(2,3)"][0] <= 1e-4 * max(1.0, ref.abs().max().item())
+    assert dist["F(4,3)xF(2,3)"][0] <= 4 * max(dist["direct"][0], 2e-6)
+
+
 @pytest.mark.parametrize("variant,slots,want", [(20, 8, (4, 4)), (20, 64, (0, 6)), (22, 4, (2, 2)), (22, 64, (0, 10))])
 def test_conv_tailsplit_matches_single_pass(gpu, monkeypatch, variant, slots, want):
     """tail-split launch (full row blocks whole, the remainder cut along K into the same grid, then the finish pass over those
