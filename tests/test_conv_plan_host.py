@@ -80,8 +80,13 @@ def test_winograd_2d_plan_rules(monkeypatch):
     assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) == (384, 6)      # 392 tile blocks x 2: the last 8 blocks cut into 6 pieces
     assert ConvPlan._plan_split(args(32, 256, (4, 14, 14)), 31) is None          # 224 workgroups: most of a round
     assert ConvPlan._plan_split(args(32, 512, (2, 7, 7)), 31) == (0, 4)          # 64 workgroups: all of them cut, 4 pieces = one dispatch round
-    # small batches: layer3 at B = 8 has 56 workgroups -> the one-dimensional kernel
-    assert not ConvPlan(256, 256, k3, s1, p1, (4, 14, 14), "cpu", batch=8).wino2
+    # small batches: layer3 at B = 8 has 56 workgroups -> still two-dimensional (4 K pieces fill the slots); layer4's 16 -> the one-dimensional
+    # forward / data gradient, but the two-dimensional weight gradient (it needs 128 tiles, not a full dispatch round)
+    p3 = ConvPlan(256, 256, k3, s1, p1, (4, 14, 14), "cpu", batch=8)
+    assert p3.wino2 and p3.wino2_wgrad and ConvPlan._plan_split(args(8, 256, (4, 14, 14)), 31) == (0, 4)
+    p4 = ConvPlan(512, 512, k3, s1, p1, (2, 7, 7), "cpu", batch=8)
+    assert p4.wino and not p4.wino2 and p4.wino2_wgrad
+    assert not ConvPlan(512, 512, k3, s1, p1, (2, 7, 7), "cpu", batch=2).wino2_wgrad       # 32 tiles
     # no batch hint (a plan built by hand): never variant 31 by default
     assert not ConvPlan(64, 64, k3, s1, p1, (16, 56, 56), "cpu").wino2
     # widths 192 / 384 (RESNET.WIDEN_FACTOR 1.5 / 3): the Winograd forward / data gradient address their K loop with shifts

@@ -524,8 +524,16 @@ __global__ __launch_bounds__(512) void conv_wino2_finish(const SlicConvArgs p, c
     if (nh) __syncthreads();
     const float* base = slab + (((int64_t)mb * gridDim.y + nb) * pieces * 2 + nh) * (2 * JS);
     for (int e = tid * 4; e < 2 * JS; e += 512 * 4) {          // e < JS: row 0; else row 1
-      f32x4 v = *(const f32x4*)(base + e);
-      for (int z = 1; z < pieces; ++z) v += *(const f32x4*)(base + (int64_t)z * 2 * (2 * JS) + e);
+      // every piece's load in flight at once (a loop of dependent adds paid a memory round trip per piece: with the 16 workgroups of a
+      // small-batch layer4 launch that was most of the launch), then the adds in piece order
+      f32x4 pv[16];
+#pragma unroll
+      for (int z = 0; z < 16; ++z)
+        if (z < pieces) pv[z] = *(const f32x4*)(base + (int64_t)z * 2 * (2 * JS) + e);
+      f32x4 v = pv[0];
+#pragma unroll
+      for (int z = 1; z < 16; ++z)
+        if (z < pieces) v += pv[z];
       if (e < JS) {
         *(f32x4*)(lds + e) = v;
         *(f32x4*)(lds + JS + e) = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -38,9 +38,11 @@ class ConvPlan:
 
     WINO_MIN_WGS = 384     # forward / data gradient: a launch of fewer 64-tile x 64-n workgroups than this (layer4 at B = 32: 112) cuts its K loop
 
-    WINO2_PIECES = (2, 3, 4, 6)     # K-split pieces of a variant-31 tail (measured at layer4 / layer2, scripts/r4/ab_wino2.sh)
-    WINO2_MIN_WGS = 64     # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (launches of less than
-                           # a dispatch round of the 256 one-per-CU slots cut their K loop by kt: _plan_split)
+    WINO2_PIECES = (2, 3, 4, 6, 8, 12, 16)     # K-split pieces of a variant-31 tail (measured at layer4 / layer2 and at small batches, scripts/r4/pieces.sh)
+    WINO2_MIN_WGS = 48     # two-dimensional Winograd (variant 31): launches of fewer 64-tile x 64-n workgroups stay on variant 30 (launches of less than
+                           # a dispatch round of the 256 one-per-CU slots cut their K loop into pieces: _plan_split).  Measured at B = 8, algorithmic
+                           # TFLOP/s forward / data gradient, 2-D vs 1-D: layer3 (56 workgroups x 4 pieces) 178 / 182 vs 140 / 144; layer4 (16
+                           # workgroups, best at 4 pieces) 53 / 54 vs 60 / 62 (scripts/r4/small_batch.sh)
 
     def __init__(self, C, N, kernel, stride, pad, in_dims, device, wrun=None, wino=None, wino2=None, batch=None, wino2_wgrad=None):
         self.C, self.N = int(C), int(N)
@@ -92,11 +94,15 @@ class ConvPlan:
         # ... and by the transposed TWO-dimensional algorithm (slic_conv_wgrad_wino2) wherever the two-dimensional forward runs and its
         # 3 x C / 64 x N / 64 workgroups per tile slice fit the 256 one-workgroup-per-CU slots (all four layers at B = 32; layer4: 192
         # workgroups, one slice).  Algorithmic TFLOP/s at B = 32, 2-D vs 1-D kernel: layer1 303 vs 230, layer2 289 vs 230, layer3 228 vs
-        # 192, layer4 150 vs 143.  SLIC_WINO2_WGRAD=0 switches it off, =2 restricts it to the 128-channel layers.
+        # 192, layer4 150 vs 143.  It takes any H and W (ragged tiles are masked), so it also runs where the forward stays one-dimensional
+        # for want of workgroups — layer4 at B = 8: 94 vs 81 — as long as the launch has 128 tiles.
+        # SLIC_WINO2_WGRAD=0 switches it off, =2 restricts it to the 128-channel layers.
         mode = os.environ.get("SLIC_WINO2_WGRAD", "1")
         blocks2 = 3 * (self.C // 64) * (self.N // 64)
         if wino2_wgrad is None:
-            wino2_wgrad = (self.wino2 and self.wino_wgrad and mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
+            tiles2 = 0 if batch is None else int(batch) * self.in_dims[0] * Hq2 * Wq2
+            wino2_wgrad = ((self.wino2 or (self.wino and tiles2 >= 128 and os.environ.get("SLIC_WINO2", "1") != "0")) and self.wino_wgrad and
+                           mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
                            (mode != "2" or (self.C == 128 and self.N == 128)))
         self.wino2_wgrad = bool(wino2_wgrad)
         assert not self.wino2_wgrad or base, "transposed 2-D Winograd weight gradient: a Winograd plan"
@@ -366,7 +372,10 @@ class ConvPlan:
             tail_x = -(-rem // ny)
             forced = int(os.environ.get("SLIC_WINO2_PIECES", "0"))
             units = 3 * a.Cs // 16
-            fit = [s for s in cls.WINO2_PIECES if units % s == 0 and tail_x * ny * s <= 256]
+            # a piece keeps >= 48 of the 3 Cs / 4 stages when the whole launch is cut (layer3 at B = 8: 4 x 48 best, 8 x 24 and 16 x 12 slower;
+            # layer4 at B = 32: 4 x 96), >= 16 in a tail beside whole workgroups (layer2: 6 x 16)
+            min_st = 48 if gx == tail_x else 16
+            fit = [s for s in cls.WINO2_PIECES if units % s == 0 and tail_x * ny * s <= 256 and 3 * (a.Cs // 4) // s >= min_st]
             s = forced or (max(fit) if fit else 2)
             return (gx - tail_x, s)
         if variant == 30:
