@@ -689,7 +689,7 @@ extern "C" int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, f
 //   Workgroup = 512 threads = one kt, one 64 c x 64 n block, one slice of the tiles, ALL FOUR H-points: wave (j, wc) owns H-point j of
 //   32 channels for all 64 columns — 6 W-points x 2 column halves = 12 accumulators, the forward kernel's budget.  The MFMA's k dimension
 //   is the TILE: lane (r, hh) reads its channel's pixels of tile 2 ks + hh (two patch rows x 6) and its column's gradients in both column
-//   halves (two output rows x 4, ds_read2_b32), forms the H-point, runs the F(4, 3) transforms along W in registers — V in scalars
+//   halves (the even and the odd columns of the block: two output rows x 4, one ds_read_b64 each), forms the H-point, runs the F(4, 3) transforms along W in registers — V in scalars
 //   (one k-step), Z packed over the two column halves — and feeds two MFMAs per W-point.
 //   Stage = 4 tiles (two k-steps), tile image [24 pixels][64 ch] + [8 gradients][64 n] = 8 KB (whole cache lines: 170 bytes per MFMA),
 //   4-stage ring (128 KB: one workgroup per CU), wave w DMAs four of the eight 1 KB pieces of tile w / 2; counted vmcnt, one barrier per
@@ -856,8 +856,10 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
   const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
   unsigned xr1 = lbase + (unsigned)(hh * WB_TILE_BYTES + a1 * 1536 + (wc * 32 + r) * 4);      // + 256 b
   unsigned xr2 = lbase + (unsigned)(hh * WB_TILE_BYTES + a2 * 1536 + (wc * 32 + r) * 4);
-  unsigned yr1 = lbase + (unsigned)(hh * WB_TILE_BYTES + 6144 + ya * 1024 + r * 4);             // + 256 o (+ 128: the second column half)
-  unsigned yr2 = lbase + (unsigned)(hh * WB_TILE_BYTES + 6144 + 1024 + r * 4);
+  // the wave's two column "halves" are the EVEN and the ODD columns of the block (lane r: columns 2 r, 2 r + 1): one ds_read_b64 per
+  // gradient instead of two dword reads 128 bytes apart — the kernel's LDS pipe was ~80 % busy with dword reads
+  unsigned yr1 = lbase + (unsigned)(hh * WB_TILE_BYTES + 6144 + ya * 1024 + r * 8);             // + 256 o
+  unsigned yr2 = lbase + (unsigned)(hh * WB_TILE_BYTES + 6144 + 1024 + r * 8);
   asm volatile("" : "+v"(xr1), "+v"(xr2), "+v"(yr1), "+v"(yr2));
   const f32x2 c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
   // operands of one k-step: V (six W-points of this lane's channel) and Z (six W-points of its column in both column halves)
@@ -872,10 +874,8 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
   auto read_y = [&](const int so, f32x2 (&yf)[4], f32x2 (&ys)[4]) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-      yf[o][0] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr1 + so + o * 256);
-      yf[o][1] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr1 + so + o * 256 + 128);
-      ys[o][0] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr2 + so + o * 256);
-      ys[o][1] = *(const __attribute__((address_space(3))) float*)((lds_cptr)yr2 + so + o * 256 + 128);
+      yf[o] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)yr1 + so + o * 256);
+      ys[o] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)yr2 + so + o * 256);
     }
   };
   // H-point, then V = B^T (.) along W (scalars: one k-step of this lane's channel)
@@ -979,7 +979,7 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
   for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
-      const int n = nb * 64 + 32 * nh + r;
+      const int n = nb * 64 + 2 * r + nh;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
