@@ -275,9 +275,10 @@ typedef struct SlicConvArgs {
   int k_run_px;            /* real pixels (kw taps) per run; run r covers taps r * k_run_px ... (slic_conv_wgrad unpacks with it) */
 } SlicConvArgs;
 
-/* rows per workgroup of the tile slic_conv_gemm picks for (args, variant); variant 0 = auto,
- * 1 = 128-row, 2 = 64-row, 3 = 256x64 tiles (register-staged kernel); 11..14 = LDS-DMA kernel with
- * 64x64x3-stage, 64x64x4, 128x64x3, 128x128x3 tiles.  Sizes stat_partial. */
+/* rows per workgroup of the tile slic_conv_gemm runs for (args, variant) — sizes stat_partial / bwd_partial.  Variants:
+ * 0 = register-staged 64 x 64 tiles (any source channel count: per-chunk table `tab`); 20 / 22 = LDS-DMA ring, 64 x 64 / 128 x 64 tiles
+ * (per-tap table `tap_tab`, Cs % 32 == 0); 30 = Winograd F(4, 3) along W; 31 = Winograd F(4, 3) x F(2, 3) over (W, H) (see
+ * slic_pack_weight_wino / slic_pack_weight_wino2). */
 int slic_conv_tile_m(const SlicConvArgs* args, int variant);
 /* dst = epilogue(gather(src) x wgt^T): forward conv, data gradient, linear. */
 int slic_conv_gemm(const SlicConvArgs* args, int variant, void* stream);
