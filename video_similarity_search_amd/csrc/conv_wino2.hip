@@ -38,7 +38,8 @@
 #define SLIC_PRIO_EDGE 3
 #endif
 #ifndef SLIC_W2_ABL
-#define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range, 2 = no stage barrier
+#define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range (both kernels), 2 = no stage
+                          // barrier (both), 32 = forward without its epilogue, 256 = forward without the row-major half of its epilogue
 #endif
 constexpr int W2_PX_FLOATS = 24 * 64 * 8;                      // pixel image of a DOUBLE stage (8 channels): 48 KB
 constexpr int W2_U_FLOATS = 24 * 64 * 4;                       // U block of a stage (4 channels): 24 KB
