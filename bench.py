@@ -496,7 +496,7 @@ def main():
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
                              traffic_source=traffic_src,
                              kernel=("conv_wino2_kernel<3> (64->64 3x3x3 convolution as Winograd F(4,3) x F(2,3) over (W, H): 24 fp32-MFMA GEMMs per kt "
-                                     "over tiles of 2 x 4 outputs, H-points split over the waves, LDS-DMA 3-stage ring; fwd + dgrad of layer1)" if wino2 else
+                                     "over tiles of 2 x 4 outputs, H-points split over the waves, LDS-DMA rings of 8-channel pixel stages and 4-channel U stages; forward launches of layer1)" if wino2 else
                                      "conv_wino_kernel<3,false,2> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
                                      "over W-tiles, LDS-DMA 3-stage ring, transforms in registers; fwd + dgrad of layer1)" if wino else
                                      "conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring; fwd + dgrad of layer1)"),
