@@ -41,6 +41,12 @@
 #define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range (both kernels), 2 = no stage
                           // barrier (both), 32 = forward without its epilogue, 256 = forward without the row-major half of its epilogue
 #endif
+#ifndef SLIC_W2_UAUX
+#define SLIC_W2_UAUX 0    // cache-policy bits of the U / pixel DMAs (experiments: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef SLIC_W2_PAUX
+#define SLIC_W2_PAUX 0
+#endif
 constexpr int W2_PX_FLOATS = 24 * 64 * 8;                      // pixel image of a DOUBLE stage (8 channels): 48 KB
 constexpr int W2_U_FLOATS = 24 * 64 * 4;                       // U block of a stage (4 channels): 24 KB
 constexpr int W2_RING_FLOATS = 2 * W2_PX_FLOATS + 2 * W2_U_FLOATS;   // two pixel slots + two U slots = 144 KB
@@ -329,7 +335,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
       // are INTERLEAVED per patch pixel, so that one lane address per patch row reaches both slots with immediate offsets
       const int pc = 8 * i + wave;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + (((pc >> 1) * 2 + slot) * 2 + (pc & 1)) * 256),
-                                               16, (int)off, (int)soff, 0, 0);
+                                               16, (int)off, (int)soff, 0, SLIC_W2_PAUX);
     }
   };
   // U block of local stage sl into U slot `slot`
@@ -346,7 +352,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
                                                16, (int)(0xFFFFFF00u + 0 * uvoff), (int)(0 * ublk), 0, 0);
 #else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + 2 * W2_PX_FLOATS + slot * W2_U_FLOATS + (i * 512 + wave * 64) * 4),
-                                               16, (int)uvoff, (int)(ublk + (unsigned)(i * 8192)), 0, 0);
+                                               16, (int)uvoff, (int)(ublk + (unsigned)(i * 8192)), 0, SLIC_W2_UAUX);
 #endif
     }
   };
