@@ -85,15 +85,15 @@ class OracleKernels:
             for r in range(ap.shape[0]):
                 tot = tot + ap[r]
             comb = tot.astype(np.float32)
-            nc = int(round(tot[K * Dp + K] + 1048576.0 * tot[K * Dp + K + 1]))
+            nc = float(round(tot[K * Dp + K] + 1048576.0 * tot[K * Dp + K + 1]))      # a double, as km_status computes it (a poisoned payload: 2^60)
         else:
             comb = np.zeros(ap.shape[1], np.float32)
             for r in range(ap.shape[0]):                 # rank order, fp32 adds
                 comb = comb + ap[r]
-            nc = int(round(float(comb[K * Dp + K]) + 1048576.0 * float(comb[K * Dp + K + 1])))
+            nc = float(round(float(comb[K * Dp + K]) + 1048576.0 * float(comb[K * Dp + K + 1])))
         sums.copy_(torch.from_numpy(comb[:K * Dp].copy()))
         counts.copy_(torch.from_numpy(comb[K * Dp:K * Dp + K].copy()))
-        self.finalize(C_old, sums, counts, C_new, shift, torch.tensor([nc], dtype=torch.int32), status, cnorm_new,
+        self.finalize(C_old, sums, counts, C_new, shift, torch.tensor([nc], dtype=torch.float64), status, cnorm_new,
                       spherical=spherical)
 
     def l2norm_rows(self, X, out):

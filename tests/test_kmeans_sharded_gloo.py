@@ -90,6 +90,56 @@ def test_sharded_kmeans_two_ranks_gloo(golden_dir, tmp_path, name, exchange, mon
         assert int(r0["n_coll"]) <= int(r0["n_iter"]) + 1 + 6, (int(r0["n_coll"]), int(r0["n_iter"]))
 
 
+def _failing_worker(rank, world, port, case, out_dir):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    torch.distributed.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    try:
+        from kmeans_cpu_kernels import OracleKernels
+        from video_similarity_search_amd.clustering.kmeans_hip import KMeans
+        g = dict(np.load(case))
+        X, init = g["X"], g["init"]
+        per = (len(X) + world - 1) // world
+        shard = torch.from_numpy(X[rank * per:(rank + 1) * per])
+
+        class Failing(OracleKernels):
+            n = 0
+
+            def lloyd_local(self, *a, **kw):
+                Failing.n += 1
+                if rank == 1 and Failing.n == 3:                    # the third iteration's local half of rank 1
+                    raise MemoryError("injected: the local half of iteration 2 failed on rank 1")
+                return super().lloyd_local(*a, **kw)
+
+        t0 = time.time()
+        msg = "no exception"
+        try:
+            KMeans(n_clusters=init.shape[0], init=init, n_init=1, max_iter=50, tol=0.0, process_group=torch.distributed.group.WORLD,
+                   kernels=Failing()).fit(shard)
+        except Exception as e:                                      # noqa: BLE001
+            msg = f"{type(e).__name__}: {e}"
+        dt = time.time() - t0
+        torch.distributed.barrier()      # both ranks get here (each caught its exception): do not tear a socket down under the peer's last receive
+        with open(os.path.join(out_dir, f"fail_r{rank}.txt"), "w") as f:
+            f.write(f"{dt:.3f}\n{msg}\n")
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_sharded_kmeans_local_failure_reaches_every_rank(golden_dir, tmp_path):
+    """a rank whose local half of an iteration raises still enters the iteration's collective with a poisoned payload: it raises the
+    cause, its peer raises a SlicError at the same iteration — within seconds, not at the process group's timeout"""
+    case = os.path.join(golden_dir, "kmeans_d128.npz")
+    mp.spawn(_failing_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+    r0 = open(os.path.join(tmp_path, "fail_r0.txt")).read().splitlines()
+    r1 = open(os.path.join(tmp_path, "fail_r1.txt")).read().splitlines()
+    assert r1[1].startswith("MemoryError: injected"), r1
+    assert r0[1].startswith("SlicError") and "peer" in r0[1], r0
+    assert float(r0[0]) < 60 and float(r1[0]) < 60
+
+
 def test_single_process_driver_matches_oracle_cpu(golden_dir):
     """the host control flow (no process group) with the oracle-backed kernels reproduces the oracle's Lloyd run"""
     import sys

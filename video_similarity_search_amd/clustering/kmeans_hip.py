@@ -32,6 +32,8 @@ from .. import _lib
 from .._lib import call, ptr, stream
 
 
+_POISON = float(2 ** 40)      # in the n_changed high slot of a sharded payload: this rank's local half failed (exact in fp32 and fp64, sums of <= 16 too)
+
 class HipKernels:
     """Thin argument marshalling for the k-means entry points of libslic_hip.so.  The only kernel
     provider the package ships; `KMeans(kernels=...)` exists so the multi-process control flow can be
@@ -433,6 +435,8 @@ class KMeans:
             else:
                 host[sl].copy_(status[sl])
 
+        local_failure = []
+
         def launch(it):
             """enqueue iteration `it` (E-step, M-step, averaging) and the async read-back of its status word"""
             sl = it & 1
@@ -448,14 +452,27 @@ class KMeans:
                 read_back(sl)
                 return
             if self._sharded:
-                # two foreign calls around the iteration's ONE collective
-                k.lloyd_local(Xc, Xp if perm else None, Cin, Cp[it % 3], cnorm[it % 3], lab, lab_old, payload[sl])
+                # two foreign calls around the iteration's ONE collective.  A rank whose local half raises (an allocation that fails, a bad
+                # argument) must still ENTER the collective, or its peers wait for it until the process group's timeout: it contributes a
+                # POISONED payload — the n_changed high slot, which a healthy rank fills with < 2^11 — from then on, and raises the cause
+                # where the loop reads that iteration's status; its peers see the poison in the same status word and raise there too.
+                if not local_failure:
+                    try:
+                        k.lloyd_local(Xc, Xp if perm else None, Cin, Cp[it % 3], cnorm[it % 3], lab, lab_old, payload[sl])
+                    except Exception as e:                              # noqa: BLE001 — re-raised by read() of this iteration
+                        local_failure.append((it, e))
+                if local_failure:
+                    payload[sl].zero_()
+                    payload[sl].view(-1)[-1] = _POISON
                 if self.exchange == "allreduce" and comm is not None:
                     call("slic_allreduce_f64", comm, ptr(payload[sl]), payload[sl].numel(), stream())
                 elif self.exchange == "allreduce":
                     torch.distributed.all_reduce(payload[sl], group=self.process_group)
                 else:
                     torch.distributed.all_gather_into_tensor(parts[sl].view(-1), payload[sl].view(-1), group=self.process_group)
+                if local_failure:
+                    return          # no global half, no read-back: read() of the failed iteration raises (the loop runs one launch ahead of
+                                    # its reads, so this rank keeps entering the collectives its peers enter until they all get there)
                 k.lloyd_global(parts[sl], Cin, gsums[sl], gcounts[sl], Cout, Cp[(it + 1) % 3], cnorm[(it + 1) % 3], shift,
                                status[sl], **sph)
                 read_back(sl)
@@ -471,12 +488,18 @@ class KMeans:
             read_back(sl)
 
         def read(it):
+            if local_failure and local_failure[0][0] <= it:
+                raise local_failure[0][1]
             if on_gpu:
                 if comm is not None:
                     # bounded: a peer that never joined the iteration's all-reduce aborts the communicator and raises here
                     call("slic_comm_wait", comm, stream(), comm_timeout_ms())
                 ev[it & 1].synchronize()
-            return host[it & 1].tolist()
+            st = host[it & 1].tolist()
+            if self._sharded and st[2] >= _POISON:                      # n_changed = low + 2^20 * high: a peer's poisoned high slot
+                raise _lib.SlicError("sharded k-means: a peer's local half of the Lloyd iteration failed (it raised the cause); "
+                                     "every rank leaves the fit here instead of waiting in the next collective")
+            return st
 
         trace = [] if self.trace else None
         strict = False
