@@ -251,9 +251,9 @@ def iterative_cluster_step(args, cfg, encoder, eval_train_loader, epoch, cuda=Tr
         start_time = time.time()
         pg = torch.distributed.group.WORLD
         # A rank whose fit_cluster raises (bad K for its shard, out of memory) must not leave the others waiting in the label
-        # all-gather below: every rank reports, and all raise together.  (A failure in the MIDDLE of the Lloyd loop still strands
-        # the peers inside that iteration's collective until the process group's timeout — the argument checks run first, on
-        # every rank, for that reason.)
+        # all-gather below: every rank reports, and all raise together.  (A rank whose local half of a Lloyd iteration raises keeps
+        # entering the loop's collectives with a poisoned payload, and every rank raises at that iteration: kmeans_hip.KMeans;
+        # only a peer that DIES strands the others until the process group's / SLIC_COMM_TIMEOUT_MS timeout.)
         def all_or_raise(failure, what):
             flag = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=embeddings.device)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=pg)
