@@ -242,6 +242,16 @@ def case_syncbn(rank, world, out):
         if "running" in k:
             worst_s = max(worst_s, float((v - stats_full[k]).abs().max() / stats_full[k].abs().max().clamp_min(1e-12)))
     res.update(worst_grad_rel=worst_g, worst_running_rel=worst_s, n_sync=sum(isinstance(x, torch.nn.SyncBatchNorm) for x in ms.modules()))
+    # for the parent's comparison with the CPU oracle (the worker itself stays product-only): this rank's embeddings, the full-batch
+    # gradient of one deep and one shallow tensor as the ranks' sum, and — from rank 0 — the initial weights
+    res["emb"] = emb.detach().cpu().numpy()
+    for k in ("conv1.weight", "layer4.1.conv2.weight"):
+        g = dict(ms.named_parameters())[k].grad.clone()
+        dist.all_reduce(g)
+        res["grad/" + k] = g.cpu().numpy()
+    if rank == 0:
+        for k, v in sd0.items():
+            res["sd0/" + k] = v.cpu().numpy()
     np.savez(out, **res)
 
 

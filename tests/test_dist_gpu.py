@@ -63,13 +63,34 @@ def test_ddp_step_equals_plain_step(gpu, tmp_path, world):
 def test_sync_batchnorm_equals_full_batch(gpu, tmp_path, world):
     """cfg.SYNC_BATCH_NORM (online_train.py:466-468): SyncBatchNorm over W ranks with B / W clips each == plain BatchNorm over
     the B clips in one process — embeddings, parameter gradients summed over the ranks, running statistics (fp32 tolerance:
-    the statistics are merged in a different association)"""
+    the statistics are merged in a different association) — and == the CPU oracle's plain BatchNorm on the same four clips"""
     res = _run("syncbn", world, tmp_path)
     for r in res:
         assert int(r["n_sync"]) == 21
         assert float(r["emb_err"]) < 1e-5, float(r["emb_err"])
         assert float(r["worst_grad_rel"]) < 5e-4, float(r["worst_grad_rel"])
         assert float(r["worst_running_rel"]) < 1e-5, float(r["worst_running_rel"])
+    # PARITY, not only the property: the same four clips through the CPU oracle's plain BatchNorm (fp32 and fp64) — embeddings within
+    # north_star's 1e-4, the ranks' summed gradients of a deep and a shallow tensor within 1e-3 of fp64 (relative to the largest entry)
+    from oracle import encoder as oe
+    sd0 = {k[4:]: v for k, v in res[0].items() if k.startswith("sd0/")}
+    rng = np.random.default_rng(77)
+    xfull = torch.from_numpy(rng.standard_normal((4, 3, 8, 32, 32)).astype(np.float32))
+    wsum = torch.from_numpy(rng.standard_normal((4, 32)).astype(np.float32))
+    t64 = oe.to_torch(sd0, dtype=torch.float64, requires_grad=True)
+    e64 = oe.encoder_forward(t64, xfull.double(), training=True)
+    names = ["conv1.weight", "layer4.1.conv2.weight"]
+    g64 = torch.autograd.grad((e64 * wsum.double()).sum(), [t64[k] for k in names])
+    with torch.no_grad():
+        e32 = oe.encoder_forward(oe.to_torch(sd0), xfull, training=True)
+    per = 4 // world
+    for rk, r in enumerate(res):
+        emb = torch.from_numpy(r["emb"])
+        assert (emb - e32[rk * per:(rk + 1) * per]).abs().max().item() <= 1e-4
+        assert (emb.double() - e64.detach()[rk * per:(rk + 1) * per]).abs().max().item() <= 1e-4
+    for k, ref in zip(names, g64):
+        d = (torch.from_numpy(res[0]["grad/" + k]).double() - ref).abs().max().item() / ref.abs().max().item()
+        assert d <= 1e-3, (k, d)
 
 
 @pytest.mark.parametrize("world", _worlds())
