@@ -19,9 +19,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Fill { NONE = 0, FMA, ADD, PKFMA, PKADD, MOV, IADD, SNOP, LDSRD, PKMUL, DMA_OOB, DMA_L2, GLD_OOB, GLD_L2, DSW128 };
+enum Fill { NONE = 0, FMA, ADD, PKFMA, PKADD, MOV, IADD, SNOP, LDSRD, PKMUL, DMA_OOB, DMA_L2, GLD_OOB, GLD_L2, DSW128, DMA_NOV, DMA_FIXV };
 static const char* fill_name[] = {"none", "v_fma_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_mov_b32", "v_add_u32", "s_nop 0",
-                                  "ds_read_b128", "v_pk_mul_f32", "lds-dma oob", "lds-dma L2", "bufload oob", "bufload L2", "ds_write_b128"};
+                                  "ds_read_b128", "v_pk_mul_f32", "lds-dma oob", "lds-dma L2", "bufload oob", "bufload L2", "ds_write_b128", "lds-dma no-vaddr", "lds-dma fixed-vaddr"};
 
 struct Regs {
   float f[8];
@@ -52,6 +52,12 @@ static __device__ __forceinline__ void filler(Regs& R, int i) {
     const unsigned voff = F == DMA_OOB ? 0xFFFFFF00u : R.lds_addr + 1024u * (unsigned)(i & 31);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(R.rsrc, (__attribute__((address_space(3))) void*)(R.ldsp + 256 * (i & 7)), 16, (int)voff, 0, 0, 0);
   }
+  // the same LDS-DMA with NO vector address operand (voffset = off: every lane reads the same 16 bytes; the scalar offset walks) and with a
+  // loop-invariant vector address (no VALU instruction per piece): is it the vector register read that holds the matrix pipe?
+  if constexpr (F == DMA_NOV)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(R.rsrc, (__attribute__((address_space(3))) void*)(R.ldsp + 256 * (i & 7)), 16, 0, (int)(1024u * (unsigned)(i & 31)), 0, 0);
+  if constexpr (F == DMA_FIXV)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(R.rsrc, (__attribute__((address_space(3))) void*)(R.ldsp + 256 * (i & 7)), 16, (int)R.lds_addr, (int)(1024u * (unsigned)(i & 31)), 0, 0);
   if constexpr (F == GLD_OOB || F == GLD_L2) {
     const unsigned voff = F == GLD_OOB ? 0xFFFFFF00u : R.lds_addr + 1024u * (unsigned)(i & 31);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
         if (g % NF == NF - 1) filler<F>(R, g / NF);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (F == DMA_OOB || F == DMA_L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (F == DMA_OOB || F == DMA_L2 || F == DMA_NOV || F == DMA_FIXV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (MODE == 1) {
       if (mfma_role) {
 #pragma unroll
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
         __builtin_amdgcn_sched_barrier(0);
       }
       if (F == LDSRD) asm volatile("s_waitcnt lgkmcnt(0)");
-      if (F == DMA_OOB || F == DMA_L2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (F == DMA_OOB || F == DMA_L2 || F == DMA_NOV || F == DMA_FIXV) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -200,6 +206,19 @@ int main(int argc, char** argv) {
     run<FMA, 2, 1, 24>(2);
     run<PKFMA, 1, 1, 24>(2);
     run<FMA, 8, 2>(2);
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "dma2")) {
+    // is it the DMA's vector address operand that costs the matrix pipe?  the same piece with no vector address / a loop-invariant one
+    for (int wps = 1; wps <= 2; ++wps) {
+      run<NONE, 0, 0, 24>(wps);
+      run<DMA_L2, 4, 3, 24>(wps);
+      run<DMA_FIXV, 4, 3, 24>(wps);
+      run<DMA_NOV, 4, 3, 24>(wps);
+      run<DMA_L2, 2, 3, 24>(wps);
+      run<DMA_FIXV, 2, 3, 24>(wps);
+      run<DMA_NOV, 2, 3, 24>(wps);
+    }
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "dma")) {
