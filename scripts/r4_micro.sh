@@ -3,6 +3,8 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 O=gpurun_out/r4_micro; mkdir -p $O
+# the binary is built in-tree (hipcc cross-compiles without a GPU) and is not part of the history
+[ -x scripts/micro/mfma_valu_coexec ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o scripts/micro/mfma_valu_coexec scripts/micro/mfma_valu_coexec.hip || exit 1
 ./scripts/micro/mfma_valu_coexec > $O/table.txt 2>&1 || exit 1
 cat $O/table.txt
 export TMPDIR=/tmp
