@@ -172,6 +172,8 @@ def kmeans_secondary(rank, world, pg, run_cpu):
                whole_iteration_frac_of_fp32_mfma=flops_iter / (dt / iters) / 1e12 / (FP32_MFMA_PEAK_TFLOPS * world),
                config=dict(workload=f"Lloyd, N=100000 D=512 K=500 fp32, explicit init, tol=0, 20 fixed iterations; {layout}"))
     if pg is not None:
+        out["exchange"] = dict(kind=km.exchange, communicator=km.communicator_kind_, payload_bytes_per_rank=km.payload_bytes_,
+                               collectives_per_iteration=1)
         # the same iteration WEAK-scaled (100k rows on every GPU, N = 100k x ranks): per-GPU work fixed, so the curve shows what the one
         # collective per iteration costs; the strong-scaled row above divides 100k rows over the ranks (per-rank E-step of ~50 us at 8)
         Xw = torch.from_numpy(X).cuda() if world > 1 else Xd
@@ -425,11 +427,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # dominant kernel (largest share of a step's kernel time): conv_wino_kernel — Winograd F(4,3) along W — on the 64->64 3x3x3 layers
-    # (layer1: 4 forward + 4 data-gradient launches per step, identical M x N x K).  Every such launch of the timed steps is
-    # bracketed with HIP events on the launch stream.  ALGORITHMIC FLOPs of a launch = the direct convolution's 2 M N K;
-    # the kernel itself executes 6/12 of those multiplies on the matrix pipe, so `achieved` may exceed the fp32 MFMA peak — the
-    # fraction of the pipe's peak actually used is reported beside it (mfma_frac_executed).
+    # dominant kernel (largest share of a step's kernel time): conv_wino2_kernel — Winograd F(4,3) along W x F(2,3) along H — on the 64->64
+    # 3x3x3 layers (layer1: 4 forward + 4 data-gradient launches per step, identical M x N x K).  Every such launch of the timed steps is
+    # bracketed with HIP events on the launch stream.  `roofline.achieved` / `frac` count the fp32 MFMA FLOPs the launch EXECUTES (a third of
+    # the direct form's 2 M N K) over its duration: a fraction of the pipe's peak, <= 1; the direct form's count is printed beside it.
     eng = net._engine(x)
     l1 = [p for (_, p1, p2, _) in eng.blocks[:2] for p in (p1, p2)]
     for p in l1:
@@ -444,6 +445,24 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     dt = time.time() - t0
+    dist_info = dict(initialised=bool(use_dist), world_size_env=world)
+    if use_dist:
+        # self-verification of a multi-GPU run: how many ranks RCCL really reduced over (a sum of ones), the library
+        # version, every rank's own step time, and what DistributedDataParallel did with the gradients
+        ones = torch.ones(1, device="cuda")
+        torch.distributed.all_reduce(ones)
+        per_rank = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        torch.distributed.all_gather(per_rank, torch.tensor([dt / args.steps * 1e3], dtype=torch.float64, device="cuda"))
+        per_rank = [float(v.item()) for v in per_rank]
+        ld = model._get_ddp_logging_data()
+        bsz = str(ld.get("rebuilt_bucket_sizes") or ld.get("bucket_sizes") or "")
+        dist_info.update(backend=torch.distributed.get_backend(), rccl_ranks_seen=int(round(float(ones.item()))),
+                         rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()),
+                         ms_per_step_per_rank=[round(v, 4) for v in per_rank], ms_per_step_min=min(per_rank), ms_per_step_max=max(per_rank),
+                         ddp=dict(buckets=len([b for b in bsz.split(",") if b.strip()]), bucket_sizes_bytes=bsz,
+                                  bucket_cap_mb=ddp_kw["bucket_cap_mb"], gradient_as_bucket_view=bool(ld.get("gradient_as_bucket_view", ddp_kw["gradient_as_bucket_view"])),
+                                  backend_name=ld.get("backend_name"), gradient_bytes=int(sum(p.numel() for p in net.parameters()) * 4)),
+                         devices=[torch.cuda.get_device_name(local_rank)], hsa_ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
     if world > 1:
         tt = torch.tensor([dt], device="cuda")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -487,7 +506,7 @@ def main():
     res = dict(metric=metric_name,
                value=world * B * args.steps / dt, unit="clips/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f32", data="synthetic",
+               dtype="f32", data="synthetic", distributed=dist_info,
                config=dict(workload="R3D-18 (3D-ResNet-18, 34.52 M params, no maxpool, 7^3 stem) fwd+bwd + NT-Xent "
                                     "(noise_contrastive, T=0.5) + SGD(lr .1, mom .5); per-GPU batch "
                                     f"{B} x 3x16x112x112 fp32 = {B//2} anchors || {B//2} positives; BASELINE configs[1]",
@@ -523,7 +542,33 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
         return bool(t.item())
 
-    if rank == 0 and use_dist and world > 1 and not args.no_secondary:
+    # The ONE JSON line of the contract is printed at the very end — but a multi-rank run must never lose its headline to a secondary row
+    # that hangs in a collective (a rank that failed alone) or outlives the driver's patience: every rank arms a watchdog with the same
+    # budget; when it fires, rank 0 prints the line with what has been measured so far and every rank leaves with exit code 0.
+    # Progress also goes to stderr: the headline before the secondary rows start, and again with the k-means rows.
+    import threading
+    printed = threading.Lock()
+    state = dict(done=False)
+
+    def emit(final):
+        with printed:
+            if state["done"]:
+                return
+            state["done"] = True
+            if rank == 0:
+                print(json.dumps(res if final else dict(res, watchdog=f"secondary rows exceeded {budget} s: line printed by the watchdog")), flush=True)
+
+    budget = int(os.environ.get("SLIC_BENCH_SECONDARY_BUDGET_S", "420"))
+    wd = None
+    if use_dist and world > 1 and not args.no_secondary:
+        def fire():
+            emit(False)
+            log(f"bench.py: rank {rank}: watchdog after {budget} s in the secondary rows; leaving")
+            os._exit(0)
+        wd = threading.Timer(budget, fire)
+        wd.daemon = True
+        wd.start()
+    if rank == 0 and use_dist and not args.no_secondary:
         print(json.dumps(dict(res, note="headline only: printed before the secondary rows, which run collectives on all ranks")),
               file=sys.stderr, flush=True)
     if not args.no_secondary:
@@ -533,6 +578,9 @@ def main():
         except Exception as e:                                    # never lose the headline line
             res["secondary"] = dict(error=repr(e))
             sec_ok = False
+        if rank == 0 and use_dist:
+            print(json.dumps(dict(res, note="headline + k-means rows (strong: secondary, weak: secondary.weak_scaled); more rows follow")),
+                  file=sys.stderr, flush=True)
         run_cpu_rows = rank == 0 and world == 1 and not args.no_cpu_baseline
         if not args.quick and rank == 0:
             for key, fn in (("retrieval", lambda: retrieval_secondary(run_cpu_rows)), ("nce", nce_secondary)):
@@ -656,8 +704,9 @@ def main():
             res["secondary"]["extra_error"] = repr(e)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_encoder(sd)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
+    if wd is not None:
+        wd.cancel()
+    emit(True)
     if use_dist:
         torch.distributed.destroy_process_group()
 

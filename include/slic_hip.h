@@ -172,8 +172,14 @@ int slic_allreduce_f64(slic_comm* comm, double* buf, int64_t n, void* stream);
  * exit non-zero instead of hanging its peers' job.  What torch.distributed's process-group timeout is to the reference's collectives
  * (misc/distributed_helper.py:30-64). */
 int slic_comm_wait(slic_comm* comm, void* stream, int timeout_ms);
-/* give up on a communicator at once (ncclCommAbort) and free the handle */
+/* The same bounded wait on ONE event (a hipEvent_t the caller recorded behind the work it wants finished — the sharded Lloyd loop records
+ * one behind every iteration's collective + status read-back and waits for iteration `it` while iteration `it + 1` is already enqueued:
+ * slic_comm_wait would drain that one too). */
+int slic_comm_wait_event(slic_comm* comm, void* event, int timeout_ms);
+/* give up on a communicator at once (ncclCommAbort) and free the handle: never blocks (what a process-exit hook calls) */
 int slic_comm_abort(slic_comm* comm);
+/* orderly teardown: ncclCommFinalize, polled to completion under the communicator's deadline (10 s when it has none), then
+ * ncclCommDestroy; a lost peer or an asynchronous error ends in ncclCommAbort (SLIC_ETIMEOUT / SLIC_EHIP).  The handle is freed either way. */
 int slic_comm_destroy(slic_comm* comm);
 
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
@@ -332,9 +338,10 @@ int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, float* U, vo
  * multiplies per (kt, c, n) and tile of 2 x 4 outputs (slic_conv_wgrad_wino: 36, the direct form: 72); replaces slic_conv_wgrad_wino
  * where variant 31 runs the forward (any H, W: ragged tiles are masked).  args as slic_conv_wgrad_wino; tile_tab: (M / (Hs Ws)) *
  * ceil(Hs / 2) * ceil(Ws / 4) records of 8 bytes written once per geometry by slic_conv_wino2_tile_table; `splits` slices of the
- * tiles, reduced in slice order (deterministic); workspace: splits x 3 x 24 x Cs x N floats.  One workgroup per (kt, pair of H-points,
- * 64 x 64 block, slice): 6 x Cs / 64 x N / 64 x splits workgroups of 512 threads, one per CU.  Stands in for the same autograd weight
- * gradient of nn.Conv3d (models/resnet.py:11-17) as slic_conv_wgrad. */
+ * tiles, reduced in slice order (deterministic); workspace: splits x 3 x 24 x Cs x N floats.  One workgroup per (kt, 64 x 64 block,
+ * slice) holding ALL FOUR H-points: 3 x Cs / 64 x N / 64 x splits workgroups of 512 threads, one per CU.  Limits (SLIC_EINVAL beyond them;
+ * models/conv_plan.py keeps such shapes on slic_conv_wgrad_wino / slic_conv_wgrad): M < 2^24 output positions, x and dy below 4 GiB - 256 B.
+ * Stands in for the same autograd weight gradient of nn.Conv3d (models/resnet.py:11-17) as slic_conv_wgrad. */
 size_t slic_conv_wgrad_wino2_workspace_bytes(const SlicConvArgs* args, int splits);
 int slic_conv_wino2_tile_table(const SlicConvArgs* args, uint32_t* tile_tab, void* stream);
 int slic_conv_wgrad_wino2(const SlicConvArgs* args, const float* dy, int splits, const uint32_t* tile_tab, float* dW,

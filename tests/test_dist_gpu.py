@@ -220,10 +220,20 @@ def test_bench_self_launch_one_rank(gpu):
     r = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--self-launch", "--force-dist", "--no-cpu-baseline", "--quick"])
     assert r["n_gpus"] == 1 and r["steps"] == 2 and r["value"] > 0 and r["config"]["parallelism"] == "dp1"
     assert "sharded" in r["secondary"]["config"]["workload"]
+    # the fields that make a multi-GPU run self-verifying (what RCCL really reduced over, not what WORLD_SIZE claims)
+    d = r["distributed"]
+    assert d["initialised"] and d["backend"] == "nccl" and d["rccl_ranks_seen"] == r["n_gpus"] == d["world_size_env"]
+    assert d["rccl_version"].count(".") == 2 and len(d["ms_per_step_per_rank"]) == 1
+    assert d["ms_per_step_min"] <= d["ms_per_step_max"] <= r["ms_per_step"] * 1.001 + 1e-6
+    assert d["ddp"]["buckets"] >= 1 and d["ddp"]["gradient_as_bucket_view"] in (True, False) and d["ddp"]["gradient_bytes"] > 100e6
+    ex = r["secondary"]["exchange"]
+    assert ex["kind"] in ("allreduce", "allgather", "oneshot") and ex["collectives_per_iteration"] == 1 and ex["payload_bytes_per_rank"] > 0
+    assert "torch.distributed" in ex["communicator"] or "slic" in ex["communicator"]
+    assert "weak_scaled" in r["secondary"] and r["secondary"]["weak_scaled"]["n_gpus"] == 1
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
 def test_bench_two_gpus_plain_invocation(gpu):
     r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--quick"])
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 64 and r["scaling"] == "weak"
-    assert r["secondary"]["n_gpus"] == 2
+    assert r["secondary"]["n_gpus"] == 2 and r["distributed"]["rccl_ranks_seen"] == 2 and len(r["distributed"]["ms_per_step_per_rank"]) == 2

@@ -41,6 +41,7 @@ SIGNATURES = {
     "slic_comm_create": (I, [P, I, I, P]),
     "slic_comm_create_timeout": (I, [P, I, I, I, P]),
     "slic_comm_wait": (I, [P, P, I]),
+    "slic_comm_wait_event": (I, [P, P, I]),
     "slic_comm_abort": (I, [P]),
     "slic_allreduce_f32": (I, [P, P, L, P]),
     "slic_allreduce_f64": (I, [P, P, L, P]),

@@ -22,6 +22,7 @@ Multi-GPU: pass `process_group`; X is then this rank's contiguo
         run with n_shards = world (== sklearn's per-thread buffers reduced in thread order);
     slic_kmeans_lloyd_global : combine + averaging + shift + next norms + status word.
 """
+import ctypes
 import os
 import time
 
@@ -183,17 +184,34 @@ import weakref
 _COMMS = weakref.WeakKeyDictionary()
 
 
+_EXITING = []
+
+
+def _mark_exiting():
+    _EXITING.append(True)
+
+
 class _CommHandle:
-    """owns one slic_comm*: slic_comm_destroy when the handle dies (the group was collected) or at interpreter exit"""
+    """owns one slic_comm*: slic_comm_destroy (finalize, bounded settle, destroy) when the handle dies because its group was collected;
+    slic_comm_abort at interpreter exit — torch may have torn its process group down by then and a peer may be gone: the exit path
+    must not wait for anybody"""
+
+    _hooked = False
 
     def __init__(self, ptr_):
         self.ptr = ptr_
         self._fin = weakref.finalize(self, _CommHandle._close, ptr_)
+        if not _CommHandle._hooked:
+            # registered AFTER weakref's own exit hook (created with the first finalize object), so it runs BEFORE it (LIFO)
+            import atexit
+            atexit.register(_mark_exiting)
+            _CommHandle._hooked = True
 
     @staticmethod
     def _close(ptr_):
         try:
-            _lib.load().slic_comm_destroy(ptr_)
+            lib = _lib.load()
+            (lib.slic_comm_abort if _EXITING else lib.slic_comm_destroy)(ptr_)
         except Exception:
             pass
 
@@ -419,6 +437,10 @@ class KMeans:
             if (self.exchange == "allreduce" and on_gpu and torch.distributed.get_backend(self.process_group) == "nccl"
                     and os.environ.get("SLIC_KMEANS_COMM", "torch") == "slic"):
                 comm = _slic_comm(self.process_group, dev)
+            # what a benchmark line reports about the iteration's one exchange (bench.py: secondary.exchange)
+            self.communicator_kind_ = ("slic_comm (the library's own RCCL communicator, slic_allreduce_f64)" if comm is not None else
+                                       f"torch.distributed process group ({torch.distributed.get_backend(self.process_group)})")
+            self.payload_bytes_ = int(payload[0].numel() * payload[0].element_size())
         else:
             gsums = [p[: K * Dp] for p in part]
             gcounts = [p[K * Dp:] for p in part]
@@ -492,8 +514,10 @@ class KMeans:
                 raise local_failure[0][1]
             if on_gpu:
                 if comm is not None:
-                    # bounded: a peer that never joined the iteration's all-reduce aborts the communicator and raises here
-                    call("slic_comm_wait", comm, stream(), comm_timeout_ms())
+                    # bounded: a peer that never joined the iteration's all-reduce aborts the communicator and raises here.  The wait is on
+                    # THIS iteration's event (recorded behind its collective and status read-back): iteration it + 1, already enqueued,
+                    # keeps running ahead, and the deadline covers one iteration
+                    call("slic_comm_wait_event", comm, ctypes.c_void_p(ev[it & 1].cuda_event), comm_timeout_ms())
                 ev[it & 1].synchronize()
             st = host[it & 1].tolist()
             if self._sharded and st[2] >= _POISON:                      # n_changed = low + 2^20 * high: a peer's poisoned high slot

@@ -22,6 +22,7 @@ struct Rccl {
   ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommFinalize)(ncclComm_t) = nullptr;          // optional (RCCL >= 2.14): flushes a non-blocking communicator before the destroy
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -50,6 +51,7 @@ int bind_rccl() {
   r.CommInitRankConfig = (decltype(r.CommInitRankConfig))dlsym(h, "ncclCommInitRankConfig");
   r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+  r.CommFinalize = (decltype(r.CommFinalize))dlsym(h, "ncclCommFinalize");
   r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -165,9 +167,51 @@ static int allreduce(slic_comm* c, void* buf, int64_t n, ncclDataType_t dt, void
 extern "C" int slic_allreduce_f32(slic_comm* c, float* buf, int64_t n, void* stream) { return allreduce(c, buf, n, ncclFloat32, stream); }
 extern "C" int slic_allreduce_f64(slic_comm* c, double* buf, int64_t n, void* stream) { return allreduce(c, buf, n, ncclFloat64, stream); }
 
-// Wait, with a deadline, until everything enqueued on `stream` so far — the collectives of this communicator included — has run.
+// Wait, with a deadline, until `event` (a hipEvent_t the caller recorded behind the work it wants to see finished — e.g. behind ONE
+// iteration's collective and status read-back, so that work enqueued later keeps running ahead) has completed.
 // SLIC_OK: done.  SLIC_ETIMEOUT: the deadline passed (a peer never joined a collective): the communicator is aborted, which releases
 // the stuck kernel, and every later call on it fails.  SLIC_EHIP: RCCL reported an asynchronous error (communicator aborted) or HIP did.
+static int wait_event(slic_comm* c, hipEvent_t ev, int timeout_ms, const char* who) {
+  const double t0 = now_ms();
+  int rc = SLIC_OK;
+  for (;;) {
+    hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) {
+      slic_set_error("%s: hipEventQuery -> %s", who, hipGetErrorString(e));
+      rc = SLIC_EHIP;
+      break;
+    }
+    ncclResult_t st = ncclSuccess;
+    g_rccl.CommGetAsyncError(c->comm, &st);
+    if (st != ncclSuccess && st != ncclInProgress) {
+      slic_set_error("%s: RCCL reports %s on rank %d of %d; communicator aborted", who, g_rccl.GetErrorString(st), c->rank, c->world);
+      g_rccl.CommAbort(c->comm);
+      c->dead = true;
+      rc = SLIC_EHIP;
+      break;
+    }
+    if (timeout_ms > 0 && now_ms() - t0 > timeout_ms) {
+      slic_set_error("%s: the awaited work did not finish within %d ms on rank %d of %d (a peer is missing or stuck); communicator aborted",
+                     who, timeout_ms, c->rank, c->world);
+      g_rccl.CommAbort(c->comm);
+      c->dead = true;
+      rc = SLIC_ETIMEOUT;
+      break;
+    }
+    nap();
+  }
+  (void)hipGetLastError();                                          // hipErrorNotReady from the queries is not an error of ours
+  return rc;
+}
+
+extern "C" int slic_comm_wait_event(slic_comm* c, void* event, int timeout_ms) {
+  SLIC_REQUIRE(c && event && timeout_ms >= 0, "slic_comm_wait_event: bad args");
+  SLIC_REQUIRE(!c->dead, "slic_comm_wait_event: the communicator was aborted");
+  return wait_event(c, (hipEvent_t)event, timeout_ms, "slic_comm_wait_event");
+}
+
+// The same for everything enqueued on `stream` so far (an event recorded here, now).
 extern "C" int slic_comm_wait(slic_comm* c, void* stream, int timeout_ms) {
   SLIC_REQUIRE(c && timeout_ms >= 0, "slic_comm_wait: bad args");
   SLIC_REQUIRE(!c->dead, "slic_comm_wait: the communicator was aborted");
@@ -179,41 +223,13 @@ extern "C" int slic_comm_wait(slic_comm* c, void* stream, int timeout_ms) {
     slic_set_error("slic_comm_wait: hipEventRecord -> %s", hipGetErrorString(e));
     return SLIC_EHIP;
   }
-  const double t0 = now_ms();
-  int rc = SLIC_OK;
-  for (;;) {
-    e = hipEventQuery(ev);
-    if (e == hipSuccess) break;
-    if (e != hipErrorNotReady) {
-      slic_set_error("slic_comm_wait: hipEventQuery -> %s", hipGetErrorString(e));
-      rc = SLIC_EHIP;
-      break;
-    }
-    ncclResult_t st = ncclSuccess;
-    g_rccl.CommGetAsyncError(c->comm, &st);
-    if (st != ncclSuccess && st != ncclInProgress) {
-      slic_set_error("slic_comm_wait: RCCL reports %s on rank %d of %d; communicator aborted", g_rccl.GetErrorString(st), c->rank, c->world);
-      g_rccl.CommAbort(c->comm);
-      c->dead = true;
-      rc = SLIC_EHIP;
-      break;
-    }
-    if (timeout_ms > 0 && now_ms() - t0 > timeout_ms) {
-      slic_set_error("slic_comm_wait: the stream did not drain within %d ms on rank %d of %d (a peer is missing or stuck); communicator aborted",
-                     timeout_ms, c->rank, c->world);
-      g_rccl.CommAbort(c->comm);
-      c->dead = true;
-      rc = SLIC_ETIMEOUT;
-      break;
-    }
-    nap();
-  }
-  (void)hipGetLastError();                                          // hipErrorNotReady from the queries is not an error of ours
+  const int rc = wait_event(c, ev, timeout_ms, "slic_comm_wait");
   (void)hipEventDestroy(ev);
   return rc;
 }
 
-// give up on a communicator at once (ncclCommAbort): kernels it has enqueued are released, the handle is freed
+// give up on a communicator at once (ncclCommAbort): kernels it has enqueued are released, the handle is freed.  This is what a
+// process-exit finalizer calls: it never blocks on a peer.
 extern "C" int slic_comm_abort(slic_comm* c) {
   if (!c) return SLIC_OK;
   if (g_rccl.h && !c->dead) g_rccl.CommAbort(c->comm);
@@ -221,16 +237,32 @@ extern "C" int slic_comm_abort(slic_comm* c) {
   return SLIC_OK;
 }
 
+// Orderly teardown of a NON-BLOCKING communicator: finalize (flush what it has enqueued), poll that to completion under the
+// communicator's deadline (10 s when it was created without one), then destroy.  A peer that is gone, or an asynchronous error,
+// ends in ncclCommAbort instead of a wait without a deadline; the handle is freed either way.
 extern "C" int slic_comm_destroy(slic_comm* c) {
   if (!c) return SLIC_OK;
+  int rc = SLIC_OK;
   if (g_rccl.h && !c->dead) {
-    ncclResult_t r = g_rccl.CommDestroy(c->comm);
-    if (r != ncclSuccess && r != ncclInProgress) {
-      slic_set_error("slic_comm_destroy: %s", g_rccl.GetErrorString(r));
-      delete c;
-      return SLIC_EHIP;
+    const int deadline = c->timeout_ms > 0 ? c->timeout_ms : 10000;
+    if (g_rccl.CommFinalize) {
+      ncclResult_t r = g_rccl.CommFinalize(c->comm);
+      if (r != ncclSuccess && r != ncclInProgress) {
+        slic_set_error("slic_comm_destroy: ncclCommFinalize -> %s; communicator aborted", g_rccl.GetErrorString(r));
+        g_rccl.CommAbort(c->comm);
+        c->dead = true;
+        rc = SLIC_EHIP;
+      }
+    }
+    if (!c->dead) rc = settle(c, deadline, "slic_comm_destroy");   // aborts on a deadline / asynchronous error
+    if (!c->dead) {
+      ncclResult_t r = g_rccl.CommDestroy(c->comm);
+      if (r != ncclSuccess && r != ncclInProgress) {
+        slic_set_error("slic_comm_destroy: ncclCommDestroy -> %s", g_rccl.GetErrorString(r));
+        rc = SLIC_EHIP;
+      }
     }
   }
   delete c;
-  return SLIC_OK;
+  return rc;
 }

@@ -319,7 +319,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
     const int a = (ab * 11) >> 6, b = ab - 6 * a;             // ab / 6 for ab < 24
     const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
     const bool ok = tvalid && (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
-    stash[i * 512] = ok ? (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4) + (unsigned)(lane >> 5) * 16u : 0x80000000u;
+    stash[i * 512] = ok ? (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4) + (unsigned)(lane >> 5) * 16u : 0xFFFFFF00u;   // past any resource wino2_check admits (a raw buffer checks the VECTOR offset only)
   }
   // bit kt: frame t - 1 + kt is outside the clip; bit 3: a dead stage
   const int tflags = (tt == 0 ? 1 : 0) | (tt == T - 1 ? 4 : 0) | 8;
@@ -643,7 +643,10 @@ static int wino2_check(const SlicConvArgs* a, int* full) {
   *full = slic_wino2_full_rows(a);
   SLIC_REQUIRE(*full > 0, "slic_conv_gemm: variant 31: blocks of 64 tiles hold different numbers of outputs at H=%d W=%d", a->Hs, a->Ws);
   const int64_t tiles = (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4);
-  SLIC_REQUIRE(tiles < (1ll << 31) && (int64_t)a->M * a->Cs * 4 < 0xFFFFFF00ll, "slic_conv_gemm: variant 31: tensor too large");
+  // the kernel's resource spans the tensor plus a frame on either side (kt rides in the scalar offset, which the range check does not see): its
+  // size must stay below the out-of-range vector offset 0xFFFFFF00 that stands for a padding pixel, and must not wrap in 32 bits
+  SLIC_REQUIRE(tiles < (1ll << 31) && (int64_t)a->M * a->Cs * 4 + 2 * (int64_t)a->Hs * a->Ws * a->Cs * 4 + 16 <= 0xFFFFFF00ll,
+               "slic_conv_gemm: variant 31: tensor too large (source + two frames must stay below 4 GiB - 256 B)");
   return SLIC_OK;
 }
 

@@ -441,7 +441,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int kt = 0; kt < NK; ++kt) {
       // step s = (tile, kt) computes from stage kt % ST.  Outstanding loads here: the DMAs of steps s + 1 .. s + ST - 2 (4 each);
       // stores of the previous tile's results may sit between them — they only make the wait stricter.
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ST - 3)) : "memory");         // step s + 1 has landed
+      // (lgkmcnt(0): this wave's ds_writes of the previous tile's (score, index) pairs — xch — must have reached LDS before the barrier
+      //  that publishes them to the other waves' flush(); gfx950's back-off barrier does not imply it)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (ST - 3)) : "memory");         // step s + 1 has landed
       __builtin_amdgcn_s_barrier();
       {
         const int kn = kt + ST - 1;                             // step s + ST - 1

@@ -83,9 +83,16 @@ class ConvPlan:
         Hq2, Wq2 = (Hd + 1) // 2, (Wd + 3) // 4
         uniform = (Wd % 4 == 0 and Hd % 2 == 0) or (Hd % 2 == 0 and 64 % Wq2 == 0) or (64 % (Hq2 * Wq2) == 0)
         elig2 = eligible and uniform
+        # size limits of the two-dimensional kernels (csrc/conv_wino2.hip: wino2_check, slic_conv_wgrad_wino2): 32-bit buffer offsets with
+        # the out-of-range offset 0xFFFFFF00 standing for padding pixels — the source plus a frame on either side must stay below it
+        # (layer1 at 112 x 112: B <= 331), and the weight gradient's tile records hold 24-bit positions.  Beyond them the plan falls
+        # back to the one-dimensional / direct kernels instead of raising in the step.
+        positions = 0 if batch is None else int(batch) * int(np.prod(self.in_dims))
+        fits2 = positions * max(self.C, self.N) * 4 + 2 * Hd * Wd * max(self.C, self.N) * 4 + 16 <= 0xFFFFFF00
+        self.wino2_size_ok = bool(fits2)
         if wino2 is None:
             wgs = 0 if batch is None else -(-(int(batch) * self.in_dims[0] * Hq2 * Wq2) // 64) * (max(self.C, self.N) // 64)
-            wino2 = (elig2 and self.wino and os.environ.get("SLIC_WINO2", "1") != "0" and
+            wino2 = (elig2 and self.wino and fits2 and os.environ.get("SLIC_WINO2", "1") != "0" and
                      wgs >= int(os.environ.get("SLIC_WINO2_MIN_WGS", self.WINO2_MIN_WGS)))
         self.wino2 = bool(wino2)
         assert (elig2 and self.wino) or not self.wino2, "Winograd F(4,3) x F(2,3): a Winograd plan with uniform 64-tile blocks"
@@ -102,7 +109,7 @@ class ConvPlan:
         if wino2_wgrad is None:
             tiles2 = 0 if batch is None else int(batch) * self.in_dims[0] * Hq2 * Wq2
             wino2_wgrad = ((self.wino2 or (self.wino and tiles2 >= 128 and os.environ.get("SLIC_WINO2", "1") != "0")) and self.wino_wgrad and
-                           mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
+                           fits2 and positions < (1 << 24) and mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
                            (mode != "2" or (self.C == 128 and self.N == 128)))
         self.wino2_wgrad = bool(wino2_wgrad)
         assert not self.wino2_wgrad or base, "transposed 2-D Winograd weight gradient: a Winograd plan"
