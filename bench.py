@@ -250,6 +250,37 @@ def kmeans_secondary(rank, world, pg, run_cpu):
     return out
 
 
+def kmeans_oneshot_row(rank, world, pg):
+    """the strong-scaled k-means row of kmeans_secondary with exchange='oneshot'"""
+    from video_similarity_search_amd.clustering import KMeans
+    N, D, K, iters = 100000, 512, 500, 20
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((N, D)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    init = X[rng.choice(N, K, replace=False)].copy()
+    per = (N + world - 1) // world
+    Xd = torch.from_numpy(X[rank * per:(rank + 1) * per]).cuda()
+    km = KMeans(n_clusters=K, init=init, n_init=1, max_iter=iters, tol=0.0, fixed_iters=True, process_group=pg, exchange="oneshot")
+    for _ in range(4):
+        km.fit(Xd)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dts = []
+    for _ in range(2):
+        km.fit(Xd)
+        torch.cuda.synchronize()
+        dts.append(km.lloyd_seconds_)
+    dt = sum(dts) / len(dts)
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dict(metric="k-means embeddings/sec 100kx512 K=500, rows sharded, one-shot exchange", value=N * iters / dt, unit="embeddings/s",
+                ms_per_iter=dt / iters * 1e3, n_gpus=world, exchange=dict(kind=km.exchange, communicator=km.communicator_kind_,
+                                                                          payload_bytes_per_rank=km.payload_bytes_))
+
+
 def _time_events(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -663,7 +694,31 @@ def main():
             res["secondary"]["train_b8"] = dict(metric="clips/sec R3D-18+NT-Xent training step at B = 8 x 3x16x112x112, per GPU", value=8 / dt8,
                                                 unit="clips/s", ms_per_step=dt8 * 1e3,
                                                 frac_of_fp32_mfma_peak_executed=exe8 / dt8 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                                algorithmic_tflops=alg8 / dt8 / 1e12)
+                                                algorithmic_tflops=alg8 / dt8 / 1e12, issue="eager: every launch issued from Python")
+            if not use_dist:
+                # the same step captured ONCE into a hipGraph (misc/graph_step.py) and replayed: at 8 clips the eager step is ~330 launches
+                # of 10-40 us kernels and the GPU waits for the host; the replay issues them with no host work in between.  Same kernels,
+                # same order, same buffers: bit-identical results (tests/test_train_loop_gpu.py::test_graphed_step_equals_eager)
+                try:
+                    from video_similarity_search_amd.misc.graph_step import GraphedStep
+
+                    def step8_graph():
+                        emb = model(x8)
+                        l8, _ = crit(emb, lab8, sampling_strategy='noise_contrastive')
+                        opt.zero_grad(set_to_none=True)
+                        l8.backward()
+                        opt.step()
+                        return l8.detach()
+                    g8 = GraphedStep(step8_graph, warmup=2)
+                    dt8g = timed_steps(g8.replay, 3, 20)
+                    res["secondary"]["train_b8_graph"] = dict(
+                        metric="clips/sec R3D-18+NT-Xent training step at B = 8 x 3x16x112x112, the whole step replayed from a hipGraph, per GPU",
+                        value=8 / dt8g, unit="clips/s", ms_per_step=dt8g * 1e3,
+                        frac_of_fp32_mfma_peak_executed=exe8 / dt8g / 1e12 / FP32_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg8 / dt8g / 1e12,
+                        final_loss=float(g8.out.item()))
+                    del g8
+                except Exception as e:
+                    res["secondary"]["train_b8_graph"] = dict(error=repr(e))
             del x8
             x39 = torch.from_numpy(np.random.default_rng(17 + rank).standard_normal((39, 3, 16, 112, 112)).astype(np.float32)).cuda()
             lab26 = torch.arange(13).repeat(2).cuda()
@@ -707,6 +762,17 @@ def main():
     if wd is not None:
         wd.cancel()
     emit(True)
+    if use_dist and not args.no_secondary and os.environ.get("SLIC_BENCH_ONESHOT", "1") != "0":
+        # AFTER the contract's line is out (nothing below can cost it): the sharded k-means row once more with the iteration's exchange as the
+        # library's one-shot all-to-all over peer-mapped memory (exchange='oneshot', csrc/oneshot.hip) instead of the RCCL all-reduce.  Its
+        # waits are bounded (20 s here); the result goes to stderr as its own JSON line.
+        try:
+            os.environ["SLIC_COMM_TIMEOUT_MS"] = os.environ.get("SLIC_BENCH_ONESHOT_TIMEOUT_MS", "20000")
+            row = kmeans_oneshot_row(rank, world, pg)
+            if rank == 0:
+                print(json.dumps(dict(row="kmeans_oneshot", **row)), file=sys.stderr, flush=True)
+        except Exception as e:
+            log(f"bench.py: rank {rank}: one-shot k-means row failed: {e!r}")
     if use_dist:
         torch.distributed.destroy_process_group()
 

@@ -182,6 +182,32 @@ int slic_comm_abort(slic_comm* comm);
  * ncclCommDestroy; a lost peer or an asynchronous error ends in ncclCommAbort (SLIC_ETIMEOUT / SLIC_EHIP).  The handle is freed either way. */
 int slic_comm_destroy(slic_comm* comm);
 
+/* The same exchange as a ONE-SHOT all-to-all over peer-mapped device memory (csrc/oneshot.hip): where the ring all-reduce above is 2 (W - 1)
+ * dependent steps over xGMI's point-to-point links, every rank here WRITES its payload into an inbox of each peer at once (one link per
+ * peer), raises a flag per 32 KB chunk, waits for its peers' flags and adds the W payloads it then holds in rank order — one kernel per
+ * exchange, no RCCL.  Sums are fp64 (exact for the k-means payload: every rank ends with bit-identical numbers).  Replaces the rank-0
+ * k-means + barrier of online_train.py:625-662 together with slic_kmeans_lloyd_local / _global; process model of
+ * misc/distributed_helper.py:30-37 (one process per GPU; two processes may also share ONE GPU, which is how a one-GPU box tests it).
+ *   slic_oneshot_create : allocates the rank's inbox for payloads of up to max_n doubles (uncached device memory) on the current device
+ *                         and writes its IPC handle (SLIC_IPC_HANDLE_BYTES) to handle_out; timeout_ms bounds every wait of an exchange
+ *                         (0 = none);
+ *   (caller)            : gathers the W handles in rank order over any channel (torch.distributed, a file, MPI);
+ *   slic_oneshot_connect: maps the peers' inboxes (hipIpcOpenMemHandle; needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver);
+ *   slic_allreduce_oneshot_f64: in-place sum of n doubles (buf 16-byte aligned) across the ranks, asynchronous on `stream`; every
+ *                         rank must issue the same sequence of exchanges with the same n;
+ *   slic_oneshot_check  : once the stream (or an event behind the exchange) has completed — SLIC_OK, or SLIC_ETIMEOUT when a wait ran out:
+ *                         a peer never pushed (lost rank).  The kernel itself never hangs: it gives up after timeout_ms, records the
+ *                         exchange number in a host-mapped word and finishes; the payloads since are garbage and the caller must raise.
+ *   slic_oneshot_info   : out[4] = {world, rank, memory kind (0 uncached, 1 fine-grained, 2 plain device memory), exchanges issued}. */
+#define SLIC_IPC_HANDLE_BYTES 64
+typedef struct slic_oneshot slic_oneshot;
+int slic_oneshot_create(int world, int rank, int64_t max_n, int timeout_ms, slic_oneshot** out, void* handle_out /* SLIC_IPC_HANDLE_BYTES */);
+int slic_oneshot_connect(slic_oneshot* c, const void* all_handles /* world x SLIC_IPC_HANDLE_BYTES, rank order */);
+int slic_allreduce_oneshot_f64(slic_oneshot* c, double* buf, int64_t n, void* stream);
+int slic_oneshot_check(slic_oneshot* c);
+int slic_oneshot_info(const slic_oneshot* c, int* out /* [4] */);
+int slic_oneshot_destroy(slic_oneshot* c);
+
 /* column sums / sums of squares in double (rows ascending in 1024-row segments, segments in
  * order) — X.mean(axis=0) and np.var(X, axis=0) of KMeans.fit / _tolerance
  * (_kmeans.py:1479-1481, 279-288). */
@@ -501,8 +527,17 @@ int slic_infonce_rows_bwd(const float* X, const float* Y, const float* state, in
 int slic_normalize_rows(const float* X, int64_t N, int D, int ldx, float* out, void* stream);
 /* for every row of Qn the k nearest rows of Gn by cosine distance clip(1 - q.g, 0, 2), ascending (ties -> lower
  * gallery index).  Qn/Gn: normalised, dense [N, D], D % 8 == 0.  self_mask != 0 skips j == i
- * (np.fill_diagonal(distance_matrix, inf), evaluate.py:221-222).  k <= 88 (the per-query lists live in LDS). */
+ * (np.fill_diagonal(distance_matrix, inf), evaluate.py:221-222).  k <= 88 (SLIC_EINVAL beyond: the per-query lists of the
+ * streaming kernels live in LDS).  Two algorithms, identical results: galleries of >= 32768 rows with D <= 512 and k >= 16 go threshold ->
+ * collect -> select (a strided sample of the gallery gives every query a score threshold that ~6 k + 100 rows reach; the similarity
+ * pass appends the rows that reach it to a candidate buffer — no list kept; one wave per query then sorts out the k best; a query
+ * whose candidate count fell outside [k, 2048] is redone by the streaming kernels: exact for any data); everything else, and
+ * SLIC_TOPK_COLLECT=0, streams per-(query, gallery slice) k-slot heaps in LDS and merges them (SLIC_TOPK_COLLECT=1: collect for any k). */
 size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k);
+/* which of the two a call takes and the collect path's sample: out[0] = 1 collect / 0 streaming, out[1] = sample slices, out[2] = rows
+ * per sample slice, out[3] = M (the threshold is the M-th best of the pooled sample), out[4] = gallery row step of the sample, out[5] = candidate
+ * slots per query.  Introspection for tests and bench lines; no device work. */
+int slic_cosine_topk_plan(int Nq, int Ng, int D, int k, int* out /* [6] */);
 int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
                      int32_t* out_idx, float* out_dist, void* workspace, void* stream);
 /* merge W per-GPU result lists ([W, Nq, k] distances ascending + GLOBAL gallery indices, -1 = empty slot) into the

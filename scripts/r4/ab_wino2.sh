@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
   wait
   for nf in $2; do
     name=${nf%%:*}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_w2_$name.so $D/_exp/w2_$name.o $D/conv.o $D/bn.o $D/common.o $D/comm.o $D/kmeans.o $D/loss.o $D/nce.o $D/topk.o -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_w2_$name.so $D/_exp/w2_$name.o $(ls $D/*.o | grep -v conv_wino2.o) -ldl
   done
 else
   for name in base $2; do

@@ -255,6 +255,88 @@ def case_syncbn(rank, world, out):
     np.savez(out, **res)
 
 
+def case_oneshot(rank, world, out):
+    """exchange='oneshot' (csrc/oneshot.hip): the library's one-shot all-to-all over IPC-mapped inboxes.  Raw exchanges of known
+    payloads (odd lengths, lengths that are not a multiple of the 4096-double chunk, 25 exchanges back to back through both parities
+    of the double-buffered inbox), then the sharded k-means on the goldens."""
+    import ctypes
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd._lib import call, ptr, stream
+    from video_similarity_search_amd.clustering import kmeans_hip as kh
+    pg = dist.group.WORLD
+    dev = torch.device("cuda", torch.cuda.current_device())
+    max_n = 70001
+    comm = kh._slic_oneshot(pg, dev, max_n)
+    res = {}
+    ok = True
+    rng = np.random.default_rng(5)
+    sizes = [1, 2, 3, 4095, 4096, 4097, 8192, 70001, 12345, 70000] + [int(v) for v in rng.integers(1, max_n, 15)]
+    for it, n in enumerate(sizes):
+        # every rank can rebuild every rank's payload: integers below 2^20 times a rank-specific scale, exact in fp64
+        parts = [np.random.default_rng(1000 * it + r).integers(-2 ** 20, 2 ** 20, n).astype(np.float64) * (r + 1) for r in range(world)]
+        buf = torch.from_numpy(parts[rank]).cuda()
+        call("slic_allreduce_oneshot_f64", comm, ptr(buf), n, stream())
+        want = parts[0].copy()
+        for r in range(1, world):
+            want += parts[r]
+        torch.cuda.synchronize()
+        call("slic_oneshot_check", comm)
+        ok = ok and np.array_equal(buf.cpu().numpy(), want)
+    res["raw_ok"] = ok
+    res["n_exchanges"] = len(sizes)
+    info = (ctypes.c_int * 4)()
+    call("slic_oneshot_info", comm, info)                          # world, rank, memory kind, exchanges issued
+    res["info"] = np.array(list(info))
+    # the sharded Lloyd iteration with this exchange: labels of every iteration bit-equal to the oracle with n_shards = -W (the parent compares)
+    from video_similarity_search_amd.clustering.kmeans_hip import KMeans
+    for name in ("clustered_empty", "d128", "unstructured"):
+        g = dict(np.load(os.path.join(HERE, "golden", f"kmeans_{name}.npz")))
+        X, init = g["X"], g["init"]
+        N = len(X)
+        per = (N + world - 1) // world
+        shard = torch.from_numpy(X[rank * per:(rank + 1) * per]).cuda()
+        km = KMeans(n_clusters=init.shape[0], init=init, n_init=1, process_group=pg, trace=True, exchange="oneshot").fit(shard)
+        res[f"{name}/labels_local"] = km.labels_
+        res[f"{name}/centers"] = km.cluster_centers_
+        res[f"{name}/n_iter"] = km.n_iter_
+        res[f"{name}/inertia"] = km.inertia_
+        res[f"{name}/trace_local"] = km.trace_
+        res[f"{name}/comm"] = np.array(km.communicator_kind_)
+    np.savez(out, **res)
+
+
+def case_oneshot_timeout(rank, world, out):
+    """a lost peer: rank 1 sets the exchange up with rank 0 and then never pushes.  Rank 0's exchange kernel gives up after
+    SLIC_COMM_TIMEOUT_MS (set to 2 s by the test), completes, and slic_oneshot_check reports SLIC_ETIMEOUT — no hang; later
+    exchanges on the communicator are refused."""
+    import time
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd._lib import call, ptr, stream
+    from video_similarity_search_amd.clustering import kmeans_hip as kh
+    pg = dist.group.WORLD
+    dev = torch.device("cuda", torch.cuda.current_device())
+    comm = kh._slic_oneshot(pg, dev, 10000)
+    res = dict(rank=rank)
+    if rank == 0:
+        buf = torch.ones(10000, dtype=torch.float64, device="cuda")
+        t0 = time.time()
+        call("slic_allreduce_oneshot_f64", comm, ptr(buf), 10000, stream())
+        torch.cuda.synchronize()
+        res["seconds"] = time.time() - t0
+        try:
+            call("slic_oneshot_check", comm)
+            res["raised"] = False
+        except _lib.SlicError as e:
+            res["raised"] = True
+            res["msg"] = np.array(str(e))
+        try:
+            call("slic_allreduce_oneshot_f64", comm, ptr(buf), 10000, stream())
+            res["refused_after"] = False
+        except _lib.SlicError:
+            res["refused_after"] = True
+    np.savez(out, **res)
+
+
 def case_launch(rank, world, out):
     raise SystemExit("case_launch is driven by the test itself (misc.distributed_helper.launch_processes)")
 
@@ -263,8 +345,14 @@ def main():
     case, out_dir = sys.argv[1], sys.argv[2]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group("nccl")
+    if os.environ.get("SLIC_TEST_SAME_GPU") == "1":
+        # every rank on GPU 0 (how a one-GPU box runs two ranks of the one-shot exchange): RCCL cannot put two ranks on one device, so the
+        # process group — which only carries set-up data and small host-staged collectives here — is gloo
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
     try:
         globals()["case_" + case](rank, world, os.path.join(out_dir, f"{case}_r{rank}.npz"))

@@ -29,9 +29,10 @@ def _free_port():
     return p
 
 
-def _run(case, world, out_dir, timeout=900):
+def _run(case, world, out_dir, timeout=900, extra_env=None):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(HERE, "dist_gpu_worker.py"), case, str(out_dir)]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
@@ -202,6 +203,42 @@ def test_launch_processes_two_gpus(gpu, tmp_path):
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
     assert open(marker).read() == "ok 2"
+
+
+def test_oneshot_exchange_two_processes_one_gpu(gpu, golden_dir, tmp_path):
+    """exchange='oneshot' (slic_allreduce_oneshot_f64, csrc/oneshot.hip: IPC-mapped inboxes, one kernel per exchange) with TWO processes on
+    the ONE leased GPU (IPC handles work on the same device; RCCL does not): 25 raw exchanges exact, and the sharded HIP k-means ==
+    the oracle with n_shards = -2 (fp64 combine), every iteration's labels bit-equal, == sklearn's golden labels"""
+    from oracle import kmeans as ok
+    world = 2
+    # (a bounded wait of 20 s per exchange instead of the default five minutes: a broken exchange fails this test in seconds)
+    res = _run("oneshot", world, tmp_path, timeout=600, extra_env={"SLIC_TEST_SAME_GPU": "1", "SLIC_COMM_TIMEOUT_MS": "20000"})
+    for rk, r in enumerate(res):
+        assert bool(r["raw_ok"]) and int(r["n_exchanges"]) == 25
+        assert [int(v) for v in r["info"][:2]] == [2, rk] and int(r["info"][3]) >= 25            # world, rank, exchanges issued
+    for name in ("clustered_empty", "d128", "unstructured"):
+        g = dict(np.load(os.path.join(golden_dir, f"kmeans_{name}.npz")))
+        X, init = g["X"], g["init"]
+        mean = ok.col_mean(X)
+        Xc = X - mean
+        ref = ok.lloyd(Xc, init - mean, tol_abs=ok.tolerance(Xc, 1e-4), n_shards=-world, trace=True)
+        labels = np.concatenate([r[f"{name}/labels_local"] for r in res])
+        trace = np.concatenate([r[f"{name}/trace_local"] for r in res], axis=1)
+        assert "oneshot" in str(res[0][f"{name}/comm"])
+        assert int(res[0][f"{name}/n_iter"]) == ref["n_iter"] == int(g["n_iter"])
+        assert np.array_equal(labels, ref["labels"]) and np.array_equal(labels, g["labels"])
+        assert np.array_equal(trace, np.asarray(ref["trace"]))
+        assert np.array_equal(res[0][f"{name}/centers"], res[1][f"{name}/centers"])            # replicas bit-identical
+        np.testing.assert_array_equal(res[0][f"{name}/centers"], (ref["centers"] + mean).astype(np.float32))
+
+
+def test_oneshot_lost_peer_times_out(gpu, tmp_path):
+    """a peer that never pushes: the exchange kernel's wait is bounded (SLIC_COMM_TIMEOUT_MS), the stream completes, slic_oneshot_check
+    raises SLIC_ETIMEOUT and the communicator refuses further exchanges — seconds, not a hang"""
+    res = _run("oneshot_timeout", 2, tmp_path, timeout=300, extra_env={"SLIC_TEST_SAME_GPU": "1", "SLIC_COMM_TIMEOUT_MS": "2000"})
+    r0 = res[0]
+    assert bool(r0["raised"]) and "did not receive every peer" in str(r0["msg"]) and bool(r0["refused_after"])
+    assert 1.5 < float(r0["seconds"]) < 30.0
 
 
 def _bench(args, timeout=1500):

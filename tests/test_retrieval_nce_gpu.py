@@ -90,6 +90,130 @@ def test_topk_shapes_vs_oracle(gpu, Nq, Ng, D, k):
     assert (idx.cpu().numpy() == ref).mean() > 0.99
 
 
+def _topk_plan(Nq, Ng, D, k):
+    import ctypes
+    from video_similarity_search_amd import _lib
+    out = (ctypes.c_int * 6)()
+    _lib.check(_lib.load().slic_cosine_topk_plan(Nq, Ng, D, k, out), "slic_cosine_topk_plan")
+    return dict(collect=bool(out[0]), S1=out[1], per1=out[2], m1=out[3], gstep=out[4], cap=out[5])
+
+
+def _topk_env(v):
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        old = os.environ.get("SLIC_TOPK_COLLECT")
+        os.environ["SLIC_TOPK_COLLECT"] = v
+        try:
+            yield
+        finally:
+            if old is None:
+                del os.environ["SLIC_TOPK_COLLECT"]
+            else:
+                os.environ["SLIC_TOPK_COLLECT"] = old
+    return cm()
+
+
+def _both_paths(Q, G, k):
+    """(idx, dist) of the collect path (SLIC_TOPK_COLLECT=1: for any k) and of the streaming path (=0); the library reads the switch at every call"""
+    from video_similarity_search_amd.evaluate import cosine_topk
+    with _topk_env("1"):
+        a = cosine_topk(Q, G, k=k)
+    with _topk_env("0"):
+        b = cosine_topk(Q, G, k=k)
+    return [t.cpu().numpy() for t in a], [t.cpu().numpy() for t in b]
+
+
+# the collect path (threshold -> collect -> select, csrc/topk.hip) against the streaming kernels: the same scores (same k order inside
+# every accumulator) and the same tie rule, so the lists must be IDENTICAL, bit for bit; and against the float64 oracle
+@pytest.mark.parametrize("Nq,Ng,D,k", [(300, 40000, 200, 50), (1000, 100000, 512, 50), (257, 65613, 128, 1), (128, 50000, 512, 88),
+                                       (5, 32768, 64, 20), (2500, 33000, 256, 7)])
+def test_topk_collect_equals_streaming(gpu, Nq, Ng, D, k):
+    from oracle import retrieval as orr
+    with _topk_env("1"):
+        assert _topk_plan(Nq, Ng, D, k)["collect"]
+    assert _topk_plan(Nq, Ng, D, k)["collect"] == (k >= 16)          # the default: where it is faster
+    rng = np.random.default_rng(Nq + Ng + k)
+    Q = rng.standard_normal((Nq, D)).astype(np.float32)
+    G = rng.standard_normal((Ng, D)).astype(np.float32)
+    G[3] = 0.0
+    (ia, da), (ib, db) = _both_paths(Q, G, k)
+    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    sub = rng.choice(Nq, min(Nq, 48), replace=False)
+    d = orr.cosine_distances(Q[sub].astype(np.float64), G.astype(np.float64))
+    ref = np.argsort(d, axis=1, kind="stable")[:, :k]
+    np.testing.assert_allclose(da[sub], np.take_along_axis(d, ref, axis=1), atol=3e-6)
+    assert (ia[sub] == ref).mean() > 0.99
+
+
+def test_topk_collect_self_mask_equals_streaming(gpu):
+    """the self-retrieval form (queries = gallery, the diagonal skipped: evaluate.py:221-222; FINCH's first neighbours)"""
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((33000, 128)).astype(np.float32)
+    with _topk_env("1"):
+        assert _topk_plan(33000, 33000, 128, 5)["collect"]
+    (ia, da), (ib, db) = _both_paths(X, None, 5)
+    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    assert not np.any(ia == np.arange(33000)[:, None])
+
+
+def test_topk_collect_fallback_too_many_candidates(gpu):
+    """a gallery of 64 distinct rows repeated 4096 times: every score a query reaches is reached by 4096 rows, the candidate buffers
+    (2048 slots) overflow, and every query is redone by the streaming kernels — exact, ties to the lower index"""
+    from oracle import retrieval as orr
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((64, 64)).astype(np.float32)
+    G = np.tile(base, (4096, 1))                                   # row i = base[i % 64]
+    Q = rng.standard_normal((200, 64)).astype(np.float32)
+    k = 50
+    pl = _topk_plan(200, G.shape[0], 64, k)
+    assert pl["collect"] and pl["cap"] < 4096
+    (ia, da), (ib, db) = _both_paths(Q, G, k)
+    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    d = orr.cosine_distances(Q.astype(np.float64), base.astype(np.float64))
+    best = np.argmin(d, axis=1)                                    # the nearest distinct row; its 4096 copies fill the list, lowest index first
+    # (fp32 scores of identical rows are identical, so the order inside the list is by index)
+    assert np.array_equal(ia, best[:, None] + 64 * np.arange(k)[None, :])
+
+
+def test_topk_collect_fallback_too_few_candidates(gpu):
+    """an unrepresentative sample: the only gallery rows close to the queries sit exactly where the strided sample looks, so the
+    thresholds come out far above what the rest of the gallery reaches, fewer than k rows pass, and the streaming kernels redo
+    every query"""
+    from oracle import retrieval as orr
+    Nq, Ng, D, k = 300, 60000, 128, 50
+    pl = _topk_plan(Nq, Ng, D, k)
+    assert pl["collect"] and pl["m1"] < k
+    rng = np.random.default_rng(9)
+    v = rng.standard_normal(D).astype(np.float32)
+    Q = (v[None, :] + 0.05 * rng.standard_normal((Nq, D))).astype(np.float32)
+    G = rng.standard_normal((Ng, D)).astype(np.float32)
+    for j in range(pl["m1"]):                                       # M sample rows (sample row i = gallery row i * gstep) next to every query
+        G[(pl["per1"] * (j % pl["S1"]) + 7 * j) * pl["gstep"]] = v + 0.01 * rng.standard_normal(D)
+    (ia, da), (ib, db) = _both_paths(Q, G, k)
+    assert np.array_equal(ia, ib) and np.array_equal(da, db)
+    d = orr.cosine_distances(Q.astype(np.float64), G.astype(np.float64))
+    ref = np.argsort(d, axis=1, kind="stable")[:, :k]
+    np.testing.assert_allclose(da, np.take_along_axis(d, ref, axis=1), atol=3e-6)
+    assert (ia == ref).mean() > 0.99
+
+
+def test_topk_k_limit(gpu):
+    """k <= 88 on both paths; beyond it the call fails loudly (include/slic_hip.h)"""
+    from video_similarity_search_amd import _lib
+    from video_similarity_search_amd.evaluate import cosine_topk
+    rng = np.random.default_rng(1)
+    Q = rng.standard_normal((10, 64)).astype(np.float32)
+    G = rng.standard_normal((40000, 64)).astype(np.float32)
+    idx, _ = cosine_topk(Q, G, k=88)
+    assert idx.shape == (10, 88)
+    with pytest.raises(_lib.SlicError):
+        cosine_topk(Q, G, k=89)
+    with pytest.raises(_lib.SlicError):
+        cosine_topk(Q, G[:500], k=89)
+
+
 def test_retrieval_full_size_properties(gpu):
     """BASELINE configs[4] size (10k x 512 queries vs 100k x 512 gallery, k = 50), checked through properties the size does
     not change: per-query distances ascending, indices unique and in range, a random subset of queries equal to the exact

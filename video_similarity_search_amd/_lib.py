@@ -46,6 +46,12 @@ SIGNATURES = {
     "slic_allreduce_f32": (I, [P, P, L, P]),
     "slic_allreduce_f64": (I, [P, P, L, P]),
     "slic_comm_destroy": (I, [P]),
+    "slic_oneshot_create": (I, [I, I, c_int64, I, P, P]),
+    "slic_oneshot_connect": (I, [P, P]),
+    "slic_allreduce_oneshot_f64": (I, [P, P, c_int64, P]),
+    "slic_oneshot_check": (I, [P]),
+    "slic_oneshot_info": (I, [P, P]),
+    "slic_oneshot_destroy": (I, [P]),
     "slic_col_stats_workspace_bytes": (c_size_t, [L, I]),
     "slic_col_stats": (I, [P, L, I, I, P, P, P, P]),
     "slic_sub_rowvec": (I, [P, L, I, I, P, P, I, P]),
@@ -122,6 +128,7 @@ SIGNATURES = {
     # retrieval
     "slic_normalize_rows": (I, [P, L, I, I, P, P]),
     "slic_cosine_topk_workspace_bytes": (c_size_t, [I, I, I]),
+    "slic_cosine_topk_plan": (I, [I, I, I, I, P]),
     "slic_cosine_topk": (I, [P, I, P, I, I, I, I, P, P, P, P]),
     "slic_topk_merge_lists": (I, [P, P, I, I, I, P, P, P]),
     "slic_pairwise_euclidean": (I, [P, I, P, I, I, P, P]),

@@ -244,6 +244,57 @@ def _slic_comm(pg, dev):
     return comm
 
 
+_ONESHOTS = weakref.WeakKeyDictionary()
+
+
+class _OneshotHandle:
+    """owns one slic_oneshot*; destroyed with its process group or at interpreter exit (slic_oneshot_destroy never waits for a peer)"""
+
+    def __init__(self, ptr_, max_n):
+        self.ptr, self.max_n = ptr_, max_n
+        self._fin = weakref.finalize(self, _OneshotHandle._close, ptr_)
+
+    @staticmethod
+    def _close(ptr_):
+        try:
+            _lib.load().slic_oneshot_destroy(ptr_)
+        except Exception:
+            pass
+
+
+def _pg_all_gather_bytes(pg, raw, dev):
+    """all-gather one small byte string per rank over the process group (RCCL: device tensors; gloo: host tensors) -> bytes, rank order"""
+    W = torch.distributed.get_world_size(pg)
+    on_dev = torch.distributed.get_backend(pg) == "nccl"
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    t = t.to(dev) if on_dev else t
+    out = torch.empty(W * t.numel(), dtype=torch.uint8, device=t.device)
+    torch.distributed.all_gather_into_tensor(out, t, group=pg)
+    return bytes(out.cpu().numpy().tobytes())
+
+
+def _slic_oneshot(pg, dev, n):
+    """the one-shot exchange of the sharded iteration (include/slic_hip.h: slic_oneshot_*): every rank allocates its inbox, the IPC handles
+    travel over the process group, every rank maps its peers.  One communicator per group, re-made when a larger payload comes along."""
+    h = _ONESHOTS.get(pg)
+    if h is not None and h.max_n >= n:
+        return h.ptr
+    lib = _lib.load()
+    W, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
+    hb = 64
+    mine = (ctypes.c_ubyte * hb)()
+    comm = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        _lib.check(lib.slic_oneshot_create(W, rank, n, comm_timeout_ms(), ctypes.byref(comm), mine), "slic_oneshot_create")
+        allh = _pg_all_gather_bytes(pg, bytes(mine), dev)
+        _lib.check(lib.slic_oneshot_connect(comm, allh), "slic_oneshot_connect")
+    # nobody may push into an inbox before its owner has mapped... (a push only needs the PUSHER's mapping; the barrier keeps a fast rank's
+    # first exchange from racing a slow rank's connect bookkeeping and gives create / connect failures a common point to surface)
+    torch.distributed.barrier(group=pg)
+    _ONESHOTS[pg] = _OneshotHandle(comm, n)
+    return comm
+
+
 def _dist_on(pg):
     # a process group of ONE rank still takes the sharded path (all-gather of one partial, ordered add): that is
     # how a single-GPU box exercises the RCCL code path
@@ -270,7 +321,7 @@ class KMeans:
         # spherical k-means (clustering/cluster_masks.py:73-77 -> spherecluster.SphericalKMeans): rows L2-normalised, no
         # mean-centring, centres renormalised after every averaging, tol compared unscaled
         self.spherical = bool(spherical)
-        assert exchange in ("allreduce", "allgather"), exchange
+        assert exchange in ("allreduce", "allgather", "oneshot"), exchange
         self.exchange = exchange               # the sharded run's one collective per iteration (module docstring)
         self.k = kernels if kernels is not None else HipKernels()
 
@@ -286,12 +337,20 @@ class KMeans:
             return self._fit_rs
         return rs
 
+    def _host_staged(self, t):
+        """device tensors over a gloo group (two ranks sharing ONE GPU — how a one-GPU box runs exchange='oneshot' with two processes; RCCL
+        cannot put two ranks on a device) go through host copies; RCCL groups and host tensors are used as they are"""
+        return t.is_cuda and torch.distributed.get_backend(self.process_group) == "gloo"
+
     def _gather(self, t):
         """all-gather a per-rank tensor [*] -> [W, *] (same shape on every rank)"""
         W = torch.distributed.get_world_size(self.process_group)
-        flat = torch.empty(W * t.numel(), dtype=t.dtype, device=t.device)      # concatenated form (gloo and RCCL)
-        torch.distributed.all_gather_into_tensor(flat, t.contiguous().reshape(-1), group=self.process_group)
-        return flat.view((W,) + tuple(t.shape))
+        src = t.contiguous().reshape(-1)
+        if self._host_staged(t):
+            src = src.cpu()
+        flat = torch.empty(W * t.numel(), dtype=t.dtype, device=src.device)    # concatenated form (gloo and RCCL)
+        torch.distributed.all_gather_into_tensor(flat, src, group=self.process_group)
+        return flat.to(t.device).view((W,) + tuple(t.shape))
 
     def _col_stats(self, X):
         """global column sum / sum of squares as float64 numpy (rank partials added in rank order)"""
@@ -422,7 +481,7 @@ class KMeans:
         if self._sharded:
             W = torch.distributed.get_world_size(self.process_group)
             PL = K * Dp + K + 2                                          # [sums | counts | n_changed lo, hi]
-            if self.exchange == "allreduce":
+            if self.exchange in ("allreduce", "oneshot"):
                 payload = [torch.empty(1, PL, dtype=torch.float64, device=dev) for _ in range(2)]
                 parts = payload                                          # reduced in place
             else:
@@ -437,8 +496,15 @@ class KMeans:
             if (self.exchange == "allreduce" and on_gpu and torch.distributed.get_backend(self.process_group) == "nccl"
                     and os.environ.get("SLIC_KMEANS_COMM", "torch") == "slic"):
                 comm = _slic_comm(self.process_group, dev)
+            # exchange="oneshot": the library's one-shot all-to-all over peer-mapped memory (slic_allreduce_oneshot_f64: one kernel per
+            # iteration instead of a ring all-reduce; csrc/oneshot.hip).  The process group only carries the IPC handles at set-up.
+            oneshot = None
+            if self.exchange == "oneshot":
+                assert on_gpu, "exchange='oneshot' moves device memory between GPUs"
+                oneshot = _slic_oneshot(self.process_group, dev, PL)
             # what a benchmark line reports about the iteration's one exchange (bench.py: secondary.exchange)
-            self.communicator_kind_ = ("slic_comm (the library's own RCCL communicator, slic_allreduce_f64)" if comm is not None else
+            self.communicator_kind_ = ("slic_oneshot (peer-mapped inboxes, one kernel per exchange; no RCCL in the loop)" if oneshot is not None else
+                                       "slic_comm (the library's own RCCL communicator, slic_allreduce_f64)" if comm is not None else
                                        f"torch.distributed process group ({torch.distributed.get_backend(self.process_group)})")
             self.payload_bytes_ = int(payload[0].numel() * payload[0].element_size())
         else:
@@ -486,8 +552,17 @@ class KMeans:
                 if local_failure:
                     payload[sl].zero_()
                     payload[sl].view(-1)[-1] = _POISON
-                if self.exchange == "allreduce" and comm is not None:
+                if self.exchange == "oneshot":
+                    call("slic_allreduce_oneshot_f64", oneshot, ptr(payload[sl]), payload[sl].numel(), stream())
+                elif self.exchange == "allreduce" and comm is not None:
                     call("slic_allreduce_f64", comm, ptr(payload[sl]), payload[sl].numel(), stream())
+                elif self._host_staged(payload[sl]):
+                    if self.exchange == "allreduce":
+                        h = payload[sl].cpu()
+                        torch.distributed.all_reduce(h, group=self.process_group)
+                        payload[sl].copy_(h)
+                    else:
+                        parts[sl].copy_(self._gather(payload[sl].view(-1)).view_as(parts[sl]))
                 elif self.exchange == "allreduce":
                     torch.distributed.all_reduce(payload[sl], group=self.process_group)
                 else:
@@ -519,6 +594,9 @@ class KMeans:
                     # keeps running ahead, and the deadline covers one iteration
                     call("slic_comm_wait_event", comm, ctypes.c_void_p(ev[it & 1].cuda_event), comm_timeout_ms())
                 ev[it & 1].synchronize()
+                if self._sharded and self.exchange == "oneshot":
+                    # the exchange kernel never hangs: a wait that ran out (a lost peer) is recorded and surfaces here
+                    call("slic_oneshot_check", oneshot)
             st = host[it & 1].tolist()
             if self._sharded and st[2] >= _POISON:                      # n_changed = low + 2^20 * high: a peer's poisoned high slot
                 raise _lib.SlicError("sharded k-means: a peer's local half of the Lloyd iteration failed (it raised the cause); "
@@ -717,7 +795,8 @@ class KMeans:
         def bcast(a):
             if not self._sharded:
                 return a
-            t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            t = t if torch.distributed.get_backend(self.process_group) == "gloo" else t.to(dev)
             src = torch.distributed.get_global_rank(self.process_group, 0)
             torch.distributed.broadcast(t, src, group=self.process_group)
             return t.cpu().numpy()

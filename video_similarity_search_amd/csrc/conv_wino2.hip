@@ -39,7 +39,9 @@
 #endif
 #ifndef SLIC_W2_ABL
 #define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range (both kernels), 2 = no stage
-                          // barrier (both), 32 = forward without its epilogue, 256 = forward without the row-major half of its epilogue
+                          // barrier (both), 32 = forward without its epilogue, 256 = forward without the row-major half of its epilogue,
+                          // 512 = the pixel DMAs of a ROW-IMAGE source ([row][C/8][W][8] planes: 16 image rows x 2 KB per double stage as 32 whole
+                          // 1 KB runs instead of 48 gathers of 32-byte pieces — what a planar activation layout would fetch; scripts/r5/ab_planar.sh)
 #endif
 #ifndef SLIC_W2_UAUX
 #define SLIC_W2_UAUX 0    // cache-policy bits of the U / pixel DMAs (experiments: 1 = sc0, 2 = nt, 16 = sc1)
@@ -339,6 +341,27 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
     kt_cd(live ? d : 0, kt, cd);
     const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(tflags, live ? kt : 3, 1);          // -1: this frame does not exist
     const unsigned soff = (unsigned)kt * HWC4 + (unsigned)(cd * 32);      // 8 channels = 32 bytes per double stage
+#if SLIC_W2_ABL & 512
+    {
+      // diagnostic: 32 contiguous 1 KB runs per double stage and workgroup (wave w: runs 4 w .. 4 w + 3 = image rows 2 w, 2 w + 1 of the block's
+      // 16, two halves each), addressed as the planar layout would be: row pitch W C 4 bytes, channel-group pitch W 32 bytes
+      const int rows_total = (int)(p.M / W);
+      const int row0 = (int)(tile0 / (unsigned)Wq) * 2 - 1;      // first image row of the block's patch rows (all frames stacked)
+#pragma unroll
+      for (int u = 2 * part; u < 2 * part + 2; ++u) {
+        const int id = 4 * wave + u;
+        // the row of frame t - 1 + kt, clamped INTO the tensor (the scalar offset is not range-checked; a block may straddle two frames, so the
+        // lanes' own frame flags do not cover every row fetched here): [0, rows_total - 2] leaves room for the run's 2 KB
+        int rg = row0 + (id >> 1) + (kt - 1) * H;
+        rg = rg < 0 ? 0 : (rg > rows_total - 2 ? rows_total - 2 : rg);
+        const unsigned so2 = HWC4 + (unsigned)rg * (unsigned)(W * C * 4) + (unsigned)(cd * W * 32) + (unsigned)((id & 1) * 1024);
+        const unsigned off = ((unsigned)lane * 16u) | inv;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + slot * W2_PX_FLOATS + id * 256),
+                                                 16, (int)off, (int)so2, 0, SLIC_W2_PAUX);
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int u = 3 * part; u < 3 * part + 3; ++u) {
       constexpr int ORD[6] = SLIC_W2_PXORDER;
@@ -424,7 +447,11 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   // issued first thing in stage s - 1.  vmcnt retires in order, so the wait in front of an odd stage leaves the six pixel pieces
   // in flight (vmcnt(6)) and the one in front of an even stage takes everything (vmcnt(0): the pixels issued two stages ago, the U
   // issued one stage ago).  Four stage bodies per loop turn: (double-stage parity, channel half) fix every LDS slot at compile time.
+#if SLIC_W2_ABL & 512
+  constexpr unsigned WAIT_VM6_LGKM0 = 4 | 0x70, WAIT_VM0_LGKM0 = 0x70;      // four pixel runs per wave and double stage
+#else
   constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
+#endif
   for (int s0 = 0; s0 < NSL; s0 += 4) {
 #pragma unroll
     for (int sidx = 0; sidx < 4; ++sidx) {

@@ -502,10 +502,17 @@ template <int NK, int GS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void topk_partial_qreg(
     const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int k, int self_mask,
     int g_per_slice, int TK_PC, float* __restrict__ pval, int32_t* __restrict__ pidx /* [slices][Nq][k] */,
-    int* __restrict__ gthr) {
+    int* __restrict__ gthr, int gstep /* gallery row r of this launch = row r * gstep of G (a strided SAMPLE; 1 = all rows) */,
+    const int* __restrict__ qmap /* query slot q reads row qmap[q] of Q (NULL: q) */,
+    const int* __restrict__ nq_dev /* number of query slots in use, read on the device (NULL: Nq) */) {
   TKC_DECL
   extern __shared__ __attribute__((aligned(16))) float lds[];
   static_assert(NK % 4 == 0, "a gallery tile is a whole number of ring turns");
+  const int Nq_cap = Nq;                                       // row pitch of the partial lists
+  if (nq_dev) {
+    Nq = *nq_dev;
+    if ((int)blockIdx.x * TK_BQ >= Nq) return;                 // (workgroup-uniform, before any barrier)
+  }
   constexpr int STAGE_FLOATS = TK_BG * TK_BK;                  // gallery rows only
   const int kh = 1 + ((k + 2) / 4) * 4;
   unsigned long long* heaps = (unsigned long long*)(lds + 4 * STAGE_FLOATS);
@@ -531,8 +538,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // lane (r, h) of MFMA step (kt, qd, t) multiplies by Q[q][32 kt + 8 qd + 4 h + t]
   f32x4 qr[NK][4];
+  int qself;                                                   // the gallery index that IS this query (self_mask)
   {
-    const float* qrow = Q + (int64_t)(q < Nq ? q : Nq - 1) * D;
+    const int qs = q < Nq ? q : Nq - 1;
+    qself = qmap ? qmap[qs] : q;
+    const float* qrow = Q + (int64_t)(qmap ? qmap[qs] : qs) * D;
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt)
 #pragma unroll
@@ -545,12 +555,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   const int srow = tid >> 3;
   const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
+  const unsigned rowb = (unsigned)D * (unsigned)gstep * 4u;    // bytes between two rows of this launch's gallery
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(G + (int64_t)gbeg * D), 0, (int)((int64_t)(gend - gbeg) * D * 4), 0x00020000);     // rows past the slice: zeros
+      (void*)(G + (int64_t)gbeg * gstep * D), 0, (int)(((int64_t)(gend - gbeg - 1) * gstep + 1) * D * 4), 0x00020000);     // rows past the slice: zeros
   constexpr unsigned OOB = 0xFFFFFF00u;
   unsigned goff[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) goff[i] = ((unsigned)(srow + 32 * i) * (unsigned)D + cq * 4) * 4u;
+  for (int i = 0; i < 4; ++i) goff[i] = (unsigned)(srow + 32 * i) * rowb + (unsigned)(cq * 16);
   const int klim = D - cq * 4;
   const int ntile = (gend - gbeg + TK_BG - 1) / TK_BG;
   // the DMAs of ring step (tile, kt): k-tiles past D are all-zero, a tile past the end is all out of range
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float* Gs = lds + stage * STAGE_FLOATS;
     const bool kin = kt * TK_BK < klim && tile < ntile;
     const unsigned kb = (unsigned)kt * (TK_BK * 4u);
-    const unsigned gb = (unsigned)tile * (unsigned)(TK_BG * D * 4);
+    const unsigned gb = (unsigned)tile * ((unsigned)TK_BG * rowb);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(Gs + (8 * wave + 32 * i) * TK_BK),
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     pc = 0;
     thr = owner ? tk_key_score(root) : INFINITY;
-    if (owner && thr > -INFINITY) {                            // publish the new root (see topk_partial_dma)
+    if (owner && gthr && thr > -INFINITY) {                    // publish the new root (see topk_partial_dma)
       const int b = __float_as_int(thr);
       atomicMax(gthr + q, b >= 0 ? b : b ^ 0x7FFFFFFF);
     }
@@ -636,7 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else if (kt == 1) {
         if (tid == 0) wflag[(tile + 1) & 1] = 0;               // everybody has read it: clear it for the tile after this one
       } else if (kt == NK - 2) {
-        if (owner) gimg = __builtin_nontemporal_load(gthr + q); // the other slices' best bound, needed when the tile ends
+        if (owner && gthr) gimg = __builtin_nontemporal_load(gthr + q); // the other slices' best bound, needed when the tile ends (NULL: the slices keep to themselves)
       }
       const float* Gs = lds + (kt & 3) * STAGE_FLOATS;
       const float* Gn = lds + ((kt + 1) & 3) * STAGE_FLOATS;
@@ -664,9 +675,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     const int g0 = gbeg + tile * TK_BG;
     const bool ragged = g0 + TK_BG > gend;
-    const bool selfhit = self_mask && g0 < q0 + 32 * wave + 32 && g0 + TK_BG > q0 + 32 * wave;
+    // (with a query map the slots of a block are arbitrary rows: the range test that skips the per-element comparison does not apply)
+    const bool selfhit = self_mask && (qmap != nullptr || (g0 < q0 + 32 * wave + 32 && g0 + TK_BG > q0 + 32 * wave));
     if (ragged || selfhit) {
-      const int qo = q0 + 32 * wave + r;
+      const int qo = qself;
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
@@ -710,12 +722,274 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   TKC_FLUSH;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
   if (h == 0 && q < Nq) {
-    float* ov = pval + ((int64_t)blockIdx.y * Nq + q) * k;
-    int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq + q) * k;
+    float* ov = pval + ((int64_t)blockIdx.y * Nq_cap + q) * k;
+    int32_t* oi = pidx + ((int64_t)blockIdx.y * Nq_cap + q) * k;
     for (int s = 0; s < k; ++s) {
       const unsigned long long e = hp[s * 32 + r];
       ov[s] = tk_key_score(e);
       oi[s] = tk_key_index(e);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The COLLECT path (round 5; D <= 512, galleries of >= 32k rows): threshold, then collect, then select.
+//   A per-query streaming top-k pays for its list: at k = 50 every (query, slice) pair makes ~75 heap insertions, each a dependent chain
+//   of LDS round trips during which the wave's matrix pipe idles (one wave per SIMD) — 9.2 ms at k = 50 against 7.9 at k = 1.
+//   Here the similarity pass keeps NO list:
+//   1. topk_partial_qreg on a strided SAMPLE of the gallery (~3 % of it in 3 slices, the M = 12 best of each: tiny heaps) ->
+//      topk_thresholds: tau_q = the M-th best of the pooled sample — about 6 k + 100 gallery rows are expected to reach it;
+//   2. topk_collect_qreg: the k = 1 kernel's matrix loop over the WHOLE gallery; a score >= tau_q is appended to the lane's pending
+//      column in LDS (one compare per group of four scores, as before) and the columns go to the query's candidate buffer in memory
+//      (one atomic add per lane and drain: a reservation, not a list) — no heap, no bound to publish, no drain stalls;
+//   3. topk_select: one wave per query sorts out the k best of its n candidates (n ~ 400: k rounds of a wave-wide maximum over 64-bit
+//      keys), ascending distance, ties -> lower index.  Exactness: every gallery row whose score reaches tau_q is a candidate, so the k best
+//      candidates ARE the k best rows whenever n >= k.  A query with n < k (tau_q too high: a < 1e-6 event per query) or n > capacity
+//      (heavy ties / duplicated rows) is put on a list, and
+//   4. the queries on that list — normally none: the launches then exit at once — go through the streaming kernels above (query map +
+//      device-side count), whose results are exact for any data.
+// ------------------------------------------------------------------------------------------
+#define TKC_CAP 2048          // most candidate slots per query (keys of 8 bytes); a call's own count: TopkCollectPlan::cap
+
+__global__ __launch_bounds__(256) void topk_thresholds(const float* __restrict__ pval /* [slices][Nq][ms]: the ms best of every sample slice */,
+                                                        int slices, int Nq, int ms, int M, float* __restrict__ tau, int* __restrict__ cnt,
+                                                        int* __restrict__ nfail) {
+  // one WAVE per query: the M-th best of the pooled lists (slices * ms <= 128 entries, two per lane).  Every entry counts the entries that
+  // come before it in (score descending, position ascending) order — the pooled values are broadcast from LDS — and the one with M - 1
+  // predecessors is the threshold.  (One THREAD per query walking M rounds over the lists took 74 us for 10k queries.)
+  __shared__ float pool[4][128];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + w;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nfail = 0;
+  if (q >= Nq) return;                                         // (whole waves leave: no barrier below)
+  const int E = slices * ms;
+  float mine[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = lane + 64 * u;
+    mine[u] = e < E ? pval[((int64_t)(e / ms) * Nq + q) * ms + (e % ms)] : -INFINITY;
+    pool[w][e] = mine[u];
+  }
+  __builtin_amdgcn_wave_barrier();
+  int before[2] = {0, 0};
+  for (int j = 0; j < E; ++j) {
+    const float x = pool[w][j];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) before[u] += (x > mine[u] || (x == mine[u] && j < lane + 64 * u)) ? 1 : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (lane + 64 * u < E && before[u] == M - 1) {
+      // -inf (a sample that never filled its lists) would admit masked scores too: the lowest finite threshold instead
+      tau[q] = fmaxf(mine[u], -3.0e38f);
+      cnt[q] = 0;
+    }
+}
+
+template <int NK, int GS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void topk_collect_qreg(
+    const float* __restrict__ Q, int Nq, const float* __restrict__ G, int Ng, int D, int self_mask, int g_per_slice, int TK_PC,
+    const float* __restrict__ tau, int* __restrict__ cnt, unsigned long long* __restrict__ cand /* [Nq][cap] keys */, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  static_assert(NK % 4 == 0, "a gallery tile is a whole number of ring turns");
+  constexpr int STAGE_FLOATS = TK_BG * TK_BK;                  // gallery rows only
+  unsigned long long* pend = (unsigned long long*)(lds + 4 * STAGE_FLOATS);      // [4 waves][TK_PC][64] keys, one column per LANE
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.x * TK_BQ;
+  const int gbeg = blockIdx.y * g_per_slice;
+  const int gend = min(gbeg + g_per_slice, Ng);
+  unsigned long long* pq = pend + wave * TK_PC * 64;
+  int pc = 0;
+  const int q = q0 + 32 * wave + r;
+  // both halves of a lane pair serve query r and test against its threshold; slots past Nq never see a candidate
+  const float filt = q < Nq ? tau[q] : INFINITY;
+  f32x4 qr[NK][4];
+  {
+    const float* qrow = Q + (int64_t)(q < Nq ? q : Nq - 1) * D;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int c = 32 * kt + 8 * qd + 4 * h;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        qr[kt][qd] = c < D ? *(const f32x4*)(qrow + c) : z;
+      }
+  }
+  const int srow = tid >> 3;
+  const int cq = (tid & 7) ^ ((srow >> 1) & 7);              // SOURCE chunk of this lane (LDS slot = tid & 7)
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(G + (int64_t)gbeg * D), 0, (int)((int64_t)(gend - gbeg) * D * 4), 0x00020000);     // rows past the slice: zeros
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned goff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) goff[i] = ((unsigned)(srow + 32 * i) * (unsigned)D + cq * 4) * 4u;
+  const int klim = D - cq * 4;
+  const int ntile = (gend - gbeg + TK_BG - 1) / TK_BG;
+  auto issue = [&](int tile, int kt, int stage) {
+    float* Gs = lds + stage * STAGE_FLOATS;
+    const bool kin = kt * TK_BK < klim && tile < ntile;
+    const unsigned kb = (unsigned)kt * (TK_BK * 4u);
+    const unsigned gb = (unsigned)tile * (unsigned)(TK_BG * D * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (__attribute__((address_space(3))) void*)(Gs + (8 * wave + 32 * i) * TK_BK),
+                                               16, (int)(kin ? gb + goff[i] + kb : OOB), 0, 0, 0);
+  };
+  // a lane's pending keys -> the query's candidate buffer: ONE atomic add reserves the lane's slots (its return is the only round trip
+  // to memory; a drain happens at the end of the slice and when a column runs full — every ~100 tiles at 400 candidates per query)
+  auto drain = [&]() {
+    if (pc > 0) {
+      const int base = atomicAdd(cnt + q, pc);
+      for (int j = 0; j < pc; ++j)
+        if (base + j < cap) {
+          const unsigned long long raw = pq[j * 64 + lane];     // {score bits, gallery index}
+          cand[(int64_t)q * cap + base + j] = tk_key(__uint_as_float((unsigned)raw), (int)(raw >> 32));
+        }
+    }
+    pc = 0;
+  };
+  f32x16 acc[4];
+  f32x4 a[2][4];
+  issue(0, 0, 0);
+  issue(NK > 1 ? 0 : 1, NK > 1 ? 1 : 0, 1);
+  issue(NK > 2 ? 0 : 1, NK > 2 ? 2 : 0, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // step 0 has landed
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) a[0][ct] = *(const f32x4*)&lds[tk_off(32 * ct + r, h)];
+  for (int tile = 0; tile < ntile; ++tile) {
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[ct][v] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+      // (a drain's stores and atomic may sit among the outstanding DMAs: they only make this wait stricter)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // step s + 1 has landed (this wave's part of it)
+      __builtin_amdgcn_s_barrier();                            // ... everybody's; and stage (kt + 3) & 3 has been read by all
+      {
+        const int kn = kt + 3;
+        issue(kn >= NK ? tile + 1 : tile, kn >= NK ? kn - NK : kn, kn & 3);
+      }
+      const float* Gs = lds + (kt & 3) * STAGE_FLOATS;
+      const float* Gn = lds + ((kt + 1) & 3) * STAGE_FLOATS;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int cur = qd & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+          a[nxt][ct] = qd < 3 ? *(const f32x4*)&Gs[tk_off(32 * ct + r, 2 * (qd + 1) + h)]
+                              : *(const f32x4*)&Gn[tk_off(32 * ct + r, h)];       // first fragments of the next step
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int ct = 0; ct < 4; ++ct)
+            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][ct][t], qr[kt][qd][t], acc[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    const int g0 = gbeg + tile * TK_BG;
+    const bool ragged = g0 + TK_BG > gend;
+    const bool selfhit = self_mask && g0 < q0 + 32 * wave + 32 && g0 + TK_BG > q0 + 32 * wave;
+    if (ragged || selfhit) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int gi = g0 + ct * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+          if (gi >= gend || (self_mask && gi == q)) acc[ct][v] = -INFINITY;      // never >= a finite threshold
+        }
+    }
+    const int gl = g0 + 4 * h;                                 // this lane's rows of the tile: gl + an immediate
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int v0 = 0; v0 < 16; v0 += GS) {
+        if (__any(pc > TK_PC - GS)) drain();                    // room for a whole group in every lane's column
+        float gm = acc[ct][v0];
+#pragma unroll
+        for (int v = v0 + 1; v < v0 + GS; ++v) gm = fmaxf(gm, acc[ct][v]);
+        if (gm >= filt) {
+#pragma unroll
+          for (int v = v0; v < v0 + GS; ++v) {
+            const float sc = acc[ct][v];
+            if (sc >= filt) {                                  // the raw pair: the key is built when the column is drained
+              pq[pc * 64 + lane] = ((unsigned long long)(unsigned)(gl + (ct * 32 + (v & 3) + 8 * (v >> 2))) << 32) | __float_as_uint(sc);
+              ++pc;
+            }
+          }
+        }
+      }
+  }
+  drain();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
+}
+
+// one WAVE per query: the k best of its n = cnt[q] candidate keys, best first.  n <= 64 * PER keys (PER = 8 covers 512: what the plan's
+// ~6 k + 100 candidates need; 16 for small sample statistics with their wider spread) sit in the lanes' registers
+// (k rounds of: lane-local maximum -> wave maximum by shuffles -> the owner retires it); more (rare) are re-read from memory every
+// round.  n < k or n > cap: the query goes on the fallback list and its output row is left to that pass.
+#define TKS_PER 16
+template <int PER>
+__global__ __launch_bounds__(256) void topk_select(const unsigned long long* __restrict__ cand, const int* __restrict__ cnt, int Nq, int k, int cap,
+                                                   int32_t* __restrict__ out_idx, float* __restrict__ out_dist, int* __restrict__ failq,
+                                                   int* __restrict__ nfail) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Nq) return;
+  const int lane = threadIdx.x & 63;
+  const int n = cnt[q];
+  if (n < k || n > cap) {
+    if (lane == 0) failq[atomicAdd(nfail, 1)] = q;
+    return;
+  }
+  const unsigned long long* c = cand + (int64_t)q * cap;
+  auto wave_max = [&](unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)v, d), hi = __shfl_xor((unsigned)(v >> 32), d);
+      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+      v = o > v ? o : v;
+    }
+    return v;
+  };
+  auto emit = [&](int o, unsigned long long w) {
+    if (lane == 0) {
+      out_idx[(int64_t)q * k + o] = tk_key_index(w);
+      out_dist[(int64_t)q * k + o] = fminf(fmaxf(1.0f - tk_key_score(w), 0.f), 2.f);
+    }
+  };
+  if (n <= 64 * PER) {
+    unsigned long long v[PER];                                 // 0 = retired / absent (no real key is 0: its low word would be ~(-1))
+#pragma unroll
+    for (int u = 0; u < PER; ++u) v[u] = lane + 64 * u < n ? c[lane + 64 * u] : 0ull;
+    for (int o = 0; o < k; ++o) {
+      unsigned long long b = 0ull;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) b = v[u] > b ? v[u] : b;
+      const unsigned long long w = wave_max(b);
+      if (b == w) {                                            // keys are unique per query (they carry the gallery index)
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+          if (v[u] == w) v[u] = 0ull;
+      }
+      emit(o, w);
+    }
+  } else {
+    unsigned long long last = ~0ull;                           // every key still in play is < last
+    for (int o = 0; o < k; ++o) {
+      unsigned long long b = 0ull;
+      for (int e = lane; e < n; e += 64) {
+        const unsigned long long x = c[e];
+        if (x < last && x > b) b = x;
+      }
+      const unsigned long long w = wave_max(b);
+      emit(o, w);
+      last = w;
     }
   }
 }
@@ -726,9 +1000,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define TKM_PER 32
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
                                                          int slices, int Nq, int k, int32_t* __restrict__ out_idx,
-                                                         float* __restrict__ out_dist) {
+                                                         float* __restrict__ out_dist, const int* __restrict__ qmap /* output row of list q (NULL: q) */,
+                                                         const int* __restrict__ nq_dev /* lists in use, read on the device (NULL: Nq) */) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= Nq) return;
+  if (q >= (nq_dev ? *nq_dev : Nq)) return;
+  const int64_t qo = qmap ? qmap[q] : q;
   const int lane = threadIdx.x & 63;
   const int tot = slices * k;
   float v[TKM_PER];
@@ -758,10 +1034,10 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
       for (int u = 0; u < TKM_PER; ++u) if (u == bu) { v[u] = -INFINITY; ix[u] = INT_MAX; }
     }
     if (lane == 0) {
-      out_idx[(int64_t)q * k + o] = wi == INT_MAX ? -1 : wi;
+      out_idx[qo * k + o] = wi == INT_MAX ? -1 : wi;
       float d = 1.0f - ws;
       d = fminf(fmaxf(d, 0.f), 2.f);
-      out_dist[(int64_t)q * k + o] = wi == INT_MAX ? INFINITY : d;
+      out_dist[qo * k + o] = wi == INT_MAX ? INFINITY : d;
     }
   }
 }
@@ -835,10 +1111,10 @@ static int topk_slices(int Nq, int Ng, int k) {
   // The LDS lists allow ONE workgroup per CU, so the grid (query blocks x gallery slices) should be a whole number of
   // 256-workgroup rounds: among the slice counts that give 3+ rounds (if the gallery allows), take the one that fills its
   // last round best — e.g. 79 query blocks: 13 slices = 1027 workgroups = 4 rounds + 3 stragglers (80 %), 16 slices =
-  // 1264 = 4.94 rounds (99 %).
+  // 1264 = 4.94 rounds (99 %).  k <= 0: no lists to merge afterwards (the collect pass), so no cap on the slice count.
   const int qb = (int)slic_cdiv(Nq, TK_BQ);
   int maxs = (int)slic_cdiv(Ng, 4 * TK_BG);               // at least 4 gallery tiles per slice
-  const int cap = (64 * TKM_PER) / (k < 1 ? 1 : k);       // the merge kernel holds slices * k entries in one wave's registers
+  const int cap = k > 0 ? (64 * TKM_PER) / k : maxs;      // the merge kernel holds slices * k entries in one wave's registers
   if (maxs > cap) maxs = cap;
   if (maxs < 1) maxs = 1;
   int lo = (int)slic_cdiv(3 * 256, qb);
@@ -854,23 +1130,61 @@ static int topk_slices(int Nq, int Ng, int k) {
   return best;
 }
 
-extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
-  return 2 * slic_align_up((size_t)topk_slices(Nq, Ng, k) * Nq * k * 4, 256) + slic_align_up((size_t)Nq * 4, 256);
+// The collect path's sample (see the comment above topk_thresholds): S1 slices of per1 strided rows each, the M best of every slice;
+// tau_q = the M-th best of the POOLED sample (it is among the slices' M best), which a fraction ~ M / (S1 per1) of the gallery is expected
+// to reach.  Aim: 6 k + 100 candidates per query from a sample of <= ~4 % of the gallery, M = 4 .. 16: both failure events (fewer than k
+// candidates, more than TKC_CAP) stay below 1e-6 per query for any continuous score distribution (scripts/r5/topk_threshold_sim.py).
+struct TopkCollectPlan { bool on; int S1, per1, m1, gstep, cap, ms; };
+static TopkCollectPlan topk_collect_plan(int Nq, int Ng, int k) {
+  TopkCollectPlan c = {false, 0, 0, 0, 1, TKC_CAP, 0};
+  // SLIC_TOPK_COLLECT: 0 = never, 1 = wherever the shape allows, unset = where it is faster: k >= 16 (10k x 100k x 512 on one MI355X, ms,
+  // collect / streaming: k = 1 8.4 / 8.0, k = 10 8.3 / 8.0, k = 50 8.6 / 9.1, k = 88 8.8 / 12.4 — a short list costs the streaming kernels
+  // almost nothing, while the collect pass pays ~0.3 ms for its sample and tests ~0.4 % of the scores one by one whatever k is)
+  const char* e = getenv("SLIC_TOPK_COLLECT");
+  const bool force = e && e[0] == '1';
+  if ((e && e[0] == '0') || Ng < 32768 || k > TK_KMAX || (k < 16 && !force)) return c;
+  const int qb = (int)slic_cdiv(Nq, TK_BQ);
+  const double target = 6.0 * k + 100.0;
+  int M = (int)(target * 0.04 + 0.5);
+  M = M < 4 ? 4 : (M > 12 ? 12 : M);
+  const double ns = M * (double)Ng / target;
+  int S1 = 256 / qb;                                            // one dispatch round of sample workgroups
+  S1 = S1 < 1 ? 1 : (S1 > 8 ? 8 : S1);
+  if (ns / S1 < 2 * TK_BG) { S1 = (int)(ns / (2 * TK_BG)); if (S1 < 1) S1 = 1; }
+  int per1 = (int)slic_cdiv((int64_t)(ns / S1), TK_BG) * TK_BG;
+  if (per1 < 2 * TK_BG) per1 = 2 * TK_BG;
+  M = (int)(target * S1 * per1 / Ng + 0.5);
+  M = M < 4 ? 4 : (M > 16 ? 16 : M);
+  if ((int64_t)S1 * per1 * 8 > Ng) return c;
+  c.on = true; c.S1 = S1; c.per1 = per1; c.m1 = M; c.gstep = Ng / (S1 * per1);
+  // entries kept per sample slice: the pooled M best are spread over the slices ~ evenly, so M / S1 + 3 per slice hold them all but
+  // rarely — and when they do not, tau comes out one or two order statistics lower: a few more candidates, never a wrong result
+  c.ms = S1 == 1 ? M : (M < (M + S1 - 1) / S1 + 3 ? M : (M + S1 - 1) / S1 + 3);
+  // candidate slots: the count is ~ Gamma(M) / M x its mean — 9 x the mean for M <= 6, 6 x up to 9, 4 x beyond keep an overflow below 1e-9
+  const double room = target * (M <= 6 ? 9.0 : (M <= 9 ? 6.0 : 4.0));
+  int cap = 512;
+  while (cap < room && cap < TKC_CAP) cap <<= 1;
+  c.cap = cap;
+  return c;
 }
 
-// Qn, Gn: L2-normalised rows (slic_normalize_rows).  out_idx / out_dist: [Nq, k], ascending distance.
-extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
-                                int32_t* out_idx, float* out_dist, void* workspace, void* stream) {
-  SLIC_REQUIRE(Qn && Gn && out_idx && out_dist && workspace, "slic_cosine_topk: null pointer");
-  SLIC_REQUIRE(Nq > 0 && Ng > 0 && D > 0 && D % 8 == 0 && k >= 1 && k <= TK_KMAX && k <= Ng,
-               "slic_cosine_topk: need D %% 8 == 0, 1 <= k <= min(%d, Ng) (Nq=%d Ng=%d D=%d k=%d)", TK_KMAX, Nq, Ng, D, k);
-  SLIC_REQUIRE(((uintptr_t)Qn % 16) == 0 && ((uintptr_t)Gn % 16) == 0, "slic_cosine_topk: unaligned");
-  hipStream_t st = S_(stream);
+extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
+  size_t b = 2 * slic_align_up((size_t)topk_slices(Nq, Ng, k) * Nq * k * 4, 256) + slic_align_up((size_t)Nq * 4, 256);
+  const TopkCollectPlan c = topk_collect_plan(Nq, Ng, k);
+  if (c.on)
+    b += 2 * slic_align_up((size_t)c.S1 * Nq * c.ms * 4, 256) + 3 * slic_align_up((size_t)Nq * 4, 256) + 256 +
+         slic_align_up((size_t)Nq * c.cap * 8, 256);
+  return b;
+}
+
+// the streaming path: per-(query, slice) lists in LDS + merge.  qmap / nq_dev (device memory; both or neither): query slot q of [0, *nq_dev)
+// is row qmap[q] of Qn and its result goes to output row qmap[q] — the exact fallback of the collect path; Nq then bounds the slot count.
+static int topk_stream(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask, int32_t* out_idx, float* out_dist,
+                       SlicCarver& w, hipStream_t st, const int* qmap, const int* nq_dev) {
   const int slices = topk_slices(Nq, Ng, k);
   int per = (int)slic_cdiv(Ng, slices);
   per = (int)slic_cdiv(per, TK_BG) * TK_BG;
   const int S = (int)slic_cdiv(Ng, per);
-  SlicCarver w(workspace);
   float* pval = w.take<float>((size_t)slices * Nq * k);
   int32_t* pidx = w.take<int32_t>((size_t)slices * Nq * k);
   // LDS: 2 ring stages + heaps [4][kh][32] keys (kh = k rounded up to 4 m + 1) + pending [4][pcap][64] keys, one column per LANE
@@ -886,8 +1200,10 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
     lds_set = lds;
   }
   dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
+  const bool dma_ok = (int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31);
+  SLIC_REQUIRE(!qmap || (dma_ok && D <= 512), "slic_cosine_topk: internal: the query map needs the register-operand kernel");
   // LDS-DMA kernel unless a gallery slice exceeds the 32-bit byte range of one buffer resource (> 2 GiB: then the register-staged one)
-  if ((int64_t)per * D * 4 < (1ll << 31) && (int64_t)TK_BQ * D * 4 < (1ll << 31)) {
+  if (dma_ok) {
     static size_t lds_set2 = 0;
     if (lds > lds_set2) {
       SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_dma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -908,7 +1224,7 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
         SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set3 = lds;
       }
-#define TK_LAUNCH_QREG(NK, GS) topk_partial_qreg<NK, GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr)
+#define TK_LAUNCH_QREG(NK, GS) topk_partial_qreg<NK, GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr, 1, qmap, nq_dev)
       if (pcap >= 12) {                                       // pending columns long enough for groups of four scores
         if (D > 256) TK_LAUNCH_QREG(16, 4); else if (D > 128) TK_LAUNCH_QREG(8, 4); else TK_LAUNCH_QREG(4, 4);
       } else {
@@ -923,9 +1239,91 @@ extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng
   topk_partial_kernel<<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, (2 * pcap) & ~1, pval, pidx);
   SLIC_LAUNCH_CHECK();
   SLIC_REQUIRE((int64_t)S * k <= 64 * TKM_PER, "slic_cosine_topk: slices * k = %d exceeds the merge kernel's %d entries", S * k, 64 * TKM_PER);
-  topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist);
+  topk_merge_kernel<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(pval, pidx, S, Nq, k, out_idx, out_dist, qmap, nq_dev);
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
+}
+
+// threshold -> collect -> select -> exact fallback for the queries whose candidate count fell outside [k, cap]
+static int topk_collect(const TopkCollectPlan& c, const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
+                        int32_t* out_idx, float* out_dist, SlicCarver& w, hipStream_t st) {
+  float* pval1 = w.take<float>((size_t)c.S1 * Nq * c.ms);
+  int32_t* pidx1 = w.take<int32_t>((size_t)c.S1 * Nq * c.ms);
+  float* tau = w.take<float>((size_t)Nq);
+  int* cnt = w.take<int>((size_t)Nq);
+  int* failq = w.take<int>((size_t)Nq);
+  int* nfail = w.take<int>(64);
+  unsigned long long* cand = w.take<unsigned long long>((size_t)Nq * c.cap);
+  // ---- 1. the sample: S1 slices of per1 rows, every gstep-th row of the gallery, the m1 best of each (tiny heaps: LDS is no constraint)
+  {
+    const int kh = 1 + ((c.ms + 2) / 4) * 4;
+    const int pcap = TK_PC_MAX;
+    const size_t lds = (size_t)2 * 2 * TK_BQ * TK_BK * sizeof(float) + (size_t)4 * kh * 32 * 8 + (size_t)4 * pcap * 64 * 8 + 16;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set = lds;
+    }
+    dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)c.S1);
+    const int ns = c.S1 * c.per1;
+#define TK_LAUNCH_S(NK) topk_partial_qreg<NK, 4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, ns, D, c.ms, 0, c.per1, pcap, pval1, pidx1, nullptr, c.gstep, nullptr, nullptr)
+    if (D > 256) TK_LAUNCH_S(16); else if (D > 128) TK_LAUNCH_S(8); else TK_LAUNCH_S(4);
+#undef TK_LAUNCH_S
+    SLIC_LAUNCH_CHECK();
+    topk_thresholds<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(pval1, c.S1, Nq, c.ms, c.m1, tau, cnt, nfail);
+    SLIC_LAUNCH_CHECK();
+  }
+  // ---- 2. the whole gallery against the thresholds
+  {
+    const int slices = topk_slices(Nq, Ng, 0);
+    int per = (int)slic_cdiv(Ng, slices);
+    per = (int)slic_cdiv(per, TK_BG) * TK_BG;
+    const int S = (int)slic_cdiv(Ng, per);
+    const int pcap = TK_PC_MAX;
+    const size_t lds = (size_t)4 * TK_BG * TK_BK * sizeof(float) + (size_t)4 * pcap * 64 * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
+#define TK_LAUNCH_C(NK) topk_collect_qreg<NK, 4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, self_mask, per, pcap, tau, cnt, cand, c.cap)
+    if (D > 256) TK_LAUNCH_C(16); else if (D > 128) TK_LAUNCH_C(8); else TK_LAUNCH_C(4);
+#undef TK_LAUNCH_C
+    SLIC_LAUNCH_CHECK();
+  }
+  // ---- 3. the k best candidates of every query; 4. whoever fell outside [k, TKC_CAP] through the streaming path (normally nobody)
+  if (c.m1 >= 10) topk_select<8><<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
+  else topk_select<TKS_PER><<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
+  SLIC_LAUNCH_CHECK();
+  return topk_stream(Qn, Nq, Gn, Ng, D, k, self_mask, out_idx, out_dist, w, st, failq, nfail);
+}
+
+extern "C" int slic_cosine_topk_plan(int Nq, int Ng, int D, int k, int* out) {
+  SLIC_REQUIRE(out && Nq > 0 && Ng > 0 && D > 0 && k >= 1, "slic_cosine_topk_plan: bad args");
+  const TopkCollectPlan c = topk_collect_plan(Nq, Ng, k);
+  const bool on = c.on && D <= 512 && D % 8 == 0 && (int64_t)Ng * D * 4 < (1ll << 31);
+  out[0] = on ? 1 : 0; out[1] = on ? c.S1 : 0; out[2] = on ? c.per1 : 0; out[3] = on ? c.m1 : 0; out[4] = on ? c.gstep : 0; out[5] = on ? c.cap : 0;
+  return SLIC_OK;
+}
+
+// Qn, Gn: L2-normalised rows (slic_normalize_rows).  out_idx / out_dist: [Nq, k], ascending distance.
+extern "C" int slic_cosine_topk(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask,
+                                int32_t* out_idx, float* out_dist, void* workspace, void* stream) {
+  SLIC_REQUIRE(Qn && Gn && out_idx && out_dist && workspace, "slic_cosine_topk: null pointer");
+  SLIC_REQUIRE(Nq > 0 && Ng > 0 && D > 0 && D % 8 == 0 && k >= 1 && k <= TK_KMAX && k <= Ng,
+               "slic_cosine_topk: need D %% 8 == 0, 1 <= k <= min(%d, Ng) (Nq=%d Ng=%d D=%d k=%d)", TK_KMAX, Nq, Ng, D, k);
+  SLIC_REQUIRE(((uintptr_t)Qn % 16) == 0 && ((uintptr_t)Gn % 16) == 0, "slic_cosine_topk: unaligned");
+  hipStream_t st = S_(stream);
+  SlicCarver w(workspace);
+  const TopkCollectPlan c = topk_collect_plan(Nq, Ng, k);
+  if (c.on && D <= 512 && (int64_t)Ng * D * 4 < (1ll << 31))
+    return topk_collect(c, Qn, Nq, Gn, Ng, D, k, self_mask, out_idx, out_dist, w, st);
+  return topk_stream(Qn, Nq, Gn, Ng, D, k, self_mask, out_idx, out_dist, w, st, nullptr, nullptr);
 }
 
 extern "C" int slic_topk_merge_lists(const float* pdist, const int32_t* pidx, int W, int Nq, int k, int32_t* out_idx,
