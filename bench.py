@@ -694,31 +694,7 @@ def main():
             res["secondary"]["train_b8"] = dict(metric="clips/sec R3D-18+NT-Xent training step at B = 8 x 3x16x112x112, per GPU", value=8 / dt8,
                                                 unit="clips/s", ms_per_step=dt8 * 1e3,
                                                 frac_of_fp32_mfma_peak_executed=exe8 / dt8 / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                                algorithmic_tflops=alg8 / dt8 / 1e12, issue="eager: every launch issued from Python")
-            if not use_dist:
-                # the same step captured ONCE into a hipGraph (misc/graph_step.py) and replayed: at 8 clips the eager step is ~330 launches
-                # of 10-40 us kernels and the GPU waits for the host; the replay issues them with no host work in between.  Same kernels,
-                # same order, same buffers: bit-identical results (tests/test_train_loop_gpu.py::test_graphed_step_equals_eager)
-                try:
-                    from video_similarity_search_amd.misc.graph_step import GraphedStep
-
-                    def step8_graph():
-                        emb = model(x8)
-                        l8, _ = crit(emb, lab8, sampling_strategy='noise_contrastive')
-                        opt.zero_grad(set_to_none=True)
-                        l8.backward()
-                        opt.step()
-                        return l8.detach()
-                    g8 = GraphedStep(step8_graph, warmup=2)
-                    dt8g = timed_steps(g8.replay, 3, 20)
-                    res["secondary"]["train_b8_graph"] = dict(
-                        metric="clips/sec R3D-18+NT-Xent training step at B = 8 x 3x16x112x112, the whole step replayed from a hipGraph, per GPU",
-                        value=8 / dt8g, unit="clips/s", ms_per_step=dt8g * 1e3,
-                        frac_of_fp32_mfma_peak_executed=exe8 / dt8g / 1e12 / FP32_MFMA_PEAK_TFLOPS, algorithmic_tflops=alg8 / dt8g / 1e12,
-                        final_loss=float(g8.out.item()))
-                    del g8
-                except Exception as e:
-                    res["secondary"]["train_b8_graph"] = dict(error=repr(e))
+                                                algorithmic_tflops=alg8 / dt8 / 1e12)
             del x8
             x39 = torch.from_numpy(np.random.default_rng(17 + rank).standard_normal((39, 3, 16, 112, 112)).astype(np.float32)).cuda()
             lab26 = torch.arange(13).repeat(2).cuda()

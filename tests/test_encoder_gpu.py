@@ -1023,3 +1023,46 @@ def test_bench_configuration_properties_b32(gpu, monkeypatch):
         assert (g3[k] - ref).abs().max().item() <= 1e-5 + 2e-4 * ref.abs().max().item(), k
     # running statistics moved exactly once per forward
     assert int(m.bn1.num_batches_tracked.item()) == int(sd0["bn1.num_batches_tracked"].item()) + 1
+
+
+# Shapes nobody tuned: batch sizes, clip sizes and widths off the B = 32 / B = 8 x 112 x 112 x width-1 grid that
+# the thresholds of models/conv_plan.py were measured on.  Whatever plan the rules pick for them (two-dimensional / one-dimensional Winograd
+# with or without K splits, the direct kernels, ragged tiles: S = 96 -> widths 48, 24, 12, 6; S = 160 -> 80, 40, 20, 10 — a width of 10 or
+# 20 is no Winograd width) must (1) satisfy every SLIC_REQUIRE of the library — a step that raises fails here — and (2) compute the same
+# network: embeddings, loss and every gradient against the same step on the direct kernels (SLIC_WINO=0).
+@pytest.mark.parametrize("B,S,widen", [(5, 96, 0.5), (13, 128, 1.0), (39, 160, 0.5), (13, 96, 1.0), (5, 160, 1.0), (39, 128, 0.5)])
+def test_untuned_shapes_pick_valid_plans(gpu, monkeypatch, B, S, widen):
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    import contextlib
+    import io
+    kw = dict(R3D18_KW, widen_factor=widen, hidden_layer=256, out_dim=64)
+    x = torch.from_numpy(np.random.default_rng(B + S).standard_normal((B + (B & 1), 3, 16, S, S)).astype(np.float32)).cuda()
+
+    def run(wino):
+        for k in ("SLIC_WINO", "SLIC_WINO2"):
+            monkeypatch.delenv(k, raising=False)
+        if not wino:
+            monkeypatch.setenv("SLIC_WINO", "0")
+        torch.manual_seed(11)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = generate_model(18, **kw).cuda().train()        # a fresh model: plans are chosen when the engine is built
+        emb = m(x)
+        loss = ntxent_loss(emb)
+        loss.backward()
+        torch.cuda.synchronize()
+        eng = m._engine(x)
+        kinds = [("wino2" if p.wino2 else "wino" if p.wino else "direct") for (_, p1, p2, _) in eng.blocks for p in (p1, p2)]
+        return float(loss.item()), emb.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}, kinds
+
+    l1, e1, g1, kinds = run(True)
+    l0, e0, g0, kinds0 = run(False)
+    assert set(kinds0) == {"direct"}
+    assert np.isfinite(l1) and torch.isfinite(e1).all()
+    assert abs(l1 - l0) <= 1e-4 and (e1 - e0).abs().max().item() <= 1e-4, (l1, l0, kinds)
+    for k in g0:
+        ref = g0[k]
+        assert torch.isfinite(g1[k]).all(), k
+        # (two fp32 runs with different summation orders may take different branches at a ReLU input within rounding of zero, and one
+        #  such flip moves a late layer's gradient by percents of its largest entry — DESIGN.md §2; a wrong plan gives garbage, not percents)
+        assert (g1[k] - ref).norm().item() <= 5e-2 * max(ref.norm().item(), 1e-9), (k, kinds)

@@ -161,69 +161,3 @@ def test_contrastive_epoch_and_cluster_step(gpu, tmp_path):
     assert np.array_equal(cl[perm.numpy()], fit_cluster.last_model.labels_)         # row i of the loader's order is item perm[i]
     assert nmi is None or 0.0 <= nmi <= 1.0
 
-
-@pytest.mark.parametrize("wide", [False, True])
-def test_graphed_step_equals_eager(gpu, wide):
-    """misc/graph_step.py: the whole training step (forward + NT-Xent + backward + SGD) captured into a hipGraph and replayed is the
-    eager step, bit for bit — the same kernels in the same order on the same buffers (side-stream weight gradients and packs are part
-    of the capture).  Tiny width: the direct kernels; width 1 at 8 clips: the Winograd plans and K splits of the B = 8 bench row."""
-    import contextlib
-    import io
-    from video_similarity_search_amd.loss import OnlineTripletLoss
-    from video_similarity_search_amd.misc.graph_step import GraphedStep
-    from video_similarity_search_amd.models import generate_model
-    kw = dict(TINY, widen_factor=1.0) if wide else TINY
-    B, S = (8, 64) if wide else (4, 32)
-    rng = np.random.default_rng(21)
-    xs = [torch.from_numpy(rng.standard_normal((B, 3, 8, S, S)).astype(np.float32)).cuda() for _ in range(3)]
-    labels = torch.arange(B // 2).repeat(2).cuda()
-
-    def make():
-        torch.manual_seed(5)
-        with contextlib.redirect_stdout(io.StringIO()):
-            m = generate_model(18, **kw).cuda().train()
-        return m, torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.5), OnlineTripletLoss(0.2, 'cosine')
-
-    # eager: three steps on three batches
-    m0, opt0, crit0 = make()
-    losses0 = []
-    for x in xs:
-        loss, _ = crit0(m0(x), labels, sampling_strategy='noise_contrastive')
-        opt0.zero_grad(set_to_none=True)
-        loss.backward()
-        opt0.step()
-        losses0.append(float(loss.item()))
-    # graphed: the same model state, the same three batches through the static input
-    m1, opt1, crit1 = make()
-    sd_start = {k: v.clone() for k, v in m1.state_dict().items()}
-    opt_start = None
-    xin = xs[0].clone()
-
-    def step():
-        loss, _ = crit1(m1(xin), labels, sampling_strategy='noise_contrastive')
-        opt1.zero_grad(set_to_none=True)
-        loss.backward()
-        opt1.step()
-        return loss.detach()
-
-    g = GraphedStep(step, warmup=2, static_inputs=(xin,))
-    # warm-up and capture ran real steps: put the model and the optimizer back to the start before replaying
-    with torch.no_grad():
-        m1.load_state_dict(sd_start)
-        for grp in opt1.param_groups:
-            for p in grp["params"]:
-                st = opt1.state.get(p)
-                if st and st.get("momentum_buffer") is not None:
-                    st["momentum_buffer"].zero_()
-    # SGD's first step COPIES the gradient into a fresh momentum buffer and later ones do buf = mom * buf + grad; with a zeroed buffer
-    # the captured update (the later form) equals the first-step form exactly: mom * 0 + grad
-    losses1 = []
-    for x in xs:
-        g.copy_inputs(x)
-        losses1.append(float(g.replay().item()))
-    assert losses0 == losses1
-    sd0, sd1 = m0.state_dict(), m1.state_dict()
-    for k in sd0:
-        if k.endswith("num_batches_tracked"):
-            continue
-        assert torch.equal(sd0[k], sd1[k]), k
