@@ -1060,9 +1060,11 @@ def test_untuned_shapes_pick_valid_plans(gpu, monkeypatch, B, S, widen):
     assert set(kinds0) == {"direct"}
     assert np.isfinite(l1) and torch.isfinite(e1).all()
     assert abs(l1 - l0) <= 1e-4 and (e1 - e0).abs().max().item() <= 1e-4, (l1, l0, kinds)
+    gmax = max(g.norm().item() for g in g0.values())
     for k in g0:
         ref = g0[k]
         assert torch.isfinite(g1[k]).all(), k
         # (two fp32 runs with different summation orders may take different branches at a ReLU input within rounding of zero, and one
         #  such flip moves a late layer's gradient by percents of its largest entry — DESIGN.md §2; a wrong plan gives garbage, not percents)
-        assert (g1[k] - ref).norm().item() <= 5e-2 * max(ref.norm().item(), 1e-9), (k, kinds)
+        # (fc1.bias sits in front of a BatchNorm: its true gradient is zero and both runs hold rounding noise — hence the absolute floor)
+        assert (g1[k] - ref).norm().item() <= 5e-2 * ref.norm().item() + 1e-4 * gmax, (k, kinds)

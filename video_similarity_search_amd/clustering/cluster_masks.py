@@ -41,10 +41,13 @@ def preprocess_features_kmeans(data, kernels=None):
 
 
 def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, finch_partition=0,
-                n_init=10, init='k-means++', process_group=None, random_state=None, kernels=None):
-    """Reference signature + keyword-only extras (n_init / init / process_group / random_state / kernels) that default
+                n_init=10, init='k-means++', process_group=None, random_state=None, kernels=None, exchange=None):
+    """Reference signature + keyword-only extras (n_init / init / process_group / random_state / kernels / exchange) that default
     to the reference's behaviour: KMeans(n_clusters=k, n_init=10).fit(embeddings).labels_.
-    process_group: `embeddings` is this rank's row shard (rank order == row order), the returned labels are this rank's."""
+    process_group: `embeddings` is this rank's row shard (rank order == row order), the returned labels are this rank's.
+    exchange: the sharded Lloyd iteration's one collective — 'allreduce' (RCCL through torch.distributed; the default), 'allgather', or
+    'oneshot' (the library's one-shot all-to-all over peer-mapped memory, csrc/oneshot.hip); None reads SLIC_KMEANS_EXCHANGE."""
+
     assert (method in _METHODS)
     print("Clustering with {}...".format(method))
     if method == 'finch':
@@ -68,13 +71,13 @@ def fit_cluster(embeddings, method='Agglomerative', k=1000, l2normalize=True, fi
         print('clustering with spherical kmeans with k={}'.format(k))
         print(tuple(x.shape))
         km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group, random_state=random_state,
-                    spherical=True, kernels=kernels).fit(x)
+                    spherical=True, kernels=kernels, exchange=exchange).fit(x)
     else:
         print("k:", k)
         if l2normalize:
             x = preprocess_features_kmeans(x, kernels)
         km = KMeans(n_clusters=k, n_init=n_init, init=init, process_group=process_group,
-                    random_state=random_state, kernels=kernels).fit(x)
+                    random_state=random_state, kernels=kernels, exchange=exchange).fit(x)
     labels = km.labels_
     print(labels.shape)
     n_clusters = len(set(labels.tolist())) - (1 if -1 in labels else 0)

@@ -308,7 +308,7 @@ class KMeans:
     copied to the current device)."""
 
     def __init__(self, n_clusters, n_init=10, max_iter=300, tol=1e-4, init="k-means++", random_state=None,
-                 process_group=None, fixed_iters=False, trace=False, kernels=None, spherical=False, exchange="allreduce"):
+                 process_group=None, fixed_iters=False, trace=False, kernels=None, spherical=False, exchange=None):
         self.n_clusters = int(n_clusters)
         self.n_init = int(n_init)
         self.max_iter = int(max_iter)
@@ -321,6 +321,7 @@ class KMeans:
         # spherical k-means (clustering/cluster_masks.py:73-77 -> spherecluster.SphericalKMeans): rows L2-normalised, no
         # mean-centring, centres renormalised after every averaging, tol compared unscaled
         self.spherical = bool(spherical)
+        exchange = exchange or os.environ.get("SLIC_KMEANS_EXCHANGE", "allreduce")
         assert exchange in ("allreduce", "allgather", "oneshot"), exchange
         self.exchange = exchange               # the sharded run's one collective per iteration (module docstring)
         self.k = kernels if kernels is not None else HipKernels()

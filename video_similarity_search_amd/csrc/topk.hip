@@ -907,10 +907,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const int gl = g0 + 4 * h;                                 // this lane's rows of the tile: gl + an immediate
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < 4; ++ct) {
+      if (__any(pc > TK_PC - 16)) drain();                      // room for the sixteen scores of this accumulator in every lane's column
 #pragma unroll
       for (int v0 = 0; v0 < 16; v0 += GS) {
-        if (__any(pc > TK_PC - GS)) drain();                    // room for a whole group in every lane's column
         float gm = acc[ct][v0];
 #pragma unroll
         for (int v = v0 + 1; v < v0 + GS; ++v) gm = fmaxf(gm, acc[ct][v]);
@@ -925,59 +925,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
         }
       }
+    }
   }
   drain();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the trailing all-zero DMAs must land before the workgroup leaves
 }
 
-// one WAVE per query: the k best of its n = cnt[q] candidate keys, best first.  n <= 64 * PER keys (PER = 8 covers 512: what the plan's
-// ~6 k + 100 candidates need; 16 for small sample statistics with their wider spread) sit in the lanes' registers
-// (k rounds of: lane-local maximum -> wave maximum by shuffles -> the owner retires it); more (rare) are re-read from memory every
-// round.  n < k or n > cap: the query goes on the fallback list and its output row is left to that pass.
-#define TKS_PER 16
-template <int PER>
+// one WAVE per query: the k best of its n = cnt[q] candidate keys, best first.  n <= TKS_NP keys are sorted in LDS by the wave — a
+// bitonic network, 64 compare-exchanges per instruction, LDS operations of one wave execute in order so no workgroup barrier is
+// involved; 45 stages for the usual ~400 candidates (padded to 512) — and the first k leave in one coalesced store.  (k rounds of a
+// wave-wide maximum over keys in registers took 135-154 us for 10k queries at k = 50: twelve dependent ds_bpermute round trips per round.)
+// More than TKS_NP keys (rare): k rounds over the keys in memory.  n < k or n > cap: the query goes on the fallback list and its output
+// row is left to that pass.
+#define TKS_NP 1024
 __global__ __launch_bounds__(256) void topk_select(const unsigned long long* __restrict__ cand, const int* __restrict__ cnt, int Nq, int k, int cap,
                                                    int32_t* __restrict__ out_idx, float* __restrict__ out_dist, int* __restrict__ failq,
                                                    int* __restrict__ nfail) {
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= Nq) return;
-  const int lane = threadIdx.x & 63;
+  __shared__ unsigned long long sk[4][TKS_NP];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + w;
+  if (q >= Nq) return;                                         // (whole waves leave; nothing below needs the workgroup)
   const int n = cnt[q];
   if (n < k || n > cap) {
     if (lane == 0) failq[atomicAdd(nfail, 1)] = q;
     return;
   }
   const unsigned long long* c = cand + (int64_t)q * cap;
-  auto wave_max = [&](unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      const unsigned lo = __shfl_xor((unsigned)v, d), hi = __shfl_xor((unsigned)(v >> 32), d);
-      const unsigned long long o = ((unsigned long long)hi << 32) | lo;
-      v = o > v ? o : v;
-    }
-    return v;
-  };
-  auto emit = [&](int o, unsigned long long w) {
-    if (lane == 0) {
-      out_idx[(int64_t)q * k + o] = tk_key_index(w);
-      out_dist[(int64_t)q * k + o] = fminf(fmaxf(1.0f - tk_key_score(w), 0.f), 2.f);
-    }
-  };
-  if (n <= 64 * PER) {
-    unsigned long long v[PER];                                 // 0 = retired / absent (no real key is 0: its low word would be ~(-1))
-#pragma unroll
-    for (int u = 0; u < PER; ++u) v[u] = lane + 64 * u < n ? c[lane + 64 * u] : 0ull;
-    for (int o = 0; o < k; ++o) {
-      unsigned long long b = 0ull;
-#pragma unroll
-      for (int u = 0; u < PER; ++u) b = v[u] > b ? v[u] : b;
-      const unsigned long long w = wave_max(b);
-      if (b == w) {                                            // keys are unique per query (they carry the gallery index)
-#pragma unroll
-        for (int u = 0; u < PER; ++u)
-          if (v[u] == w) v[u] = 0ull;
+  if (n <= TKS_NP) {
+    unsigned long long* key = sk[w];
+    int NP = 64;
+    while (NP < n) NP <<= 1;                                   // wave-uniform
+    for (int i = lane; i < NP; i += 64) key[i] = i < n ? c[i] : 0ull;      // 0 sorts last (no real key is 0: its low word would be ~(-1))
+    for (int size = 2; size <= NP; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < (NP >> 1); t += 64) {
+          const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+          const bool desc = (lo & size) == 0;                  // blocks alternate direction; the last merge (size == NP) is all descending
+          const unsigned long long a = key[lo], b = key[hi];
+          if ((a < b) == desc) { key[lo] = b; key[hi] = a; }
+        }
       }
-      emit(o, w);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int o = lane; o < k; o += 64) {
+      const unsigned long long e = key[o];
+      out_idx[(int64_t)q * k + o] = tk_key_index(e);
+      out_dist[(int64_t)q * k + o] = fminf(fmaxf(1.0f - tk_key_score(e), 0.f), 2.f);
     }
   } else {
     unsigned long long last = ~0ull;                           // every key still in play is < last
@@ -987,9 +982,17 @@ __global__ __launch_bounds__(256) void topk_select(const unsigned long long* __r
         const unsigned long long x = c[e];
         if (x < last && x > b) b = x;
       }
-      const unsigned long long w = wave_max(b);
-      emit(o, w);
-      last = w;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)b, d), hi = __shfl_xor((unsigned)(b >> 32), d);
+        const unsigned long long o2 = ((unsigned long long)hi << 32) | lo;
+        b = o2 > b ? o2 : b;
+      }
+      if (lane == 0) {
+        out_idx[(int64_t)q * k + o] = tk_key_index(b);
+        out_dist[(int64_t)q * k + o] = fminf(fmaxf(1.0f - tk_key_score(b), 0.f), 2.f);
+      }
+      last = b;
     }
   }
 }
@@ -1285,20 +1288,25 @@ static int topk_collect(const TopkCollectPlan& c, const float* Qn, int Nq, const
     const size_t lds = (size_t)4 * TK_BG * TK_BK * sizeof(float) + (size_t)4 * pcap * 64 * 8;
     static bool attr_set = false;
     if (!attr_set) {
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define TK_ATTR(NK, GS) SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_collect_qreg<NK, GS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds))
+      TK_ATTR(16, 4); TK_ATTR(8, 4); TK_ATTR(4, 4); TK_ATTR(16, 2); TK_ATTR(8, 2); TK_ATTR(4, 2); TK_ATTR(16, 1); TK_ATTR(8, 1); TK_ATTR(4, 1);
+#undef TK_ATTR
       attr_set = true;
     }
     dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)S);
-#define TK_LAUNCH_C(NK) topk_collect_qreg<NK, 4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, self_mask, per, pcap, tau, cnt, cand, c.cap)
-    if (D > 256) TK_LAUNCH_C(16); else if (D > 128) TK_LAUNCH_C(8); else TK_LAUNCH_C(4);
+    // scores tested per wave-wide branch: with ~0.4 % of the scores passing, SOME lane of the wave passes in most groups of four, so the
+    // group maximum of the streaming kernels buys little here; SLIC_TOPK_GS = 1 / 2 / 4 selects (experiments; default below)
+    const char* ge = getenv("SLIC_TOPK_GS");
+    const int gs = ge ? atoi(ge) : 4;
+#define TK_LAUNCH_C(NK, GS) topk_collect_qreg<NK, GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, self_mask, per, pcap, tau, cnt, cand, c.cap)
+#define TK_LAUNCH_CG(NK) do { if (gs == 1) TK_LAUNCH_C(NK, 1); else if (gs == 2) TK_LAUNCH_C(NK, 2); else TK_LAUNCH_C(NK, 4); } while (0)
+    if (D > 256) TK_LAUNCH_CG(16); else if (D > 128) TK_LAUNCH_CG(8); else TK_LAUNCH_CG(4);
+#undef TK_LAUNCH_CG
 #undef TK_LAUNCH_C
     SLIC_LAUNCH_CHECK();
   }
   // ---- 3. the k best candidates of every query; 4. whoever fell outside [k, TKC_CAP] through the streaming path (normally nobody)
-  if (c.m1 >= 10) topk_select<8><<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
-  else topk_select<TKS_PER><<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
+  topk_select<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
   SLIC_LAUNCH_CHECK();
   return topk_stream(Qn, Nq, Gn, Ng, D, k, self_mask, out_idx, out_dist, w, st, failq, nfail);
 }
