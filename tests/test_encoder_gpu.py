@@ -1068,3 +1068,81 @@ def test_untuned_shapes_pick_valid_plans(gpu, monkeypatch, B, S, widen):
         #  such flip moves a late layer's gradient by percents of its largest entry — DESIGN.md §2; a wrong plan gives garbage, not percents)
         # (fc1.bias sits in front of a BatchNorm: its true gradient is zero and both runs hold rounding noise — hence the absolute floor)
         assert (g1[k] - ref).norm().item() <= 5e-2 * ref.norm().item() + 1e-4 * gmax, (k, kinds)
+
+
+# A batch beyond ONE launch's 32-bit range (activations of 4 GiB, 2^24 positions: layer1 at 331 clips of 112 x 112) runs in chunks of
+# whole clips inside the plan (models/conv_plan.py: _launch_batch).  SLIC_CONV_MAX_POSITIONS forces the chunking at a small size: the
+# chunked forward / data gradient are the single launch's bit for bit (same kernels per clip; the BatchNorm statistic slabs concatenate
+# because a chunk is a whole number of slab rows), the weight gradient differs by the association of the chunk sums only.
+@pytest.mark.parametrize("C,N,k,s,p,dims,B", [(64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 8, 16), 24),       # two-dimensional Winograd
+                                                (16, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), (4, 8, 16), 20),       # direct, stride 2, ragged last chunk
+                                                (3, 16, (7, 7, 7), (1, 2, 2), (3, 3, 3), (4, 16, 16), 16)])      # the W-run stem
+def test_conv_batch_chunks_equal_single_launch(gpu, monkeypatch, C, N, k, s, p, dims, B):
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(C + N + B)
+    x = torch.from_numpy(rng.standard_normal((B, C) + dims).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((N, C) + k) / np.sqrt(C * int(np.prod(k)))).astype(np.float32)).cuda()
+
+    def run(chunked):
+        monkeypatch.delenv("SLIC_CONV_MAX_POSITIONS", raising=False)
+        if chunked:
+            probe = ConvPlan(C, N, k, s, p, dims, "cuda", batch=B)
+            per_clip = max(int(np.prod(probe.src_dims)), int(np.prod(probe.out_dims)))              # (the W-run stem's source is W-padded)
+            monkeypatch.setenv("SLIC_CONV_MAX_POSITIONS", str(8 * per_clip + 1))                    # eight clips per launch
+        plan = ConvPlan(C, N, k, s, p, dims, "cuda", batch=B)
+        assert (plan._chunks(B) is not None) == chunked
+        xd = plan.make_source(x)
+        z, (part, rows) = plan.forward(xd, plan.pack_fwd(w), B, want_stats=True)
+        dy = torch.from_numpy(np.random.default_rng(1).standard_normal(tuple(z.shape)).astype(np.float32)).cuda()
+        dW = plan.wgrad(xd, dy, B, torch.empty_like(w))
+        out = dict(z=z, part=part, rows=rows, dW=dW, kind=("wino2" if plan.wino2 else "wino" if plan.wino else "direct"))
+        if C > 3:
+            out["dx"] = plan.dgrad(dy, plan.pack_dgrad(w), B)
+            mask, zz = [torch.from_numpy(np.random.default_rng(2 + i).standard_normal(tuple(out["dx"].shape)).astype(np.float32)).cuda()
+                        for i in range(2)]
+            mean = torch.zeros(plan.Cs, device="cuda")
+            invstd = torch.ones(plan.Cs, device="cuda")
+            out["g"], out["bpart"] = plan.dgrad(dy, plan.pack_dgrad(w), B, mask=mask, bwd=(zz, mean, invstd))
+        return out
+
+    one, many = run(False), run(True)
+    assert one["kind"] == many["kind"]
+    assert torch.equal(one["z"], many["z"]) and one["rows"] == many["rows"] and torch.equal(one["part"], many["part"])
+    assert (one["dW"] - many["dW"]).abs().max().item() <= 1e-5 * one["dW"].abs().max().item()
+    if "dx" in one:
+        assert torch.equal(one["dx"], many["dx"]) and torch.equal(one["g"], many["g"])
+        for c in (0, 1):
+            assert torch.allclose(one["bpart"][:, c].double().sum(0), many["bpart"][:, c].double().sum(0), atol=1e-3, rtol=1e-5)
+
+
+def test_batch_beyond_one_launch_312_clips_128(gpu):
+    """104 clips x 3 views of 3 x 16 x 128 x 128 on ONE GPU (BASELINE configs[3]'s global batch; layer1's activations are 5.2 GB and
+    20.4 M positions: both beyond one launch's range — the step used to raise 'split the batch', which a caller of train-mode BatchNorm
+    cannot do): the plans run it in chunks; finite loss and gradients, BatchNorm statistics over ALL 312 clips (the first channel's batch
+    mean against a float64 reduction of the same stem output)."""
+    from video_similarity_search_amd.models import generate_model
+    from video_similarity_search_amd.loss.triplet_loss import ntxent_loss
+    import contextlib
+    import io
+    torch.manual_seed(3)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = generate_model(18, **R3D18_KW).cuda().train()
+    B = 312
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn((B, 3, 16, 128, 128), device="cuda", generator=g)
+    emb = m(x)
+    eng = m._engine(x)
+    l1 = [p for (_, p1, p2, _) in eng.blocks[:2] for p in (p1, p2)]
+    assert all(p._chunks(B) is not None for p in l1) and eng.stem._chunks(B) is not None
+    loss = ntxent_loss(emb)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert emb.shape == (B, 128) and torch.isfinite(emb).all() and np.isfinite(float(loss.item()))
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    # running_mean after one step = 0.1 x the batch mean of the stem's output over all 312 clips
+    with torch.no_grad():
+        eng.stem.drop_packs()
+        z, _ = eng.stem.forward(eng.stem.make_source(x), eng.stem.pack_fwd(m.conv1.weight.detach(), fresh=True), B)
+        ref = torch.stack([z[b0:b0 + 24].double().reshape(-1, z.shape[-1]).sum(0) for b0 in range(0, B, 24)]).sum(0) / (B * 16 * 64 * 64) * 0.1
+    # (the weights moved by nothing between the forward and here: no optimizer step was taken)
+    assert torch.allclose(m.bn1.running_mean.double(), ref, atol=1e-6, rtol=1e-4)

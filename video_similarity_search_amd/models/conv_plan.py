@@ -85,8 +85,12 @@ class ConvPlan:
         elig2 = eligible and uniform
         # size limits of the two-dimensional kernels (csrc/conv_wino2.hip: wino2_check, slic_conv_wgrad_wino2): 32-bit buffer offsets with
         # the out-of-range offset 0xFFFFFF00 standing for padding pixels — the source plus a frame on either side must stay below it
-        # (layer1 at 112 x 112: B <= 331), and the weight gradient's tile records hold 24-bit positions.  Beyond them the plan falls
-        # back to the one-dimensional / direct kernels instead of raising in the step.
+        # (layer1 at 112 x 112: B <= 331), and the weight gradient's tile records hold 24-bit positions.  A batch beyond the limits of
+        # ONE launch is run in chunks of whole clips (_launch_batch; forward / dgrad / wgrad loop over them), so the gates below see
+        # the clips of one launch, not the whole batch.
+        self._base333 = bool(base)
+        if batch is not None:
+            batch = min(int(batch), self._launch_batch(int(batch)))
         positions = 0 if batch is None else int(batch) * int(np.prod(self.in_dims))
         fits2 = positions * max(self.C, self.N) * 4 + 2 * Hd * Wd * max(self.C, self.N) * 4 + 16 <= 0xFFFFFF00
         self.wino2_size_ok = bool(fits2)
@@ -310,16 +314,61 @@ class ConvPlan:
         a.ldw, a.ldo = self.Kp, self.N
         return a
 
+    # ---- batches beyond one launch's range ------------------------------------------------------------------------------------------
+    # The kernels address their operands with 32-bit byte offsets (buffer resources: out-of-range lanes read zeros, which is what makes
+    # padding taps and ragged tiles branch-free) and the two-dimensional Winograd weight gradient keeps 24-bit positions in its tile
+    # records.  A tensor of one launch must therefore stay below 4 GiB - 4 KiB (less two frames for variant 31, whose resource starts a
+    # frame early) and, for the 3 x 3 x 3 stride-1 layers, below 2^24 positions: layer1 at 112 x 112 reaches that at 331 clips, at 128 x 128
+    # at 253.  The reference's cuDNN path has no such limit (train-mode BatchNorm needs the whole batch, so the CALLER cannot split), so a
+    # larger batch is run in chunks of whole clips inside the plan: convolution is independent per clip, the BatchNorm statistic slabs of
+    # the chunks concatenate (a chunk is a whole number of slab rows), the weight gradients of the chunks are added in chunk order.
+    # SLIC_CONV_MAX_BYTES / SLIC_CONV_MAX_POSITIONS lower the limits (tests force chunking at small sizes).
+    def _launch_batch(self, B):
+        lim_b = int(os.environ.get("SLIC_CONV_MAX_BYTES", 0xFFFFFF00 - 4096))
+        lim_p = int(os.environ.get("SLIC_CONV_MAX_POSITIONS", ((1 << 24) - 1) if self._base333 else ((1 << 31) - 1)))
+        src_dims = getattr(self, "src_dims", self.in_dims)
+        pin, pout = int(np.prod(src_dims)), int(np.prod(self.out_dims))
+        cmax = max(self.Cs, self.N)
+        per_clip = max(pin, int(np.prod(self.in_dims)), pout) * cmax * 4
+        margin = 2 * self.in_dims[1] * self.in_dims[2] * cmax * 4 + 256 if self._base333 else 0
+        Bc = min(B, max(0, lim_b - margin) // per_clip, lim_p // max(pin, pout))
+        if Bc >= B:
+            return B
+        Bc = Bc // 8 * 8                       # whole slab rows per chunk at every block size in use (128 / 392 / 448 / 512 rows)
+        if Bc < 8:
+            raise _lib.SlicError(f"ConvPlan: eight clips of {self.in_dims} x {cmax} channels exceed one launch's 32-bit range")
+        return Bc
+
+    def _chunks(self, B):
+        Bc = self._launch_batch(B)
+        return None if Bc >= B else [(b0, min(b0 + Bc, B)) for b0 in range(0, B, Bc)]
+
     def forward(self, x, wp, B, bias=None, scale=None, shift=None, addend=None, relu=False, want_stats=False,
-                variant=0):
+                variant=0, _out=None):
         """x: [B, T, H, W, Cs] -> z: [B, To, Ho, Wo, N]; returns (z, (stat_partial, rows_per_partial) or None)"""
         lib = _lib.load()
+        chunks = self._chunks(B)
+        if chunks is not None:
+            z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
+            parts, tms = [], set()
+            for b0, b1 in chunks:
+                _, st = self.forward(x[b0:b1], wp, b1 - b0, bias, scale, shift, None if addend is None else addend[b0:b1], relu,
+                                     want_stats, variant, _out=z[b0:b1])
+                if want_stats:
+                    parts.append(st[0])
+                    tms.add(st[1])
+                    assert b1 == B or ((b1 - b0) * int(np.prod(self.out_dims))) % st[1] == 0, "a chunk must be whole slab rows"
+            if not want_stats:
+                return z, None
+            assert len(tms) == 1
+            return z, (torch.cat(parts), tms.pop())
         self._prof_tag = "fwd"
         a = self._fwd_args(x, B)
         if self.wino:
             assert variant in (0, 30, 31) and bias is None, "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
             variant = 31 if self.wino2 else 30
-        z = torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
+        z = _out if _out is not None else torch.empty((B,) + self.out_dims + (self.N,), dtype=torch.float32, device=x.device)
+        assert z.is_contiguous() and tuple(z.shape) == (B,) + self.out_dims + (self.N,)
         a.wgt = wp.data_ptr()
         a.wgt_bytes = _lib.u32_bytes(wp, 'packed weights')
         a.dst = z.data_ptr()
@@ -457,6 +506,18 @@ class ConvPlan:
         addend_classes: the parity classes on which `addend` is defined (tap_classes() of the plan that wrote it); the other classes'
         launches take no addend."""
         lib = _lib.load()
+        chunks = self._chunks(B)
+        if chunks is not None:
+            T, H, W = self.in_dims
+            dx = out if out is not None else torch.empty((B, T, H, W, self.Cs), dtype=torch.float32, device=dz.device)
+            parts = []
+            for b0, b1 in chunks:
+                r = self.dgrad(dz[b0:b1], wd, b1 - b0, None if addend is None else addend[b0:b1], dx[b0:b1], variant,
+                               None if mask is None else mask[b0:b1], None if bwd is None else (bwd[0][b0:b1], bwd[1], bwd[2]),
+                               skip_empty, addend_classes)
+                if bwd is not None:
+                    parts.append(r[1])
+            return dx if bwd is None else (dx, torch.cat(parts))       # (sum dx, sum dx * xhat) partial rows: plain sums, any number of rows
         self._prof_tag = "dgrad"
         if self.wino:
             assert variant in (0, 30, 31), "a Winograd plan runs variant 30 / 31 only (build the plan with wino=False)"
@@ -572,6 +633,14 @@ class ConvPlan:
     def wgrad(self, x, dz, B, dW, splits=None):
         """dW (reference layout [N, C, kt, kh, kw], written in place) = gather(x)^T dz"""
         lib = _lib.load()
+        chunks = self._chunks(B)
+        if chunks is not None:
+            tmp = torch.empty_like(dW)
+            for i, (b0, b1) in enumerate(chunks):                      # chunk order: a fixed summation order
+                self.wgrad(x[b0:b1], dz[b0:b1], b1 - b0, dW if i == 0 else tmp, splits)
+                if i:
+                    dW.add_(tmp)
+            return dW
         a = self._fwd_args(x, B)
         if self.wino2_wgrad:
             # transposed F(4, 3) x F(2, 3): one workgroup of 512 threads per kt, 64 x 64 block and slice of the 2 x 4
