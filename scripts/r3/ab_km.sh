@@ -10,7 +10,7 @@ if [ "$1" = build ]; then
   for v in "${VARS[@]}"; do
     i=$((i+1))
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=off -I include $v -c $D/kmeans.hip -o $D/_exp/km_v$i.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_km$i.so $D/_exp/km_v$i.o $D/bn.o $D/common.o $D/comm.o $D/conv.o $D/loss.o $D/nce.o $D/topk.o -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_km$i.so $D/_exp/km_v$i.o $(ls $D/*.o | grep -v "/kmeans.o") -ldl
   done
 else
   export FIT_ONLY=1

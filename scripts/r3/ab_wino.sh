@@ -8,7 +8,7 @@ if [ "$1" = build ]; then
   mkdir -p $D/_exp
   for abl in 1 2 3 4; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -DSLIC_WINO_ABL=$abl -c $D/conv.hip -o $D/_exp/conv_abl$abl.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_abl$abl.so $D/_exp/conv_abl$abl.o $D/bn.o $D/common.o $D/comm.o $D/kmeans.o $D/loss.o $D/nce.o $D/topk.o -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_abl$abl.so $D/_exp/conv_abl$abl.o $(ls $D/*.o | grep -v "/conv.o") -ldl
   done
 else
   for abl in 0 1 2 3 4; do

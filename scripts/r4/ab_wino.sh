@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
   done
   wait
   for abl in $ABLS; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_abl$abl.so $D/_exp/conv_abl$abl.o $D/bn.o $D/common.o $D/comm.o $D/kmeans.o $D/loss.o $D/nce.o $D/topk.o -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/_exp/libslic_abl$abl.so $D/_exp/conv_abl$abl.o $(ls $D/*.o | grep -v "/conv.o") -ldl
   done
 else
   for abl in 0 $ABLS; do

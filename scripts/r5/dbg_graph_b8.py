@@ -1,11 +1,35 @@
-"""round 5: the B = 8 training step of bench.py replayed from a hipGraph, in the order bench.py reaches it (eager B = 32 steps first)"""
+"""round 5: the B = 8 training step of bench.py — forward + NT-Xent + backward + SGD, ~310 launches — captured ONCE into a
+hipGraph and replayed, against the eager step.  Measured: eager 12.31 ms, replay 12.78 ms (the GPU is busy 94.5 % of the eager step: kernel
+trace, scripts/r5/prof_b8.sh) — the small batch is bound by its small launches, not by the host; with earlier eager steps of another batch
+size in the process (--b32first) torch's capture_end segfaults on this image.  Not shipped; this script is the experiment."""
 import faulthandler, os, sys, time
 faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from video_similarity_search_amd.loss import OnlineTripletLoss
-from video_similarity_search_amd.misc.graph_step import GraphedStep
+
+
+class GraphedStep:
+    """fn(): one whole step on static tensors, warmed up on a side stream, captured once, replayed"""
+
+    def __init__(self, fn, warmup=3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 model, _ = bench.build_model()
 model = model.cuda().train()
 crit = OnlineTripletLoss(0.2, 'cosine')

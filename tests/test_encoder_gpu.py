@@ -262,7 +262,9 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     assert (y.cpu().permute(0, 4, 1, 2, 3).double() - ref).abs().max() <= 4 * tol * max(1.0, ref.abs().max().item())
     # data gradient, plain and with the fused mask + BatchNorm-backward sums
     dx = w2.dgrad(dyd, w2.pack_dgrad(wd_), B)
-    assert (dx.cpu().permute(0, 4, 1, 2, 3) - gx64.float()).abs().max() <= 5e-5 * max(1.0, gx64.abs().max().item())
+    # (2e-5 of the largest entry — the measured error of this kernel is 1.1e-6, test_winograd_error_growth_measured; the one-dimensional
+    #  kernel's 5e-5 would let a slipped transform constant through)
+    assert (dx.cpu().permute(0, 4, 1, 2, 3) - gx64.float()).abs().max() <= 2e-5 * max(1.0, gx64.abs().max().item())
     assert torch.equal(dx, w2.dgrad(dyd, w2.pack_dgrad(wd_), B))
     shp = (B,) + dims + (C,)
     mask, zz, add = [torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda() for _ in range(3)]
@@ -316,7 +318,7 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     assert w2.wino2_wgrad == (3 * (C // 64) * (N // 64) <= 256)
     for splits in (None, 3, 1):
         dW = w2.wgrad(xd, dyd, B, torch.empty_like(wd_), splits=splits).cpu()
-        assert (dW - gw64.float()).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item()), splits
+        assert (dW - gw64.float()).abs().max() <= 2e-5 * max(1.0, gw64.abs().max().item()), splits      # measured 1.1e-6
     assert (dW - dW1).abs().max() <= 1e-4 * max(1.0, gw64.abs().max().item())
     assert torch.equal(w2.wgrad(xd, dyd, B, torch.empty_like(wd_)), w2.wgrad(xd, dyd, B, torch.empty_like(wd_)))
 
