@@ -92,4 +92,19 @@ for log in ("rows.log", "topk_k.log", "conv_shapes.log", "wino_ablations.log"):
     if os.path.exists(pth):
         other[log[:-4]] = [l.rstrip() for l in open(pth) if l.strip() and "amdgpu.ids" not in l]
 json.dump(other, open(os.path.join(out, f"{tag}_other_rows.json"), "w"), indent=1)
+# round 5: plain-text rows and the one-rank distributed line (its fields make a multi-GPU run self-verifying)
+for log, name in (("topk_kernels.log", "topk_kernels.txt"), ("b8_kernels.log", "small_batch_b8_kernels.txt"), ("planar_diag.log", "planar_layout_diagnostic.txt")):
+    pth = os.path.join(scratch, log)
+    if os.path.exists(pth):
+        open(os.path.join(out, f"{tag}_{name}"), "w").write("".join(l for l in open(pth) if "amdgpu.ids" not in l and "warning" not in l))
+fd = os.path.join(scratch, "force_dist.log")
+if os.path.exists(fd):
+    j = json_line(fd)
+    if j:
+        one = os.path.join(scratch, "force_dist_oneshot.json")
+        if os.path.exists(one):
+            for line in open(one):
+                if line.startswith("{"):
+                    j["kmeans_oneshot_row_from_stderr"] = json.loads(line)
+        json.dump(j, open(os.path.join(out, f"{tag}_bench_force_dist_one_rank.json"), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("hbm_bytes_per_launch", "rocprof_trace_avg_ms", "hip_event_avg_ms")}), d["value"], p["value"])
