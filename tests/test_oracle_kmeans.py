@@ -75,3 +75,22 @@ def test_reference_shaped_call_statistics(golden_dir):
     inits = [X[rng.choice(len(X), 8, replace=False)] for _ in range(10)]
     r = ok.kmeans_fit(X, inits)
     assert r["inertia"] <= 1.02 * float(g["inertia"])
+
+
+def test_reference_shaped_call_exact_labels_host_logic(golden_dir):
+    """The reference-shaped call end to end — np.random.seed(1), fit_cluster(X, 'kmeans', k) = KMeans(n_clusters=k, n_init=10) with
+    k-means++ (clustering/cluster_masks.py:27, 70-71) — through the PRODUCT's host logic (RNG draws in sklearn 1.7.2's order: the first
+    centre by choice, n_local_trials uniforms per further centre, ten initialisations in sequence, best inertia kept) on the CPU
+    kernels that stand in for the device here: sklearn's golden labels EXACTLY, cluster numbering included, its n_iter and inertia.
+    (tests/test_kmeans_gpu.py::test_fit_cluster_reference_call asserts the same with the HIP kernels computing the distances.)"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kmeans_cpu_kernels as ck
+    from video_similarity_search_amd.clustering import fit_cluster
+    g = _load(golden_dir, "reference_call")
+    np.random.seed(1)
+    labels = fit_cluster(torch.from_numpy(g["X"]), method="kmeans", k=8, l2normalize=True, kernels=ck.OracleKernels())
+    km = fit_cluster.last_model
+    assert np.array_equal(labels, g["labels"])
+    assert km.n_iter_ == int(g["n_iter"]) and km.inertia_ == pytest.approx(float(g["inertia"]), rel=1e-6)
