@@ -147,6 +147,34 @@ def test_topk_collect_equals_streaming(gpu, Nq, Ng, D, k):
     assert (ia[sub] == ref).mean() > 0.99
 
 
+def test_topk_collect_fuzz_equals_streaming(gpu):
+    """random shapes over the collect path's whole domain — any query count, galleries from 32 768 rows (ragged last tiles and slices),
+    every D % 8 == 0 up to 512 (the three register-operand instantiations), k from 1 to 88 (forced on below 16), with and without the
+    self mask, score distributions from flat to heavily clustered (many near-ties) — the two algorithms must return identical lists"""
+    from video_similarity_search_amd.evaluate import cosine_topk
+    rng = np.random.default_rng(2025)
+    for trial in range(14):
+        Nq = int(rng.integers(1, 700))
+        Ng = int(rng.integers(32768, 90000))
+        D = int(rng.integers(1, 65)) * 8
+        k = int(rng.choice([1, 3, 16, 17, 31, 50, 64, 88]))
+        self_mask = trial % 5 == 4
+        if self_mask:
+            Nq = Ng = int(rng.integers(32768, 40000))
+        G = rng.standard_normal((Ng, D)).astype(np.float32)
+        if trial % 3 == 1:                                          # clustered gallery: 40 directions + small noise -> crowds of near-equal scores
+            cent = rng.standard_normal((40, D)).astype(np.float32)
+            G = (cent[rng.integers(0, 40, Ng)] + 0.05 * rng.standard_normal((Ng, D))).astype(np.float32)
+        if trial % 3 == 2:                                          # exact duplicates of a few rows sprinkled in (ties broken by index)
+            dup = rng.integers(0, Ng, 200)
+            G[dup] = G[dup[0]]
+        Q = None if self_mask else (G[rng.integers(0, Ng, Nq)] + 0.3 * rng.standard_normal((Nq, D))).astype(np.float32)
+        with _topk_env("1"):
+            assert _topk_plan(Nq, Ng, D, k)["collect"], (Nq, Ng, D, k)
+        (ia, da), (ib, db) = _both_paths(G if self_mask else Q, None if self_mask else G, k)
+        assert np.array_equal(ia, ib) and np.array_equal(da, db), (trial, Nq, Ng, D, k, self_mask)
+
+
 def test_topk_collect_self_mask_equals_streaming(gpu):
     """the self-retrieval form (queries = gallery, the diagonal skipped: evaluate.py:221-222; FINCH's first neighbours)"""
     rng = np.random.default_rng(77)
