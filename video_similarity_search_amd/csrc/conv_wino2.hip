@@ -41,7 +41,8 @@
 #define SLIC_W2_ABL 0     // diagnostic builds only (scripts/r4/ab_wino2.sh; wrong results, right timing): 1 = DMAs out of range (both kernels), 2 = no stage
                           // barrier (both), 32 = forward without its epilogue, 256 = forward without the row-major half of its epilogue,
                           // 512 = the pixel DMAs of a ROW-IMAGE source ([row][C/8][W][8] planes: 16 image rows x 2 KB per double stage as 32 whole
-                          // 1 KB runs instead of 48 gathers of 32-byte pieces — what a planar activation layout would fetch; scripts/r5/ab_planar.sh)
+                          // 1 KB runs instead of 48 gathers of 32-byte pieces — what a planar activation layout would fetch; scripts/r5/ab_planar.sh),
+                          // 1024 / 2048 = the forward's BatchNorm statistics without their second moment / skipped (scripts/r5/ab_epilogue.sh: ~2 % of a launch)
 #endif
 #ifndef SLIC_W2_UAUX
 #define SLIC_W2_UAUX 0    // cache-policy bits of the U / pixel DMAs (experiments: 1 = sc0, 2 = nt, 16 = sc1)
@@ -221,7 +222,11 @@ __device__ __forceinline__ void w2_epilogue_impl(const SlicConvArgs& p, float* l
       }
     }
   }
+#if SLIC_W2_ABL & 2048
+  if (false) {      // diagnostic: the forward's statistics skipped although asked for (scripts/r5/ab_epilogue.sh)
+#else
   if (want_stats) {
+#endif
     // BatchNorm partials over this block's real outputs, per channel: (sum v, sum (v - mean_blk)^2), the second from the kept values
     const int64_t left = p.M - mblk * (int64_t)full_rows;
     const float inv_rows = 1.0f / (float)(left < full_rows ? left : full_rows);
@@ -237,6 +242,9 @@ __device__ __forceinline__ void w2_epilogue_impl(const SlicConvArgs& p, float* l
       const int nn = n0h + tid;
       if (nn < p.N) p.stat_partial[(mblk * 2 + 0) * p.N + nn] = t;
     }
+#if SLIC_W2_ABL & 1024
+    return;          // diagnostic: the sums only, no second moment
+#endif
     __syncthreads();
     const f32x4 mu = *(const f32x4*)&bmean[cq * 4];
     f32x4 q2 = {0.f, 0.f, 0.f, 0.f};
