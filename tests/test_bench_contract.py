@@ -25,3 +25,26 @@ def test_bench_line_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
     # value = clips of all ranks / max-over-ranks time
     assert abs(d["value"] - d["n_gpus"] * d["config"]["global_batch"] / d["n_gpus"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_line_self_verifying_distributed_fields():
+    """round 5: the line of a run with a process group (`profiles/r05_bench_force_dist_one_rank.json`: `bench.py --gpus 1 --force-dist`,
+    the code path of N = 2, 4, 8) carries what makes a multi-GPU run verify itself — how many ranks RCCL really reduced over, the
+    library version, every rank's step time, what DistributedDataParallel did with the gradients, and the k-means row's exchange"""
+    path = os.path.join(ROOT, "profiles", "r05_bench_force_dist_one_rank.json")
+    d = json.load(open(path))
+    dist = d["distributed"]
+    assert dist["initialised"] is True and dist["backend"] == "nccl"
+    assert dist["rccl_ranks_seen"] == d["n_gpus"] == dist["world_size_env"] == len(dist["ms_per_step_per_rank"])
+    assert dist["rccl_version"].count(".") == 2
+    assert dist["ms_per_step_min"] <= dist["ms_per_step_max"] <= d["ms_per_step"] * 1.001
+    ddp = dist["ddp"]
+    assert ddp["buckets"] == len([b for b in ddp["bucket_sizes_bytes"].split(",") if b.strip()]) >= 1
+    assert isinstance(ddp["gradient_as_bucket_view"], bool) and ddp["gradient_bytes"] == 34520896 * 4       # R3D-18: 34.52 M parameters
+    sec = d["secondary"]
+    ex = sec["exchange"]
+    assert ex["kind"] in ("allreduce", "allgather", "oneshot") and ex["collectives_per_iteration"] == 1
+    assert ex["payload_bytes_per_rank"] == (500 * 512 + 500 + 2) * 8                                      # fp64 [K D sums | K counts | n_changed]
+    assert sec["weak_scaled"]["scaling"] == "weak" and sec["weak_scaled"]["n_gpus"] == d["n_gpus"]
+    one = d.get("kmeans_oneshot_row_from_stderr")
+    assert one and one["exchange"]["kind"] == "oneshot" and one["value"] > 0
