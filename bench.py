@@ -589,13 +589,19 @@ def main():
     printed = threading.Lock()
     state = dict(done=False)
 
+    headline_only = json.dumps(dict(res, watchdog="secondary rows cut short by the watchdog: headline only"))
+
     def emit(final):
         with printed:
             if state["done"]:
                 return
             state["done"] = True
             if rank == 0:
-                print(json.dumps(res if final else dict(res, watchdog=f"secondary rows exceeded {budget} s: line printed by the watchdog")), flush=True)
+                try:
+                    line = json.dumps(res if final else dict(res, watchdog=f"secondary rows exceeded {budget} s: line printed by the watchdog"))
+                except Exception:                 # the main thread was adding a row while the watchdog serialised the dictionary
+                    line = headline_only
+                print(line, flush=True)
 
     budget = int(os.environ.get("SLIC_BENCH_SECONDARY_BUDGET_S", "420"))
     wd = None
