@@ -938,12 +938,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // More than TKS_NP keys (rare): k rounds over the keys in memory.  n < k or n > cap: the query goes on the fallback list and its output
 // row is left to that pass.
 #define TKS_NP 1024
-__global__ __launch_bounds__(256) void topk_select(const unsigned long long* __restrict__ cand, const int* __restrict__ cnt, int Nq, int k, int cap,
+#ifndef TKS_WAVES
+#define TKS_WAVES 1           // queries (waves) per workgroup (4 / 2 / 1 measured 141 / 122 / 119 us for 10k queries: scripts/r5/ab_select.sh)
+#endif
+__global__ __launch_bounds__(64 * TKS_WAVES) void topk_select(const unsigned long long* __restrict__ cand, const int* __restrict__ cnt, int Nq, int k, int cap,
                                                    int32_t* __restrict__ out_idx, float* __restrict__ out_dist, int* __restrict__ failq,
                                                    int* __restrict__ nfail) {
-  __shared__ unsigned long long sk[4][TKS_NP];
+  __shared__ unsigned long long sk[TKS_WAVES][TKS_NP];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + w;
+  const int q = blockIdx.x * TKS_WAVES + w;
   if (q >= Nq) return;                                         // (whole waves leave; nothing below needs the workgroup)
   const int n = cnt[q];
   if (n < k || n > cap) {
@@ -1306,7 +1309,7 @@ static int topk_collect(const TopkCollectPlan& c, const float* Qn, int Nq, const
     SLIC_LAUNCH_CHECK();
   }
   // ---- 3. the k best candidates of every query; 4. whoever fell outside [k, TKC_CAP] through the streaming path (normally nobody)
-  topk_select<<<dim3((unsigned)slic_cdiv(Nq, 4)), dim3(256), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
+  topk_select<<<dim3((unsigned)slic_cdiv(Nq, TKS_WAVES)), dim3(64 * TKS_WAVES), 0, st>>>(cand, cnt, Nq, k, c.cap, out_idx, out_dist, failq, nfail);
   SLIC_LAUNCH_CHECK();
   return topk_stream(Qn, Nq, Gn, Ng, D, k, self_mask, out_idx, out_dist, w, st, failq, nfail);
 }
