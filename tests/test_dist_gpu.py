@@ -205,17 +205,17 @@ def test_launch_processes_two_gpus(gpu, tmp_path):
     assert open(marker).read() == "ok 2"
 
 
-def test_oneshot_exchange_two_processes_one_gpu(gpu, golden_dir, tmp_path):
-    """exchange='oneshot' (slic_allreduce_oneshot_f64, csrc/oneshot.hip: IPC-mapped inboxes, one kernel per exchange) with TWO processes on
-    the ONE leased GPU (IPC handles work on the same device; RCCL does not): 25 raw exchanges exact, and the sharded HIP k-means ==
-    the oracle with n_shards = -2 (fp64 combine), every iteration's labels bit-equal, == sklearn's golden labels"""
+@pytest.mark.parametrize("world", [2, 3])
+def test_oneshot_exchange_two_processes_one_gpu(gpu, golden_dir, tmp_path, world):
+    """exchange='oneshot' (slic_allreduce_oneshot_f64, csrc/oneshot.hip: IPC-mapped inboxes, one kernel per exchange) with TWO (and THREE)
+    processes on the ONE leased GPU (IPC handles work on the same device; RCCL does not): 25 raw exchanges exact, and the sharded HIP
+    k-means == the oracle with n_shards = -W (fp64 combine), every iteration's labels bit-equal, == sklearn's golden labels"""
     from oracle import kmeans as ok
-    world = 2
     # (a bounded wait of 20 s per exchange instead of the default five minutes: a broken exchange fails this test in seconds)
     res = _run("oneshot", world, tmp_path, timeout=600, extra_env={"SLIC_TEST_SAME_GPU": "1", "SLIC_COMM_TIMEOUT_MS": "20000"})
     for rk, r in enumerate(res):
         assert bool(r["raw_ok"]) and int(r["n_exchanges"]) == 25
-        assert [int(v) for v in r["info"][:2]] == [2, rk] and int(r["info"][3]) >= 25            # world, rank, exchanges issued
+        assert [int(v) for v in r["info"][:2]] == [world, rk] and int(r["info"][3]) >= 25        # world, rank, exchanges issued
     for name in ("clustered_empty", "d128", "unstructured"):
         g = dict(np.load(os.path.join(golden_dir, f"kmeans_{name}.npz")))
         X, init = g["X"], g["init"]
@@ -228,7 +228,7 @@ def test_oneshot_exchange_two_processes_one_gpu(gpu, golden_dir, tmp_path):
         assert int(res[0][f"{name}/n_iter"]) == ref["n_iter"] == int(g["n_iter"])
         assert np.array_equal(labels, ref["labels"]) and np.array_equal(labels, g["labels"])
         assert np.array_equal(trace, np.asarray(ref["trace"]))
-        assert np.array_equal(res[0][f"{name}/centers"], res[1][f"{name}/centers"])            # replicas bit-identical
+        assert all(np.array_equal(res[0][f"{name}/centers"], r[f"{name}/centers"]) for r in res[1:])      # replicas bit-identical
         np.testing.assert_array_equal(res[0][f"{name}/centers"], (ref["centers"] + mean).astype(np.float32))
 
 
