@@ -417,6 +417,8 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (with NCCL_DEBUG=VERSION in the environment — the GPU boxes set it — RCCL prints its version banner to stdout at the first
+        #  communicator; NCCL_DEBUG_FILE does not move it.  The JSON line is the only stdout line that starts with '{'.)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
