@@ -746,6 +746,107 @@ __global__ __launch_bounds__(128) void km_accumulate(
   }
 }
 
+// The M-step's sums for a SMALL shard (N <= 32768 rows, D <= 512) as ONE launch, no counting sort: workgroup j scans the shard's labels
+// itself — eight waves, an eighth of the rows each, 16 consecutive labels per lane and step, an exclusive scan of the lanes' match counts
+// placing the row ids in ascending order in the wave's LDS list — and then adds cluster j's rows in row order (the order km_place's stable
+// sort gives km_accumulate: bit-identical sums), 16 rows in flight.  For the shard one rank holds in a strong-scaled run (12 500 of 100k
+// rows over 8 GPUs) km_place + km_accumulate were two launches of 13 and 500 workgroups at 13.7 + 9.1 us: grids too small to be anything but
+// latency; this is one launch of K workgroups (scripts/r5/kmeans_small_shard.py).  TOut / nch_out / xperm as km_accumulate.
+#define KM_SCAN_MAXN 32768
+template <typename TOut>
+__global__ __launch_bounds__(512) void km_scan_accumulate(
+    const float* __restrict__ X, int N, int D, int ldx, const int32_t* __restrict__ labels, int seg,
+    TOut* __restrict__ sums, TOut* __restrict__ counts_f, const int32_t* __restrict__ n_changed, TOut* __restrict__ nch_out, int xperm) {
+  extern __shared__ unsigned short km_ids[];                  // [8 waves][seg] row offsets inside the wave's segment
+  __shared__ int wcnt[8];
+  const int j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int sbeg = w * seg, send = min(N, sbeg + seg);
+  unsigned short* my = km_ids + (size_t)w * seg;
+  int pos = 0;
+  for (int base = sbeg; base < send; base += 64 * 16) {
+    const int r0 = base + lane * 16;
+    unsigned m = 0;
+    if (r0 + 16 <= send) {
+      const int4* lp = (const int4*)(labels + r0);           // 64-byte aligned: sbeg and 16-label steps are multiples of 16
+      const int4 a = lp[0], b = lp[1], c = lp[2], d = lp[3];
+      m = (a.x == j ? 1u : 0u) | (a.y == j ? 2u : 0u) | (a.z == j ? 4u : 0u) | (a.w == j ? 8u : 0u) |
+          (b.x == j ? 16u : 0u) | (b.y == j ? 32u : 0u) | (b.z == j ? 64u : 0u) | (b.w == j ? 128u : 0u) |
+          (c.x == j ? 256u : 0u) | (c.y == j ? 512u : 0u) | (c.z == j ? 1024u : 0u) | (c.w == j ? 2048u : 0u) |
+          (d.x == j ? 4096u : 0u) | (d.y == j ? 8192u : 0u) | (d.z == j ? 16384u : 0u) | (d.w == j ? 32768u : 0u);
+    } else {
+      for (int u = 0; u < 16; ++u)
+        if (r0 + u < send && labels[r0 + u] == j) m |= 1u << u;
+    }
+    const int c = __popc(m);
+    int incl = c;                                              // inclusive scan of the lanes' counts (ascending lanes = ascending rows)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d);
+      if (lane >= d) incl += o;
+    }
+    int p = pos + incl - c;
+    while (m) {
+      const int u = __ffs(m) - 1;
+      my[p++] = (unsigned short)(r0 + u - sbeg);
+      m &= m - 1;
+    }
+    pos += __shfl(incl, 63);
+  }
+  if (lane == 0) wcnt[w] = pos;
+  __syncthreads();
+  int n = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) n += wcnt[u];
+  if (tid == 0 && counts_f) counts_f[j] = (TOut)n;
+  if (j == 0 && tid == 0 && nch_out) {
+    const int nc = *n_changed;
+    nch_out[0] = (TOut)(nc & 0xFFFFF);
+    nch_out[1] = (TOut)(nc >> 20);
+  }
+  if (tid * 4 >= D) return;                                    // D <= 512: threads 0 .. D / 4 - 1 own four columns each
+  const uint32_t rowbytes = (uint32_t)ldx * 4u;
+  const char* xc = (const char*)(X + tid * 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // the eight lists read as ONE list, rows ascending, 16 rows in flight whatever list they come from (a cluster of 25 rows has ~3 per
+  // list: list by list the loads went out one at a time — 17 us for the kernel)
+  int off[9];
+  off[0] = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) off[u + 1] = off[u] + wcnt[u];
+  auto row_of = [&](int q) -> uint32_t {                       // q-th row of the cluster (q < n; the same for every thread)
+    int ww = 0;
+#pragma unroll
+    for (int u = 1; u < 8; ++u) ww += q >= off[u] ? 1 : 0;
+    return (uint32_t)(ww * seg) + km_ids[(size_t)ww * seg + (q - off[ww])];
+  };
+  int q = 0;
+  for (; q + 16 <= n; q += 16) {
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = *(const f32x4*)(xc + row_of(q + u) * rowbytes);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  if (q < n) {                                                 // the last, partial batch: its loads in flight together as well
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = q + u < n ? *(const f32x4*)(xc + row_of(q + u) * rowbytes) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (q + u < n) acc += v[u];
+  }
+  if (xperm) {
+    TOut* d = sums + (int64_t)j * D + (tid >> 1) * 8 + (tid & 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[2 * i] = (TOut)acc[i];
+    return;
+  }
+  TOut* d = sums + (int64_t)j * D + tid * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) d[i] = (TOut)acc[i];
+}
+
 __global__ void km_combine_shards(const float* __restrict__ ps, const float* __restrict__ pc,
                                   int64_t stride, int S, int K, int D, float* __restrict__ sums,
                                   float* __restrict__ counts) {
@@ -1850,6 +1951,20 @@ extern "C" int slic_kmeans_cnorm(const float* C, int K, int D, int ldc, float* c
 
 static int km_nct() { return 4; }     // centroid tiles (of 32) per workgroup of the natural-layout E-step (2 was slower)
 
+// quarter tiles (32-point sub-tiles) a workgroup of the centroids-in-registers E-step must have for the kernel to be chosen.  Rounds 2-4: 16
+// (four 128-point tiles).  Round 5: 6 — the shard of one rank in an 8-GPU strong-scaled run (12 500 of 100k rows, K = 500: 1.5 tiles per
+// workgroup) runs its whole iteration in 125 us with this kernel against 133 with the 128 x 64-tile kernel, 25 000 rows 175 against 186
+// (scripts/r5/kmeans_small_shard.py; 4 measured the same as 6).  Same labels either way.  SLIC_KM_CREG_MIN_SUBTILES overrides.
+static int km_creg_min_quarter_tiles() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SLIC_KM_CREG_MIN_SUBTILES");
+    v = e ? atoi(e) : 6;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+
 extern "C" size_t slic_kmeans_assign_workspace_bytes(int64_t N, int K) {
   const int64_t G = slic_cdiv(K, 32);          // sized for the finest partial lists (one per 32-centroid wave column)
   return 2 * slic_align_up((size_t)(G * N) * 4, 256);
@@ -1943,7 +2058,7 @@ static int km_assign_perm_impl(const float* Xp, int64_t N, int D, int ldx, const
   const bool creg = D <= 512 &&
 #endif
                      slices >= 1 && (int64_t)ncb * 128 * 7 <= (int64_t)K * 8 &&          // <= 1/8 padding
-                    tiles >= 4 * (int64_t)slices &&                                              // a few tiles per workgroup
+                    tiles * 4 >= km_creg_min_quarter_tiles() * (int64_t)slices &&             // enough points per workgroup to pay for loading its centroids
                     (slic_cdiv(tiles, slices) * 128 + 128) * (int64_t)ldx * 4 < (1ll << 31);        // slice inside one resource
   if (creg) {
     const size_t lds = (size_t)4 * 128 * KM_BK * sizeof(float) + 4 * 128 * 2 * sizeof(float);     // the ring + the tile's four pair lists
@@ -1994,6 +2109,15 @@ extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
 
 // the per-block histogram slab the accumulate workspace starts with (km_assign_perm_impl can fill it in its combine pass)
 static int32_t* km_accumulate_hist_slab(void* workspace) { return (int32_t*)workspace; }
+// the shard sizes km_scan_accumulate takes (SLIC_KM_SCAN=0 switches it off: tests compare with the counting-sort path)
+static bool km_small_shard(int64_t N, int D, int ldx) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SLIC_KM_SCAN");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on && N <= KM_SCAN_MAXN && D <= 512 && D % 4 == 0 && (uint64_t)N * (uint64_t)ldx * 4ull < (1ull << 32);
+}
 
 // what km_accumulate_average needs beyond the sums: the arguments of slic_kmeans_finalize
 struct KmFinish {
@@ -2022,6 +2146,20 @@ static int km_accumulate_impl(const float* X, int64_t N, int D, int ldx, const i
   int32_t* order = w.take<int32_t>((size_t)N);
   hipStream_t st = S(stream);
   SLIC_REQUIRE(K <= 16384, "slic_kmeans_accumulate: K > 16384");
+  if (km_small_shard(N, D, ldx) && !fin && ((uintptr_t)labels % 16) == 0) {
+    // small shard: the workgroups find their rows themselves (no histogram, no counting sort)
+    const int seg = (int)slic_cdiv(slic_cdiv(N, 8), 16) * 16;
+    const size_t lds = (size_t)8 * seg * sizeof(unsigned short);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_scan_accumulate<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
+      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)km_scan_accumulate<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)));
+      lds_set = 64 * 1024;
+    }
+    km_scan_accumulate<TOut><<<dim3(K), dim3(512), lds, st>>>(X, (int)N, D, ldx, labels, seg, sums, counts, n_changed, nch_out, xperm);
+    SLIC_LAUNCH_CHECK();
+    return SLIC_OK;
+  }
   if (!have_hist) {
     km_block_hist<<<dim3(nblk), dim3(KM_SB), (size_t)K * 4, st>>>(labels, N, K, bc);
     SLIC_LAUNCH_CHECK();
@@ -2177,15 +2315,15 @@ extern "C" int slic_kmeans_lloyd_local(const float* X, const float* Xp, int64_t 
   void* ws2 = ws + a1;
   int32_t* n_changed = (int32_t*)(ws + slic_kmeans_lloyd_step_workspace_bytes(N, K));
   int rc = km_assign_perm_impl(Xp, N, D, ldx, Cp_old, K, D, cnorm_old, labels, labels_old, n_changed, nullptr, ws, stream,
-                               km_accumulate_hist_slab(ws2), n_changed);
+                               km_small_shard(N, D, ldx) ? nullptr : km_accumulate_hist_slab(ws2), n_changed);
   if (rc) return rc;
   const int64_t KD = (int64_t)K * D;
   if (payload_f64) {
     double* p = (double*)payload;
-    return km_accumulate_impl<double>(Xp, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true, nullptr, 1);
+    return km_accumulate_impl<double>(Xp, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, !km_small_shard(N, D, ldx), nullptr, 1);
   }
   float* p = (float*)payload;
-  return km_accumulate_impl<float>(Xp, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, true, nullptr, 1);
+  return km_accumulate_impl<float>(Xp, N, D, ldx, labels, K, p, p + KD, n_changed, p + KD + K, ws2, stream, !km_small_shard(N, D, ldx), nullptr, 1);
 }
 
 extern "C" int slic_kmeans_lloyd_global(const void* parts, int parts_f64, int64_t stride, int n_parts, const float* C_old,
