@@ -441,3 +441,36 @@ def test_sharded_kmeans_through_the_library_communicator(gpu, monkeypatch):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "routes agree" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_scan_accumulate_equals_counting_sort(gpu, monkeypatch):
+    """the M-step sums of a small shard by label scan (km_scan_accumulate: one launch, every cluster's workgroup finds its rows itself) against
+    the counting sort + ordered sums (SLIC_KM_SCAN=0): the same row order, so the SAME sums bit for bit and the same counts — random shapes up
+    to the 32 768-row limit: row counts off every 16 / 1024 boundary, empty clusters, one giant cluster, D from 4 to 512, against a float64
+    reference too; and the sharded local half (fp64 payload, permuted source) through both"""
+    from video_similarity_search_amd.clustering.kmeans_hip import HipKernels
+    k = HipKernels()
+    rng = np.random.default_rng(31)
+    cases = [(1, 1, 4), (17, 3, 8), (1000, 500, 512), (12500, 500, 512), (32768, 37, 128), (32767, 1000, 64), (4097, 130, 200), (20000, 2, 512),
+             (12345, 500, 40)]
+    for N, K, D in cases:
+        X = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32)).cuda()
+        lab = rng.integers(0, K, N).astype(np.int32)
+        if K > 3:
+            lab[lab == 1] = 0                                       # an empty cluster and a crowded one
+        if N == 20000:
+            lab[:] = 1                                              # every row in one cluster
+        labd = torch.from_numpy(lab).cuda()
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("SLIC_KM_SCAN", mode)
+            sums = torch.full((K, D), -7.0, device="cuda")
+            counts = torch.full((K,), -7.0, device="cuda")
+            k.accumulate(X, labd, K, sums, counts)
+            out[mode] = (sums.cpu().numpy(), counts.cpu().numpy())
+        monkeypatch.delenv("SLIC_KM_SCAN")
+        assert np.array_equal(out["1"][0].view(np.uint32), out["0"][0].view(np.uint32)), (N, K, D)
+        assert np.array_equal(out["1"][1], out["0"][1]) and np.array_equal(out["1"][1], np.bincount(lab, minlength=K).astype(np.float32))
+        ref = np.zeros((K, D))
+        np.add.at(ref, lab, X.cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(out["1"][0], ref, rtol=2e-5, atol=2e-4 * np.sqrt(max(1, N / K)))

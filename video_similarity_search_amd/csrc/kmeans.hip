@@ -2111,11 +2111,8 @@ extern "C" size_t slic_kmeans_accumulate_workspace_bytes(int64_t N, int K) {
 static int32_t* km_accumulate_hist_slab(void* workspace) { return (int32_t*)workspace; }
 // the shard sizes km_scan_accumulate takes (SLIC_KM_SCAN=0 switches it off: tests compare with the counting-sort path)
 static bool km_small_shard(int64_t N, int D, int ldx) {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("SLIC_KM_SCAN");
-    on = (e && e[0] == '0') ? 0 : 1;
-  }
+  const char* e = getenv("SLIC_KM_SCAN");                     // read per call: the tests switch it inside one process
+  const bool on = !(e && e[0] == '0');
   return on && N <= KM_SCAN_MAXN && D <= 512 && D % 4 == 0 && (uint64_t)N * (uint64_t)ldx * 4ull < (1ull << 32);
 }
 
