@@ -27,6 +27,23 @@ def _pack_off(oa, ob, oc):
     return (oa + 128) | ((ob + 128) << 8) | ((oc + 128) << 16)
 
 
+_ENV_KEYS = {}
+
+
+def _env(name, default=None):
+    """os.environ.get without its exception path: the launch rules below read a dozen switches in front of every launch (350 reads per
+    training step), almost all unset — Mapping.get raises and catches a KeyError for each of those (~1.2 us); a lookup in the
+    environment's own byte dictionary does not.  Sees monkeypatched / late-set variables like os.environ does."""
+    data = getattr(os.environ, "_data", None)
+    if data is None:
+        return os.environ.get(name, default)
+    key = _ENV_KEYS.get(name)
+    if key is None:
+        key = _ENV_KEYS[name] = os.environ.encodekey(name)
+    v = data.get(key)
+    return default if v is None else os.environ.decodevalue(v)
+
+
 def _tap_mask(oa, ob, oc):
     """bit (7*dim + o + 3): the row's precomputed in-bounds mask must contain all three"""
     assert max(abs(oa), abs(ob), abs(oc)) <= 3, "tap offsets beyond +-3 are not supported by the row mask"
@@ -72,7 +89,7 @@ class ConvPlan:
         # channels are N) must be powers of two — widths such as 192 or 384 (RESNET.WIDEN_FACTOR 1.5 / 3) stay on the direct kernels
         pow2 = lambda v: v > 0 and (v & (v - 1)) == 0
         eligible = base and (Wd % 4 == 0 or 128 % Wp == 0) and pow2(self.C // 8) and pow2(self.N // 8)
-        on = os.environ.get("SLIC_WINO", "1") != "0"
+        on = _env("SLIC_WINO", "1") != "0"
         self.wino = (eligible and on) if wino is None else bool(wino)
         assert eligible or not self.wino, "Winograd F(4,3): 3x3x3 / stride 1 / pad 1, C and N 64 x a power of two, W % 4 == 0 or 4 ceil(W/4) | 128"
         # Winograd in two dimensions, F(4, 3) along W x F(2, 3) along H (variant 31, csrc/conv_wino2.hip): a third of the direct form's
@@ -96,24 +113,24 @@ class ConvPlan:
         self.wino2_size_ok = bool(fits2)
         if wino2 is None:
             wgs = 0 if batch is None else -(-(int(batch) * self.in_dims[0] * Hq2 * Wq2) // 64) * (max(self.C, self.N) // 64)
-            wino2 = (elig2 and self.wino and fits2 and os.environ.get("SLIC_WINO2", "1") != "0" and
-                     wgs >= int(os.environ.get("SLIC_WINO2_MIN_WGS", self.WINO2_MIN_WGS)))
+            wino2 = (elig2 and self.wino and fits2 and _env("SLIC_WINO2", "1") != "0" and
+                     wgs >= int(_env("SLIC_WINO2_MIN_WGS", self.WINO2_MIN_WGS)))
         self.wino2 = bool(wino2)
         assert (elig2 and self.wino) or not self.wino2, "Winograd F(4,3) x F(2,3): a Winograd plan with uniform 64-tile blocks"
         # weight gradient by the transposed algorithm: any width (its work splits over taps, channel blocks and tile slices)
-        self.wino_wgrad = (base and on and os.environ.get("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
+        self.wino_wgrad = (base and on and _env("SLIC_WINO_WGRAD", "1") != "0") if wino is None else (bool(wino) and base)
         # ... and by the transposed TWO-dimensional algorithm (slic_conv_wgrad_wino2) wherever the two-dimensional forward runs and its
         # 3 x C / 64 x N / 64 workgroups per tile slice fit the 256 one-workgroup-per-CU slots (all four layers at B = 32; layer4: 192
         # workgroups, one slice).  Algorithmic TFLOP/s at B = 32, 2-D vs 1-D kernel: layer1 303 vs 230, layer2 289 vs 230, layer3 228 vs
         # 192, layer4 150 vs 143.  It takes any H and W (ragged tiles are masked), so it also runs where the forward stays one-dimensional
         # for want of workgroups — layer4 at B = 8: 94 vs 81 — as long as the launch has 128 tiles.
         # SLIC_WINO2_WGRAD=0 switches it off, =2 restricts it to the 128-channel layers.
-        mode = os.environ.get("SLIC_WINO2_WGRAD", "1")
+        mode = _env("SLIC_WINO2_WGRAD", "1")
         blocks2 = 3 * (self.C // 64) * (self.N // 64)
         if wino2_wgrad is None:
             tiles2 = 0 if batch is None else int(batch) * self.in_dims[0] * Hq2 * Wq2
-            wino2_wgrad = ((self.wino2 or (self.wino and tiles2 >= 128 and os.environ.get("SLIC_WINO2", "1") != "0")) and self.wino_wgrad and
-                           fits2 and positions < (1 << 24) and mode != "0" and blocks2 <= int(os.environ.get("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
+            wino2_wgrad = ((self.wino2 or (self.wino and tiles2 >= 128 and _env("SLIC_WINO2", "1") != "0")) and self.wino_wgrad and
+                           fits2 and positions < (1 << 24) and mode != "0" and blocks2 <= int(_env("SLIC_WINO2_WGRAD_MAXBLOCKS", "256")) and
                            (mode != "2" or (self.C == 128 and self.N == 128)))
         self.wino2_wgrad = bool(wino2_wgrad)
         assert not self.wino2_wgrad or base, "transposed 2-D Winograd weight gradient: a Winograd plan"
@@ -324,19 +341,28 @@ class ConvPlan:
     # the chunks concatenate (a chunk is a whole number of slab rows), the weight gradients of the chunks are added in chunk order.
     # SLIC_CONV_MAX_BYTES / SLIC_CONV_MAX_POSITIONS lower the limits (tests force chunking at small sizes).
     def _launch_batch(self, B):
-        lim_b = int(os.environ.get("SLIC_CONV_MAX_BYTES", 0xFFFFFF00 - 4096))
-        lim_p = int(os.environ.get("SLIC_CONV_MAX_POSITIONS", ((1 << 24) - 1) if self._base333 else ((1 << 31) - 1)))
+        # (called in front of every launch: the answer is cached per batch size and limit setting — 43 calls per backward at ~16 us each
+        #  were 0.7 ms of a 6.8 ms host step before the cache, scripts/r5/host_parts.py)
+        key = (B, _env("SLIC_CONV_MAX_BYTES"), _env("SLIC_CONV_MAX_POSITIONS"), hasattr(self, "src_dims"))
+        cache = self.__dict__.setdefault("_lb_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        lim_b = int(key[1]) if key[1] is not None else 0xFFFFFF00 - 4096
+        lim_p = int(key[2]) if key[2] is not None else (((1 << 24) - 1) if self._base333 else ((1 << 31) - 1))
         src_dims = getattr(self, "src_dims", self.in_dims)
         pin, pout = int(np.prod(src_dims)), int(np.prod(self.out_dims))
         cmax = max(self.Cs, self.N)
         per_clip = max(pin, int(np.prod(self.in_dims)), pout) * cmax * 4
         margin = 2 * self.in_dims[1] * self.in_dims[2] * cmax * 4 + 256 if self._base333 else 0
         Bc = min(B, max(0, lim_b - margin) // per_clip, lim_p // max(pin, pout))
-        if Bc >= B:
-            return B
-        Bc = Bc // 8 * 8                       # whole slab rows per chunk at every block size in use (128 / 392 / 448 / 512 rows)
-        if Bc < 8:
-            raise _lib.SlicError(f"ConvPlan: eight clips of {self.in_dims} x {cmax} channels exceed one launch's 32-bit range")
+        if Bc < B:
+            Bc = Bc // 8 * 8                   # whole slab rows per chunk at every block size in use (128 / 392 / 448 / 512 rows)
+            if Bc < 8:
+                raise _lib.SlicError(f"ConvPlan: eight clips of {self.in_dims} x {cmax} channels exceed one launch's 32-bit range")
+        else:
+            Bc = B
+        cache[key] = Bc
         return Bc
 
     def _chunks(self, B):
@@ -417,16 +443,16 @@ class ConvPlan:
             # two-dimensional Winograd, ONE workgroup per CU (256 slots): a launch's partly filled last dispatch round — when it is at
             # most half full — and launches of less than a round cut their K loop into as many even pieces as fill the slots once
             # (pieces | 3 Cs / 16; + a finish pass): layer2 at B = 32 is 784 workgroups = 3.06 rounds (16 in the tail), layer4 64 x 4 pieces
-            if os.environ.get("SLIC_WINO2_SPLIT", "1") == "0":
+            if _env("SLIC_WINO2_SPLIT", "1") == "0":
                 return None
             H2, W2 = a.Hs, a.Ws
             gx, ny = -(-((a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)) // 64), a.N // 64
             wgs = gx * ny
             rem = wgs % 256
-            if rem == 0 or rem > 128 or wgs > int(os.environ.get("SLIC_WINO2_TAIL_MAXROUNDS", "6")) * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
+            if rem == 0 or rem > 128 or wgs > int(_env("SLIC_WINO2_TAIL_MAXROUNDS", "6")) * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
                 return None                                  # pass measured no faster there)
             tail_x = -(-rem // ny)
-            forced = int(os.environ.get("SLIC_WINO2_PIECES", "0"))
+            forced = int(_env("SLIC_WINO2_PIECES", "0"))
             units = 3 * a.Cs // 16
             # a piece keeps >= 48 of the 3 Cs / 4 stages when the whole launch is cut (layer3 at B = 8: 4 x 48 best, 8 x 24 and 16 x 12 slower;
             # layer4 at B = 32: 4 x 96), >= 16 in a tail beside whole workgroups (layer2: 6 x 16)
@@ -439,14 +465,14 @@ class ConvPlan:
             # the 512 slots (2 workgroups / CU), each piece keeping >= 48 stages.  Measured at layer4, B = 32 (112 workgroups, 576
             # stages; scripts/r3/ab_split.sh): 4 pieces 167 / 171 TFLOP/s forward / data gradient, 8 pieces 157 / 161, 6 152 / 155,
             # 10 (two rounds and a fifth) 143 / 146, 3 129 / 131
-            if os.environ.get("SLIC_WINO_SPLIT", "1") == "0":
+            if _env("SLIC_WINO_SPLIT", "1") == "0":
                 return None
             Wd = a.Ws
             gx, ny = ((a.M // Wd) * ((Wd + 3) // 4) + 63) // 64, a.N // 64
             wgs = gx * ny
             ns = 9 * (a.Cs // 8)
-            forced = os.environ.get("SLIC_WINO_SPLIT", "1")
-            if wgs >= int(os.environ.get("SLIC_WINO_MIN_WGS", cls.WINO_MIN_WGS)):
+            forced = _env("SLIC_WINO_SPLIT", "1")
+            if wgs >= int(_env("SLIC_WINO_MIN_WGS", cls.WINO_MIN_WGS)):
                 # More than a round: a partly filled LAST dispatch round costs most of a round's time (layer2 at B = 32: 1568
                 # workgroups on 512 slots = 3.06 rounds, 218 / 224 TFLOP/s against 236 / 237 at B = 31's 2.97 rounds).  The blocks
                 # of the full rounds run whole; the few behind them cut their K loop so that they fill the slots once more.
@@ -454,16 +480,16 @@ class ConvPlan:
                 # Pieces of >= 36 stages (layer2: 4 x 36, 231 / 234; 6 x 24 and 3 x 48 gained less); launches of many rounds are
                 # left alone (layer1: 12.25 rounds — cutting its 72-stage K loop cost the data gradient 3 %).
                 rem = wgs % 512
-                if forced == "0" or os.environ.get("SLIC_WINO_TAIL", "1") == "0" or Wd % 4 or rem == 0 or rem > 256 or wgs > 6 * 512:
+                if forced == "0" or _env("SLIC_WINO_TAIL", "1") == "0" or Wd % 4 or rem == 0 or rem > 256 or wgs > 6 * 512:
                     return None
                 tail_x = -(-rem // ny)
-                s = min(512 // (tail_x * ny), ns // int(os.environ.get("SLIC_WINO_TAIL_MIN", "36")))
+                s = min(512 // (tail_x * ny), ns // int(_env("SLIC_WINO_TAIL_MIN", "36")))
                 return (gx - tail_x, s) if s >= 2 else None
             s = int(forced) if forced not in ("0", "1") else min(512 // wgs, ns // 48)
             return (0, s) if s >= 2 else None
-        if variant not in (20, 22) or os.environ.get("SLIC_CONV_TAIL", "1") == "0":
+        if variant not in (20, 22) or _env("SLIC_CONV_TAIL", "1") == "0":
             return None
-        slots = int(os.environ.get("SLIC_CONV_TAIL_SLOTS", "0")) or cls.SLOTS[variant]
+        slots = int(_env("SLIC_CONV_TAIL_SLOTS", "0")) or cls.SLOTS[variant]
         BM = 128 if variant == 22 else 64
         nrb, ny = (a.M + BM - 1) // BM, (a.N + 63) // 64
         tiles, nk = nrb * ny, a.nchunks // 8
@@ -611,7 +637,7 @@ class ConvPlan:
         slots (layer4: 576 = one round and an eighth): each slice costs a 6-point slab of 2 x the weight's size to write and re-read,
         so only 1-3 slices are weighed — how full the rounds are x the main loop's share of a workgroup's time, less the slab traffic
         (measured at layer4, B = 32: 1 slice 128 TFLOP/s, 2 143, 3 144, 4 131, 7 106; scripts/r3/ab_split.sh)."""
-        forced = os.environ.get("SLIC_WINO_WGRAD_WGS")
+        forced = _env("SLIC_WINO_WGRAD_WGS")
         if forced is not None:
             return max(1, min(int(forced) // blocks, mt // 64))
         if blocks <= 512:
@@ -649,7 +675,7 @@ class ConvPlan:
             H2, W2 = self.in_dims[1], self.in_dims[2]
             mt = (a.M // (H2 * W2)) * ((H2 + 1) // 2) * ((W2 + 3) // 4)
             if splits is None:
-                forced = os.environ.get("SLIC_WINO2_WGRAD_WGS")
+                forced = _env("SLIC_WINO2_WGRAD_WGS")
                 splits = max(1, min((int(forced) if forced else 256) // blocks, mt // 64))
             tab = self._wino2_tabs.get(B)
             if tab is None:
