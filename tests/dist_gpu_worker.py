@@ -284,6 +284,23 @@ def case_oneshot(rank, world, out):
         ok = ok and np.array_equal(buf.cpu().numpy(), want)
     res["raw_ok"] = ok
     res["n_exchanges"] = len(sizes)
+    # 300 exchanges back to back with NO host synchronisation between them (the k-means loop runs one iteration ahead of its reads): the
+    # double buffering of the inboxes by exchange parity must hold when a fast rank is a whole exchange ahead of a slow one.  Every rank
+    # refills the buffer in stream order, a checksum accumulates in stream order; rank 1 dawdles (extra work on its stream) every few steps.
+    n = 40001
+    buf = torch.empty(n, dtype=torch.float64, device="cuda")
+    acc = torch.zeros(n, dtype=torch.float64, device="cuda")
+    junk = torch.randn(2048, 2048, device="cuda")
+    for it in range(300):
+        buf.fill_(float(rank + 1 + (it % 7)))
+        if rank == 1 and it % 5 == 0:
+            junk = torch.tanh(junk) + 1.0                           # ~100 us of unrelated work in front of this rank's push
+        call("slic_allreduce_oneshot_f64", comm, ptr(buf), n, stream())
+        acc += buf
+    torch.cuda.synchronize()
+    call("slic_oneshot_check", comm)
+    want = sum(sum(r + 1 + (it % 7) for r in range(world)) for it in range(300))
+    res["stress_ok"] = bool((acc == float(want)).all().item())
     info = (ctypes.c_int * 4)()
     call("slic_oneshot_info", comm, info)                          # world, rank, memory kind, exchanges issued
     res["info"] = np.array(list(info))
