@@ -45,6 +45,17 @@ def test_no_gpu_fails_loudly():
     from video_similarity_search_amd.clustering import fit_cluster
     with pytest.raises(_lib.SlicError):
         fit_cluster(torch.randn(64, 8), "kmeans", k=4)
+    # round 5's entry points: retrieval (both algorithms sit behind the same wrapper), the one-shot exchange's set-up, the plan query (host only)
+    import ctypes
+    from video_similarity_search_amd.evaluate import cosine_topk
+    with pytest.raises(_lib.SlicError):
+        cosine_topk(torch.randn(4, 8), torch.randn(40000, 8), k=20)
+    lib = _lib.load()
+    comm, handle = ctypes.c_void_p(), (ctypes.c_ubyte * 64)()
+    assert lib.slic_oneshot_create(2, 0, 1000, 100, ctypes.byref(comm), handle) != 0 and not comm.value
+    assert b"slic_oneshot_create" in lib.slic_last_error()
+    out = (ctypes.c_int * 6)()
+    assert lib.slic_cosine_topk_plan(10000, 100000, 512, 50, out) == 0 and out[0] == 1 and out[5] == 2048      # no device work: answers anywhere
 
 
 def test_product_never_imports_oracle():
