@@ -364,7 +364,8 @@ int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, float* U, vo
  * multiplies per (kt, c, n) and tile of 2 x 4 outputs (slic_conv_wgrad_wino: 36, the direct form: 72); replaces slic_conv_wgrad_wino
  * where variant 31 runs the forward (any H, W: ragged tiles are masked).  args as slic_conv_wgrad_wino; tile_tab: (M / (Hs Ws)) *
  * ceil(Hs / 2) * ceil(Ws / 4) records of 8 bytes written once per geometry by slic_conv_wino2_tile_table; `splits` slices of the
- * tiles, reduced in slice order (deterministic); workspace: splits x 3 x 24 x Cs x N floats.  One workgroup per (kt, 64 x 64 block,
+ * tiles, reduced in a fixed order (deterministic: groups of consecutive slices, then the groups); workspace: splits x 3 x 12 x Cs x N floats (the
+ * W-points are taken back through Gw before they leave the kernel).  One workgroup per (kt, 64 x 64 block,
  * slice) holding ALL FOUR H-points: 3 x Cs / 64 x N / 64 x splits workgroups of 512 threads, one per CU.  Limits (SLIC_EINVAL beyond them;
  * models/conv_plan.py keeps such shapes on slic_conv_wgrad_wino / slic_conv_wgrad): M < 2^24 output positions, x and dy below 4 GiB - 256 B.
  * Stands in for the same autograd weight gradient of nn.Conv3d (models/resnet.py:11-17) as slic_conv_wgrad. */

@@ -43,6 +43,7 @@
                           // 512 = the pixel DMAs of a ROW-IMAGE source ([row][C/8][W][8] planes: 16 image rows x 2 KB per double stage as 32 whole
                           // 1 KB runs instead of 48 gathers of 32-byte pieces — what a planar activation layout would fetch; scripts/r5/ab_planar.sh),
                           // 1024 / 2048 = the forward's BatchNorm statistics without their second moment / skipped (scripts/r5/ab_epilogue.sh: ~2 % of a launch)
+                          // 4096 = the weight gradient without its slice-sum and Gh^T .. Gw passes (scripts/r5/ab_wgrad_passes.sh: what they cost a STEP)
 #endif
 #ifndef SLIC_W2_UAUX
 #define SLIC_W2_UAUX 0    // cache-policy bits of the U / pixel DMAs (experiments: 1 = sc0, 2 = nt, 16 = sc1)
@@ -759,7 +760,8 @@ extern "C" int slic_pack_weight_wino2(const float* W, int N, int C, int dgrad, f
 //   {pixel index, invalid bits} from slic_conv_wino2_tile_table come by SCALAR loads, a stage ahead (a vector load would sit in the
 //   in-order vmcnt queue behind the DMAs: waiting for the record then drains the ring — the round's first kernel, one H-point PAIR per
 //   workgroup with 32 c x 32 n waves, did exactly that and ran at 0.50 of the pipe; this form: 0.64 at layer1).
-//   Slabs [slice][kt][j][p][c][n]; conv_wgrad_wino2_sum adds the slices in order, conv_wgrad_wino2_reduce applies Gh^T .. Gw.
+//   Slabs [slice][kt][j][kw][c][n] (Gw^T applied by the wave that holds the six W-points); conv_wgrad_wino2_sum adds groups of slices in
+//   order, conv_wgrad_wino2_reduce adds the groups and applies Gh^T.
 // ------------------------------------------------------------------------------------------
 // tab[tile] = {pixel index of (b, t, 2 h2, 4 wt); bits 0-23: patch pixel (a, b) = (2 h2 - 1 + a, 4 wt - 1 + b) is OUTSIDE the frame
 //              (bit a * 6 + b); bits 24-26: frame t - 1 + kt is outside the clip; bit 27: always set (a record read past the slice is all zeros)}
@@ -1035,52 +1037,65 @@ void conv_wgrad_wino2_kernel(const SlicConvArgs p, const float* __restrict__ dy,
   mfma_pts(prev, 0, 6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
-  // slab[z][kt][j][p][c][n]
-  float* out = slab + (((int64_t)z * 3 + kt) * 4 + j) * 6 * (int64_t)C * N;
+  // slab[z][kt][j][kw][c][n]: the six W-points of an H-point sit in this wave's accumulators, so they go back through Gw^T here, before the
+  // slices are summed (both are linear) — the slabs, the summing pass and the reduce pass move 36 values per (c, n) instead of 72
+  // Gw^T rows: kw 0: [1/4 -1/6 -1/6 1/24 1/24 0], kw 1: [0 -1/6 1/6 1/12 -1/12 0], kw 2: [0 -1/6 -1/6 1/6 1/6 1]
+  float* out = slab + (((int64_t)z * 3 + kt) * 4 + j) * 3 * (int64_t)C * N + nb * 64 + 2 * r;
 #pragma unroll
-  for (int pp = 0; pp < 6; ++pp)
+  for (int g = 0; g < 16; ++g) {
+    const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
+    f32x2 t[3];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh) {
-      const int n = nb * 64 + 2 * r + nh;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int c = cb * 64 + 32 * wc + (g & 3) + 8 * (g >> 2) + 4 * hh;
-        out[((int64_t)pp * C + c) * N + n] = acc[pp][nh][g];
-      }
+      const float s12 = acc[1][nh][g] + acc[2][nh][g], d12 = acc[2][nh][g] - acc[1][nh][g];
+      const float s34 = acc[3][nh][g] + acc[4][nh][g], d34 = acc[3][nh][g] - acc[4][nh][g];
+      t[0][nh] = 0.25f * acc[0][nh][g] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+      t[1][nh] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+      t[2][nh] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + acc[5][nh][g];
     }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) *(f32x2*)(out + ((int64_t)kw * C + c) * N) = t[kw];      // columns 2 r, 2 r + 1: 256-byte runs per half wave
+  }
 }
 
-// dW[n][c][kt][kh][kw] = sum_j sum_p Gh[j][kh] Gw[p][kw] * (sum over slices z, ascending, of slab[z][kt][j][p][c][n])
+// dW[n][c][kt][kh][kw] = sum_j Gh[j][kh] * (sum over the G partial slabs g, ascending, of slab[g * gstride][kt][j][kw][c][n])
 // Gh as the kernel left the points: rows 2 and 3 negated — [1 0 0; 1/2 1/2 1/2; -1/2 1/2 -1/2; 0 0 -1]
-// Workgroup = 8 channels x 32 columns, all three kt: a thread reads the 72 point sums of its (c, n) — columns fastest: 128-byte runs —
+// Workgroup = 8 channels x 32 columns, all three kt: a thread reads the 36 sums of its (c, n) — columns fastest: 128-byte runs —
 // and the 27 weights leave through LDS, so that the stores are 864-byte runs of dW's [n][c 8][27] (a thread writing its own 9 values
-// wrote 4 bytes every 27 C floats: 210 us for layer4's 75 MB)
-__global__ __launch_bounds__(256) void conv_wgrad_wino2_reduce(const float* __restrict__ slab, int S, int C, int N, float* __restrict__ dW) {
+// wrote 4 bytes every 27 C floats: 210 us for layer4's 75 MB).
+// The loads of one kt — 12 values x G partial slabs — are written out unrolled so that they are all in flight together: a launch of
+// 16 workgroups (layer1) is latency and nothing else, and the earlier form (a run-time slice loop inside the point loops: one
+// round trip per point) took 75 us for 1.2 MB.  G <= 8 partial slabs: the slices themselves where the tile dimension is cut few ways (layers 3 / 4: no
+// separate summing pass), the groups conv_wgrad_wino2_sum leaves otherwise.
+template <int G>
+__global__ __launch_bounds__(256) void conv_wgrad_wino2_reduce(const float* __restrict__ slab, int64_t gstride, int C, int N, float* __restrict__ dW) {
   __shared__ float outs[32 * 217];                               // [n 32][c 8][27], rows padded to 217 floats (bank spread)
   const int tid = threadIdx.x;
   const int nl = tid & 31, cl = tid >> 5;
   const int c0 = blockIdx.x * 8, n0 = blockIdx.y * 32;
   const int n = n0 + nl, c = c0 + cl;
   const int64_t CN = (int64_t)C * N;
-  const int64_t zs = 3 * 24 * CN;
+#pragma unroll
   for (int kt = 0; kt < 3; ++kt) {
-    float t[4][3];      // [j][kw]: the W-points taken back through Gw^T
+    float v[4][3][G];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      float sp[6];
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-      for (int pp = 0; pp < 6; ++pp) {
-        const float* q = slab + (((int64_t)kt * 4 + jj) * 6 + pp) * CN + (int64_t)c * N + n;
-        float a = 0.f;
-        for (int zi = 0; zi < S; ++zi) a += q[zi * zs];          // slices in order
-        sp[pp] = a;
+      for (int kw = 0; kw < 3; ++kw) {
+        const float* q = slab + (((int64_t)kt * 4 + jj) * 3 + kw) * CN + (int64_t)c * N + n;
+#pragma unroll
+        for (int g = 0; g < G; ++g) v[jj][kw][g] = q[g * gstride];
       }
-      // Gw^T rows: kw 0: [1/4 -1/6 -1/6 1/24 1/24 0], kw 1: [0 -1/6 1/6 1/12 -1/12 0], kw 2: [0 -1/6 -1/6 1/6 1/6 1]
-      const float s12 = sp[1] + sp[2], d12 = sp[2] - sp[1], s34 = sp[3] + sp[4], d34 = sp[3] - sp[4];
-      t[jj][0] = 0.25f * sp[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-      t[jj][1] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
-      t[jj][2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + sp[5];
-    }
+    float t[4][3];      // [j][kw]
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        float a = v[jj][kw][0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) a += v[jj][kw][g];           // partial slabs in order
+        t[jj][kw] = a;
+      }
     float* o = outs + nl * 217 + cl * 27 + kt * 9;
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
@@ -1097,24 +1112,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_wino2_reduce(const float* __re
   }
 }
 
-// slab[0][e] = sum over slices z, ascending, of slab[z][e]  (e over the 72 x C x N point sums, 16 bytes per thread, four slices in
-// flight at first, eight now): the reduce kernel's own slice loop ran on 3 x C x N threads — 48 workgroups at layer1, each thread walking 24 x 42 values —
-// and took 150 us for 50 MB; with the slices summed here by 72 x C x N / 4 threads it is one pass at memory speed
-__global__ __launch_bounds__(256) void conv_wgrad_wino2_sum(float* __restrict__ slab, int S, int64_t n4) {
+// Group g = blockIdx.y of the slices: slab[g * per][e] = sum over slices z = g * per .. min(S, (g + 1) * per) - 1, ascending, of slab[z][e]
+// (e over the 36 x C x N values, 16 bytes per thread, eight slices in flight).  Layer1 at B = 32 cuts the tiles 85 ways (one 64 x 64
+// block per kt: 85 x 3 workgroups fill the 256 slots) = 50 MB of slabs; ONE chain per element — 36 x C x N / 4 = 36 864 threads, 85
+// dependent steps each — read them at 0.7 TB/s (138 us); eight chains of eleven run eight times the threads, and the reduce kernel adds
+// the eight partial slabs as it reads them.  (Alone the two passes take 18 + 12 us at layer1; beside the data gradient's workgroups,
+// which is where a step runs them, 110 + 95 — raised wave priority and non-temporal loads measured equal, scripts/r5/ab_wgrad_passes.sh.)
+__global__ __launch_bounds__(256) void conv_wgrad_wino2_sum(float* __restrict__ slab, int S, int per, int64_t n4) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n4) return;
-  f32x4* q = (f32x4*)slab + e;
+  const int z0 = blockIdx.y * per;
+  const int n = min(S, z0 + per) - z0;
+  f32x4* q = (f32x4*)slab + (int64_t)z0 * n4 + e;
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   int zi = 0;
-  for (; zi + 8 <= S; zi += 8) {                                // eight slices in flight, added in slice order
+  for (; zi + 8 <= n; zi += 8) {                                // eight slices in flight, added in slice order
     f32x4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = q[(zi + u) * n4];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a += v[u];
   }
-  for (; zi < S; ++zi) a += q[zi * n4];
+  if (zi < n) {                                                 // the rest of the group in flight together as well
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = zi + u < n ? q[(zi + u) * n4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (zi + u < n) a += v[u];
+  }
   q[0] = a;
+}
+
+// how the S tile slices reach the reduce kernel: as they are (S <= 8), or summed in G <= 8 groups of `per` consecutive slices first
+static void wino2_wgrad_groups(int S, int* per, int* G) {
+  if (S <= 8) { *per = 1; *G = S; return; }
+  const int p = (int)slic_cdiv(S, 8) < 8 ? 8 : (int)slic_cdiv(S, 8);
+  *per = p;
+  *G = (int)slic_cdiv(S, p);
 }
 
 static int64_t wino2_tiles(const SlicConvArgs* a) { return (a->M / ((int64_t)a->Hs * a->Ws)) * ((a->Hs + 1) / 2) * ((a->Ws + 3) / 4); }
@@ -1131,7 +1166,7 @@ extern "C" size_t slic_conv_wgrad_wino2_workspace_bytes(const SlicConvArgs* a, i
   if (!a || a->M <= 0) return 0;
   int tps, S;
   wino2_wgrad_plan(a, splits, &tps, &S);
-  return slic_align_up((size_t)S * 3 * 24 * a->Cs * a->N * sizeof(float), 256);
+  return slic_align_up((size_t)S * 3 * 12 * a->Cs * a->N * sizeof(float), 256);
 }
 
 extern "C" int slic_conv_wino2_tile_table(const SlicConvArgs* a, uint32_t* tile_tab, void* stream) {
@@ -1167,12 +1202,24 @@ extern "C" int slic_conv_wgrad_wino2(const SlicConvArgs* a, const float* dy, int
   const unsigned gx = (unsigned)((total + 7) / 8 * 8);
   conv_wgrad_wino2_kernel<<<dim3(gx), dim3(512), lds, st>>>(*a, dy, (unsigned)dyb, (const uint2*)tile_tab, (float*)workspace, tps, S);
   SLIC_LAUNCH_CHECK();
-  if (S > 1) {
-    const int64_t n4 = (int64_t)72 * a->Cs * a->N / 4;
-    conv_wgrad_wino2_sum<<<dim3((unsigned)slic_cdiv(n4, 256)), dim3(256), 0, st>>>((float*)workspace, S, n4);
+#if SLIC_W2_ABL & 4096
+  return SLIC_OK;
+#endif
+  int per, G;
+  wino2_wgrad_groups(S, &per, &G);
+  const int64_t n4 = (int64_t)36 * a->Cs * a->N / 4;
+  if (per > 1) {
+    conv_wgrad_wino2_sum<<<dim3((unsigned)slic_cdiv(n4, 256), (unsigned)G), dim3(256), 0, st>>>((float*)workspace, S, per, n4);
     SLIC_LAUNCH_CHECK();
   }
-  conv_wgrad_wino2_reduce<<<dim3((unsigned)(a->Cs / 8), (unsigned)(a->N / 32)), dim3(256), 0, st>>>((const float*)workspace, 1, a->Cs, a->N, dW);
+  const dim3 rg((unsigned)(a->Cs / 8), (unsigned)(a->N / 32));
+  const int64_t gstride = (int64_t)per * n4 * 4;
+  switch (G) {
+#define W2_RED(g) case g: conv_wgrad_wino2_reduce<g><<<rg, dim3(256), 0, st>>>((const float*)workspace, gstride, a->Cs, a->N, dW); break;
+    W2_RED(1) W2_RED(2) W2_RED(3) W2_RED(4) W2_RED(5) W2_RED(6) W2_RED(7) W2_RED(8)
+#undef W2_RED
+    default: SLIC_REQUIRE(false, "slic_conv_wgrad_wino2: %d partial slabs", G);
+  }
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
