@@ -379,6 +379,11 @@ __global__ void colsum_kernel(const float* __restrict__ x, int64_t M, int C, flo
 }
 
 // ------------------------------------ C ABI ------------------------------------------------
+#ifndef SLIC_BN_DIAG
+#define SLIC_BN_DIAG 0    // diagnostic builds only (scripts/r5/ab_bn_merges.sh; wrong statistics, right timing): 1 = the statistic merges are not launched
+                          // (0.65-0.8 ms of a 36.7 ms step; level + final as ONE launch with a last-workgroup ticket measured equal to the two launches,
+                          // 36.70 vs 36.71 ms, for the second time — round 2 — and is not kept)
+#endif
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
 static inline unsigned ew_grid(int64_t tot) {
   int64_t g = slic_cdiv(tot, 256);
@@ -405,8 +410,10 @@ static int run_merge(const float* partial, int R, int64_t rows, int C, int64_t M
   if (Rl > BN_MG) {
     const int Ro = (int)slic_cdiv(Rl, BN_MG);
     dim3 grid((unsigned)slic_cdiv(C, 64), (unsigned)Ro);
+#if !SLIC_BN_DIAG
     if (CHAN) bn_merge_level<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, buf[cur]);
     else sum_merge_level<float><<<grid, blk, 0, st>>>(partial, Rl, C, buf[cur]);
+#endif
     SLIC_LAUNCH_CHECK();
     Rl = Ro;
     rows_l *= BN_MG;
@@ -444,10 +451,12 @@ extern "C" int slic_bn_finalize(const float* partial, int R, int rows, int C, in
   int rc = run_merge<true>(partial, R, rows, C, M, workspace, st, &dsrc, &Rl, &rows_l);
   if (rc) return rc;
   const dim3 grid((unsigned)slic_cdiv(C, 64)), blk(64, BN_MQ);
+#if !SLIC_BN_DIAG
   if (dsrc) bn_merge_final<double><<<grid, blk, 0, st>>>(dsrc, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
                                                         running_mean, running_var);
   else bn_merge_final<float><<<grid, blk, 0, st>>>(partial, Rl, rows_l, C, M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
                                                    running_mean, running_var);
+#endif
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -552,8 +561,10 @@ static int bwd_merge_finalize(const float* partial, int R, int64_t rows, int C, 
   int rc = run_merge<false>(partial, R, rows, C, M, mws, st, &dsrc, &Rl, &rows_l);
   if (rc) return rc;
   const dim3 grid((unsigned)slic_cdiv(C, 64)), blk(64, BN_MQ);
+#if !SLIC_BN_DIAG
   if (dsrc) sum_merge_final<double><<<grid, blk, 0, st>>>(dsrc, Rl, C, M, dgamma, dbeta, ka, kb);
   else sum_merge_final<float><<<grid, blk, 0, st>>>(partial, Rl, C, M, dgamma, dbeta, ka, kb);
+#endif
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
