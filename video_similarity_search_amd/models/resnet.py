@@ -347,11 +347,19 @@ class _Engine:
     def seg_forward(self, si, inp, training, save):
         """returns (out, ctx).  Segment 0 takes the NCDHW clip batch; 1..4 take/return NDHWC activations;
         5 returns the [B, out_dim] (or [B, 512]) embedding."""
+        pend = self.__dict__.setdefault("_nbt_pending", [])
+        if si == 0 and pend:                           # a pass that never reached its head segment: its counters are bumped now
+            torch._foreach_add_(pend, 1)
+            pend.clear()
         self._nbt = []
         out = self._seg_forward(si, inp, training, save)
-        if self._nbt:
-            torch._foreach_add_(self._nbt, 1)          # num_batches_tracked += 1 for every BatchNorm of the segment
-            self._nbt = []
+        # num_batches_tracked += 1 for every BatchNorm of the pass by ONE fused add, at the head segment (a tiny launch between two
+        # dependent ones costs the forward's chain ~9 us, scripts/r5/ab_bn_merges.sh; per segment that was six of them)
+        pend.extend(self._nbt)
+        self._nbt = []
+        if pend and si == self.N_SEG - 1:
+            torch._foreach_add_(pend, 1)
+            pend.clear()
         return out
 
     def _seg_forward(self, si, inp, training, save):
