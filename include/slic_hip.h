@@ -501,6 +501,12 @@ int slic_ntxent_euclid_bwd(const float* E, const float* dist, const float* wm, i
 int slic_triplet_select(const float* dist, const int64_t* labels, int n, const int32_t* anchors,
                         const int32_t* positives, int P, float margin, int mode, const float* u, int32_t* negatives,
                         void* stream);
+/* the K (<= 8) negatives per pair of the reference's 'all_semi_hard' branch (loss/triplet_loss.py:158-183, K = 5 there): K distinct rows
+ * among the first max(K, #semi-hard) rows of the anchor's negatives list (ascending rows); u[P][K] uniforms in [0, 1) stand in for
+ * random.sample (draw t = the floor(u (L - t))-th position not taken yet).  negatives: int32 [P][K].  *status (int32, caller-zeroed) is
+ * raised to 1 when an anchor has fewer than K negatives (the reference's topk fails there); such pairs get -1. */
+int slic_triplet_select_k(const float* dist, const int64_t* labels, int n, const int32_t* anchors, const int32_t* positives, int P,
+                          float margin, int K, const float* u, int32_t* negatives, int32_t* status, void* stream);
 /* the same over a rectangular matrix dist[rows][ncols] (MemTripletLoss, loss/triplet_loss.py:9-81, 239-272: rows = the batch,
  * columns = the queue): col_labels int64 [ncols], the pair's anchor row / anchor label / positive COLUMN; mode 3 =
  * 'adapted_hard' (the reference's sampler returns nothing, so every pair takes the hardest-easy fallback). */

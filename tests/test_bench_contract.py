@@ -33,6 +33,7 @@ def test_bench_line_self_verifying_distributed_fields():
     library version, every rank's step time, what DistributedDataParallel did with the gradients, and the k-means row's exchange"""
     path = os.path.join(ROOT, "profiles", "r05_bench_force_dist_one_rank.json")
     d = json.load(open(path))
+    assert "watchdog" not in d, "the secondary rows of this run were cut short by bench.py's watchdog: the line is a headline only"
     dist = d["distributed"]
     assert dist["initialised"] is True and dist["backend"] == "nccl"
     assert dist["rccl_ranks_seen"] == d["n_gpus"] == dist["world_size_env"] == len(dist["ms_per_step_per_rank"])

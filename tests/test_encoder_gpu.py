@@ -323,6 +323,78 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     assert torch.equal(w2.wgrad(xd, dyd, B, torch.empty_like(wd_)), w2.wgrad(xd, dyd, B, torch.empty_like(wd_)))
 
 
+@pytest.mark.parametrize("C,N,B,dims,split", [(64, 64, 1, (16, 56, 56), "0"),       # 98 whole blocks on a grid of 8: lists of 12-13 blocks, a short last XCD range
+                                              (128, 128, 2, (3, 28, 28), "0"),      # 588 tiles: 9 whole blocks x 2 n blocks persistent + the partly filled block on the one-block kernel
+                                              (64, 128, 2, (6, 16, 32), "0"),       # 12 blocks x two n blocks: the lists cross the n blocks
+                                              (64, 64, 3, (14, 56, 56), "1")])      # 258 blocks: the plan cuts the launch into 256 whole blocks (persistent) + a K-split tail
+def test_conv_winograd_2d_persistent(gpu, C, N, B, dims, split):
+    """conv_wino2p_kernel — the persistent form of variant 31 (a workgroup walks a list of tile blocks, the next block's first stages are
+    issued from inside the epilogue, the BatchNorm statistics of both column halves are reduced once) — against the one-block-per-workgroup
+    kernel (SLIC_WINO2_PERSIST=0): outputs and data gradients BIT-equal (same K loop, same combination order), the fused epilogues equal,
+    statistics equal to fp64 within the one-block kernel's tolerance; a grid of 8 workgroups (SLIC_WINO2_PERSIST_GRID) makes these small
+    shapes walk lists of 3-13 blocks."""
+    import os as _os
+    from video_similarity_search_amd.models.conv_plan import ConvPlan
+    rng = np.random.default_rng(C + N + dims[2] + 7)
+    k, s, p = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    x = torch.from_numpy(rng.standard_normal((B, C) + dims).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((N, C) + k) / np.sqrt(C * 27)).astype(np.float32))
+    plan = ConvPlan(C, N, k, s, p, dims, "cuda", wino=True, wino2=True, wino2_wgrad=False)
+    xd = _ndhwc(x, C).cuda()
+    wd_ = w.cuda().contiguous()
+    dyd = torch.from_numpy(rng.standard_normal((B,) + dims + (N,)).astype(np.float32)).cuda()
+    shp = (B,) + dims + (C,)
+    mask, zz, add = [torch.from_numpy(rng.standard_normal(shp).astype(np.float32)).cuda() for _ in range(3)]
+    mean = torch.from_numpy(rng.standard_normal(C).astype(np.float32)).cuda()
+    invstd = torch.from_numpy((0.5 + rng.random(C)).astype(np.float32)).cuda()
+    sc, sh = [torch.from_numpy(rng.standard_normal(N).astype(np.float32)).cuda() for _ in range(2)]
+    res = torch.from_numpy(rng.standard_normal((B,) + dims + (N,)).astype(np.float32)).cuda()
+
+    def run():
+        z, (part, rows) = plan.forward(xd, plan.pack_fwd(wd_), B, want_stats=True)
+        y, _ = plan.forward(xd, plan.pack_fwd(wd_), B, scale=sc, shift=sh, addend=res, relu=True)
+        dx = plan.dgrad(dyd, plan.pack_dgrad(wd_), B)
+        g, bpart = plan.dgrad(dyd, plan.pack_dgrad(wd_), B, addend=add, mask=mask, bwd=(zz, mean, invstd))
+        torch.cuda.synchronize()
+        return z.clone(), part.clone(), rows, y.clone(), dx.clone(), g.clone(), bpart.clone()
+
+    old = {kk: _os.environ.get(kk) for kk in ("SLIC_WINO2_PERSIST", "SLIC_WINO2_PERSIST_GRID", "SLIC_WINO2_SPLIT")}
+    try:
+        _os.environ["SLIC_WINO2_SPLIT"] = split                    # "0": one launch over all blocks (these small shapes would be cut along K as few-workgroup launches)
+        _os.environ["SLIC_WINO2_PERSIST"] = "0"
+        ref = run()
+        _os.environ["SLIC_WINO2_PERSIST"] = "1"
+        _os.environ["SLIC_WINO2_PERSIST_GRID"] = "8"
+        got = run()
+        got2 = run()
+    finally:
+        for kk, v in old.items():
+            if v is None:
+                _os.environ.pop(kk, None)
+            else:
+                _os.environ[kk] = v
+    z0, p0, r0, y0, dx0, g0, b0 = ref
+    z1, p1, r1, y1, dx1, g1, b1 = got
+    assert r0 == r1 == 512
+    assert torch.equal(z1, z0) and torch.equal(y1, y0) and torch.equal(dx1, dx0) and torch.equal(g1, g0)
+    for a_, b_ in zip(got, got2):                                   # bit-equal run to run, statistics included
+        assert not torch.is_tensor(a_) or torch.equal(a_, b_)
+    # statistics: per block (sum, M2) against fp64 of the kernel's own outputs, and against the one-block kernel's
+    T, H, W = dims
+    zt = z1.double().reshape(B * T, H // 2, 2, W // 4, 4, N).permute(0, 1, 3, 2, 4, 5).reshape(-1, 8, N)     # [tile][8 outputs][N]
+    nblk = p1.shape[0]
+    assert nblk == -(-zt.shape[0] // 64) and p0.shape == p1.shape
+    nfull = zt.shape[0] // 64
+    blk = zt[:nfull * 64].reshape(nfull, 512, N)
+    assert torch.allclose(p1[:nfull, 0].double(), blk.sum(1), atol=1e-4, rtol=1e-5)
+    assert torch.allclose(p1[:nfull, 1].double(), ((blk - blk.mean(1, keepdim=True)) ** 2).sum(1), atol=1e-4, rtol=1e-5)
+    assert torch.allclose(p1.double(), p0.double(), atol=2e-4, rtol=1e-4)
+    assert torch.allclose(b1.double(), b0.double(), atol=2e-3, rtol=1e-4)
+    gd = g1.double().reshape(-1, C)
+    assert torch.allclose(b1[:, 0].double().sum(0), gd.sum(0), atol=2e-3, rtol=1e-4)
+    assert torch.allclose(b1[:, 1].double().sum(0), (gd * ((zz.double().reshape(-1, C) - mean.double()) * invstd.double())).sum(0), atol=2e-3, rtol=1e-4)
+
+
 def test_wgrad_wino2_slice_groups(gpu):
     """slic_conv_wgrad_wino2's slice reduction (csrc/conv_wino2.hip): the tile slices leave the kernel with Gw^T applied, are summed in
     up to 8 groups of consecutive slices by conv_wgrad_wino2_sum where there are more than 8, and conv_wgrad_wino2_reduce<G> adds the

@@ -81,3 +81,45 @@ def test_r3d_hip_matches_reference_golden(gpu, golden_dir):
     with torch.no_grad():
         ev = m(x)
     np.testing.assert_allclose(ev.cpu().numpy(), g["eval/emb"], atol=1e-4, rtol=0)
+
+
+def test_r3d_model_head_keeps_reference_state_dict_keys():
+    """r3d_model()'s head layers are nn.Linear subclasses on the library's GEMM: the Sequential's keys stay the reference's
+    (models/model_utils.py:90-93: 1.weight / 1.bias / 3.weight / 3.bias)"""
+    from video_similarity_search_amd.models import r3d_model
+    from video_similarity_search_amd.models.r3d import HipLinear
+    m = r3d_model(dim=128)
+    keys = [k for k in m.state_dict() if not k.startswith("0.")]
+    assert keys == ["1.weight", "1.bias", "3.weight", "3.bias"]
+    assert isinstance(m[1], torch.nn.Linear) and isinstance(m[1], HipLinear) and isinstance(m[3], HipLinear)
+    assert tuple(m[3].weight.shape) == (128, 512)
+    import copy
+    m2 = copy.deepcopy(m)                                           # plans are rebuilt on demand
+    assert m2[1]._plans == {}
+
+
+@pytest.mark.gpu
+def test_hip_linear_matches_fp64_linear(gpu):
+    """HipLinear (slic_conv_gemm + slic_conv_wgrad + slic_colsum) forward and the three gradients against fp64 F.linear; a torch optimizer
+    step on its parameters works as on nn.Linear"""
+    from video_similarity_search_amd.models.r3d import HipLinear
+    torch.manual_seed(3)
+    for B, fin, fout in ((8, 512, 512), (5, 512, 128), (3, 64, 20)):
+        lin = HipLinear(fin, fout).cuda()
+        x = torch.randn(B, fin, device="cuda", requires_grad=True)
+        dy = torch.randn(B, fout, device="cuda")
+        y = lin(x)
+        y.backward(dy)
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        w64, b64 = lin.weight.detach().double().cpu().requires_grad_(True), lin.bias.detach().double().cpu().requires_grad_(True)
+        y64 = torch.nn.functional.linear(x64, w64, b64)
+        y64.backward(dy.double().cpu())
+        for got, ref in ((y, y64), (x.grad, x64.grad), (lin.weight.grad, w64.grad), (lin.bias.grad, b64.grad)):
+            assert (got.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+        w0 = lin.weight.detach().clone()
+        opt.step()
+        assert torch.allclose(lin.weight, w0 - 0.1 * lin.weight.grad)
+        y2 = lin(x.detach())                                        # the updated weight is re-packed (fresh pack per call)
+        ref2 = torch.nn.functional.linear(x64.detach(), lin.weight.detach().double().cpu(), lin.bias.detach().double().cpu())
+        assert (y2.detach().cpu().double() - ref2).abs().max().item() < 2e-5 * max(1.0, ref2.abs().max().item())

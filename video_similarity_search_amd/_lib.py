@@ -120,6 +120,7 @@ SIGNATURES = {
     "slic_ntxent_euclid_fwd": (I, [P, I, I, F, P, P, P, P, P]),
     "slic_ntxent_euclid_bwd": (I, [P, P, P, I, I, P, P, P]),
     "slic_triplet_select": (I, [P, P, I, P, P, I, F, I, P, P, P]),
+    "slic_triplet_select_k": (I, [P, P, I, P, P, I, F, I, P, P, P, P]),
     "slic_triplet_select_cross": (I, [P, P, I, P, P, P, I, F, I, P, P, P]),
     "slic_pdist": (I, [P, I, I, F, I, P, P]),
     "slic_pdist2": (I, [P, I, P, I, I, F, I, P, P]),

@@ -281,6 +281,18 @@ def _slic_oneshot(pg, dev, n):
         return h.ptr
     lib = _lib.load()
     W, rank = torch.distributed.get_world_size(pg), torch.distributed.get_rank(pg)
+    if W > 1 and os.environ.get("SLIC_ONESHOT_MULTI_GPU", "0") != "1":
+        # EXPERIMENTAL between GPUs: every test of this exchange ran its ranks as processes on ONE device (one-GPU boxes); a run over xGMI has
+        # never been compared with the all-reduce route.  Ranks on different devices must opt in.  Every rank sees the same
+        # gathered identities, so every rank raises (or none does).
+        import socket
+        pr = torch.cuda.get_device_properties(dev)
+        ident = "%s/%s/%s/%s/%s" % (socket.gethostname(), getattr(pr, "uuid", ""), getattr(pr, "pci_domain_id", ""), getattr(pr, "pci_bus_id", ""),
+                                    getattr(pr, "pci_device_id", ""))
+        ids = _pg_all_gather_bytes(pg, ident.encode()[:96].ljust(96, b"\0"), dev)
+        if len({ids[i * 96:(i + 1) * 96] for i in range(W)}) > 1:
+            raise _lib.SlicError("exchange='oneshot' between different GPUs is experimental (never verified against the RCCL all-reduce on a multi-GPU "
+                                 "node): set SLIC_ONESHOT_MULTI_GPU=1 to opt in, or use exchange='allreduce'")
     hb = 64
     mine = (ctypes.c_ubyte * hb)()
     comm = ctypes.c_void_p()

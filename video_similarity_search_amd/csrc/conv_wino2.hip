@@ -33,6 +33,7 @@
 #include "conv_internal.h"
 #include "wino_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 #ifndef SLIC_PRIO_EDGE
 #define SLIC_PRIO_EDGE 3
@@ -44,6 +45,42 @@
                           // 1 KB runs instead of 48 gathers of 32-byte pieces — what a planar activation layout would fetch; scripts/r5/ab_planar.sh),
                           // 1024 / 2048 = the forward's BatchNorm statistics without their second moment / skipped (scripts/r5/ab_epilogue.sh: ~2 % of a launch)
                           // 4096 = the weight gradient without its slice-sum and Gh^T .. Gw passes (scripts/r5/ab_wgrad_passes.sh: what they cost a STEP)
+#endif
+// In-kernel stamps of the workgroup's phases (s_memrealtime, 100 MHz) + the CU it ran on: ONLY in the diagnostic build of
+// scripts/r6/stamps_wino2.py (-DSLIC_W2_STAMPS, csrc/_exp/); the shipped library has none.
+#ifdef SLIC_W2_STAMPS
+__device__ unsigned long long* slic_w2_stamps_buf = nullptr;     // [workgroups][16]
+extern "C" int slic_debug_set_w2_stamps(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(slic_w2_stamps_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define W2_STAMP(slot)                                                                                                         \
+  do {                                                                                                                         \
+    if (threadIdx.x == 0 && slic_w2_stamps_buf)                                                                                \
+      slic_w2_stamps_buf[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();      \
+  } while (0)
+#define W2_STAMP_ID()                                                                                                          \
+  do {                                                                                                                         \
+    if (threadIdx.x == 0 && slic_w2_stamps_buf)                                                                                \
+      slic_w2_stamps_buf[(size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 16] =                                                 \
+          ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);                      \
+  } while (0)
+// persistent kernel: [workgroup][item 16][slot 8]; slot 0 of item 0 carries the CU id
+#define W2P_STAMP(item, slot)                                                                                                  \
+  do {                                                                                                                         \
+    if (threadIdx.x == 0 && slic_w2_stamps_buf && (item) < 16)                                                                 \
+      slic_w2_stamps_buf[((size_t)blockIdx.x * 16 + (item)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();                  \
+  } while (0)
+#define W2P_STAMP_ID()                                                                                                         \
+  do {                                                                                                                         \
+    if (threadIdx.x == 0 && slic_w2_stamps_buf)                                                                                \
+      slic_w2_stamps_buf[(size_t)blockIdx.x * 16 * 8 + 7] =                                                                    \
+          ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);                      \
+  } while (0)
+#else
+#define W2_STAMP(slot)
+#define W2_STAMP_ID()
+#define W2P_STAMP(item, slot)
+#define W2P_STAMP_ID()
 #endif
 #ifndef SLIC_W2_UAUX
 #define SLIC_W2_UAUX 0    // cache-policy bits of the U / pixel DMAs (experiments: 1 = sc0, 2 = nt, 16 = sc1)
@@ -204,6 +241,7 @@ __device__ __forceinline__ void w2_epilogue_impl(const SlicConvArgs& p, float* l
       }
     }
   }
+  W2_STAMP(5 + 3 * ((n0h >> 5) & 1));
   if (want_bwd) {
     s1 = wave_rows_sum(s1);
     s2 = wave_rows_sum(s2);
@@ -296,6 +334,8 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int64_t tile0 = (int64_t)(mb_off + mb) * 64;
   if (tile0 >= Mt) return;
   const int nb = blockIdx.y, n0 = nb * 64;
+  W2_STAMP_ID();
+  W2_STAMP(1);
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
   const int CCH = C >> 2;                                     // 4-channel stages per kt (a power of two >= 16: checked on the host)
   const int NB = p.N >> 6;
@@ -416,6 +456,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   issue_u(0, 0);
   issue_px(0, 0, 0);
   issue_px(0, 0, 1);
+  W2_STAMP(2);
   __builtin_amdgcn_s_setprio(0);
   // reader offsets (floats): pixel (a, b) of this lane's tile, channel half e2 of the double stage, its channel pair:
   //   (((ab * 2 + slot) * 2 + th) * 2 + e2) * 128 + r * 4 + 2 hh;   point (j, p) of column half nh: ((j * 6 + p) * 2 + nh) * 128 + hh * 64 + r * 2
@@ -519,6 +560,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   mfma_point(5, ut);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+  W2_STAMP(3);
   if (tid < 64) w2_tile_records(p, lds, tile0, tid);           // visible behind the barrier in front of w2_epilogue
 #if SLIC_W2_ABL & 32
   if (acc[0][0][0] != 12345.678f) return;                      // diagnostic build: no epilogue
@@ -547,6 +589,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
         lds[((j * 64 + tl) * 4 + o) * 32 + r] = acc[o][nh][g];
       }
     __syncthreads();
+    W2_STAMP(4 + 3 * nh);
 #if SLIC_W2_ABL & 256
     if (tid < 64) p.dst[(tile0 * 8) * p.ldo + n0 + tid] = lds[tid * 97];      // diagnostic build: no row-major epilogue at all
 #else
@@ -565,7 +608,530 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
       }
     } else {
       w2_epilogue(p, lds, tile0, n0 + nh * 32, tid, full_rows);
+      W2_STAMP(6 + 3 * nh);
     }
+#endif
+  }
+#ifdef SLIC_W2_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // diagnostic build only: this wave's stores have been acknowledged
+  W2_STAMP(10);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 6: the PERSISTENT form of conv_wino2_kernel, for launches of many FULL blocks (H even, W % 4 == 0, every block 64 whole tiles,
+// one K piece; layers 1 and 2 at B = 32).  In-kernel stamps of the one-block-per-workgroup kernel (scripts/r6/stamps_wino2.py,
+// profiles/r06_wino2_stamps.txt; layer1 forward, us per workgroup): decode + first DMAs issued 2.1, K loop 80.8, epilogue 8.1 (image of
+// column half 0 written 1.1, its passes 1.5, its statistics 1.6, half 1: 1.0 / 1.3 / 1.4, stores acknowledged 0.2), hand-over to the next
+// workgroup of the CU 0.66 — 11 of 91.7 us outside the K loop, none of it hidden: one workgroup fills the CU's LDS.  Here a workgroup
+// walks a list of blocks and
+//   * the next block's piece offsets are decoded while the waves sit at the epilogue's barriers, and its first U stage and pixel double
+//     stage are ISSUED as soon as the last read of the epilogue's LDS image is behind a barrier — they land under the statistics'
+//     reduction and the stores; no workgroup launch, no kernel-argument loads, no first-DMA latency per block;
+//   * the BatchNorm statistics of BOTH column halves are reduced once, from registers, behind ONE barrier (they were three
+//     barrier-separated steps per half): a thread keeps (sum, sum of squares) of its eight values per channel about its FIRST value
+//     (a sample of the same distribution: no cancellation to speak of), the row groups of a wave and then the eight waves are merged
+//     with Chan's formula in a fixed order — the same quantities (sum v, sum (v - mean_block)^2) as w2_epilogue_impl writes.
+// Blocks are dealt statically: XCD x (workgroups with blockIdx.x % 8 == x) owns tile blocks [x gx / 8, (x + 1) gx / 8) of every n block, and
+// its workgroups take consecutive entries of that list round-robin — at any moment the workgroups of an XCD work on neighbouring tile
+// blocks of one n block (shared halo rows and U block in its L2), as the hardware's dispatch order gives the one-shot kernel.
+// lane id WITHOUT the work-item id register: in the persistent kernel every value derived from threadIdx.x that lives across the K loop is a
+// register the allocator spills, and a scratch reload in the epilogue waits for vmcnt(0) — i.e. for the next block's DMAs that were just
+// issued.  v_mbcnt recomputes the lane where it is needed (volatile: not hoisted out of the block loop); the wave index is scalar.
+__device__ __forceinline__ int w2_lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+struct W2Stats {
+  f32x4 ref[2], sd[2], sq[2], s1[2], s2[2];
+};
+
+// The passes of one column half over the LDS image buf[j 4][tile 64][col 4][n 32] (see w2_epilogue_impl), every tile whole, in TWO steps:
+//   w2p_read  — the thread's eight output rows combined from the image (row 0 = (Y0 + Y1) + Y2, row 1 = (Y1 - Y2) - Y3) into registers;
+//   w2p_write — (ReLU,) store, statistics accumulated into `st` (registers; no reduction here).  No per-channel or per-element operand: a
+//               load of one issued behind the next block's DMAs makes its first use wait for those DMAs (one in-order counter) — launches
+//               with an affine, an addend, a mask or BatchNorm-backward sums take the LOADS kernel and w2p_passes_loads.
+// The second half's steps are split by the barrier that frees the ring: the next block's first DMAs are issued BETWEEN them, in front of this
+// half's stores in the vector-memory queue (issued behind the stores they waited ~1 us for the queue to drain: scripts/r6/stamps_wino2p.py).
+struct W2Half {
+  f32x4 v[8];
+  unsigned offs[8];
+};
+
+__device__ __forceinline__ void w2p_read(const SlicConvArgs& p, const float* lds, const int n0h, const int ewave, W2Half& h) {
+  constexpr int BNH = 32, NPASS = 8;
+  constexpr int JSTRIDE = 64 * 4 * BNH;
+  const int tid = ewave * 64 + w2_lane_now();
+  const int cq = tid & 7, rr = tid >> 3;
+  const int n = n0h + cq * 4;
+  const int hp = (rr >> 2) & 1, o = rr & 3;
+  const float sgn = hp ? -1.f : 1.f;
+  const float* src = lds + hp * JSTRIDE + (((rr >> 3) * 4 + o) * BNH + cq * 4);
+  const uint2* trec = (const uint2*)(lds + W2_TREC_FLOATS) + (rr >> 3);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) h.offs[ps] = ((trec[ps * 8].x + (unsigned)(hp * p.Ws + o)) * (unsigned)p.ldo + (unsigned)n) * 4u;
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const float* sp = src + ps * (8 * 4 * BNH);
+    const f32x4 ya = *(const f32x4*)sp, yb = *(const f32x4*)(sp + JSTRIDE), yc = *(const f32x4*)(sp + 2 * JSTRIDE);
+    h.v[ps] = (ya + sgn * yb) + sgn * yc;
+  }
+}
+
+template <int NH>
+__device__ __forceinline__ void w2p_write(const SlicConvArgs& p, W2Half& h, W2Stats& st) {
+  constexpr int NPASS = 8;
+  const bool want_stats = p.stat_partial != nullptr, do_relu = p.relu != 0;
+  const unsigned dst_bytes = (unsigned)(((p.M - 1) * (int64_t)p.ldo + p.N) * 4);
+  const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dst_bytes, 0x00020000);
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    f32x4 v = h.v[ps];
+    if (want_stats) {
+      if (ps == 0) st.ref[NH] = v;
+      const f32x4 d = v - st.ref[NH];
+      st.sd[NH] += d;
+      st.sq[NH] += d * d;
+    }
+    if (do_relu) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs_dst, h.offs[ps], 0, 0);
+  }
+}
+
+// the same in ONE step for the launches that load optional operands (addend / ReLU-backward mask / the BatchNorm z of a data gradient): their
+// loads are issued four passes at a time, and holding eight combined rows beside them spilled registers
+template <int NH>
+__device__ __forceinline__ void w2p_passes_loads(const SlicConvArgs& p, const float* lds, const int n0h, const int ewave, W2Stats& st) {
+  constexpr int BNH = 32, NPASS = 8;
+  const int tid = ewave * 64 + w2_lane_now();
+  constexpr int JSTRIDE = 64 * 4 * BNH;
+  const int W = p.Ws;
+  const bool want_stats = p.stat_partial != nullptr, want_bwd = p.bwd_partial != nullptr;
+  const bool has_mask = p.mask_src != nullptr, do_relu = p.relu != 0;
+  const bool has_affine = p.scale != nullptr || p.shift != nullptr;
+  const unsigned dst_bytes = (unsigned)(((p.M - 1) * (int64_t)p.ldo + p.N) * 4);
+  const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc((void*)p.dst, 0, dst_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void*)p.addend, 0, p.addend ? dst_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_msk = __builtin_amdgcn_make_buffer_rsrc((void*)p.mask_src, 0, has_mask ? dst_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bz = __builtin_amdgcn_make_buffer_rsrc((void*)p.bwd_z, 0, p.bwd_z ? dst_bytes : 0, 0x00020000);
+  const int cq = tid & 7, rr = tid >> 3;
+  const int n = n0h + cq * 4;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bmu = sh, bis = sh;
+  if (p.scale) sc = *(const f32x4*)(p.scale + n);
+  if (p.shift) sh = *(const f32x4*)(p.shift + n);
+  if (want_bwd) { bmu = *(const f32x4*)(p.bwd_mean + n); bis = *(const f32x4*)(p.bwd_invstd + n); }
+  const int hp = (rr >> 2) & 1, o = rr & 3;
+  const float sgn = hp ? -1.f : 1.f;
+  const float* src = lds + hp * JSTRIDE + (((rr >> 3) * 4 + o) * BNH + cq * 4);
+  const uint2* trec = (const uint2*)(lds + W2_TREC_FLOATS) + (rr >> 3);
+  unsigned offs[NPASS];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) offs[ps] = ((trec[ps * 8].x + (unsigned)(hp * W + o)) * (unsigned)p.ldo + (unsigned)n) * 4u;
+  constexpr int LB = 4;
+  f32x4 ldadd[LB], ldmsk[LB], ldz[LB];
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    if (ps % LB == 0) {
+#pragma unroll
+      for (int q = 0; q < LB; ++q) {
+        ldadd[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, offs[ps + q], 0, 0));
+        ldmsk[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_msk, offs[ps + q], 0, 0));
+        ldz[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bz, offs[ps + q], 0, 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float* sp = src + ps * (8 * 4 * BNH);
+    const f32x4 ya = *(const f32x4*)sp, yb = *(const f32x4*)(sp + JSTRIDE), yc = *(const f32x4*)(sp + 2 * JSTRIDE);
+    f32x4 v = (ya + sgn * yb) + sgn * yc;
+    if (want_stats) {
+      if (ps == 0) st.ref[NH] = v;
+      const f32x4 d = v - st.ref[NH];
+      st.sd[NH] += d;
+      st.sq[NH] += d * d;
+    }
+    if (has_affine) v = v * sc + sh;
+    v += ldadd[ps % LB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (has_mask && !(ldmsk[ps % LB][c] > 0.f)) ? 0.f : v[c];
+    if (do_relu) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs_dst, offs[ps], 0, 0);
+    if (want_bwd) {
+      const f32x4 zz = ldz[ps % LB];
+      st.s1[NH] += v;
+      st.s2[NH] += v * ((zz - bmu) * bis);
+    }
+  }
+}
+
+__device__ __forceinline__ float* w2p_red() {
+  __shared__ float red[8 * 2 * 64];
+  return red;
+}
+
+// The value of lanes L and L ^ 8 / L ^ 16 / L ^ 32 as a pair (lo, hi) WITHOUT the LDS crossbar: a DPP row rotation (rows of 16 lanes) and
+// gfx950's v_permlane16_swap / v_permlane32_swap — vector instructions of a few cycles where ds_bpermute_b32 is an LDS round trip per step
+// (the three-level butterflies of the statistics measured 1.2 us per block with it).  Every use below is symmetric in the pair.
+// (inline assembly for the swaps: through __builtin_amdgcn_permlane16_swap(x, x) this compiler used the FIRST result for both halves of the pair
+//  — `v_sub_f32 v28, v22, v22` behind `v_permlane16_swap_b32 v22, v28` — and every statistic came out wrong; the test caught it.  The two
+//  wait states cover the VALU write of the operands in front of the swap, as the compiler's own sequence does.)
+__device__ __forceinline__ void w2_pair(const float x, const int off, float& lo, float& hi) {
+  if (off == 8) {
+    lo = x;
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));      // row_ror:8
+  } else if (off == 16) {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+  } else {
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+  }
+}
+
+// one reduction for both column halves, behind one barrier (the caller has passed the barrier that ends the image reads); first half: the row
+// groups of a wave merged by lane exchanges, the wave's rows to LDS
+__device__ __forceinline__ void w2p_stats_finish(const SlicConvArgs& p, float* lds, const int64_t mblk, const int n0, const int ewave, W2Stats& st) {
+  const bool want_stats = p.stat_partial != nullptr, want_bwd = p.bwd_partial != nullptr;
+  if (!want_stats && !want_bwd) return;                          // workgroup-uniform
+  const bool do_bwd = want_bwd && !want_stats;                   // (never both: see w2p_red)
+  float* red = w2p_red();
+  const int elane = w2_lane_now(), cq = elane & 7;
+#pragma unroll
+  for (int nh = 0; nh < 2; ++nh) {
+    if (want_stats) {
+      f32x4 sum = 8.f * st.ref[nh] + st.sd[nh];
+      f32x4 m2 = st.sq[nh] - st.sd[nh] * st.sd[nh] * 0.125f;
+      // Chan, equal counts n on both sides: M2 = M2a + M2b + (sa - sb)^2 / (2 n); n = 8, 16, 32
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float sv = sum[c], mv = m2[c];
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+          float sa, sb, ma, mb;
+          w2_pair(sv, 8 << lv, sa, sb);
+          w2_pair(mv, 8 << lv, ma, mb);
+          const float dm = sa - sb;
+          mv = (ma + mb) + dm * dm * (1.f / (float)(16 << lv));
+          sv = sa + sb;
+        }
+        sum[c] = sv;
+        m2[c] = mv;
+      }
+      if (elane < 8) {
+        *(f32x4*)&red[(ewave * 2 + 0) * 64 + nh * 32 + cq * 4] = sum;
+        *(f32x4*)&red[(ewave * 2 + 1) * 64 + nh * 32 + cq * 4] = m2;
+      }
+    }
+    if (do_bwd) {
+      f32x4 a = st.s1[nh], b = st.s2[nh];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+          float lo, hi;
+          w2_pair(a[c], 8 << lv, lo, hi);
+          a[c] = lo + hi;
+          w2_pair(b[c], 8 << lv, lo, hi);
+          b[c] = lo + hi;
+        }
+      if (elane < 8) {
+        *(f32x4*)&red[(ewave * 2 + 0) * 64 + nh * 32 + cq * 4] = a;
+        *(f32x4*)&red[(ewave * 2 + 1) * 64 + nh * 32 + cq * 4] = b;
+      }
+    }
+  }
+}
+
+// second half: the eight waves' rows merged by 64 threads.  Called AFTER the next block's first DMAs have been issued (reads of a distinct
+// static array: the compiler's wait-count pass does not hold them back behind the in-flight LDS-DMAs; the first half, whose LDS accesses it
+// could not tell apart from the DMAs' destinations, drew an s_waitcnt vmcnt when it ran behind the issue)
+__device__ __forceinline__ void w2p_stats_merge(const SlicConvArgs& p, const int64_t mblk, const int n0, const int ewave) {
+  const bool want_stats = p.stat_partial != nullptr, want_bwd = p.bwd_partial != nullptr;
+  if (!want_stats && !want_bwd) return;                          // workgroup-uniform
+  const bool do_bwd = want_bwd && !want_stats;
+  float* red = w2p_red();
+  const int tid = ewave * 64 + w2_lane_now();
+  // (a raw barrier: __syncthreads() is also a fence, and with the next block's LDS-DMAs in flight the compiler makes it wait for vmcnt(0))
+  __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0): this wave's rows are in LDS
+  __builtin_amdgcn_s_barrier();
+  if (tid < 64) {
+    const int n = n0 + tid;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { v0[w] = red[(w * 2 + 0) * 64 + tid]; v1[w] = red[(w * 2 + 1) * 64 + tid]; }
+    if (want_stats) {
+      // the eight waves (64 rows each) in order: running (64 w rows: S, M) + (64 rows: sw, mw); d = mean_w - mean_run, weight 64 w * 64 / (64 w + 64)
+      float S = v0[0], M = v1[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) {
+        const float d = v0[w] * (1.f / 64.f) - S * (1.f / (64.f * (float)w));
+        M = (M + v1[w]) + d * d * (64.f * (float)w / (float)(w + 1));
+        S += v0[w];
+      }
+      p.stat_partial[(mblk * 2 + 0) * p.N + n] = S;
+      p.stat_partial[(mblk * 2 + 1) * p.N + n] = M;
+    }
+    if (do_bwd) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { t1 += v0[w]; t2 += v1[w]; }
+      p.bwd_partial[(mblk * 2 + 0) * p.N + n] = t1;
+      p.bwd_partial[(mblk * 2 + 1) * p.N + n] = t2;
+    }
+  }
+}
+
+// LOADS: the launch reads optional operands in its epilogue (a per-channel affine, an addend, the ReLU-backward mask, the BatchNorm z of a data gradient) — two kernels,
+// so that each has one straight-line epilogue (with both behind workgroup-uniform branches the register allocator spilled the rows the
+// forward holds across the DMA issue)
+template <bool LOADS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = wave & 3, th = wave >> 2;
+  const int r = lane & 31, hh = lane >> 5;
+  const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
+  const int Wq = W >> 2, Hq = H >> 1;
+  // ---- this workgroup's list: entries e = l, l + GL, ... of XCD x's list (n block major, its tile blocks inside)
+  const int x = blockIdx.x & 7, l = blockIdx.x >> 3, GL = gridDim.x >> 3;
+  const int per = (gx + 7) >> 3;                               // tile blocks per XCD
+  const int mb_lo = x * per, mb_n = min(per, gx - mb_lo);      // (mb_n <= 0: nothing for this XCD)
+  const int nent = mb_n > 0 ? mb_n * ny : 0;
+  if (l >= nent) return;
+  __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+  const int CCH = C >> 2;
+  const int NB = p.N >> 6;
+  const int NSL = 3 * CCH;
+  const unsigned HWC4 = (unsigned)(H * W * C * 4);
+  unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid;
+  // entry -> (first tile, n block); the piece offsets of its DMAs into the stash, its frame flags returned
+  auto entry_mb = [&](int e) { return mb_lo + e % mb_n; };
+  auto entry_nb = [&](int e) { return e / mb_n; };
+  auto decode = [&](int e) -> int {
+    const int64_t tile0 = (int64_t)entry_mb(e) * 64;
+    unsigned q = (unsigned)(tile0 + (wave & 1) * 32 + (lane & 31));
+    const int wt = (int)(q % (unsigned)Wq); q /= (unsigned)Wq;
+    const int h2 = (int)(q % (unsigned)Hq); q /= (unsigned)Hq;
+    const int tt = (int)(q % (unsigned)T);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int ab = 4 * i + (wave >> 1);
+      const int a = (ab * 11) >> 6, b = ab - 6 * a;
+      const int hr = 2 * h2 - 1 + a, wc = 4 * wt - 1 + b;
+      const bool ok = (unsigned)hr < (unsigned)H && (unsigned)wc < (unsigned)W;
+      stash[i * 512] = ok ? (unsigned)(((((int64_t)q * H + hr) * W + wc) * C) * 4) + (unsigned)(lane >> 5) * 16u : 0xFFFFFF00u;
+    }
+    return (tt == 0 ? 1 : 0) | (tt == T - 1 ? 4 : 0) | 8;
+  };
+  int tflags = 0, nb_dma = 0;                                   // state of the DMA issue: the entry whose stages are being fetched
+  const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src - HWC4), 0, p.src_bytes + 2 * HWC4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_wgt = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, p.wgt_bytes, 0x00020000);
+  const unsigned uvoff = (unsigned)tid * 16u;
+  auto kt_cd = [&](int d, int& kt, int& cd) {
+    cd = (int)(((unsigned)d * 43691u) >> 17);
+    kt = d - 3 * cd;
+  };
+  auto issue_px = [&](int d, int slot, int part) {
+    const bool live = 2 * d < NSL;
+    int kt, cd;
+    kt_cd(live ? d : 0, kt, cd);
+    const unsigned inv = (unsigned)__builtin_amdgcn_sbfe(tflags, live ? kt : 3, 1);
+    const unsigned soff = (unsigned)kt * HWC4 + (unsigned)(cd * 32);
+#pragma unroll
+    for (int u = 3 * part; u < 3 * part + 3; ++u) {
+      constexpr int ORD[6] = SLIC_W2_PXORDER;
+      const int i = ORD[u];
+      const unsigned off = stash[i * 512] | inv;
+      const int pc = 8 * i + wave;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + (((pc >> 1) * 2 + slot) * 2 + (pc & 1)) * 256),
+                                               16, (int)off, (int)soff, 0, SLIC_W2_PAUX);
+    }
+  };
+  auto issue_u = [&](int sl, int slot) {
+    const bool live = sl < NSL;
+    int kt, cd;
+    kt_cd(live ? (sl >> 1) : 0, kt, cd);
+    const int cc = 2 * cd + (live ? (sl & 1) : 0);
+    const unsigned ublk = (unsigned)((kt * CCH + cc) * NB + nb_dma) * (unsigned)(W2_U_FLOATS * 4);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + 2 * W2_PX_FLOATS + slot * W2_U_FLOATS + (i * 512 + wave * 64) * 4),
+                                               16, (int)uvoff, (int)(ublk + (unsigned)(i * 8192)), 0, SLIC_W2_UAUX);
+  };
+  // reader state (as conv_wino2_kernel)
+  const int a1 = j == 0 ? 0 : 1, a2 = j == 3 ? 3 : 2;
+  typedef __attribute__((address_space(3))) const char* lds_cptr;
+  const unsigned lbase = (unsigned)(size_t)((__attribute__((address_space(3))) float*)lds);
+  unsigned ar1 = lbase + (unsigned)(a1 * 6144 + th * 256 + r * 4 + 2 * hh) * 4u;
+  unsigned ar2 = lbase + (unsigned)(a2 * 6144 + th * 256 + r * 4 + 2 * hh) * 4u;
+  unsigned bro = lbase + (unsigned)(2 * W2_PX_FLOATS + j * 6 * 256 + hh * 64 + r * 2) * 4u;
+  asm volatile("" : "+v"(ar1), "+v"(ar2), "+v"(bro));
+  const float sg = j == 1 ? 1.f : -1.f;
+  const f32x2 sgn = {sg, sg};
+  const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
+  constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
+  // first entry: decode, first U stage and pixel double stage
+  tflags = decode(l);
+  nb_dma = entry_nb(l);
+  issue_u(0, 0);
+  issue_px(0, 0, 0);
+  issue_px(0, 0, 1);
+  W2P_STAMP_ID();
+  [[maybe_unused]] int item = 0;
+  for (int e = l; e < nent; e += GL) {
+    const int64_t tile0 = (int64_t)entry_mb(e) * 64;
+    const int n0 = entry_nb(e) * 64;
+    W2P_STAMP(item, 0);
+    __builtin_amdgcn_s_setprio(0);
+    f32x16 acc[6][2];
+#pragma unroll
+    for (int pp = 0; pp < 6; ++pp)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
+    f32x2 V[6], ut[2];
+#pragma unroll
+    for (int pp = 0; pp < 6; ++pp) V[pp] = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) ut[nh] = (f32x2){0.f, 0.f};
+    auto mfma_point = [&](const int pp, const f32x2 (&u)[2]) {
+#pragma unroll
+      for (int e2_ = 0; e2_ < 2; ++e2_)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) acc[pp][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][e2_], u[nh][e2_], acc[pp][nh], 0, 0, 0);
+    };
+    auto read_u = [&](const int uslot, const int pp, f32x2 (&u)[2]) {
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) u[nh] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)bro + (uslot * W2_U_FLOATS + pp * 256 + nh * 128) * 4);
+    };
+    for (int s0 = 0; s0 < NSL; s0 += 4) {
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const int sgl = s0 + sidx;
+        const int e2 = sidx & 1, pslot = (sidx >> 1) & 1, uslot = sidx & 1;
+        if (e2) __builtin_amdgcn_s_waitcnt(WAIT_VM6_LGKM0);
+        else __builtin_amdgcn_s_waitcnt(WAIT_VM0_LGKM0);
+        __builtin_amdgcn_s_barrier();
+        const int pso = (pslot * 512 + e2 * 128) * 4;
+        f32x2 d1[6], d2[6], cmb[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          d1[b] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)ar1 + pso + b * 4096);
+          d2[b] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)ar2 + pso + b * 4096);
+        }
+        f32x2 ua[2], ub[2];
+        __builtin_amdgcn_sched_barrier(0);
+        issue_u(sgl + 1, uslot ^ 1);
+        mfma_point(5, ut);
+        __builtin_amdgcn_sched_barrier(0);
+        read_u(uslot, 0, ua);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) cmb[b] = pk_fma(d2[b], sgn, d1[b]);
+        wino_bt6(cmb, V, c2, c4, c5);
+        asm volatile("s_nop 1" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        read_u(uslot, 1, ub);
+        mfma_point(0, ua);
+        read_u(uslot, 2, ua);
+        mfma_point(1, ub);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!e2) issue_px((sgl >> 1) + 1, pslot ^ 1, 0);
+        read_u(uslot, 3, ub);
+        mfma_point(2, ua);
+        read_u(uslot, 4, ua);
+        mfma_point(3, ub);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!e2) issue_px((sgl >> 1) + 1, pslot ^ 1, 1);
+        read_u(uslot, 5, ut);
+        mfma_point(4, ua);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    mfma_point(5, ut);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    W2P_STAMP(item, 1);
+    // ---- epilogue.  The ring is dead; the piece offsets of the NEXT entry go into the stash now (every DMA of this entry has been issued)
+    const int en = e + GL;
+    const bool more = en < nent;                                 // workgroup-uniform
+    int tflags_n = 0;
+    if (more) tflags_n = decode(en);
+    if (tid < 64) w2_tile_records(p, lds, tile0, tid);
+    __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const f32x16 s12 = acc[1][nh] + acc[2][nh], d12 = acc[1][nh] - acc[2][nh];
+      const f32x16 s34 = acc[3][nh] + acc[4][nh], d34 = acc[3][nh] - acc[4][nh];
+      acc[0][nh] = acc[0][nh] + s12 + s34;
+      acc[1][nh] = d12 + 2.f * d34;
+      acc[2][nh] = s12 + 4.f * s34;
+      acc[3][nh] = d12 + 8.f * d34 + acc[5][nh];
+    }
+    W2Stats st;
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      st.ref[nh] = st.sd[nh] = st.sq[nh] = st.s1[nh] = st.s2[nh] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto write_image = [&](const int nh) {
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+          const int tl = th * 32 + (g & 3) + 8 * (g >> 2) + 4 * hh;
+          lds[((j * 64 + tl) * 4 + o) * 32 + r] = acc[o][nh][g];
+        }
+    };
+    // column half 0
+    write_image(0);
+    __syncthreads();
+    if constexpr (LOADS) {
+      w2p_passes_loads<0>(p, lds, n0, wave, st);
+    } else {
+      W2Half h0;
+      w2p_read(p, lds, n0, wave, h0);
+      w2p_write<0>(p, h0, st);
+    }
+    __syncthreads();                                             // the first half's readers are done with the image
+    // column half 1: without optional operands its rows are combined into registers first; behind the barrier that follows nothing reads the
+    // image or the tile records any more, the ring may be written — the next block's first U stage and pixel double stage go out in FRONT of
+    // this half's stores
+    write_image(1);
+    __syncthreads();
+    [[maybe_unused]] W2Half h1;
+    if constexpr (LOADS) w2p_passes_loads<1>(p, lds, n0 + 32, wave, st);
+    else w2p_read(p, lds, n0 + 32, wave, h1);
+    __syncthreads();
+    W2P_STAMP(item, 2);
+    if (more) {
+      tflags = tflags_n;
+      nb_dma = entry_nb(en);
+      issue_u(0, 0);                                             // U slot 0 / pixel slot 0
+      issue_px(0, 0, 0);
+      issue_px(0, 0, 1);
+    }
+    W2P_STAMP(item, 3);
+    if constexpr (!LOADS) w2p_write<1>(p, h1, st);
+    w2p_stats_finish(p, lds, tile0 >> 6, n0, wave, st);
+    W2P_STAMP(item, 4);
+    w2p_stats_merge(p, tile0 >> 6, n0, wave);
+    W2P_STAMP(item, 5);
+#ifdef SLIC_W2_STAMPS
+    ++item;
 #endif
   }
 }
@@ -700,6 +1266,51 @@ size_t slic_conv_wino2_split_workspace_bytes(const SlicConvArgs* a, int nfull, i
   return tail <= 0 || !wino2_pieces_ok(a, pieces) ? 0 : slic_align_up((size_t)tail * (a->N / 64) * pieces * 2 * (2 * 64 * 4 * 32) * sizeof(float), 256);
 }
 
+// compute units of the current device (one 160 KB workgroup each: the persistent kernel's grid); SLIC_WINO2_PERSIST_GRID overrides (tests:
+// a grid of 8 makes small shapes walk lists of several blocks)
+static int w2_persist_grid() {
+  const char* e = getenv("SLIC_WINO2_PERSIST_GRID");
+  if (e && atoi(e) >= 8) return atoi(e) / 8 * 8;
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    n = pr.multiProcessorCount >= 8 ? pr.multiProcessorCount / 8 * 8 : 8;
+  }
+  return n;
+}
+
+// SLIC_WINO2_PERSIST: 0 = the one-block-per-workgroup kernel everywhere; 1 (default) = the whole tile blocks of a launch with at least two
+// blocks per compute unit go to the persistent kernel (conv_wino2p_kernel); 2 = only the launches that emit forward BatchNorm statistics
+// (a training step's forward: nothing shares the chip with them; the data gradients run beside the side stream's weight gradients)
+static int w2_persist_mode() {
+  const char* e = getenv("SLIC_WINO2_PERSIST");
+  return e ? atoi(e) : 1;
+}
+
+// how many of the tile blocks [0, nblocks) go to the persistent kernel: the whole ones (all of them when the tile count is a multiple of
+// 64), or 0 when the launch is not eligible.  full = real outputs of a full block (512 = whole 2 x 4 tiles everywhere)
+static int w2_persist_blocks(const SlicConvArgs* a, int full, int64_t tiles, int nblocks, unsigned ny) {
+  const int mode = w2_persist_mode();
+  if (mode <= 0 || (mode == 2 && !a->stat_partial)) return 0;
+  if (full != 512 || (a->Ws & 3) || (a->Hs & 1)) return 0;
+  const int64_t whole = tiles / 64 < nblocks ? tiles / 64 : nblocks;
+  return whole * ny >= 2ll * w2_persist_grid() ? (int)whole : 0;
+}
+
+// dynamic LDS of the persistent kernel: the rings + the piece offsets (+ the epilogue image, inside the rings); 4 KB of static reduction rows beside it
+constexpr size_t W2P_LDS_BYTES = (size_t)W2_RING_FLOATS * sizeof(float) + 6 * 512 * 4;
+static_assert(W2P_LDS_BYTES + 4096 <= 160 * 1024 && W2P_LDS_BYTES >= (size_t)(W2_TREC_FLOATS + 128) * sizeof(float), "LDS");
+
+static int w2_launch_persist(const SlicConvArgs* a, hipStream_t st, int nblocks, unsigned ny, size_t lds) {
+  (void)lds;
+  if (a->addend || a->mask_src || a->bwd_z || a->scale || a->shift) conv_wino2p_kernel<true><<<dim3((unsigned)w2_persist_grid()), dim3(512), W2P_LDS_BYTES, st>>>(*a, nblocks, (int)ny);
+  else conv_wino2p_kernel<false><<<dim3((unsigned)w2_persist_grid()), dim3(512), W2P_LDS_BYTES, st>>>(*a, nblocks, (int)ny);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
+
 // nfull < 0: the plain launch.  nfull >= 0: tile blocks [0, nfull) whole, the rest with the K loop cut into `pieces` + the finish pass.
 int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, float* slab, int pieces) {
   int full;
@@ -710,6 +1321,8 @@ int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, flo
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2P_LDS_BYTES));
+    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2P_LDS_BYTES));
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -717,15 +1330,28 @@ int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, flo
   const int gx = (int)slic_cdiv(tiles, 64);
   const unsigned ny = (unsigned)(a->N / 64);
   if (nfull < 0 || nfull >= gx) {
-    conv_wino2_kernel<<<dim3((unsigned)((gx + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, 0, gx);
+    const int np = w2_persist_blocks(a, full, tiles, gx, ny);
+    if (np > 0) {
+      rc = w2_launch_persist(a, st, np, ny, lds);
+      if (rc || np == gx) return rc;
+    }
+    // (np < gx: the last, partly filled block — a tile count that is not a multiple of 64 — on the one-block kernel)
+    conv_wino2_kernel<<<dim3((unsigned)((gx - np + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, np, gx - np);
     SLIC_LAUNCH_CHECK();
     return SLIC_OK;
   }
   SLIC_REQUIRE(slab, "slic_conv_gemm_tailsplit: variant 31 needs a workspace");
   SLIC_REQUIRE(wino2_pieces_ok(a, pieces), "slic_conv_gemm_tailsplit: variant 31: splits = %d must divide 3 Cs / 16 = %d (2 .. 16)", pieces, 3 * a->Cs / 16);
   if (nfull > 0) {
-    conv_wino2_kernel<<<dim3((unsigned)((nfull + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, 0, nfull);
-    SLIC_LAUNCH_CHECK();
+    const int np = w2_persist_blocks(a, full, tiles, nfull, ny);
+    if (np > 0) {
+      rc = w2_launch_persist(a, st, np, ny, lds);
+      if (rc) return rc;
+    }
+    if (np < nfull) {
+      conv_wino2_kernel<<<dim3((unsigned)((nfull - np + 7) / 8 * 8), ny), dim3(512), lds, st>>>(*a, full, nullptr, np, nfull - np);
+      SLIC_LAUNCH_CHECK();
+    }
   }
   const int tail = gx - nfull;
   conv_wino2_kernel<<<dim3((unsigned)((tail + 7) / 8 * 8), ny, (unsigned)pieces), dim3(512), lds, st>>>(*a, full, slab, nfull, tail);

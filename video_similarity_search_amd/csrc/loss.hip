@@ -429,7 +429,77 @@ __global__ void triplet_select_kernel(const float* __restrict__ Dm, const int64_
   if (lane == 0) neg[pr] = result;
 }
 
+// The negatives of the reference's 'all_semi_hard' branch (loss/triplet_loss.py:158-183): per (anchor, positive) pair K distinct rows among
+// the first L = max(K, #{j negative : d(a,p) + margin - d(a,j) > 0}) rows of the anchor's negatives list (ascending row order) — the
+// reference draws K distinct ENUMERATE indices of its semi-hard list, topped up with the closest negatives when that list is short.
+// One wave per pair; u[pair][K] uniforms in [0, 1) stand in for its random.sample: draw t takes the floor(u_t (L - t))-th position not
+// taken yet (a uniform K-subset of the L positions, in draw order).  A pair whose anchor has fewer than K negatives raises *status
+// (the reference's topk fails there) and gets -1.
+constexpr int TSK_MAX = 8;
+__global__ void triplet_select_k_kernel(const float* __restrict__ Dm, const int64_t* __restrict__ labels, int n, const int32_t* __restrict__ anc,
+                                        const int32_t* __restrict__ pos, int P, float margin, int K, const float* __restrict__ u,
+                                        int32_t* __restrict__ neg, int32_t* __restrict__ status) {
+  const int pr = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pr >= P) return;
+  const int lane = threadIdx.x & 63;
+  const int a = anc[pr];
+  const int64_t la = labels[a];
+  const float* row = Dm + (int64_t)a * n;
+  const float thr = row[pos[pr]] + margin;
+  int cnt_neg = 0, cnt_c = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const bool isneg = j < n && labels[j] != la;
+    const bool c = isneg && (thr - row[j] > 0.f);
+    cnt_neg += __popcll(__ballot(isneg));
+    cnt_c += __popcll(__ballot(c));
+  }
+  if (cnt_neg < K) {
+    if (lane == 0) { atomicMax(status, 1); for (int t = 0; t < K; ++t) neg[(int64_t)pr * K + t] = -1; }
+    return;
+  }
+  const int L = cnt_c > K ? cnt_c : K;
+  // K distinct positions in [0, L): wave-uniform arithmetic (every lane computes the same)
+  int chosen[TSK_MAX], sorted[TSK_MAX];
+  for (int t = 0; t < K; ++t) {
+    int rsel = (int)(u[(int64_t)pr * K + t] * (float)(L - t));
+    if (rsel >= L - t) rsel = L - t - 1;
+    for (int q = 0; q < t; ++q)                                  // skip the positions taken so far, ascending
+      if (rsel >= sorted[q]) ++rsel;
+    chosen[t] = rsel;
+    int q = t;
+    while (q > 0 && sorted[q - 1] > rsel) { sorted[q] = sorted[q - 1]; --q; }
+    sorted[q] = rsel;
+  }
+  // position in the negatives list -> row
+  int seen = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const unsigned long long m = __ballot(j < n && labels[j] != la);
+    const int pc = __popcll(m);
+    for (int t = 0; t < K; ++t) {
+      const int rk = chosen[t] - seen;
+      if (rk >= 0 && rk < pc) {
+        unsigned long long mm = m;
+        for (int k = 0; k < rk; ++k) mm &= mm - 1;
+        if (lane == 0) neg[(int64_t)pr * K + t] = j0 + (__ffsll((long long)mm) - 1);
+      }
+    }
+    seen += pc;
+  }
+}
+
 static inline hipStream_t S_(void* s) { return (hipStream_t)s; }
+
+extern "C" int slic_triplet_select_k(const float* dist, const int64_t* labels, int n, const int32_t* anchors, const int32_t* positives, int P,
+                                     float margin, int K, const float* u, int32_t* negatives, int32_t* status, void* stream) {
+  SLIC_REQUIRE(dist && labels && anchors && positives && negatives && u && status && n > 1 && P > 0 && K >= 1 && K <= TSK_MAX,
+               "slic_triplet_select_k: bad args (1 <= K <= %d)", TSK_MAX);
+  triplet_select_k_kernel<<<dim3((unsigned)slic_cdiv(P, 4)), dim3(256), 0, S_(stream)>>>(dist, labels, n, anchors, positives, P, margin, K, u,
+                                                                                          negatives, status);
+  SLIC_LAUNCH_CHECK();
+  return SLIC_OK;
+}
 
 extern "C" int slic_triplet_select(const float* dist, const int64_t* labels, int n, const int32_t* anchors,
                                    const int32_t* positives, int P, float margin, int mode, const float* u,

@@ -10,7 +10,7 @@
 //             with hipIpcGetMemHandle; the W handles travel by any channel (torch.distributed, a file); every rank maps its peers' inboxes
 //             (hipIpcOpenMemHandle: xGMI peer access between GPUs; between two processes on ONE GPU — how a one-GPU box tests this — the same
 //             memory through a second mapping).
-//   exchange: ONE kernel, exchange number seq = 1, 2, ...: workgroup b copies chunk b (4096 doubles) of the rank's payload into
+//   exchange: ONE kernel of at most 128 workgroups, exchange number seq = 1, 2, ...: workgroup b copies chunk b (4096 doubles; then b + grid, ...) of the rank's payload into
 //             inbox[seq & 1][rank] of every peer, makes the stores visible at system scope (release fence), stores seq into the peer's flag
 //             (seq & 1, rank, b); then waits — one lane per peer, a bounded spin — until its OWN flags (seq & 1, peer, b) hold seq, acquires,
 //             and writes the sum of the W chunks, added in RANK order (the rank's own from the payload itself), back to the payload.
@@ -24,7 +24,8 @@
 #include <string.h>
 
 #define ONESHOT_MAX_WORLD 16
-#define ONESHOT_CHUNK 4096            // doubles per workgroup and exchange (32 KB)
+#define ONESHOT_CHUNK 4096            // doubles per workgroup step (32 KB)
+#define ONESHOT_MAX_GRID 128          // workgroups per exchange kernel: larger payloads walk their chunks (see the kernel)
 
 struct slic_oneshot {
   int world, rank;
@@ -48,8 +49,13 @@ struct OneshotPeers {
 __global__ __launch_bounds__(256) void oneshot_allreduce_f64_kernel(OneshotPeers peers, int world, int rank, int64_t max_n, int nchunk_max,
                                                                     size_t inbox_off, double* __restrict__ buf, int64_t n, unsigned seq,
                                                                     long long timeout_ticks, int* __restrict__ status) {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int par = (int)(seq & 1u);
+  const int nchunk = (int)((n + ONESHOT_CHUNK - 1) / ONESHOT_CHUNK);
+  // The grid is BOUNDED (<= ONESHOT_MAX_GRID workgroups, far below what one GPU keeps resident even when several ranks share it) and a
+  // workgroup walks chunks b, b + grid, ...: the wait for chunk b needs workgroup (b mod grid) of every peer to have run its earlier
+  // chunks, never a workgroup that is not resident yet — the spin cannot depend on co-residency of a large grid.
+  for (int b = blockIdx.x; b < nchunk; b += gridDim.x) {
   const int64_t e0 = (int64_t)b * ONESHOT_CHUNK;
   const int64_t e1 = e0 + ONESHOT_CHUNK < n ? e0 + ONESHOT_CHUNK : n;
   // ---- 1. this rank's chunk into every peer's inbox[par][rank] (16 bytes per lane)
@@ -110,6 +116,8 @@ __global__ __launch_bounds__(256) void oneshot_allreduce_f64_kernel(OneshotPeers
     buf[e] = acc.x;
     if (pair) buf[e + 1] = acc.y;
   }
+  __syncthreads();                                             // the next chunk's timed_out / flag lanes start from a quiet workgroup
+  }
 }
 
 static size_t oneshot_flag_bytes(int world, int nchunk_max) { return slic_align_up((size_t)2 * world * nchunk_max * sizeof(unsigned), 4096); }
@@ -127,16 +135,25 @@ extern "C" int slic_oneshot_create(int world, int rank, int64_t max_n, int timeo
   c->bytes = c->inbox_off + (size_t)2 * world * c->max_n * sizeof(double);
   c->seq = 0; c->timeout_ms = timeout_ms; c->connected = false;
   for (int p = 0; p < ONESHOT_MAX_WORLD; ++p) c->peer[p] = nullptr;
-  // memory another device writes while kernels of this one read it: uncached, else fine-grained; plain device memory as the last resort
-  // (the kernel's flag and inbox loads are system-scope either way)
+  // memory another device writes while kernels of this one read it must be uncached or fine-grained: plain (coarse-grained) device memory
+  // is not kept coherent with remote writers — a system-scope load may be served by the XCD's L2 — so a rank could spin on a stale flag or
+  // add a stale payload.  With peers there is NO plain-memory fallback: the create fails and the caller keeps the RCCL
+  // all-reduce.  A world of one has no remote writer; plain memory is fine there.
   void* mem = nullptr;
   c->mem_kind = 0;
   if (hipExtMallocWithFlags(&mem, c->bytes, hipDeviceMallocUncached) != hipSuccess) {
     (void)hipGetLastError();
     c->mem_kind = 1;
     if (hipExtMallocWithFlags(&mem, c->bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
+      const hipError_t e2 = hipGetLastError();
       c->mem_kind = 2;
+      if (world > 1) {
+        slic_set_error("slic_oneshot_create: neither uncached nor fine-grained device memory is available for the %zu-byte inbox (%s); "
+                       "coarse-grained memory is not coherent with peer writes — use the RCCL all-reduce (exchange='allreduce')",
+                       c->bytes, hipGetErrorString(e2));
+        delete c;
+        return SLIC_EHIP;
+      }
       if (hipMalloc(&mem, c->bytes) != hipSuccess) {
         slic_set_error("slic_oneshot_create: cannot allocate %zu bytes of device memory: %s", c->bytes, hipGetErrorString(hipGetLastError()));
         delete c;
@@ -198,7 +215,8 @@ extern "C" int slic_allreduce_oneshot_f64(slic_oneshot* c, double* buf, int64_t 
   for (int p = 0; p < ONESHOT_MAX_WORLD; ++p) pp.p[p] = c->peer[p];
   const unsigned seq = ++c->seq;
   const long long ticks = c->timeout_ms > 0 ? (long long)c->timeout_ms * 100000ll : (1ll << 62);      // wall_clock64: 100 MHz
-  const unsigned nb = (unsigned)slic_cdiv(n, ONESHOT_CHUNK);
+  const int64_t nchunks = slic_cdiv(n, ONESHOT_CHUNK);
+  const unsigned nb = (unsigned)(nchunks < ONESHOT_MAX_GRID ? nchunks : ONESHOT_MAX_GRID);
   oneshot_allreduce_f64_kernel<<<dim3(nb), dim3(256), 0, (hipStream_t)stream>>>(pp, c->world, c->rank, c->max_n, c->nchunk_max, c->inbox_off, buf, n,
                                                                                seq, ticks, c->status_dev);
   SLIC_LAUNCH_CHECK();

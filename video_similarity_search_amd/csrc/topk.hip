@@ -1185,6 +1185,24 @@ extern "C" size_t slic_cosine_topk_workspace_bytes(int Nq, int Ng, int k) {
 
 // the streaming path: per-(query, slice) lists in LDS + merge.  qmap / nq_dev (device memory; both or neither): query slot q of [0, *nq_dev)
 // is row qmap[q] of Qn and its result goes to output row qmap[q] — the exact fallback of the collect path; Nq then bounds the slot count.
+// The streaming launch (topk_stream) and the collect path's sample pass (topk_collect) launch the SAME topk_partial_qreg instantiations with
+// different dynamic-LDS sizes.  Two per-call-site "largest size set so far" caches could lower the attribute under each other's feet (the
+// smaller call site overwriting the larger one's value: ADVICE round 5); the attribute is therefore set ONCE, for every instantiation, to
+// the device maximum (160 KB) — every launch size of either site fits below it.
+static int topk_qreg_lds_attr() {
+  static bool done = false;
+  if (done) return SLIC_OK;
+  constexpr int LDS_MAX = 160 * 1024;
+  SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+  done = true;
+  return SLIC_OK;
+}
+
 static int topk_stream(const float* Qn, int Nq, const float* Gn, int Ng, int D, int k, int self_mask, int32_t* out_idx, float* out_dist,
                        SlicCarver& w, hipStream_t st, const int* qmap, const int* nq_dev) {
   const int slices = topk_slices(Nq, Ng, k);
@@ -1220,16 +1238,7 @@ static int topk_stream(const float* Qn, int Nq, const float* Gn, int Ng, int D, 
     SLIC_HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)gthr, (int)0x807FFFFF, (size_t)Nq, st));   // the image of -inf
 #ifndef TK_NO_QREG
     if (D <= 512) {
-      static size_t lds_set3 = 0;
-      if (lds > lds_set3) {
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set3 = lds;
-      }
+      { const int rc_ = topk_qreg_lds_attr(); if (rc_) return rc_; }
 #define TK_LAUNCH_QREG(NK, GS) topk_partial_qreg<NK, GS><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, Ng, D, k, self_mask, per, pcap, pval, pidx, gthr, 1, qmap, nq_dev)
       if (pcap >= 12) {                                       // pending columns long enough for groups of four scores
         if (D > 256) TK_LAUNCH_QREG(16, 4); else if (D > 128) TK_LAUNCH_QREG(8, 4); else TK_LAUNCH_QREG(4, 4);
@@ -1265,13 +1274,7 @@ static int topk_collect(const TopkCollectPlan& c, const float* Qn, int Nq, const
     const int kh = 1 + ((c.ms + 2) / 4) * 4;
     const int pcap = TK_PC_MAX;
     const size_t lds = (size_t)2 * 2 * TK_BQ * TK_BK * sizeof(float) + (size_t)4 * kh * 32 * 8 + (size_t)4 * pcap * 64 * 8 + 16;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)topk_partial_qreg<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      lds_set = lds;
-    }
+    { const int rc_ = topk_qreg_lds_attr(); if (rc_) return rc_; }
     dim3 grid((unsigned)slic_cdiv(Nq, TK_BQ), (unsigned)c.S1);
     const int ns = c.S1 * c.per1;
 #define TK_LAUNCH_S(NK) topk_partial_qreg<NK, 4><<<grid, dim3(256), lds, st>>>(Qn, Nq, Gn, ns, D, c.ms, 0, c.per1, pcap, pval1, pidx1, nullptr, c.gstep, nullptr, nullptr)

@@ -30,11 +30,33 @@ def _pack_off(oa, ob, oc):
 _ENV_KEYS = {}
 
 
+def _env_fast_path():
+    """os.environ's private byte dictionary, or None where it cannot be trusted: `_data` is a CPython implementation detail (bytes keys on
+    POSIX), so the fast path is taken only on POSIX, only when `_data` is a real dict, and only after a self-check against os.environ.get on
+    a key that is set AND one that is not — anywhere else every switch goes through os.environ.get (a different
+    implementation would otherwise read every switch, the launch limits included, as unset)."""
+    data = getattr(os.environ, "_data", None)
+    if os.name != "posix" or not isinstance(data, dict) or not hasattr(os.environ, "encodekey") or not hasattr(os.environ, "decodevalue"):
+        return None
+    try:
+        probe = next(iter(os.environ), None)
+        if probe is not None and os.environ.decodevalue(data[os.environ.encodekey(probe)]) != os.environ.get(probe):
+            return None
+        if data.get(os.environ.encodekey("SLIC__NEVER_SET__PROBE")) is not None:
+            return None
+    except Exception:
+        return None
+    return data
+
+
+_ENV_DATA = _env_fast_path()
+
+
 def _env(name, default=None):
     """os.environ.get without its exception path: the launch rules below read a dozen switches in front of every launch (350 reads per
     training step), almost all unset — Mapping.get raises and catches a KeyError for each of those (~1.2 us); a lookup in the
     environment's own byte dictionary does not.  Sees monkeypatched / late-set variables like os.environ does."""
-    data = getattr(os.environ, "_data", None)
+    data = _ENV_DATA
     if data is None:
         return os.environ.get(name, default)
     key = _ENV_KEYS.get(name)

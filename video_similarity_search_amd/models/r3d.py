@@ -14,7 +14,9 @@ import torch.nn as nn
 from torch.nn.modules.utils import _triple
 
 from .. import _lib
-from .resnet import _Engine, run_engine
+from .._lib import call, ptr, stream
+from .conv_plan import ConvPlan
+from .resnet import _Engine, _flush_engine_counters, run_engine
 
 
 class SpatioTemporalConv(nn.Module):
@@ -112,6 +114,7 @@ class R3DNet(nn.Module):
         self.pool = nn.AdaptiveAvgPool3d(1)
         self._view = None
         self._engines = {}
+        self.register_state_dict_pre_hook(_flush_engine_counters)
 
     def __getstate__(self):
         # copy.deepcopy(model) / torch.save(model): the module views and execution plans are rebuilt on demand
@@ -134,8 +137,70 @@ class R3DNet(nn.Module):
         return run_engine(eng, self, x)
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the library's GEMM (slic_conv_gemm: a 1x1x1 convolution on a [B, 1, 1, 1, C] tensor — the route of the ResNet
+    head's fc1 / fc2, models/resnet.py), with its data / weight / bias gradients (slic_conv_gemm on the transposed operand, slic_conv_wgrad,
+    slic_colsum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mod):
+        B = x.shape[0]
+        plan = mod._plan(x.device)
+        xc = x.contiguous()
+        y, _ = plan.forward(xc.view(B, 1, 1, 1, -1), plan.pack_fwd(weight, fresh=True), B, bias=bias)
+        ctx.save_for_backward(xc, weight)
+        ctx.mod, ctx.has_bias = mod, bias is not None
+        return y.view(B, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B = x.shape[0]
+        plan = ctx.mod._plan(x.device)
+        d5 = dy.contiguous().view(B, 1, 1, 1, -1)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = plan.dgrad(d5, plan.pack_dgrad(weight, fresh=True), B).view(B, -1)
+        if ctx.needs_input_grad[1]:
+            dW = plan.wgrad(x.view(B, 1, 1, 1, -1), d5, B, torch.empty_like(weight))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
+            call("slic_colsum", ptr(d5), B, weight.shape[0], ptr(db), stream())
+        return dx, dW, db, None
+
+
+class HipLinear(nn.Linear):
+    """nn.Linear (same parameters, state_dict keys and initialisation) whose forward / backward run on libslic_hip.so instead of rocBLAS:
+    the projection head of r3d_model (models/model_utils.py:90-93).  2-D inputs [B, in_features], in_features % 4 == 0."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__(in_features, out_features, bias=bias)
+        assert in_features % 4 == 0, "HipLinear: in_features must be a multiple of 4 (16-byte channel runs)"
+        self._plans = {}
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plans"] = {}
+        return state
+
+    def _plan(self, device):
+        key = str(device)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = ConvPlan(self.in_features, self.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), device)
+        return plan
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise _lib.SlicError("HipLinear.forward needs a gfx950 device tensor: no CPU/PyTorch fallback")
+        assert x.dim() == 2 and x.shape[1] == self.in_features, "HipLinear takes [B, in_features]"
+        _lib.load()
+        return _LinearFn.apply(x.to(torch.float32), self.weight, self.bias, self)
+
+
 def r3d_model(dim=128, feature_size=512):
     """models/model_utils.py:87-94: nn.Sequential(R3DNet((1,1,1,1)), Linear(512, 512), ReLU, Linear(512, dim)).
-    The two head layers are a few MFLOP per clip and stay torch modules."""
+    The two head layers run on the library's GEMM like the ResNet head's fc1 / fc2 (HipLinear: an nn.Linear subclass, so the state_dict keys
+    1.weight / 1.bias / 3.weight / 3.bias and the optimizer's view of the parameters are the reference's)."""
     return nn.Sequential(R3DNet(layer_sizes=(1, 1, 1, 1), with_classifier=False),
-                         nn.Linear(feature_size, feature_size), nn.ReLU(), nn.Linear(feature_size, dim))
+                         HipLinear(feature_size, feature_size), nn.ReLU(), HipLinear(feature_size, dim))

@@ -352,7 +352,15 @@ class _Engine:
             torch._foreach_add_(pend, 1)
             pend.clear()
         self._nbt = []
-        out = self._seg_forward(si, inp, training, save)
+        try:
+            out = self._seg_forward(si, inp, training, save)
+        except BaseException:
+            # a forward that aborts after some BatchNorm layers have updated their running statistics: their counters are bumped NOW, so that a
+            # checkpoint written from the handler agrees with its own running statistics (the reference bumps inside each BatchNorm forward)
+            pend.extend(self._nbt)
+            self._nbt = []
+            self.flush_counters()
+            raise
         # num_batches_tracked += 1 for every BatchNorm of the pass by ONE fused add, at the head segment (a tiny launch between two
         # dependent ones costs the forward's chain ~9 us, scripts/r5/ab_bn_merges.sh; per segment that was six of them)
         pend.extend(self._nbt)
@@ -361,6 +369,14 @@ class _Engine:
             torch._foreach_add_(pend, 1)
             pend.clear()
         return out
+
+    def flush_counters(self):
+        """bump the num_batches_tracked counters a pass has not bumped yet (called when a pass aborts, and by the module's state_dict hook: saved
+        counters always match the saved running statistics)"""
+        pend = self.__dict__.get("_nbt_pending")
+        if pend:
+            torch._foreach_add_(pend, 1)
+            pend.clear()
 
     def _seg_forward(self, si, inp, training, save):
         net = self.net
@@ -737,6 +753,7 @@ class ResNet(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         self._engines = {}
+        self.register_state_dict_pre_hook(_flush_engine_counters)
 
     def _make_layer(self, block, planes, blocks, shortcut_type, stride=1):
         downsample = None
@@ -777,6 +794,13 @@ class ResNet(nn.Module):
         _lib.load()
         x = x.to(torch.float32)
         return run_engine(self._engine(x), self, x)
+
+
+def _flush_engine_counters(module, prefix, keep_vars):
+    """state_dict pre-hook: the engines bump num_batches_tracked once per pass, at the head segment — a state_dict taken between two segments
+    (or after an aborted pass) first gets the pending bumps"""
+    for eng in getattr(module, "_engines", {}).values():
+        eng.flush_counters()
 
 
 def run_engine(eng, module, x):
