@@ -453,7 +453,14 @@ def main():
     if use_dist:
         ddp_kw = dict(gradient_as_bucket_view=os.environ.get("SLIC_DDP_BUCKET_VIEW", "1") != "0",
                       bucket_cap_mb=int(os.environ.get("SLIC_DDP_BUCKET_MB", "25")))
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], **ddp_kw)
+        # SLIC_DDP_FAST=1 (default): misc.distributed_helper.data_parallel — the same DistributedDataParallel wrapper with its per-step copies
+        # removed (flat buffer broadcast, gradients written into the bucket views, ReduceOp.AVG hook); 0: the reference's plain call
+        # (online_train.py:485-494)
+        if os.environ.get("SLIC_DDP_FAST", "1") != "0":
+            from video_similarity_search_amd.misc.distributed_helper import data_parallel
+            model = data_parallel(model, local_rank, bucket_cap_mb=ddp_kw["bucket_cap_mb"])
+        else:
+            model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], **ddp_kw)
     crit = OnlineTripletLoss(0.2, 'cosine')
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.5)
     B = args.batch
@@ -471,7 +478,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    # dominant kernel (largest share of a step's kernel time): conv_wino2_kernel — Winograd F(4,3) along W x F(2,3) along H — on the 64->64
+    # dominant kernel (largest share of a step's kernel time): conv_wino2p_kernel (round 6: the persistent form of conv_wino2_kernel) — Winograd F(4,3) along W x F(2,3) along H — on the 64->64
     # 3x3x3 layers (layer1: 4 forward + 4 data-gradient launches per step, identical M x N x K).  Every such launch of the timed steps is
     # bracketed with HIP events on the launch stream.  `roofline.achieved` / `frac` count the fp32 MFMA FLOPs the launch EXECUTES (a third of
     # the direct form's 2 M N K) over its duration: a fraction of the pipe's peak, <= 1; the direct form's count is printed beside it.
@@ -505,7 +512,9 @@ def main():
                          ms_per_step_per_rank=[round(v, 4) for v in per_rank], ms_per_step_min=min(per_rank), ms_per_step_max=max(per_rank),
                          ddp=dict(buckets=len([b for b in bsz.split(",") if b.strip()]), bucket_sizes_bytes=bsz,
                                   bucket_cap_mb=ddp_kw["bucket_cap_mb"], gradient_as_bucket_view=bool(ld.get("gradient_as_bucket_view", ddp_kw["gradient_as_bucket_view"])),
-                                  backend_name=ld.get("backend_name"), gradient_bytes=int(sum(p.numel() for p in net.parameters()) * 4)),
+                                  backend_name=ld.get("backend_name"), gradient_bytes=int(sum(p.numel() for p in net.parameters()) * 4),
+                                  wrapper=("misc.distributed_helper.data_parallel" if hasattr(model, "slic_ddp") else "torch.nn.parallel.DistributedDataParallel (plain)"),
+                                  slic_ddp=getattr(model, "slic_ddp", None)),
                          devices=[torch.cuda.get_device_name(local_rank)], hsa_ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
     if world > 1:
         tt = torch.tensor([dt], device="cuda")
@@ -560,8 +569,10 @@ def main():
                roofline=dict(bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                              frac=ach / FP32_MFMA_PEAK_TFLOPS, traffic=None, traffic_from_profile=traffic_prof,
                              traffic_source=traffic_src,
-                             kernel=("conv_wino2_kernel<3> (64->64 3x3x3 convolution as Winograd F(4,3) x F(2,3) over (W, H): 24 fp32-MFMA GEMMs per kt "
-                                     "over tiles of 2 x 4 outputs, H-points split over the waves, LDS-DMA rings of 8-channel pixel stages and 4-channel U stages; forward launches of layer1)" if wino2 else
+                             kernel=((("conv_wino2p_kernel<false> — the PERSISTENT form (256 workgroups walk the 3136 tile blocks; the next block's first DMAs are issued "
+                                       "from inside the epilogue, one statistics reduction per block) of " if os.environ.get("SLIC_WINO2_PERSIST", "1") != "0" else "") +
+                                      "conv_wino2_kernel (64->64 3x3x3 convolution as Winograd F(4,3) x F(2,3) over (W, H): 24 fp32-MFMA GEMMs per kt "
+                                      "over tiles of 2 x 4 outputs, H-points split over the waves, LDS-DMA rings of 8-channel pixel stages and 4-channel U stages; forward launches of layer1)") if wino2 else
                                      "conv_wino_kernel<3,false,2> (64->64 3x3x3 convolution as Winograd F(4,3) along W: six fp32-MFMA GEMMs per (kt, kh) "
                                      "over W-tiles, LDS-DMA 3-stage ring, transforms in registers; fwd + dgrad of layer1)" if wino else
                                      "conv_gemm_dma_kernel<128,64,2,2,2,32> (64->64 3x3x3 gather-GEMM, LDS-DMA 2-stage ring; fwd + dgrad of layer1)"),

@@ -50,11 +50,12 @@ for g in range(G):
         rows.append([g, it] + [(st[g, it, k] - t0) / 100.0 for k in range(6)])
 R = np.array(rows)
 T = R[:, 2:]
-names = ["K loop (incl. the wait for the first stage)", "Aw^T + both images + passes (to the barrier that frees the ring)", "statistics, first half (lane exchanges)",
-         "next block's first DMAs issued", "statistics merge + stores"]
+names = ["K loop (incl. the wait for the first stage)", "decode of the next block, Aw^T, both images, first half's stores, second half's rows read (ring free)",
+         "next block's first U stage + pixel double stage issued", "second half's stores (forward) + statistics, first half (lane exchanges)",
+         "statistics merged by 64 threads + their stores"]
 d = np.diff(T, axis=1)
 for i, nm in enumerate(names):
-    print(f"  {nm:66s} mean {d[:, i].mean():7.2f} us   p10 {np.percentile(d[:, i], 10):7.2f}   p90 {np.percentile(d[:, i], 90):7.2f}")
+    print(f"  {nm:126s} mean {d[:, i].mean():7.2f} us   p10 {np.percentile(d[:, i], 10):7.2f}   p90 {np.percentile(d[:, i], 90):7.2f}")
 per = T[:, 5] - T[:, 0]
 print(f"  one block, start to start of the next: mean {per.mean():.2f} us; blocks per workgroup: min {int(R[:, 1].max()) if False else int(min(np.bincount(R[:, 0].astype(int))))} "
       f"max {int(max(np.bincount(R[:, 0].astype(int))))}")

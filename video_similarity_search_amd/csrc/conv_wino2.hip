@@ -45,6 +45,9 @@
                           // 1 KB runs instead of 48 gathers of 32-byte pieces — what a planar activation layout would fetch; scripts/r5/ab_planar.sh),
                           // 1024 / 2048 = the forward's BatchNorm statistics without their second moment / skipped (scripts/r5/ab_epilogue.sh: ~2 % of a launch)
                           // 4096 = the weight gradient without its slice-sum and Gh^T .. Gw passes (scripts/r5/ab_wgrad_passes.sh: what they cost a STEP)
+                          // 16384 / 32768 (round 6, scripts/r6/ab_taxis.sh: the ceiling of a THIRD Winograd axis, F(2,3) along T — 2/9 of the direct
+                          // form's multiplies instead of 1/3): the K loop of two of the three kt (the MFMA count of a three-dimensional kernel at today's
+                          // L2 -> LDS bytes per MFMA) / every DMA piece fetched twice (at the 2 x bytes per MFMA its 96-point tiles would need)
 #endif
 // In-kernel stamps of the workgroup's phases (s_memrealtime, 100 MHz) + the CU it ran on: ONLY in the diagnostic build of
 // scripts/r6/stamps_wino2.py (-DSLIC_W2_STAMPS, csrc/_exp/); the shipped library has none.
@@ -360,7 +363,11 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   // spill); whether frame t - 1 / t + 1 exists is one flag word per lane.  A double stage then costs ONE vector instruction + one per
   // piece: kt and the channel group ride in the DMA's SCALAR offset (the resource starts one frame before the tensor, so that the
   // scalar part is never negative); U = a per-lane constant + the stage's block as scalar offset.
+#if SLIC_W2_ABL & 16384
+  const int NSL = 2 * CCH;                                     // diagnostic (scripts/r6/ab_taxis.sh): the K loop of two of the three kt
+#else
   const int NSL = slab ? 3 * CCH / (int)gridDim.z : 3 * CCH;   // stages of this workgroup (a multiple of 4: checked on the host)
+#endif
   const int dbeg = slab ? (int)blockIdx.z * (NSL >> 1) : 0;   // its first double stage
   const unsigned HWC4 = (unsigned)(H * W * C * 4);
   unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid;   // word i of thread tid at [i][tid]: conflict-free (a row per thread was 8-way)
@@ -425,6 +432,11 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
       const int pc = 8 * i + wave;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + (((pc >> 1) * 2 + slot) * 2 + (pc & 1)) * 256),
                                                16, (int)off, (int)soff, 0, SLIC_W2_PAUX);
+#if SLIC_W2_ABL & 32768
+      // diagnostic: every piece fetched twice — a neighbouring frame's pixels into the same place (twice the L2 -> LDS bytes per MFMA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_src, (__attribute__((address_space(3))) void*)(lds + (((pc >> 1) * 2 + slot) * 2 + (pc & 1)) * 256),
+                                               16, (int)off, (int)(soff ^ 64u), 0, SLIC_W2_PAUX);
+#endif
     }
   };
   // U block of local stage sl into U slot `slot`
@@ -442,6 +454,10 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
 #else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + 2 * W2_PX_FLOATS + slot * W2_U_FLOATS + (i * 512 + wave * 64) * 4),
                                                16, (int)uvoff, (int)(ublk + (unsigned)(i * 8192)), 0, SLIC_W2_UAUX);
+#if SLIC_W2_ABL & 32768
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_wgt, (__attribute__((address_space(3))) void*)(lds + 2 * W2_PX_FLOATS + slot * W2_U_FLOATS + (i * 512 + wave * 64) * 4),
+                                               16, (int)uvoff, (int)((ublk + (unsigned)(i * 8192)) ^ 32768u), 0, SLIC_W2_UAUX);
+#endif
 #endif
     }
   };
@@ -499,6 +515,8 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   // issued one stage ago).  Four stage bodies per loop turn: (double-stage parity, channel half) fix every LDS slot at compile time.
 #if SLIC_W2_ABL & 512
   constexpr unsigned WAIT_VM6_LGKM0 = 4 | 0x70, WAIT_VM0_LGKM0 = 0x70;      // four pixel runs per wave and double stage
+#elif SLIC_W2_ABL & 32768
+  constexpr unsigned WAIT_VM6_LGKM0 = 12 | 0x70, WAIT_VM0_LGKM0 = 0x70;     // twelve pixel pieces per wave and double stage
 #else
   constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
 #endif

@@ -103,6 +103,21 @@ class _Bn:
 COUNTS = {"bn_bwd": 0, "bn_bwd_fused": 0}     # launches by flavour (diagnostics / tests)
 
 
+_GRAD_VIEWS = [None]       # the pass's {parameter: DistributedDataParallel bucket view} (misc.distributed_helper.data_parallel), or None
+
+
+def _grad_out(p):
+    """where the gradient of parameter p is written: a FRESH alias of its DistributedDataParallel bucket view when one was handed over
+    (autograd installs a gradient nobody else references as .grad without a copy; the reducer then finds .grad aliasing its bucket and
+    copies nothing), else a new tensor"""
+    gv = _GRAD_VIEWS[0]
+    if gv:
+        v = gv.get(p)
+        if v is not None and v.shape == p.shape and v.device == p.device and v.dtype == p.dtype:
+            return v.detach()
+    return torch.empty_like(p, memory_format=torch.contiguous_format)
+
+
 class _Engine:
     """Execution plan of one ResNet at one input shape: conv plans (tables on the device), forward and backward
     passes written out layer by layer.  Mirrors ResNet.forward / BasicBlock.forward of the reference
@@ -253,8 +268,7 @@ class _Engine:
         M = z.numel() // bn.C
         dz = torch.empty_like(z)
         g = torch.empty_like(z) if want_g else None
-        dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
-        dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        dgamma, dbeta = _grad_out(bn.mod.weight), _grad_out(bn.mod.bias)
         if bn.sync or bn.frozen:
             if out is None:      # no ReLU to undo: the gradient that reaches z's BatchNorm IS dy (slic_bn_bwd_sums writes no g then)
                 _Engine._bn_bwd_sync(None, dy, None, z, bn, None, dz, dgamma, dbeta)
@@ -299,8 +313,7 @@ class _Engine:
         M = z.numel() // bn.C
         R = part.shape[0]
         dz = torch.empty_like(z)
-        dgamma = torch.empty(bn.C, dtype=torch.float32, device=z.device)
-        dbeta = torch.empty(bn.C, dtype=torch.float32, device=z.device)
+        dgamma, dbeta = _grad_out(bn.mod.weight), _grad_out(bn.mod.bias)
         if bn.sync or bn.frozen:
             _Engine._bn_bwd_sync(part, None, None, z, bn, g, dz, dgamma, dbeta)
             return dz, dgamma, dbeta
@@ -466,8 +479,8 @@ class _Engine:
         dout = dout.contiguous()
         self._await_packs()
 
-        def new_like(p):
-            return torch.empty_like(p, memory_format=torch.contiguous_format)
+        _GRAD_VIEWS[0] = getattr(self, "grad_views", None)
+        new_like = _grad_out
 
         def bias_grad(d2, p):
             g = new_like(p)
@@ -800,7 +813,9 @@ def _flush_engine_counters(module, prefix, keep_vars):
     """state_dict pre-hook: the engines bump num_batches_tracked once per pass, at the head segment — a state_dict taken between two segments
     (or after an aborted pass) first gets the pending bumps"""
     for eng in getattr(module, "_engines", {}).values():
-        eng.flush_counters()
+        flush = getattr(eng, "flush_counters", None)
+        if flush is not None:
+            flush()
 
 
 def run_engine(eng, module, x):
@@ -808,6 +823,7 @@ def run_engine(eng, module, x):
     or eval mode (BatchNorm frozen on its running statistics: the reference's ResNet.forward is an ordinary autograd graph in
     any mode, models/resnet.py:255-312) — a plain inference pass with BatchNorm folded into the conv epilogues otherwise"""
     params = [p for p in module.parameters() if p.requires_grad]
+    eng.grad_views = getattr(module, "_slic_grad_views", None)
     if torch.is_grad_enabled() and params:
         a = x
         eng.prepack(with_dgrad=True)
