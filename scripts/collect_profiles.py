@@ -3,8 +3,12 @@ usage: collect_profiles.py <scratch dir> <out dir> <round tag>"""
 import csv, glob, json, os, sys
 
 scratch, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-KERNEL = "conv_wino2_kernel"
-GRID = 3136 * 512                       # layer1 shape at B = 32: 200 704 tiles of 2 x 4 outputs / 64 per workgroup of 512 threads (one n block)
+# round 6: the dominant kernel is the PERSISTENT form — 256 workgroups walk layer1's 3136 tile blocks — specialised on the channel count, so the
+# kernel NAME tells the layers apart (the one-block kernel's grid size did): <false, 64> = layer1's four forward launches per step (training
+# forward: BatchNorm statistics, no optional operand), <true, 64> = its four data-gradient launches (mask / addend / BatchNorm-backward sums)
+KERNEL = "conv_wino2p_kernel<false, 64>"
+KERNEL_DG = "conv_wino2p_kernel<true, 64>"
+GRID = 256 * 512
 
 
 def find(sub, pat):
@@ -27,11 +31,9 @@ def trace_mean(sub):
     forward launches then four data-gradient launches (which share the GPU with the side stream's weight gradients) — bench.py's
     roofline object times the forward ones, so the trace is cut the same way.  Returns (forward ms, n, data-gradient ms)"""
     f = find(sub, "*kernel_trace.csv")
-    rows = sorted((r for r in csv.DictReader(open(f)) if KERNEL in r["Kernel_Name"] and int(r["Grid_Size_X"]) == GRID),
-                  key=lambda r: int(r["Start_Timestamp"]))
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
-    fwd = [v for i, v in enumerate(d) if i % 8 < 4]
-    dg = [v for i, v in enumerate(d) if i % 8 >= 4]
+    allr = list(csv.DictReader(open(f)))
+    fwd = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in allr if KERNEL in r["Kernel_Name"] and int(r["Grid_Size_X"]) == GRID]
+    dg = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in allr if KERNEL_DG in r["Kernel_Name"] and int(r["Grid_Size_X"]) == GRID]
     return sum(fwd) / len(fwd) / 1e6, len(fwd), (sum(dg) / len(dg) / 1e6 if dg else None)
 
 
@@ -62,9 +64,9 @@ if find("pmc_sq", "*counter_collection.csv"):
             pass
 res = {
     "FETCH_SIZE_KB_mean": fetch, "FETCH_SIZE_launches": nf, "WRITE_SIZE_KB_mean": write, "WRITE_SIZE_launches": nw,
-    "note": f"{KERNEL} (Winograd F(4,3) x F(2,3) over (W, H)) at the layer1 shape (grid 3136 x 512 threads: M=1605632 rows = 200704 "
-            "tiles of 2 x 4 outputs, N=64, K=1728; B=32): 4 forward launches (fused BN statistics) + 4 data-gradient launches (fused ReLU "
-            "mask + BN-backward sums: they also read the mask and z tensors) per step. Separate rocprofv3 --pmc passes (FETCH_SIZE, "
+    "note": f"{KERNEL} (the persistent form of the Winograd F(4,3) x F(2,3) kernel) at the layer1 shape (256 workgroups of 512 threads walk 3136 tile "
+            "blocks: M=1605632 rows = 200704 tiles of 2 x 4 outputs, N=64, K=1728; B=32): the 4 FORWARD launches per step (fused BN statistics); the "
+            "4 data-gradient launches are conv_wino2p_kernel<true, 64>. Separate rocprofv3 --pmc passes (FETCH_SIZE, "
             "WRITE_SIZE; each with --kernel-trace only) over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary`. "
             "Units KiB. Per MI355X_MICROARCH.md §HBM, gfx950 FETCH_SIZE reports 1/2 of the bytes of a wide (16 B/lane) coalesced read, so "
             "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (the pixel gather reads 16-byte pieces: the factor 2 is an upper "
@@ -93,7 +95,8 @@ for log in ("rows.log", "topk_k.log", "conv_shapes.log", "wino_ablations.log"):
         other[log[:-4]] = [l.rstrip() for l in open(pth) if l.strip() and "amdgpu.ids" not in l]
 json.dump(other, open(os.path.join(out, f"{tag}_other_rows.json"), "w"), indent=1)
 # round 5: plain-text rows and the one-rank distributed line (its fields make a multi-GPU run self-verifying)
-for log, name in (("topk_kernels.log", "topk_kernels.txt"), ("b8_kernels.log", "small_batch_b8_kernels.txt"), ("planar_diag.log", "planar_layout_diagnostic.txt")):
+for log, name in (("topk_kernels.log", "topk_kernels.txt"), ("b8_kernels.log", "small_batch_b8_kernels.txt"), ("planar_diag.log", "planar_layout_diagnostic.txt"),
+                  ("persist_ab.log", "persistent_kernel_ab.txt"), ("ddp_ab.log", "ddp_one_rank_ab.txt"), ("ddp_seq.log", "ddp_one_rank_step_kernels.txt")):
     pth = os.path.join(scratch, log)
     if os.path.exists(pth):
         open(os.path.join(out, f"{tag}_{name}"), "w").write("".join(l for l in open(pth) if "amdgpu.ids" not in l and "warning" not in l))

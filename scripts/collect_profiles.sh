@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (gpurun -- 'bash scripts/collect_profiles.sh'): default bench, rocprofv3 kernel stats, two PMC passes.
-# Outputs land in gpurun_out/prof_r05/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r05 profiles r05` files them.
+# Outputs land in gpurun_out/prof_r06/ (merged back); `python scripts/collect_profiles.py gpurun_out/prof_r06 profiles r05` files them.
 set -u
 R="$(pwd)"
-S="$R/gpurun_out/prof_r05"
+S="$R/gpurun_out/prof_r06"
 rm -rf "$S"; mkdir -p "$S"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 python "$R/bench.py" > "$S/default.log" 2>&1 < /dev/null
@@ -26,7 +26,10 @@ timeout 300 python "$R/scripts/bench_conv.py" 32 > "$S/conv_shapes.log" 2>&1 < /
 timeout 400 python "$R/bench.py" --gpus 1 --force-dist --quick --no-cpu-baseline --steps 5 --warmup 2 > "$S/force_dist.log" 2> "$S/force_dist.err" < /dev/null
 grep '"row": "kmeans_oneshot"' "$S/force_dist.err" > "$S/force_dist_oneshot.json"
 (cd "$R" && timeout 300 bash scripts/r5/prof_b8.sh) > "$S/b8_kernels.log" 2>&1 < /dev/null
-(cd "$R" && timeout 400 bash scripts/r5/ab_planar.sh "l1 c4 c7" 2>&1 | grep -E "^(base|planar|abl1)") > "$S/planar_diag.log" < /dev/null
+# round 6 rows: the persistent kernel against the one-block kernel (per launch, per shape, whole steps), DistributedDataParallel at one rank
+(cd "$R" && timeout 500 bash scripts/r6/ab_persist.sh) > "$S/persist_ab.log" 2>&1 < /dev/null
+(cd "$R" && timeout 500 bash scripts/r6/ab_ddp.sh) > "$S/ddp_ab.log" 2>&1 < /dev/null
+(cd "$R" && timeout 300 bash scripts/r6/ddp_sequence.sh) > "$S/ddp_seq.log" 2>&1 < /dev/null
 rm -f "$R/gpurun_out/r5_b8_kernel_trace.csv"
 find "$S" -name "*kernel_trace.csv" -path "*stats_*" -delete
 find "$S" -name "*agent_info.csv" -delete

@@ -11,5 +11,5 @@ bash scripts/r4/ab_wino2.sh build "kt2:-DSLIC_W2_ABL=16384 kt2x2:-DSLIC_W2_ABL=4
 export SLIC_WINO2_PERSIST=0
 for name in base kt2 kt2x2 x2; do
   if [ $name = base ]; then unset SLIC_LIB_PATH; else export SLIC_LIB_PATH=$PWD/$D/_exp/libslic_w2_$name.so; fi
-  for sh in l1 c4 c7; do echo "$name $sh: $(python scripts/bench_conv.py 32 "$sh" 2>/dev/null | sed 's/.*| wino2 fwd/wino2 fwd/')"; done
+  for sh in l1 c7; do echo "$name $sh: $(python scripts/bench_conv.py 32 "$sh" 2>/dev/null | sed 's/.*| wino2 fwd/wino2 fwd/')"; done
 done

@@ -323,16 +323,20 @@ def test_conv_winograd_2d(gpu, C, N, B, dims):
     assert torch.equal(w2.wgrad(xd, dyd, B, torch.empty_like(wd_)), w2.wgrad(xd, dyd, B, torch.empty_like(wd_)))
 
 
-@pytest.mark.parametrize("C,N,B,dims,split", [(64, 64, 1, (16, 56, 56), "0"),       # 98 whole blocks on a grid of 8: lists of 12-13 blocks, a short last XCD range
-                                              (128, 128, 2, (3, 28, 28), "0"),      # 588 tiles: 9 whole blocks x 2 n blocks persistent + the partly filled block on the one-block kernel
-                                              (64, 128, 2, (6, 16, 32), "0"),       # 12 blocks x two n blocks: the lists cross the n blocks
-                                              (64, 64, 3, (14, 56, 56), "1")])      # 258 blocks: the plan cuts the launch into 256 whole blocks (persistent) + a K-split tail
-def test_conv_winograd_2d_persistent(gpu, C, N, B, dims, split):
+@pytest.mark.parametrize("C,N,B,dims,split,grid", [
+    (64, 64, 1, (16, 56, 56), "0", "8"),       # 98 whole blocks on a grid of 8: lists of 12-13 blocks, a short last XCD range
+    (64, 64, 1, (16, 56, 56), "0", "32"),      # the same on 4 workgroups per XCD: 13 entries = 3 rounds + 1 -> the left-over block as two COLUMN-HALF items
+    (64, 64, 2, (9, 56, 56), "0", "32"),       # 110 whole blocks (+ a partly filled one): 14 entries per XCD = 3 rounds + 2 -> four half items per XCD
+    (128, 128, 2, (3, 28, 28), "0", "8"),      # 588 tiles: 9 whole blocks x 2 n blocks persistent + the partly filled block on the one-block kernel
+    (64, 128, 2, (6, 16, 32), "0", "8"),       # 12 blocks x two n blocks: the lists cross the n blocks
+    (64, 128, 2, (9, 16, 32), "0", "16"),      # 18 blocks x two n blocks on 2 workgroups per XCD: 5 entries = 2 rounds + 1 -> half items of the second n block
+    (64, 64, 3, (14, 56, 56), "1", "8")])      # 258 blocks: the plan cuts the launch into 256 whole blocks (persistent) + a K-split tail
+def test_conv_winograd_2d_persistent(gpu, C, N, B, dims, split, grid):
     """conv_wino2p_kernel — the persistent form of variant 31 (a workgroup walks a list of tile blocks, the next block's first stages are
     issued from inside the epilogue, the BatchNorm statistics of both column halves are reduced once) — against the one-block-per-workgroup
     kernel (SLIC_WINO2_PERSIST=0): outputs and data gradients BIT-equal (same K loop, same combination order), the fused epilogues equal,
-    statistics equal to fp64 within the one-block kernel's tolerance; a grid of 8 workgroups (SLIC_WINO2_PERSIST_GRID) makes these small
-    shapes walk lists of 3-13 blocks."""
+    statistics equal to fp64 within the one-block kernel's tolerance; grids of 8 / 16 / 32 workgroups (SLIC_WINO2_PERSIST_GRID) make these small
+    shapes walk lists of 3-13 blocks and end in COLUMN-HALF items (two workgroups share a left-over block, 32 columns each)."""
     import os as _os
     from video_similarity_search_amd.models.conv_plan import ConvPlan
     rng = np.random.default_rng(C + N + dims[2] + 7)
@@ -364,7 +368,7 @@ def test_conv_winograd_2d_persistent(gpu, C, N, B, dims, split):
         _os.environ["SLIC_WINO2_PERSIST"] = "0"
         ref = run()
         _os.environ["SLIC_WINO2_PERSIST"] = "1"
-        _os.environ["SLIC_WINO2_PERSIST_GRID"] = "8"
+        _os.environ["SLIC_WINO2_PERSIST_GRID"] = grid
         got = run()
         got2 = run()
     finally:

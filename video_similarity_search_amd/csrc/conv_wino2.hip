@@ -323,7 +323,25 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   const int j = wave & 3, th = wave >> 2;
   const int r = lane & 31, hh = lane >> 5;
   const int bx = blockIdx.x, gdx = gridDim.x;
-  const int mb = (bx & 7) * (gdx >> 3) + (bx >> 3);          // XCD-aware order: neighbouring tile blocks share an L2
+  int mb = (bx & 7) * (gdx >> 3) + (bx >> 3);                // XCD-aware order: neighbouring tile blocks share an L2
+  int nb = blockIdx.y, zpiece = blockIdx.z;
+#ifndef SLIC_W2_UMAP
+#define SLIC_W2_UMAP 1
+#endif
+#if SLIC_W2_UMAP
+  // Round 6 — launches of at most EIGHT tile blocks (layer4 at B = 32: 512 tiles, 8 n blocks x 4 K pieces): there the U operand is the traffic
+  // (75 MB at layer4, a different 2.3 MB slice per (n block, K piece)), and with the order above every XCD runs ONE tile block against ALL
+  // 32 slices — each XCD streams the whole U through its 4 MB L2, 600 MB per launch.  Turned round: XCD x takes the (n block, K piece)
+  // combinations x, x + 8, ... and runs all eight tile blocks against each — a slice is read by one XCD only and shared by eight workgroups
+  // through its L2.  (The hardware deals workgroups to XCDs round-robin in dispatch order, x fastest: with gridDim.x == 8, XCD = blockIdx.x.)
+  if (gdx == 8 && ((gridDim.y * gridDim.z) & 7) == 0) {
+    const int q = (int)(blockIdx.y + gridDim.y * blockIdx.z);
+    const int combo = bx + 8 * (q >> 3);
+    mb = q & 7;
+    nb = combo % (int)gridDim.y;
+    zpiece = combo / (int)gridDim.y;
+  }
+#endif
   const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
   const int Wq = (W + 3) >> 2, Hq = (H + 1) >> 1;
   const int64_t Mt = (p.M / ((int64_t)H * W)) * Hq * Wq;     // tiles
@@ -336,7 +354,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   if (mb >= mb_cnt) return;
   const int64_t tile0 = (int64_t)(mb_off + mb) * 64;
   if (tile0 >= Mt) return;
-  const int nb = blockIdx.y, n0 = nb * 64;
+  const int n0 = nb * 64;
   W2_STAMP_ID();
   W2_STAMP(1);
   __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
@@ -364,11 +382,13 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
   // piece: kt and the channel group ride in the DMA's SCALAR offset (the resource starts one frame before the tensor, so that the
   // scalar part is never negative); U = a per-lane constant + the stage's block as scalar offset.
 #if SLIC_W2_ABL & 16384
-  const int NSL = 2 * CCH;                                     // diagnostic (scripts/r6/ab_taxis.sh): the K loop of two of the three kt
+  // diagnostic (scripts/r6/ab_taxis.sh): the K loop of two of the three kt — whole-K launches only (a K-split piece keeps its range: its first
+  // double stage rides in the DMA's scalar offset, which no range check sees; the first version of this build cut the pieces too and faulted)
+  const int NSL = slab ? 3 * CCH / (int)gridDim.z : 2 * CCH;
 #else
   const int NSL = slab ? 3 * CCH / (int)gridDim.z : 3 * CCH;   // stages of this workgroup (a multiple of 4: checked on the host)
 #endif
-  const int dbeg = slab ? (int)blockIdx.z * (NSL >> 1) : 0;   // its first double stage
+  const int dbeg = slab ? zpiece * (NSL >> 1) : 0;             // its first double stage
   const unsigned HWC4 = (unsigned)(H * W * C * 4);
   unsigned* stash = (unsigned*)(lds + W2_RING_FLOATS) + tid;   // word i of thread tid at [i][tid]: conflict-free (a row per thread was 8-way)
 #pragma unroll
@@ -613,7 +633,7 @@ void conv_wino2_kernel(const SlicConvArgs p, const int full_rows, float* __restr
 #else
     if (slab) {
       // K-split piece: the two output rows' partial sums, combined as the epilogue combines them, to the slab (16 bytes per lane)
-      float* out = slab + ((((int64_t)mb * gridDim.y + nb) * gridDim.z + blockIdx.z) * 2 + nh) * (2 * 64 * 4 * 32);
+      float* out = slab + ((((int64_t)mb * gridDim.y + nb) * gridDim.z + zpiece) * 2 + nh) * (2 * 64 * 4 * 32);
       const int cq = tid & 7, rr = tid >> 3;
       const int hp = (rr >> 2) & 1, o = rr & 3;
       const float sgn = hp ? -1.f : 1.f;
@@ -819,6 +839,7 @@ __device__ __forceinline__ void w2_pair(const float x, const int off, float& lo,
 
 // one reduction for both column halves, behind one barrier (the caller has passed the barrier that ends the image reads); first half: the row
 // groups of a wave merged by lane exchanges, the wave's rows to LDS
+template <int NHN>
 __device__ __forceinline__ void w2p_stats_finish(const SlicConvArgs& p, float* lds, const int64_t mblk, const int n0, const int ewave, W2Stats& st) {
   const bool want_stats = p.stat_partial != nullptr, want_bwd = p.bwd_partial != nullptr;
   if (!want_stats && !want_bwd) return;                          // workgroup-uniform
@@ -826,7 +847,7 @@ __device__ __forceinline__ void w2p_stats_finish(const SlicConvArgs& p, float* l
   float* red = w2p_red();
   const int elane = w2_lane_now(), cq = elane & 7;
 #pragma unroll
-  for (int nh = 0; nh < 2; ++nh) {
+  for (int nh = 0; nh < NHN; ++nh) {
     if (want_stats) {
       f32x4 sum = 8.f * st.ref[nh] + st.sd[nh];
       f32x4 m2 = st.sq[nh] - st.sd[nh] * st.sd[nh] * 0.125f;
@@ -874,6 +895,7 @@ __device__ __forceinline__ void w2p_stats_finish(const SlicConvArgs& p, float* l
 // second half: the eight waves' rows merged by 64 threads.  Called AFTER the next block's first DMAs have been issued (reads of a distinct
 // static array: the compiler's wait-count pass does not hold them back behind the in-flight LDS-DMAs; the first half, whose LDS accesses it
 // could not tell apart from the DMAs' destinations, drew an s_waitcnt vmcnt when it ran behind the issue)
+template <int NHN>
 __device__ __forceinline__ void w2p_stats_merge(const SlicConvArgs& p, const int64_t mblk, const int n0, const int ewave) {
   const bool want_stats = p.stat_partial != nullptr, want_bwd = p.bwd_partial != nullptr;
   if (!want_stats && !want_bwd) return;                          // workgroup-uniform
@@ -883,7 +905,7 @@ __device__ __forceinline__ void w2p_stats_merge(const SlicConvArgs& p, const int
   // (a raw barrier: __syncthreads() is also a fence, and with the next block's LDS-DMAs in flight the compiler makes it wait for vmcnt(0))
   __builtin_amdgcn_s_waitcnt(0xC07F);                            // lgkmcnt(0): this wave's rows are in LDS
   __builtin_amdgcn_s_barrier();
-  if (tid < 64) {
+  if (tid < 32 * NHN) {                                            // (a half item: its 32 columns, n0 = the first of them)
     const int n = n0 + tid;
     float v0[8], v1[8];
 #pragma unroll
@@ -913,7 +935,10 @@ __device__ __forceinline__ void w2p_stats_merge(const SlicConvArgs& p, const int
 // LOADS: the launch reads optional operands in its epilogue (a per-channel affine, an addend, the ReLU-backward mask, the BatchNorm z of a data gradient) — two kernels,
 // so that each has one straight-line epilogue (with both behind workgroup-uniform branches the register allocator spilled the rows the
 // forward holds across the DMA issue)
-template <bool LOADS>
+// CT: the reduction channel count as a compile-time constant (64 / 128 / 256: the K loop's trip count and the stage -> (kt, channel group)
+// arithmetic fold; 0 = read it from the arguments) — which also puts the layer into the kernel's NAME: the profiles tell layer1's launches
+// (conv_wino2p_kernel<false, 64>) from layer2's by it, where the one-block kernel's grid size did
+template <bool LOADS, int CT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -921,7 +946,7 @@ void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = wave & 3, th = wave >> 2;
   const int r = lane & 31, hh = lane >> 5;
-  const int C = p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
+  const int C = CT ? CT : p.Cs, T = p.Ts, H = p.Hs, W = p.Ws;
   const int Wq = W >> 2, Hq = H >> 1;
   // ---- this workgroup's list: entries e = l, l + GL, ... of XCD x's list (n block major, its tile blocks inside)
   const int x = blockIdx.x & 7, l = blockIdx.x >> 3, GL = gridDim.x >> 3;
@@ -1001,40 +1026,56 @@ void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
   const f32x2 sgn = {sg, sg};
   const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c5 = {5.f, 5.f};
   constexpr unsigned WAIT_VM6_LGKM0 = 6 | 0x70, WAIT_VM0_LGKM0 = 0x70;
-  // first entry: decode, first U stage and pixel double stage
-  tflags = decode(l);
-  nb_dma = entry_nb(l);
+  // ---- this workgroup's items: whole blocks e = l, l + GL, ..., and — when the XCD's list leaves fewer than GL / 2 entries behind its last whole
+  // round (layer1 at B = 32: 392 entries on 32 workgroups = 12 rounds + 8) — ONE COLUMN HALF of a left-over entry: two workgroups share such a
+  // block, each runs its K loop for 32 of the 64 columns (12 instead of 24 MFMAs per stage and wave, the same pixel stages) and finishes its own
+  // columns — no partial sums to exchange — so the launch ends half a block, not a whole one, behind its last whole round
+  const int Rx = nent / GL, Lx = nent - Rx * GL;
+  const bool halfmode = Lx > 0 && 2 * Lx <= GL;
+  const int nwhole = Rx + ((!halfmode && l < Lx) ? 1 : 0);
+  const bool has_half = halfmode && l < 2 * Lx;
+  const int e_half = Rx * GL + (l >> 1), nh_half = l & 1;
+  if (nwhole == 0 && !has_half) return;
+  // first item: decode, first U stage and pixel double stage
+  tflags = decode(nwhole ? l : e_half);
+  nb_dma = entry_nb(nwhole ? l : e_half);
   issue_u(0, 0);
   issue_px(0, 0, 0);
   issue_px(0, 0, 1);
   W2P_STAMP_ID();
   [[maybe_unused]] int item = 0;
-  for (int e = l; e < nent; e += GL) {
+  // one item: HALF = only column half `nhsel` (accumulators, MFMAs, U reads and epilogue of that half); en >= 0 = the entry whose first stages
+  // the epilogue prefetches
+  auto run_item = [&](auto half_tag, const int e, const int nhsel, const int en) {
+    constexpr bool HALF = decltype(half_tag)::value;
+    constexpr int NHN = HALF ? 1 : 2;
     const int64_t tile0 = (int64_t)entry_mb(e) * 64;
     const int n0 = entry_nb(e) * 64;
     W2P_STAMP(item, 0);
     __builtin_amdgcn_s_setprio(0);
-    f32x16 acc[6][2];
+    f32x16 acc[6][NHN];
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
+      for (int nh = 0; nh < NHN; ++nh)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[pp][nh][g] = 0.f;
-    f32x2 V[6], ut[2];
+    f32x2 V[6], ut[NHN];
 #pragma unroll
     for (int pp = 0; pp < 6; ++pp) V[pp] = (f32x2){0.f, 0.f};
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) ut[nh] = (f32x2){0.f, 0.f};
-    auto mfma_point = [&](const int pp, const f32x2 (&u)[2]) {
+    for (int nh = 0; nh < NHN; ++nh) ut[nh] = (f32x2){0.f, 0.f};
+    unsigned brh = bro + (unsigned)(HALF ? nhsel * 512 : 0);      // U reads: the column half's 512 bytes inside a point's block
+    asm volatile("" : "+v"(brh));
+    auto mfma_point = [&](const int pp, const f32x2 (&u)[NHN]) {
 #pragma unroll
       for (int e2_ = 0; e2_ < 2; ++e2_)
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) acc[pp][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][e2_], u[nh][e2_], acc[pp][nh], 0, 0, 0);
+        for (int nh = 0; nh < NHN; ++nh) acc[pp][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(V[pp][e2_], u[nh][e2_], acc[pp][nh], 0, 0, 0);
     };
-    auto read_u = [&](const int uslot, const int pp, f32x2 (&u)[2]) {
+    auto read_u = [&](const int uslot, const int pp, f32x2 (&u)[NHN]) {
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) u[nh] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)bro + (uslot * W2_U_FLOATS + pp * 256 + nh * 128) * 4);
+      for (int nh = 0; nh < NHN; ++nh) u[nh] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)brh + (uslot * W2_U_FLOATS + pp * 256 + nh * 128) * 4);
     };
     for (int s0 = 0; s0 < NSL; s0 += 4) {
 #pragma unroll
@@ -1051,7 +1092,7 @@ void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
           d1[b] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)ar1 + pso + b * 4096);
           d2[b] = *(const __attribute__((address_space(3))) f32x2*)((lds_cptr)ar2 + pso + b * 4096);
         }
-        f32x2 ua[2], ub[2];
+        f32x2 ua[NHN], ub[NHN];
         __builtin_amdgcn_sched_barrier(0);
         issue_u(sgl + 1, uslot ^ 1);
         mfma_point(5, ut);
@@ -1084,15 +1125,14 @@ void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     W2P_STAMP(item, 1);
-    // ---- epilogue.  The ring is dead; the piece offsets of the NEXT entry go into the stash now (every DMA of this entry has been issued)
-    const int en = e + GL;
-    const bool more = en < nent;                                 // workgroup-uniform
+    // ---- epilogue.  The ring is dead; the piece offsets of the NEXT item go into the stash now (every DMA of this one has been issued)
+    const bool more = en >= 0;                                   // workgroup-uniform
     int tflags_n = 0;
     if (more) tflags_n = decode(en);
     if (tid < 64) w2_tile_records(p, lds, tile0, tid);
     __builtin_amdgcn_s_setprio(SLIC_PRIO_EDGE);
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
+    for (int nh = 0; nh < NHN; ++nh) {
       const f32x16 s12 = acc[1][nh] + acc[2][nh], d12 = acc[1][nh] - acc[2][nh];
       const f32x16 s34 = acc[3][nh] + acc[4][nh], d34 = acc[3][nh] - acc[4][nh];
       acc[0][nh] = acc[0][nh] + s12 + s34;
@@ -1114,44 +1154,52 @@ void conv_wino2p_kernel(const SlicConvArgs p, const int gx, const int ny) {
           lds[((j * 64 + tl) * 4 + o) * 32 + r] = acc[o][nh][g];
         }
     };
-    // column half 0
+    const int n0a = n0 + (HALF ? nhsel * 32 : 0);                // first column of the item's first (or only) half
+    // column half 0 (a half item: its only one)
     write_image(0);
     __syncthreads();
     if constexpr (LOADS) {
-      w2p_passes_loads<0>(p, lds, n0, wave, st);
+      w2p_passes_loads<0>(p, lds, n0a, wave, st);
     } else {
       W2Half h0;
-      w2p_read(p, lds, n0, wave, h0);
+      w2p_read(p, lds, n0a, wave, h0);
       w2p_write<0>(p, h0, st);
     }
-    __syncthreads();                                             // the first half's readers are done with the image
-    // column half 1: without optional operands its rows are combined into registers first; behind the barrier that follows nothing reads the
-    // image or the tile records any more, the ring may be written — the next block's first U stage and pixel double stage go out in FRONT of
-    // this half's stores
-    write_image(1);
-    __syncthreads();
-    [[maybe_unused]] W2Half h1;
-    if constexpr (LOADS) w2p_passes_loads<1>(p, lds, n0 + 32, wave, st);
-    else w2p_read(p, lds, n0 + 32, wave, h1);
-    __syncthreads();
-    W2P_STAMP(item, 2);
-    if (more) {
-      tflags = tflags_n;
-      nb_dma = entry_nb(en);
-      issue_u(0, 0);                                             // U slot 0 / pixel slot 0
-      issue_px(0, 0, 0);
-      issue_px(0, 0, 1);
+    __syncthreads();                                             // the half's readers are done with the image
+    if constexpr (!HALF) {
+      // column half 1: without optional operands its rows are combined into registers first; behind the barrier that follows nothing reads the
+      // image or the tile records any more, the ring may be written — the next item's first U stage and pixel double stage go out in FRONT of
+      // this half's stores
+      write_image(1);
+      __syncthreads();
+      [[maybe_unused]] W2Half h1;
+      if constexpr (LOADS) w2p_passes_loads<1>(p, lds, n0 + 32, wave, st);
+      else w2p_read(p, lds, n0 + 32, wave, h1);
+      __syncthreads();
+      W2P_STAMP(item, 2);
+      if (more) {
+        tflags = tflags_n;
+        nb_dma = entry_nb(en);
+        issue_u(0, 0);                                           // U slot 0 / pixel slot 0
+        issue_px(0, 0, 0);
+        issue_px(0, 0, 1);
+      }
+      W2P_STAMP(item, 3);
+      if constexpr (!LOADS) w2p_write<1>(p, h1, st);
     }
-    W2P_STAMP(item, 3);
-    if constexpr (!LOADS) w2p_write<1>(p, h1, st);
-    w2p_stats_finish(p, lds, tile0 >> 6, n0, wave, st);
+    w2p_stats_finish<NHN>(p, lds, tile0 >> 6, n0a, wave, st);
     W2P_STAMP(item, 4);
-    w2p_stats_merge(p, tile0 >> 6, n0, wave);
+    w2p_stats_merge<NHN>(p, tile0 >> 6, n0a, wave);
     W2P_STAMP(item, 5);
 #ifdef SLIC_W2_STAMPS
     ++item;
 #endif
+  };
+  for (int k = 0; k < nwhole; ++k) {
+    const int e = l + k * GL;
+    run_item(std::false_type{}, e, 0, k + 1 < nwhole ? e + GL : (has_half ? e_half : -1));
   }
+  if (has_half) run_item(std::true_type{}, e_half, nh_half, -1);
 }
 
 // second pass of a K-split launch: one workgroup per (tail block, n block) adds the `pieces` pieces in order, lays the sums out as the
@@ -1323,8 +1371,17 @@ static_assert(W2P_LDS_BYTES + 4096 <= 160 * 1024 && W2P_LDS_BYTES >= (size_t)(W2
 
 static int w2_launch_persist(const SlicConvArgs* a, hipStream_t st, int nblocks, unsigned ny, size_t lds) {
   (void)lds;
-  if (a->addend || a->mask_src || a->bwd_z || a->scale || a->shift) conv_wino2p_kernel<true><<<dim3((unsigned)w2_persist_grid()), dim3(512), W2P_LDS_BYTES, st>>>(*a, nblocks, (int)ny);
-  else conv_wino2p_kernel<false><<<dim3((unsigned)w2_persist_grid()), dim3(512), W2P_LDS_BYTES, st>>>(*a, nblocks, (int)ny);
+  const bool loads = a->addend || a->mask_src || a->bwd_z || a->scale || a->shift;
+  const dim3 grid((unsigned)w2_persist_grid());
+#define W2P_GO(L, C_) conv_wino2p_kernel<L, C_><<<grid, dim3(512), W2P_LDS_BYTES, st>>>(*a, nblocks, (int)ny)
+#define W2P_PICK(L)                                                                    \
+  do {                                                                                  \
+    if (a->Cs == 64) W2P_GO(L, 64); else if (a->Cs == 128) W2P_GO(L, 128);               \
+    else if (a->Cs == 256) W2P_GO(L, 256); else W2P_GO(L, 0);                            \
+  } while (0)
+  if (loads) W2P_PICK(true); else W2P_PICK(false);
+#undef W2P_PICK
+#undef W2P_GO
   SLIC_LAUNCH_CHECK();
   return SLIC_OK;
 }
@@ -1339,8 +1396,10 @@ int slic_conv_wino2_launch(const SlicConvArgs* a, hipStream_t st, int nfull, flo
   static bool attr_set = false;
   if (!attr_set) {
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2P_LDS_BYTES));
-    SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2P_LDS_BYTES));
+#define W2P_ATTR(L, C_) SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2p_kernel<L, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)W2P_LDS_BYTES))
+    W2P_ATTR(false, 0); W2P_ATTR(false, 64); W2P_ATTR(false, 128); W2P_ATTR(false, 256);
+    W2P_ATTR(true, 0); W2P_ATTR(true, 64); W2P_ATTR(true, 128); W2P_ATTR(true, 256);
+#undef W2P_ATTR
     SLIC_HIP_CHECK(hipFuncSetAttribute((const void*)conv_wino2_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
