@@ -473,6 +473,11 @@ class ConvPlan:
             rem = wgs % 256
             if rem == 0 or rem > 128 or wgs > int(_env("SLIC_WINO2_TAIL_MAXROUNDS", "6")) * 256:       # launches of many rounds are left alone (layer1: 12.25 — the tail's pieces + finish
                 return None                                  # pass measured no faster there)
+            # round 6: a launch the PERSISTENT kernel takes (whole 2 x 4 tiles everywhere, >= 2 blocks per compute unit) ends in column-half items
+            # instead — two workgroups share a left-over block, no slab, no finish pass (SLIC_WINO2_HALFTAIL=0: the K-split tail as before)
+            if (_env("SLIC_WINO2_HALFTAIL", "1") != "0" and _env("SLIC_WINO2_PERSIST", "1") != "0" and H2 % 2 == 0 and W2 % 4 == 0
+                    and wgs >= 512 and not _env("SLIC_WINO2_PERSIST_GRID")):
+                return None
             tail_x = -(-rem // ny)
             forced = int(_env("SLIC_WINO2_PIECES", "0"))
             units = 3 * a.Cs // 16
