@@ -59,7 +59,8 @@ def test_winograd_2d_plan_rules(monkeypatch):
     tiles are uniform and the launch has at least 64 workgroups; its K split by kt for a partly filled last dispatch round (layer2 at
     B = 32: 784 workgroups = three rounds + 16) and for launches of less than half a round (layer4: 64); the transposed two-dimensional
     weight gradient wherever its 3 x C/64 x N/64 workgroups per slice fit the 256 slots (all four layers; layer4: 192, one slice); channel counts that are not 64 x a power of two stay off the Winograd kernels"""
-    for k in ("SLIC_WINO", "SLIC_WINO2", "SLIC_WINO2_MIN_WGS", "SLIC_WINO2_SPLIT", "SLIC_WINO2_WGRAD", "SLIC_WINO_WGRAD"):
+    for k in ("SLIC_WINO", "SLIC_WINO2", "SLIC_WINO2_MIN_WGS", "SLIC_WINO2_SPLIT", "SLIC_WINO2_WGRAD", "SLIC_WINO_WGRAD", "SLIC_WINO2_PERSIST",
+              "SLIC_WINO2_PERSIST_GRID", "SLIC_WINO2_HALFTAIL"):
         monkeypatch.delenv(k, raising=False)
     k3, s1, p1 = (3, 3, 3), (1, 1, 1), (1, 1, 1)
     shapes = [(64, (16, 56, 56)), (128, (8, 28, 28)), (256, (4, 14, 14)), (512, (2, 7, 7))]
@@ -77,7 +78,13 @@ def test_winograd_2d_plan_rules(monkeypatch):
         a.M, a.Ts, a.Hs, a.Ws, a.N, a.Cs = B * T * H * W, T, H, W, C, C
         return a
     assert ConvPlan._plan_split(args(32, 64, (16, 56, 56)), 31) is None          # 3136 workgroups: 12.25 rounds, remainder 64 ... of 256
-    assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) == (384, 6)      # 392 tile blocks x 2: the last 8 blocks cut into 6 pieces
+    # 392 tile blocks x 2 = three rounds + 16: round 6 leaves the launch whole — the persistent kernel ends it in column-half items — and
+    # with the persistent kernel (or its half items) off the last 8 blocks are cut into 6 pieces as in round 5
+    assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) is None
+    for var in ("SLIC_WINO2_HALFTAIL", "SLIC_WINO2_PERSIST"):
+        monkeypatch.setenv(var, "0")
+        assert ConvPlan._plan_split(args(32, 128, (8, 28, 28)), 31) == (384, 6)
+        monkeypatch.delenv(var)
     assert ConvPlan._plan_split(args(32, 256, (4, 14, 14)), 31) is None          # 224 workgroups: most of a round
     assert ConvPlan._plan_split(args(32, 512, (2, 7, 7)), 31) == (0, 4)          # 64 workgroups: all of them cut, 4 pieces = one dispatch round
     # small batches: layer3 at B = 8 has 56 workgroups -> still two-dimensional (4 K pieces fill the slots); layer4's 16 -> the one-dimensional
