@@ -743,6 +743,12 @@ __device__ __forceinline__ void w2p_write(const SlicConvArgs& p, W2Half& h, W2St
 
 // the same in ONE step for the launches that load optional operands (addend / ReLU-backward mask / the BatchNorm z of a data gradient): their
 // loads are issued four passes at a time, and holding eight combined rows beside them spilled registers
+#ifndef SLIC_W2P_LB0
+#define SLIC_W2P_LB0 4     // passes whose optional-operand loads are in flight together, column half 0 / 1 (8 = all of a half's at once)
+#endif
+#ifndef SLIC_W2P_LB1
+#define SLIC_W2P_LB1 8
+#endif
 template <int NH>
 __device__ __forceinline__ void w2p_passes_loads(const SlicConvArgs& p, const float* lds, const int n0h, const int ewave, W2Stats& st) {
   constexpr int BNH = 32, NPASS = 8;
@@ -770,7 +776,9 @@ __device__ __forceinline__ void w2p_passes_loads(const SlicConvArgs& p, const fl
   unsigned offs[NPASS];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) offs[ps] = ((trec[ps * 8].x + (unsigned)(hp * W + o)) * (unsigned)p.ldo + (unsigned)n) * 4u;
-  constexpr int LB = 4;
+  // (the second half's accumulators are dead by then: all eight passes' loads fit the registers and pay ONE memory round trip — these
+  //  tensors come from HBM, ~2 us — where batches of four paid two; the first half holds the second's accumulators beside them)
+  constexpr int LB = NH ? SLIC_W2P_LB1 : SLIC_W2P_LB0;
   f32x4 ldadd[LB], ldmsk[LB], ldz[LB];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
