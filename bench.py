@@ -506,7 +506,11 @@ def main():
         # (online_train.py:485-494)
         if os.environ.get("SLIC_DDP_FAST", "1") != "0":
             from video_similarity_search_amd.misc.distributed_helper import data_parallel
-            model = data_parallel(model, local_rank, bucket_cap_mb=ddp_kw["bucket_cap_mb"])
+            try:
+                model = data_parallel(model, local_rank, bucket_cap_mb=ddp_kw["bucket_cap_mb"])
+            except Exception as e:                                # never lose a multi-GPU run to the fast wrapper: the reference's call still works
+                log(f"bench.py: rank {rank}: data_parallel failed ({e!r}); falling back to the plain DistributedDataParallel call")
+                model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local_rank], **ddp_kw)
         else:
             model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], **ddp_kw)
     crit = OnlineTripletLoss(0.2, 'cosine')

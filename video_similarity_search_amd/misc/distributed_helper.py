@@ -97,7 +97,7 @@ def _flatten_buffers(module):
     values); returns ([flat tensors], [buffer names])"""
     groups = {}
     for name, buf in module.named_buffers():
-        if buf is None or not buf.is_cuda or buf.dtype not in (torch.float32, torch.int64):
+        if buf is None or buf.dtype not in (torch.float32, torch.int64):
             continue
         groups.setdefault(buf.dtype, []).append((name, buf))
     flats, names = [], []
@@ -122,7 +122,8 @@ def data_parallel(model, device=None, process_group=None, broadcast_buffers=True
     """DistributedDataParallel(module=model, device_ids=[device]) for a model of this package, without the wrapper's per-step copies
     (see above).  Returns the DistributedDataParallel instance; `.slic_ddp` on it says what was set up."""
     from torch.nn.parallel import DistributedDataParallel as DDP
-    if device is None:
+    on_gpu = next(model.parameters()).is_cuda
+    if device is None and on_gpu:
         device = torch.cuda.current_device()
     pg = process_group if process_group is not None else torch.distributed.group.WORLD
     info = dict(flat_buffers=False, buffer_broadcasts_per_forward=None, gradient_into_bucket_views=False, scale="per-parameter division (torch default)")
@@ -136,8 +137,8 @@ def data_parallel(model, device=None, process_group=None, broadcast_buffers=True
         for mod in model.modules():                      # plans cache nothing of the buffers, but an engine built before the re-pointing is dropped anyway
             if hasattr(mod, "_engines"):
                 mod._engines = {}
-    ddp = DDP(model, device_ids=[device], process_group=pg, broadcast_buffers=broadcast_buffers, gradient_as_bucket_view=True,
-              bucket_cap_mb=bucket_cap_mb, **ddp_kwargs)
+    ddp = DDP(model, device_ids=[device] if on_gpu else None, process_group=pg, broadcast_buffers=broadcast_buffers, gradient_as_bucket_view=True,
+              bucket_cap_mb=bucket_cap_mb, **ddp_kwargs)      # (a CPU model over gloo — tests — takes the same route; ReduceOp.AVG is RCCL's: gloo keeps the default scale)
     world = torch.distributed.get_world_size(pg)
 
     def avg_hook(group, bucket):
