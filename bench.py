@@ -315,7 +315,7 @@ def measure_traffic():
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-traffic"]
             env = dict(os.environ, TMPDIR="/tmp", SLIC_BENCH_CHILD="1")
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             f = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
             per = {}
             for r in csv.DictReader(open(f[-1])):
